@@ -1,0 +1,324 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (this container only).
+
+TEST INFRASTRUCTURE ONLY.  Imports /root/reference/src/fdiff *by path* (nothing is copied
+into this repo) after registering stand-in modules for three third-party packages that
+are absent from the image and are NOT on the arithmetic path (pytorch_lightning,
+diffusers, torchvision -- SURVEY 8c / Appendix B).  Inputs and weights come from the
+counter-based recipe in oracle/weights.py, so the fixtures hold expected OUTPUTS only.
+
+    python oracle/make_golden.py            # rewrites tests/golden/*.npz
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+from contextlib import contextmanager
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import weights as W  # noqa: E402
+
+REF = "/root/reference/src"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference not present; golden fixtures can only be regenerated in the build container")
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class LightningModule(nn.Module):
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log_dict(self, *a, **k):
+            pass
+
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+    stub("pytorch_lightning", LightningModule=LightningModule, LightningDataModule=object,
+         Callback=object, Trainer=object)
+    stub("pytorch_lightning.utilities")
+    stub("pytorch_lightning.utilities.types", OptimizerLRScheduler=object)
+    stub("diffusers")
+    stub("diffusers.optimization", get_cosine_schedule_with_warmup=lambda **k: None)
+    stub("torchvision")
+    stub("torchvision.ops", MLP=object)
+    sys.path.insert(0, REF)
+    import fdiff.models.score_models as sm
+    import fdiff.sampling.sampler as sp
+    import fdiff.schedulers.sde as sde
+    import fdiff.utils.dataclasses as dc
+    import fdiff.utils.fourier as fourier
+    import fdiff.utils.losses as losses
+    return types.SimpleNamespace(sm=sm, sp=sp, sde=sde, dc=dc, fourier=fourier, losses=losses)
+
+
+@contextmanager
+def replay_noise(randn_like_seq=None, randn_seq=None):
+    """Replace torch.randn_like / torch.randn by replaying stored tensors."""
+    orig_like, orig_randn = torch.randn_like, torch.randn
+    like_it = iter(randn_like_seq or [])
+    randn_it = iter(randn_seq or [])
+    if randn_like_seq is not None:
+        torch.randn_like = lambda x, *a, **k: next(like_it).to(x.dtype)
+    if randn_seq is not None:
+        torch.randn = lambda *a, **k: next(randn_it)
+    try:
+        yield
+    finally:
+        torch.randn_like, torch.randn = orig_like, orig_randn
+
+
+def t_(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def build_ref_model(R, cfg, sde_kind, sde_p, scaling, seed):
+    if sde_kind == "vp":
+        sch = R.sde.VPScheduler(beta_min=sde_p[0], beta_max=sde_p[1], fourier_noise_scaling=scaling)
+    else:
+        sch = R.sde.VEScheduler(sigma_min=sde_p[0], sigma_max=sde_p[1], fourier_noise_scaling=scaling)
+    sch.set_noise_scaling(cfg["T"])
+    m = R.sm.ScoreModule(n_channels=cfg["C"], max_len=cfg["T"], noise_scheduler=sch,
+                         fourier_noise_scaling=scaling, d_model=cfg["D"], num_layers=cfg["L"],
+                         n_head=cfg["H"])
+    sd = W.make_state_dict(cfg["C"], cfg["T"], cfg["D"], cfg["L"], seed=seed)
+    m.load_state_dict({k: t_(v) for k, v in sd.items()}, strict=True)
+    return m, sch, sd
+
+
+# Shared with tests/: model configurations used by the fixtures.
+CFG_DEFAULT = dict(T=100, C=12, D=72, L=10, H=12)      # hydra default score model, ecg-synth shape
+CFG_TINY = dict(T=20, C=3, D=8, L=2, H=4)             # the reference tests' config (tests/test_score_models.py:13-19)
+CFG_ODD = dict(T=37, C=5, D=24, L=2, H=4)             # odd T, head_dim 6
+DFT_T = [16, 24, 100, 101, 187, 251, 252, 256, 365, 1024]
+DFT_C = [1, 12, 28]
+DFT_B = 2
+
+
+def gen_dft(R):
+    out = {}
+    for T in DFT_T:
+        for C in DFT_C:
+            x = W.randn(f"dft_x_{T}_{C}", (DFT_B, T, C), 0)
+            out[f"dft_{T}_{C}"] = R.fourier.dft(t_(x)).numpy()
+            xt = W.randn(f"idft_x_{T}_{C}", (DFT_B, T, C), 0)
+            out[f"idft_{T}_{C}"] = R.fourier.idft(t_(xt)).numpy()
+    # known-answer pairs: impulse and a pure cosine
+    for T in (16, 15):
+        imp = np.zeros((1, T, 1), np.float32)
+        imp[0, 3, 0] = 1.0
+        out[f"dft_impulse_{T}"] = R.fourier.dft(t_(imp)).numpy()
+        n = np.arange(T, dtype=np.float64)
+        cosw = np.cos(2 * np.pi * 2 * n / T).astype(np.float32).reshape(1, T, 1)
+        out[f"dft_cos2_{T}"] = R.fourier.dft(t_(cosw)).numpy()
+    np.savez_compressed(os.path.join(OUT, "dft.npz"), **out)
+
+
+SDE_CASES = [("vp", (0.1, 20.0)), ("ve", (0.01, 2.0)), ("ve", (0.01, 50.0))]
+
+
+def make_ref_sde(R, kind, p, scaling, T):
+    s = (R.sde.VPScheduler(beta_min=p[0], beta_max=p[1], fourier_noise_scaling=scaling) if kind == "vp"
+         else R.sde.VEScheduler(sigma_min=p[0], sigma_max=p[1], fourier_noise_scaling=scaling))
+    s.set_noise_scaling(T)
+    return s
+
+
+def gen_sde(R):
+    out = {}
+    for T in (100, 101):
+        for scaling in (False, True):
+            s = make_ref_sde(R, "vp", (0.1, 20.0), scaling, T)
+            out[f"G_{T}_{int(scaling)}"] = s.G.numpy()
+    for N in (10, 1000, 2000):
+        s = make_ref_sde(R, "vp", (0.1, 20.0), True, 100)
+        s.set_timesteps(N)
+        out[f"timesteps_{N}"] = s.timesteps.numpy()
+        out[f"step_size_{N}"] = s.step_size.numpy()
+    B, T, C = 4, 20, 3
+    x = W.randn("sde_x", (B, T, C), 1)
+    score = W.randn("sde_score", (B, T, C), 1)
+    z = W.randn("sde_z", (B, T, C), 1)
+    tvals = np.array([1e-5, 0.1, 0.5, 1.0], np.float32)
+    for ci, (kind, p) in enumerate(SDE_CASES):
+        for scaling in (False, True):
+            tag = f"{kind}{ci}_{int(scaling)}"
+            s = make_ref_sde(R, kind, p, scaling, T)
+            mean, std = s.marginal_prob(t_(x), t_(tvals))
+            out[f"mean_{tag}"] = mean.numpy()
+            out[f"std_{tag}"] = std.numpy()
+            s.set_timesteps(1000)
+            for ti, tv in enumerate((0.37, 1e-5, 1.0)):
+                with replay_noise(randn_like_seq=[t_(z)]):
+                    o = s.step(t_(score), tv, t_(x)).prev_sample
+                out[f"step_{tag}_{ti}"] = o.numpy()
+            with replay_noise(randn_seq=[t_(z)]):
+                out[f"prior_{tag}"] = s.prior_sampling((B, T, C)).numpy()
+    np.savez_compressed(os.path.join(OUT, "sde.npz"), **out)
+
+
+def gen_score(R):
+    out = {}
+    for name, cfg, B in (("default", CFG_DEFAULT, 4), ("tiny", CFG_TINY, 3), ("odd", CFG_ODD, 3)):
+        m, sch, _ = build_ref_model(R, cfg, "vp", (0.1, 20.0), True, seed=1234)
+        m.eval()
+        X = W.randn(f"score_x_{name}", (B, cfg["T"], cfg["C"]), 2)
+        t = W.uniform(f"score_t_{name}", (B,), 2, 1e-5, 1.0)
+        batch = R.dc.DiffusableBatch(X=t_(X), y=None, timesteps=t_(t))
+        with torch.no_grad():
+            fast = m(batch).numpy()
+        torch.backends.mha.set_fastpath_enabled(False)
+        with torch.no_grad():
+            slow = m(batch).numpy()
+        torch.backends.mha.set_fastpath_enabled(True)
+        out[f"fast_{name}"] = fast
+        out[f"slow_{name}"] = slow
+        print(f"score {name}: fast-vs-slow max abs {np.abs(fast - slow).max():.3e}, |out| max {np.abs(fast).max():.3f}")
+    np.savez_compressed(os.path.join(OUT, "score_forward.npz"), **out)
+
+
+def zero_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, nn.MultiheadAttention):
+            mod.dropout = 0.0
+
+
+def gen_loss(R):
+    out = {}
+    for name, cfg, B in (("tiny", CFG_TINY, 5), ("odd", CFG_ODD, 3)):
+        X = W.randn(f"loss_x_{name}", (B, cfg["T"], cfg["C"]), 3)
+        z = W.randn(f"loss_z_{name}", (B, cfg["T"], cfg["C"]), 3)
+        t = W.uniform(f"loss_t_{name}", (B,), 3, 0.05, 1.0)
+        for ci, (kind, p) in enumerate(SDE_CASES[:2]):
+            for lw in (False, True):
+                m, sch, _ = build_ref_model(R, cfg, kind, p, True, seed=1234)
+                zero_dropout(m)
+                batch = R.dc.DiffusableBatch(X=t_(X), y=None, timesteps=t_(t))
+                # eval-mode value
+                fn_eval = R.losses.get_sde_loss_fn(sch, train=False, likelihood_weighting=lw)
+                with replay_noise(randn_like_seq=[t_(z)]):
+                    with torch.no_grad():
+                        lv = fn_eval(m, batch)
+                tag = f"{name}_{kind}{ci}_{int(lw)}"
+                out[f"loss_{tag}"] = np.array(lv.item(), np.float64)
+                # train-mode value + gradients with dropout p forced to 0
+                fn_tr = R.losses.get_sde_loss_fn(sch, train=True, likelihood_weighting=lw)
+                m.zero_grad()
+                with replay_noise(randn_like_seq=[t_(z)]):
+                    lt = fn_tr(m, batch)
+                lt.backward()
+                out[f"loss_train_{tag}"] = np.array(lt.item(), np.float64)
+                if not lw:
+                    for k, prm in m.named_parameters():
+                        if prm.grad is not None:
+                            out[f"grad_{tag}/{k}"] = prm.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+
+
+def gen_sampler(R):
+    out = {}
+    N = 20
+    for name, cfg, B in (("tiny", CFG_TINY, 6), ("default", CFG_DEFAULT, 2)):
+        for ci, (kind, p) in enumerate(SDE_CASES[:2]):
+            m, sch, _ = build_ref_model(R, cfg, kind, p, True, seed=1234)
+            shape = (B, cfg["T"], cfg["C"])
+            zp = W.randn(f"samp_prior_{name}", shape, 4)
+            zs = [W.randn(f"samp_z_{name}_{i}", shape, 4) for i in range(N)]
+            sampler = R.sp.DiffusionSampler(score_model=m, sample_batch_size=B)
+            rec = {}
+            # record intermediate X by wrapping reverse_diffusion_step
+            orig = sampler.reverse_diffusion_step
+            cnt = {"i": 0}
+
+            def wrapped(batch, orig=orig, cnt=cnt, rec=rec):
+                Xn = orig(batch)
+                cnt["i"] += 1
+                if cnt["i"] in (1, 5, 20):
+                    rec[cnt["i"]] = Xn.numpy().copy()
+                return Xn
+
+            sampler.reverse_diffusion_step = wrapped
+            with replay_noise(randn_like_seq=[t_(z) for z in zs], randn_seq=[t_(zp)]):
+                Xf = sampler.sample(num_samples=B, num_diffusion_steps=N)
+            tag = f"{name}_{kind}{ci}"
+            out[f"final_{tag}"] = Xf.numpy()
+            for k, v in rec.items():
+                out[f"step{k}_{tag}"] = v
+            print(f"sampler {tag}: |X| max {np.abs(Xf.numpy()).max():.3f}")
+    # batching rule (sampler.py:63,74-77): shapes only
+    m, sch, _ = build_ref_model(R, CFG_TINY, "vp", (0.1, 20.0), True, seed=1234)
+    shapes = []
+    for ns, bs in ((48, 12), (50, 12), (5, 12), (12, 12)):
+        s = R.sp.DiffusionSampler(score_model=m, sample_batch_size=bs)
+        shapes.append([ns, bs, s.sample(num_samples=ns, num_diffusion_steps=2).shape[0]])
+    out["batching"] = np.array(shapes, np.int64)
+    np.savez_compressed(os.path.join(OUT, "sampler.npz"), **out)
+
+
+def gen_dataset(R):
+    """DiffusionDataset statistics (datamodules.py:42-62) restated with the reference's dft + torch mean/std
+    (fdiff.dataloaders.datamodules itself needs pytorch_lightning/pandas-kaggle and is not importable)."""
+    out = {}
+    X = W.randn("ds_x", (16, 24, 3), 5)
+    Xt = R.fourier.dft(t_(X))
+    out["mean"] = Xt.mean(dim=0).numpy()
+    out["std"] = Xt.std(dim=0).numpy()
+    out["item3"] = ((Xt[3] - Xt.mean(dim=0)) / Xt.std(dim=0)).numpy()
+    np.savez_compressed(os.path.join(OUT, "dataset.npz"), **out)
+
+
+def gen_optim(R):
+    """AdamW + clip from this image's torch 2.10 (the reference delegates to torch, score_models.py:123;
+    Lightning's gradient_clip_val=1.0 is torch.nn.utils.clip_grad_norm_)."""
+    out = {}
+    p0 = W.randn("opt_p", (257,), 6)
+    prm = nn.Parameter(t_(p0.copy()))
+    opt = torch.optim.AdamW([prm], lr=1e-3)
+    for it in range(3):
+        g = W.randn(f"opt_g{it}", (257,), 6) * np.float32(3.0)
+        prm.grad = t_(g.copy())
+        tn = torch.nn.utils.clip_grad_norm_([prm], 1.0)
+        out[f"total_norm_{it}"] = np.array(tn.item())
+        for grp in opt.param_groups:
+            grp["lr"] = 1e-3 * (it + 1) / 3
+        opt.step()
+        out[f"param_{it}"] = prm.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "optim.npz"), **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    R = import_reference()
+    gen_dft(R)
+    gen_sde(R)
+    gen_score(R)
+    gen_loss(R)
+    gen_sampler(R)
+    gen_dataset(R)
+    gen_optim(R)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
