@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the fdiff hot path on MI355X.
+
+metric  : sampled series/sec at (T=100, C=12)  [BASELINE.json]
+workload: configs[1] -- "ecg (T=100, C=12) fourier_transform=true, default transformer
+          (d_model=72, L=10, H=12, ff=2048), batch=512 on 1xMI355X", VP-SDE(0.1, 20), N=1000 reverse
+          diffusion steps, synthetic prior / random-init weights (seed 42), inputs resident in HBM.
+step    : ONE full reverse diffusion of one batch of 512 series (1000 x {score net + SDE step}).
+N GPUs  : one process per GPU, each samples its own batch of 512 series (the sample batch is sharded;
+          no data-path collective) -> weak scaling; value = N*512*K / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T, CH, D, L, H, F = 100, 12, 72, 10, 12, 2048
+
+
+def flops_per_series_forward(T=T, C=CH, D=D, L=L, F=F):
+    """T*(L*(2*D*3D + 2*D*D + 4*D*F + 4*T*D) + 4*C*D) + 2*D*D  (padding flops do not count)."""
+    return T * (L * (2 * D * 3 * D + 2 * D * D + 4 * D * F + 4 * T * D) + 4 * C * D) + 2 * D * D
+
+
+def cpu_baseline(batch: int, n_timed: int = 3):
+    """The reference's CPU path = the same torch-op sequence it executes (nn.TransformerEncoder eval fast path +
+    diag_embed/matmul scheduler step), timed on this host's cores by oracle/torch_cpu_baseline.py on a bounded
+    sample (a few reverse-diffusion steps, extrapolated x1000: every step costs the same)."""
+    from oracle import torch_cpu_baseline as cb
+    return cb.time_sampler_steps(batch=batch, T=T, C=CH, d_model=D, num_layers=L, n_head=H, n_timed=n_timed)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--diffusion-steps", type=int, default=1000)
+    ap.add_argument("--precision", default=os.environ.get("FDIFF_PRECISION", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
+                         f"(WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", device_id=dev)
+        dist = dist_mod
+
+    from fourierdiffusion_amd import _C, _rng
+    from fourierdiffusion_amd.models.score_models import ScoreModule
+    from fourierdiffusion_amd.schedulers.sde import VPScheduler
+
+    torch.manual_seed(42)
+    _rng.set_rank(rank)
+    sch = VPScheduler(beta_min=0.1, beta_max=20.0, fourier_noise_scaling=True)
+    sch.set_noise_scaling(T)
+    model = ScoreModule(n_channels=CH, max_len=T, noise_scheduler=sch, fourier_noise_scaling=True, d_model=D,
+                        num_layers=L, n_head=H).to(dev)
+    model.precision = args.precision
+    model.eval()
+    N = args.diffusion_steps
+    B = args.batch
+    sch.set_timesteps(N)
+    ctx, h = model._engine()
+    lib = _C.lib()
+    ts_arr = (C.c_float * N)(*sch.timesteps.tolist())
+    prm = sch._c_params()
+    G = sch.G_on(dev)
+    mode = _C.FD_MODE_BF16 if args.precision == "bf16" else _C.FD_MODE_F32
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    X = torch.empty(B, T, CH, device=dev)
+
+    def one_step(i):
+        # prior (on device) + N x {score net, SDE step}: all enqueued on `stream`, no host sync inside
+        key, off = _rng.stream()
+        _C.check(lib.fd_prior_sample(ctx, C.byref(prm), G.data_ptr(), None, key, off, X.data_ptr(), B, T, CH,
+                                     stream), ctx)
+        key, off = _rng.stream()
+        _C.check(lib.fd_sampler_run(h, C.byref(prm), G.data_ptr(), ts_arr, N, float(sch.step_size), X.data_ptr(),
+                                    None, key, off, B, mode, stream), ctx)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    prof = hasattr(lib, "fd_prof_begin")
+    if prof:
+        lib.fd_prof_begin(ctx, 16)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(X).all(), "sampler produced non-finite values"
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        series = world * B * args.steps
+        value = series / elapsed
+        ms_per_step = 1e3 * elapsed / args.steps
+        fwd_flops = flops_per_series_forward() * B          # per score-net forward of the batch
+        out = {
+            "metric": "sampled series/sec (T=100, C=12)",
+            "value": value,
+            "unit": "series/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "score_net_step_ms": ms_per_step / N,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision if args.precision == "bf16" else "f32",
+            "data": "synthetic (Philox prior, random-init weights seed 42)",
+            "config": {"workload": "BASELINE.json configs[1]: ecg-synth (T=100, C=12), default transformer "
+                                   "(d_model=72, L=10, H=12, ff=2048), VP-SDE, fourier_noise_scaling, "
+                                   f"batch={B}/GPU, {N} reverse-diffusion steps per bench step",
+                       "global_batch": world * B, "seq_len": T, "parallelism": f"sample-batch shard x{world}"},
+            "achieved_tflops_whole_step": fwd_flops * N * world * args.steps / elapsed / 1e12,
+        }
+        roof = None
+        if prof:
+            avg_us = C.c_double(0)
+            cnt = C.c_int(0)
+            flops = C.c_double(0)
+            name = C.create_string_buffer(128)
+            if lib.fd_prof_end(ctx, name, C.byref(avg_us), C.byref(cnt), C.byref(flops)) == 0 and cnt.value > 0:
+                peak = 2500.0 if args.precision == "bf16" else 157.3
+                ach = flops.value / (avg_us.value * 1e-6) / 1e12
+                roof = {"bound": "mfma", "kernel": name.value.decode(), "achieved": ach, "peak": peak,
+                        "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                        "avg_kernel_us": avg_us.value, "launches_sampled": cnt.value,
+                        "flops_per_launch": flops.value}
+        out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(B)
+            except Exception as e:   # the GPU result must still be reported
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,76 @@
+// fd_common.h -- shared host-side plumbing for libfdiff_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fdiff_hip.h"
+
+struct fd_ctx {
+    int device = 0;
+    std::string err;
+    // grow-only scratch arena; carved per call by fd_ws
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    // small pinned staging buffer for per-call coefficient tables
+    void* comm = nullptr;   // ncclComm_t when fd_comm_init succeeded
+    int rank = 0, nranks = 1;
+    int num_cu = 256;
+};
+
+inline int fd_fail(fd_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define FD_HIP(ctx, expr)                                                                     \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fd_fail((ctx), FD_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                 \
+                           hipGetErrorString(_e), __FILE__, __LINE__);                        \
+    } while (0)
+
+#define FD_LAUNCH_CHECK(ctx)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e != hipSuccess)                                                                 \
+            return fd_fail((ctx), FD_ERR_HIP, "kernel launch failed: %s (%s:%d)",            \
+                           hipGetErrorString(_e), __FILE__, __LINE__);                        \
+    } while (0)
+
+#define FD_REQUIRE(ctx, cond, ...)                                                            \
+    do {                                                                                      \
+        if (!(cond)) return fd_fail((ctx), FD_ERR_ARG, __VA_ARGS__);                          \
+    } while (0)
+
+// Ensure the ctx arena holds >= bytes.  Growth frees + reallocates (device-synchronising);
+// steady-state calls never allocate.
+int fd_ws_reserve(fd_ctx* ctx, size_t bytes);
+
+// Bump allocator over the arena for one API call.
+struct fd_ws {
+    char* base;
+    size_t off = 0, cap;
+    explicit fd_ws(fd_ctx* c) : base((char*)c->ws), cap(c->ws_bytes) {}
+    template <typename T>
+    T* take(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        T* p = (T*)(base + off);
+        off += bytes;
+        return p;
+    }
+    static size_t padded(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+};
+
+static inline int fd_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,47 @@
+// fd_ctx.hip -- context, error string, workspace arena.
+#include "fd_common.h"
+
+extern "C" int fd_version(void) { return 100; }
+
+extern "C" int fd_ctx_create(int device, fd_ctx** out) {
+    if (!out) return FD_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return FD_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return FD_ERR_HIP;
+    fd_ctx* c = new fd_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    *out = c;
+    return FD_OK;
+}
+
+extern "C" int fd_comm_destroy(fd_ctx* ctx);
+
+extern "C" int fd_ctx_destroy(fd_ctx* ctx) {
+    if (!ctx) return FD_ERR_ARG;
+    fd_comm_destroy(ctx);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    delete ctx;
+    return FD_OK;
+}
+
+extern "C" const char* fd_last_error(fd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" size_t fd_ctx_workspace_bytes(fd_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
+
+int fd_ws_reserve(fd_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return FD_OK;
+    FD_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->ws) {
+        FD_HIP(ctx, hipDeviceSynchronize());
+        FD_HIP(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    size_t want = bytes + (bytes >> 3);   // 12.5% slack so near-equal sizes do not thrash
+    FD_HIP(ctx, hipMalloc(&ctx->ws, want));
+    ctx->ws_bytes = want;
+    return FD_OK;
+}

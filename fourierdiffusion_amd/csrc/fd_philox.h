@@ -1,0 +1,44 @@
+// fd_philox.h -- Philox4x32-10 counter RNG + Box-Muller, device side.
+// One counter value yields 4 standard normals; element e of a tensor uses counter
+// (offset + e/4) and lane e%4, so any kernel shape reproduces the same stream.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+struct fd_u4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ fd_u4 fd_philox4x32_10(uint64_t counter, uint64_t seed) {
+    uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return fd_u4{c0, c1, c2, c3};
+}
+
+// uniform in (0,1): 24 random bits, centred
+__device__ __forceinline__ float fd_u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+__device__ __forceinline__ void fd_box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float u1 = fd_u01(a), u2 = fd_u01(b);
+    const float r = sqrtf(-2.0f * __logf(u1));
+    float s, c;
+    sincospif(2.0f * u2, &s, &c);
+    n0 = r * c;
+    n1 = r * s;
+}
+
+__device__ __forceinline__ void fd_randn4(uint64_t counter, uint64_t seed, float (&n)[4]) {
+    const fd_u4 r = fd_philox4x32_10(counter, seed);
+    fd_box_muller(r.x, r.y, n[0], n[1]);
+    fd_box_muller(r.z, r.w, n[2], n[3]);
+}

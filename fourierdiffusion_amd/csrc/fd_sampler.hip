@@ -1,0 +1,53 @@
+// fd_sampler.hip -- the reverse-diffusion loop of DiffusionSampler.sample
+// (src/fdiff/sampling/sampler.py:83-104): n_steps x { score = model(x, t_i); x = sde.step(score, t_i, x) }.
+// The reference syncs the device every step (`timesteps[0].item()`, sampler.py:37) and draws the prior on
+// the CPU (sde.py:85); here the whole loop is enqueued on one stream with per-step coefficients computed on
+// the host up front, and the noise comes from the on-device Philox stream unless injected.
+#include "fd_philox.h"
+#include "fd_score.h"
+#include "fd_sde.h"
+
+namespace {
+__global__ __launch_bounds__(256) void k_fill(float* __restrict__ p, int n, float v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+}  // namespace
+
+int fd_sampler_run_bf16(fd_score* m, const fd_sde_params* sde, const float* G, const float* timesteps, int n_steps,
+                        float dt, float* x, const float* z_steps, uint64_t seed, uint64_t offset, int B,
+                        hipStream_t s);
+
+extern "C" int fd_sampler_run(fd_score* m, const fd_sde_params* sde, const float* G, const float* timesteps,
+                              int n_steps, float dt, float* x, const float* z_steps, uint64_t seed, uint64_t offset,
+                              int B, int mode, void* stream) {
+    if (!m) return FD_ERR_ARG;
+    fd_ctx* ctx = m->ctx;
+    FD_REQUIRE(ctx, sde && G && timesteps && x, "fd_sampler_run: null pointer");
+    FD_REQUIRE(ctx, sde->kind == 0 || sde->kind == 1, "fd_sampler_run: unknown SDE kind %d", sde->kind);
+    FD_REQUIRE(ctx, n_steps > 0 && B > 0, "fd_sampler_run: n_steps=%d B=%d", n_steps, B);
+    FD_REQUIRE(ctx, dt > 0.f, "fd_sampler_run: step size must be > 0 (sde.py:158)");
+    if (!m->prepared) return fd_fail(ctx, FD_ERR_STATE, "fd_sampler_run: call fd_score_prepare first");
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == FD_MODE_BF16)
+        return fd_sampler_run_bf16(m, sde, G, timesteps, n_steps, dt, x, z_steps, seed, offset, B, s);
+    FD_REQUIRE(ctx, mode == FD_MODE_F32, "fd_sampler_run: unknown mode %d", mode);
+
+    const int T = m->d.max_len, C = m->d.n_channels;
+    const size_t n = (size_t)B * T * C;
+    const size_t fwd = fd_score_f32_workspace(m, B, false);
+    const size_t own = fd_ws::padded(n * sizeof(float)) + fd_ws::padded((size_t)B * sizeof(float));
+    if (int rc = fd_ws_reserve(ctx, fwd + own)) return rc;
+    float* score = (float*)((char*)ctx->ws + fwd);
+    float* tvec = (float*)((char*)score + fd_ws::padded(n * sizeof(float)));
+    const uint64_t per_step = (uint64_t)((n + 3) / 4);
+    for (int i = 0; i < n_steps; ++i) {
+        hipLaunchKernelGGL(k_fill, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, timesteps[i]);
+        if (int rc = fd_score_forward_f32(m, x, tvec, score, B, s, false, 0.f, 0, 0)) return rc;
+        const float* z = z_steps ? z_steps + (size_t)i * n : nullptr;
+        if (int rc = fd_sde_step(ctx, sde, G, x, score, z, seed, offset + (uint64_t)i * per_step,
+                                 (double)timesteps[i], dt, x, B, T, C, stream))
+            return rc;
+    }
+    return FD_OK;
+}

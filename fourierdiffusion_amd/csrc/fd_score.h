@@ -1,0 +1,63 @@
+// fd_score.h -- internal definition of the score-network object (fd_score) shared by the fp32
+// parity path, the bf16 MFMA path, the backward pass and the sampler.
+#pragma once
+#include <vector>
+
+#include "fd_common.h"
+
+struct fd_layer_off {
+    int64_t in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b;
+};
+
+struct fd_bf16_images;   // fd_score_bf16.hip
+
+struct fd_score {
+    fd_ctx* ctx = nullptr;
+    fd_model_dims d{};
+    int64_t nparams = 0;
+    int64_t pos = 0, tW = 0, td_w = 0, td_b = 0, emb_w = 0, emb_b = 0, un_w = 0, un_b = 0;
+    std::vector<fd_layer_off> layers;
+    float* params = nullptr;        // caller-owned flat fp32 masters (set by fd_score_prepare)
+    bool prepared = false;
+    fd_bf16_images* bf16 = nullptr; // engine-owned bf16 weight images (built by prepare)
+    // ---- training state (valid between forward_train and backward)
+    bool have_saved = false;
+    int saved_B = 0;
+    float saved_p = 0.f;
+    uint64_t saved_seed = 0, saved_offset = 0;
+    const float* saved_x = nullptr;
+    const float* saved_t = nullptr;
+};
+
+// activations kept by the training forward, carved from the ctx workspace
+struct fd_saved_layer {
+    float* x0;     // (M,D)  layer input
+    float* qkv;    // (M,3D)
+    float* lse;    // (B,H,T) log-sum-exp of scaled scores
+    float* att;    // (M,D)  concatenated head outputs
+    float* s1;     // (M,D)  x0 + drop(out_proj)
+    float* mr1;    // (M,2)  mean, rstd of LN1
+    float* x1;     // (M,D)  LN1 output
+    float* hact;   // (M,F)  drop(relu(linear1))
+    float* s2;     // (M,D)  x1 + drop(linear2)
+    float* mr2;    // (M,2)
+};
+
+struct fd_saved {
+    float* emb;    // (B,D)  Gaussian-Fourier features (input of time_encoder.dense)
+    float* temb;   // (B,D)
+    float* hL;     // (M,D)  last layer output
+    std::vector<fd_saved_layer> layers;
+};
+
+// fd_score_f32.hip
+int fd_score_forward_f32(fd_score* m, const float* x, const float* t, float* out, int B, hipStream_t s,
+                         bool train, float dropout_p, uint64_t seed, uint64_t offset);
+size_t fd_score_f32_workspace(const fd_score* m, int B, bool train);
+void fd_score_carve_saved(const fd_score* m, int B, fd_ws& ws, fd_saved& sv);
+
+// fd_score_bf16.hip
+int fd_bf16_create(fd_score* m);
+void fd_bf16_destroy(fd_score* m);
+int fd_bf16_prepare(fd_score* m, hipStream_t s);
+int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* out, int B, hipStream_t s);

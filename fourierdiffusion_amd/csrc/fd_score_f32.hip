@@ -1,0 +1,505 @@
+// fd_score_f32.hip -- score network object + the exact-f32 forward (parity / training path).
+//
+// Reference: ScoreModule.forward (src/fdiff/models/score_models.py:67-94), PositionalEncoding
+// (src/fdiff/models/transformer.py:8-29), GaussianFourierProjection (transformer.py:61-91) and
+// torch's nn.TransformerEncoderLayer(batch_first, post-LN, relu, dim_ff) built at
+// score_models.py:57-62.  SURVEY.md A.3 is the op-by-op specification this file follows.
+#include "fd_gemm_f32.h"
+#include "fd_philox.h"
+#include "fd_score.h"
+
+// ------------------------------------------------------------------ layout
+namespace {
+
+struct LayoutBuilder {
+    int64_t off = 0;
+    std::vector<fd_param_entry>* out;
+    int64_t add(const std::string& name, int rows, int cols, int trainable = 1) {
+        const int64_t numel = (int64_t)rows * (cols ? cols : 1);
+        const int64_t at = off;
+        if (out) {
+            fd_param_entry e;
+            memset(&e, 0, sizeof e);
+            snprintf(e.name, sizeof e.name, "%s", name.c_str());
+            e.offset = at;
+            e.numel = numel;
+            e.rows = rows;
+            e.cols = cols;
+            e.trainable = trainable;
+            out->push_back(e);
+        }
+        off += (numel + 3) & ~int64_t(3);   // every tensor starts on a 16-byte boundary
+        return at;
+    }
+};
+
+int64_t build_layout(const fd_model_dims& d, fd_score* m, std::vector<fd_param_entry>* entries) {
+    LayoutBuilder lb;
+    lb.out = entries;
+    const int D = d.d_model, C = d.n_channels, T = d.max_len, F = d.dim_ff;
+    int64_t pos = lb.add("pos_encoder.embedding.weight", T, D);
+    int64_t tW = lb.add("time_encoder.W", (D + 1) / 2, 0, 0);
+    int64_t td_w = lb.add("time_encoder.dense.weight", D, D);
+    int64_t td_b = lb.add("time_encoder.dense.bias", D, 0);
+    int64_t emb_w = lb.add("embedder.weight", D, C);
+    int64_t emb_b = lb.add("embedder.bias", D, 0);
+    int64_t un_w = lb.add("unembedder.weight", C, D);
+    int64_t un_b = lb.add("unembedder.bias", C, 0);
+    if (m) {
+        m->pos = pos; m->tW = tW; m->td_w = td_w; m->td_b = td_b;
+        m->emb_w = emb_w; m->emb_b = emb_b; m->un_w = un_w; m->un_b = un_b;
+        m->layers.clear();
+    }
+    for (int i = 0; i < d.num_layers; ++i) {
+        const std::string p = "backbone.layers." + std::to_string(i) + ".";
+        fd_layer_off lo;
+        lo.in_w = lb.add(p + "self_attn.in_proj_weight", 3 * D, D);
+        lo.in_b = lb.add(p + "self_attn.in_proj_bias", 3 * D, 0);
+        lo.out_w = lb.add(p + "self_attn.out_proj.weight", D, D);
+        lo.out_b = lb.add(p + "self_attn.out_proj.bias", D, 0);
+        lo.l1_w = lb.add(p + "linear1.weight", F, D);
+        lo.l1_b = lb.add(p + "linear1.bias", F, 0);
+        lo.l2_w = lb.add(p + "linear2.weight", D, F);
+        lo.l2_b = lb.add(p + "linear2.bias", D, 0);
+        lo.n1_w = lb.add(p + "norm1.weight", D, 0);
+        lo.n1_b = lb.add(p + "norm1.bias", D, 0);
+        lo.n2_w = lb.add(p + "norm2.weight", D, 0);
+        lo.n2_b = lb.add(p + "norm2.bias", D, 0);
+        if (m) m->layers.push_back(lo);
+    }
+    return lb.off;
+}
+
+bool dims_ok(const fd_model_dims* d) {
+    return d && d->n_channels > 0 && d->max_len > 0 && d->d_model > 0 && d->n_head > 0 && d->num_layers >= 0 &&
+           d->dim_ff > 0 && d->d_model % d->n_head == 0;
+}
+
+}  // namespace
+
+extern "C" int64_t fd_score_param_count(const fd_model_dims* dims) {
+    if (!dims_ok(dims)) return FD_ERR_ARG;
+    return build_layout(*dims, nullptr, nullptr);
+}
+
+extern "C" int fd_score_layout(const fd_model_dims* dims, fd_param_entry* entries, int* n_entries) {
+    if (!dims_ok(dims) || !n_entries) return FD_ERR_ARG;
+    std::vector<fd_param_entry> v;
+    build_layout(*dims, nullptr, &v);
+    if (entries) {
+        if (*n_entries < (int)v.size()) return FD_ERR_ARG;
+        memcpy(entries, v.data(), v.size() * sizeof(fd_param_entry));
+    }
+    *n_entries = (int)v.size();
+    return FD_OK;
+}
+
+extern "C" int fd_score_create(fd_ctx* ctx, const fd_model_dims* dims, fd_score** out) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, out != nullptr, "fd_score_create: null out");
+    FD_REQUIRE(ctx, dims_ok(dims), "fd_score_create: bad dims (need positive sizes and d_model %% n_head == 0)");
+    FD_REQUIRE(ctx, dims->d_model / dims->n_head <= 64, "fd_score_create: head_dim %d > 64 unsupported",
+               dims->d_model / dims->n_head);
+    FD_REQUIRE(ctx, dims->d_model <= 1024, "fd_score_create: d_model %d > 1024 unsupported", dims->d_model);
+    fd_score* m = new fd_score();
+    m->ctx = ctx;
+    m->d = *dims;
+    m->nparams = build_layout(*dims, m, nullptr);
+    int rc = fd_bf16_create(m);
+    if (rc != FD_OK) {
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return FD_OK;
+}
+
+extern "C" int fd_score_destroy(fd_score* m) {
+    if (!m) return FD_ERR_ARG;
+    fd_bf16_destroy(m);
+    delete m;
+    return FD_OK;
+}
+
+// ------------------------------------------------------------------ kernels
+namespace {
+
+// torch embedding_renorm_ (nn.Embedding(max_norm=sqrt(D)), transformer.py:13-15): rows with
+// ||row|| > max_norm are scaled IN PLACE by max_norm/(norm+1e-7).  One wave per row.
+__global__ __launch_bounds__(64) void k_renorm_rows(float* __restrict__ P, int T, int D, float max_norm) {
+    const int row = blockIdx.x;
+    float* r = P + (size_t)row * D;
+    float ss = 0.f;
+    for (int d = threadIdx.x; d < D; d += 64) ss += r[d] * r[d];
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float nrm = sqrtf(ss);
+    if (nrm > max_norm) {
+        const float sc = max_norm / (nrm + 1e-7f);
+        for (int d = threadIdx.x; d < D; d += 64) r[d] *= sc;
+    }
+}
+
+// Gaussian-Fourier features + dense (transformer.py:80-89).  The phase is formed in float32 in the
+// reference's op order ((t*W)*2)*pi; sinf/cosf are the full-range-reduction OCML versions.
+__global__ __launch_bounds__(128) void k_time_embed(const float* __restrict__ t, const float* __restrict__ W,
+                                                     const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                     float* __restrict__ emb_out, float* __restrict__ temb, int D) {
+    extern __shared__ float emb[];
+    const int b = blockIdx.x;
+    const int half = (D + 1) / 2;
+    const float tb = t[b];
+    for (int j = threadIdx.x; j < D; j += blockDim.x) {
+        const int jj = (j < half) ? j : j - half;
+        const float ph = ((tb * W[jj]) * 2.0f) * 3.14159274101257324f;   // float32(np.pi)
+        const float v = (j < half) ? sinf(ph) : cosf(ph);
+        emb[j] = v;
+        if (emb_out) emb_out[(size_t)b * D + j] = v;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float acc = bd[d];
+        const float* w = Wd + (size_t)d * D;
+        for (int j = 0; j < D; ++j) acc = fmaf(w[j], emb[j], acc);
+        temb[(size_t)b * D + d] = acc;
+    }
+}
+
+// h[b,t,:] = x[b,t,:] . We^T + be + pe[t,:] + temb[b,:]     (score_models.py:78-84)
+__global__ __launch_bounds__(256) void k_embed(const float* __restrict__ x, const float* __restrict__ We,
+                                                const float* __restrict__ be, const float* __restrict__ pe,
+                                                const float* __restrict__ temb, float* __restrict__ h, int M, int T,
+                                                int C, int D) {
+    const size_t id = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (id >= (size_t)M * D) return;
+    const int m = (int)(id / D), d = (int)(id % D);
+    const int b = m / T, tt = m % T;
+    const float* xr = x + (size_t)m * C;
+    const float* w = We + (size_t)d * C;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc = fmaf(xr[c], w[c], acc);
+    h[id] = ((acc + be[d]) + pe[(size_t)tt * D + d]) + temb[(size_t)b * D + d];
+}
+
+// Multi-head attention core for one (b, h): thread per query, keys in LDS tiles, online softmax.
+// qkv: (M, 3D) rows [q | k | v]; out: (M, D) heads concatenated (torch MHA layout).
+template <int HDP>
+__global__ __launch_bounds__(64) void k_attention_f32(const float* __restrict__ qkv, float* __restrict__ out,
+                                                        float* __restrict__ lse, int T, int H, int hd, float scale,
+                                                        float drop_p, uint64_t seed, uint64_t offset) {
+    constexpr int KT = 32;
+    __shared__ float Ks[KT][HDP];
+    __shared__ float Vs[KT][HDP];
+    const int D = H * hd;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    const bool active = q < T;
+    const size_t row0 = (size_t)b * T;
+    float qr[HDP];
+#pragma unroll
+    for (int d = 0; d < HDP; ++d) qr[d] = 0.f;
+    if (active) {
+        const float* qp = qkv + (row0 + q) * 3 * D + h * hd;
+        for (int d = 0; d < hd; ++d) qr[d] = qp[d] * scale;
+    }
+    float mrun = -INFINITY, l = 0.f;
+    float o[HDP];
+#pragma unroll
+    for (int d = 0; d < HDP; ++d) o[d] = 0.f;
+    const float keep_scale = (drop_p > 0.f) ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const int groups_per_row = (T + 3) / 4;
+
+    for (int k0 = 0; k0 < T; k0 += KT) {
+        const int kn = min(KT, T - k0);
+        __syncthreads();
+        for (int id = threadIdx.x; id < KT * HDP; id += 64) {
+            const int j = id / HDP, d = id % HDP;
+            float kv = 0.f, vv = 0.f;
+            if (j < kn && d < hd) {
+                const float* base = qkv + (row0 + k0 + j) * 3 * D + h * hd + d;
+                kv = base[D];
+                vv = base[2 * D];
+            }
+            Ks[j][d] = kv;
+            Vs[j][d] = vv;
+        }
+        __syncthreads();
+        float s[KT];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < HDP; ++d) a = fmaf(qr[d], Ks[j][d], a);
+            s[j] = (j < kn) ? a : -INFINITY;
+            mt = fmaxf(mt, s[j]);
+        }
+        const float mnew = fmaxf(mrun, mt);
+        const float alpha = __expf(mrun - mnew);   // exp(-inf) = 0 on the first tile
+        l *= alpha;
+#pragma unroll
+        for (int d = 0; d < HDP; ++d) o[d] *= alpha;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            const float p = expf(s[j] - mnew);
+            l += p;
+            float pk = p;
+            if (drop_p > 0.f) {
+                // attention-probability dropout (nn.MultiheadAttention dropout=0.1): one Philox counter
+                // per 4 consecutive keys of a (b,h,q) row
+                const int key = k0 + j;
+                const uint64_t grp = (((uint64_t)(b * H + h) * T + (active ? q : 0)) * groups_per_row) + key / 4;
+                const fd_u4 r = fd_philox4x32_10(offset + grp, seed);
+                const uint32_t rv = (key & 3) == 0 ? r.x : (key & 3) == 1 ? r.y : (key & 3) == 2 ? r.z : r.w;
+                pk = (fd_u01(rv) >= drop_p) ? p * keep_scale : 0.f;
+            }
+#pragma unroll
+            for (int d = 0; d < HDP; ++d) o[d] = fmaf(pk, Vs[j][d], o[d]);
+        }
+        mrun = mnew;
+    }
+    if (active) {
+        const float inv = 1.0f / l;
+        float* op = out + (row0 + q) * D + h * hd;
+        for (int d = 0; d < hd; ++d) op[d] = o[d] * inv;
+        if (lse) lse[((size_t)b * H + h) * T + q] = mrun + logf(l);
+    }
+}
+
+// y = LayerNorm(a + r) * gamma + beta (eps 1e-5, biased variance); optionally keep the pre-norm sum and
+// (mean, rstd) for the backward pass.  One wave per token.
+__global__ __launch_bounds__(256) void k_add_layernorm(const float* __restrict__ a, const float* __restrict__ r,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ sum_out,
+                                                        float* __restrict__ mr_out, float* __restrict__ y, int M,
+                                                        int D) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (m >= M) return;
+    const float* ap = a + (size_t)m * D;
+    const float* rp = r + (size_t)m * D;
+    float v[16];   // D <= 1024
+    float s = 0.f;
+    int n = 0;
+    for (int d = lane; d < D; d += 64, ++n) {
+        v[n] = ap[d] + rp[d];
+        s += v[n];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)D;
+    float q = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float c = v[i] - mean;
+        q += c * c;
+    }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)D + 1e-5f);
+    n = 0;
+    for (int d = lane; d < D; d += 64, ++n) {
+        if (sum_out) sum_out[(size_t)m * D + d] = v[n];
+        y[(size_t)m * D + d] = (v[n] - mean) * rstd * gamma[d] + beta[d];
+    }
+    if (mr_out && lane == 0) {
+        mr_out[(size_t)m * 2] = mean;
+        mr_out[(size_t)m * 2 + 1] = rstd;
+    }
+}
+
+}  // namespace
+
+// In-place inverted dropout, 4 elements per Philox counter (exported for the backward pass).
+__global__ __launch_bounds__(256) void fd_k_dropout(float* __restrict__ x, size_t n, float p, uint64_t seed,
+                                                     uint64_t offset) {
+    const size_t ng = (n + 3) / 4;
+    const float sc = 1.0f / (1.0f - p);
+    for (size_t g = blockIdx.x * (size_t)256 + threadIdx.x; g < ng; g += (size_t)gridDim.x * 256) {
+        const fd_u4 r = fd_philox4x32_10(offset + g, seed);
+        const uint32_t rv[4] = {r.x, r.y, r.z, r.w};
+        for (int i = 0; i < 4; ++i) {
+            const size_t e = g * 4 + i;
+            if (e < n) x[e] = (fd_u01(rv[i]) >= p) ? x[e] * sc : 0.f;
+        }
+    }
+}
+
+void fd_dropout_inplace(fd_ctx* ctx, float* x, size_t n, float p, uint64_t seed, uint64_t offset, hipStream_t s) {
+    if (p <= 0.f) return;
+    size_t blocks = ((n + 3) / 4 + 255) / 256;
+    if (blocks > (size_t)ctx->num_cu * 8) blocks = (size_t)ctx->num_cu * 8;
+    hipLaunchKernelGGL(fd_k_dropout, dim3((unsigned)blocks), dim3(256), 0, s, x, n, p, seed, offset);
+}
+
+// Philox counter ranges of the dropout sites (disjoint per layer/site; each <= 2^40 counters)
+uint64_t fd_dropout_site_offset(uint64_t base, int layer, int site) {
+    return base + (((uint64_t)layer * 4 + (uint64_t)site) << 40);
+}
+
+// ------------------------------------------------------------------ workspace
+namespace {
+inline size_t fl(size_t n) { return fd_ws::padded(n * sizeof(float)); }
+}
+
+size_t fd_score_f32_workspace(const fd_score* m, int B, bool train) {
+    const size_t M = (size_t)B * m->d.max_len, D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head;
+    const size_t T = m->d.max_len;
+    size_t per_layer = fl(M * D) /*x0*/ + fl(M * 3 * D) + fl((size_t)B * H * T) + fl(M * D) /*att*/ +
+                       fl(M * D) /*s1*/ + fl(M * 2) + fl(M * D) /*x1*/ + fl(M * F) + fl(M * D) /*s2*/ + fl(M * 2);
+    size_t fixed = 2 * fl((size_t)B * D) + fl(M * D) /*hL*/ + fl(M * D) /*tmp proj*/;
+    return fixed + per_layer * (train ? (size_t)std::max(1, m->d.num_layers) : 1) + 4096;
+}
+
+void fd_score_carve_saved(const fd_score* m, int B, fd_ws& ws, fd_saved& sv) {
+    const size_t M = (size_t)B * m->d.max_len, D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head;
+    const size_t T = m->d.max_len;
+    sv.emb = ws.take<float>((size_t)B * D);
+    sv.temb = ws.take<float>((size_t)B * D);
+    sv.hL = ws.take<float>(M * D);
+    sv.layers.resize(m->d.num_layers);
+    for (auto& L : sv.layers) {
+        L.x0 = ws.take<float>(M * D);
+        L.qkv = ws.take<float>(M * 3 * D);
+        L.lse = ws.take<float>((size_t)B * H * T);
+        L.att = ws.take<float>(M * D);
+        L.s1 = ws.take<float>(M * D);
+        L.mr1 = ws.take<float>(M * 2);
+        L.x1 = ws.take<float>(M * D);
+        L.hact = ws.take<float>(M * F);
+        L.s2 = ws.take<float>(M * D);
+        L.mr2 = ws.take<float>(M * 2);
+    }
+}
+
+template <int HDP>
+static void launch_attn(const float* qkv, float* out, float* lse, int B, int T, int H, int hd, float drop_p,
+                        uint64_t seed, uint64_t offset, hipStream_t s) {
+    dim3 grid((T + 63) / 64, H, B);
+    hipLaunchKernelGGL((k_attention_f32<HDP>), grid, dim3(64), 0, s, qkv, out, lse, T, H, hd,
+                       1.0f / sqrtf((float)hd), drop_p, seed, offset);
+}
+
+void fd_attention_f32(const float* qkv, float* out, float* lse, int B, int T, int H, int hd, float drop_p,
+                      uint64_t seed, uint64_t offset, hipStream_t s) {
+    if (hd <= 8) launch_attn<8>(qkv, out, lse, B, T, H, hd, drop_p, seed, offset, s);
+    else if (hd <= 16) launch_attn<16>(qkv, out, lse, B, T, H, hd, drop_p, seed, offset, s);
+    else if (hd <= 32) launch_attn<32>(qkv, out, lse, B, T, H, hd, drop_p, seed, offset, s);
+    else launch_attn<64>(qkv, out, lse, B, T, H, hd, drop_p, seed, offset, s);
+}
+
+// ------------------------------------------------------------------ forward
+int fd_score_forward_f32(fd_score* m, const float* x, const float* t, float* out, int B, hipStream_t s, bool train,
+                         float p, uint64_t seed, uint64_t offset) {
+    fd_ctx* ctx = m->ctx;
+    const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model, H = m->d.n_head, F = m->d.dim_ff;
+    const int L = m->d.num_layers, hd = D / H;
+    const int M = B * T;
+    const float* P = m->params;
+    if (int rc = fd_ws_reserve(ctx, fd_score_f32_workspace(m, B, train))) return rc;
+    fd_ws ws(ctx);
+    fd_saved sv;
+    fd_saved_layer scratch{};
+    float* tmp;   // (M,D) projection scratch
+    if (train) {
+        fd_score_carve_saved(m, B, ws, sv);
+        tmp = ws.take<float>((size_t)M * D);
+    } else {
+        sv.emb = nullptr;
+        sv.temb = ws.take<float>((size_t)B * D);
+        (void)ws.take<float>((size_t)B * D);
+        sv.hL = ws.take<float>((size_t)M * D);
+        scratch.x0 = ws.take<float>((size_t)M * D);
+        scratch.qkv = ws.take<float>((size_t)M * 3 * D);
+        scratch.lse = nullptr;
+        (void)ws.take<float>((size_t)B * H * T);
+        scratch.att = ws.take<float>((size_t)M * D);
+        scratch.s1 = nullptr;
+        (void)ws.take<float>((size_t)M * D);
+        scratch.mr1 = nullptr;
+        (void)ws.take<float>((size_t)M * 2);
+        scratch.x1 = ws.take<float>((size_t)M * D);
+        scratch.hact = ws.take<float>((size_t)M * F);
+        scratch.s2 = nullptr;
+        (void)ws.take<float>((size_t)M * D);
+        scratch.mr2 = nullptr;
+        (void)ws.take<float>((size_t)M * 2);
+        tmp = ws.take<float>((size_t)M * D);
+    }
+
+    hipLaunchKernelGGL(k_time_embed, dim3(B), dim3(128), D * sizeof(float), s, t, P + m->tW, P + m->td_w,
+                       P + m->td_b, sv.emb, sv.temb, D);
+    float* h_in = (L > 0) ? (train ? sv.layers[0].x0 : scratch.x0) : sv.hL;
+    {
+        const size_t n = (size_t)M * D;
+        hipLaunchKernelGGL(k_embed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, P + m->emb_w,
+                           P + m->emb_b, P + m->pos, sv.temb, h_in, M, T, C, D);
+    }
+    for (int i = 0; i < L; ++i) {
+        const fd_layer_off& lo = m->layers[i];
+        fd_saved_layer& A = train ? sv.layers[i] : scratch;
+        float* x0 = A.x0;
+        // next layer's input buffer (eval: ping-pong x0 <- hL is avoided by writing LN2 straight into x0)
+        float* x_next = (i + 1 < L) ? (train ? sv.layers[i + 1].x0 : scratch.x0) : sv.hL;
+        fdgemm::linear_fwd(x0, P + lo.in_w, P + lo.in_b, A.qkv, M, 3 * D, D, false, s);
+        fd_attention_f32(A.qkv, A.att, A.lse, B, T, H, hd, p, seed, fd_dropout_site_offset(offset, i, 0), s);
+        fdgemm::linear_fwd(A.att, P + lo.out_w, P + lo.out_b, tmp, M, D, D, false, s);
+        if (train) fd_dropout_inplace(ctx, tmp, (size_t)M * D, p, seed, fd_dropout_site_offset(offset, i, 1), s);
+        hipLaunchKernelGGL(k_add_layernorm, dim3((M + 3) / 4), dim3(256), 0, s, x0, tmp, P + lo.n1_w, P + lo.n1_b,
+                           A.s1, A.mr1, A.x1, M, D);
+        fdgemm::linear_fwd(A.x1, P + lo.l1_w, P + lo.l1_b, A.hact, M, F, D, true, s);
+        if (train) fd_dropout_inplace(ctx, A.hact, (size_t)M * F, p, seed, fd_dropout_site_offset(offset, i, 2), s);
+        fdgemm::linear_fwd(A.hact, P + lo.l2_w, P + lo.l2_b, tmp, M, D, F, false, s);
+        if (train) fd_dropout_inplace(ctx, tmp, (size_t)M * D, p, seed, fd_dropout_site_offset(offset, i, 3), s);
+        hipLaunchKernelGGL(k_add_layernorm, dim3((M + 3) / 4), dim3(256), 0, s, A.x1, tmp, P + lo.n2_w, P + lo.n2_b,
+                           A.s2, A.mr2, x_next, M, D);
+    }
+    fdgemm::linear_fwd(sv.hL, P + m->un_w, P + m->un_b, out, M, C, D, false, s);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" int fd_score_prepare(fd_score* m, const float* params, void* stream) {
+    if (!m) return FD_ERR_ARG;
+    fd_ctx* ctx = m->ctx;
+    FD_REQUIRE(ctx, params != nullptr, "fd_score_prepare: null params");
+    m->params = const_cast<float*>(params);
+    // The reference renorms the looked-up rows of the positional table in place on every forward
+    // (nn.Embedding(max_norm), transformer.py:13-15,27); all T rows are looked up, so do it here once.
+    hipLaunchKernelGGL(k_renorm_rows, dim3(m->d.max_len), dim3(64), 0, (hipStream_t)stream, m->params + m->pos,
+                       m->d.max_len, m->d.d_model, sqrtf((float)m->d.d_model));
+    FD_LAUNCH_CHECK(ctx);
+    if (int rc = fd_bf16_prepare(m, (hipStream_t)stream)) return rc;
+    m->prepared = true;
+    return FD_OK;
+}
+
+extern "C" int fd_score_forward(fd_score* m, const float* x, const float* t, float* out, int B, int mode,
+                                void* stream) {
+    if (!m) return FD_ERR_ARG;
+    fd_ctx* ctx = m->ctx;
+    FD_REQUIRE(ctx, x && t && out, "fd_score_forward: null pointer");
+    FD_REQUIRE(ctx, B > 0, "fd_score_forward: B=%d", B);
+    if (!m->prepared) return fd_fail(ctx, FD_ERR_STATE, "fd_score_forward: call fd_score_prepare first");
+    if (mode == FD_MODE_F32) return fd_score_forward_f32(m, x, t, out, B, (hipStream_t)stream, false, 0.f, 0, 0);
+    if (mode == FD_MODE_BF16) return fd_score_forward_bf16(m, x, t, out, B, (hipStream_t)stream);
+    return fd_fail(ctx, FD_ERR_ARG, "fd_score_forward: unknown mode %d", mode);
+}
+
+extern "C" int fd_score_forward_train(fd_score* m, const float* x, const float* t, float* out, int B,
+                                      float dropout_p, uint64_t seed, uint64_t offset, void* stream) {
+    if (!m) return FD_ERR_ARG;
+    fd_ctx* ctx = m->ctx;
+    FD_REQUIRE(ctx, x && t && out, "fd_score_forward_train: null pointer");
+    FD_REQUIRE(ctx, B > 0, "fd_score_forward_train: B=%d", B);
+    FD_REQUIRE(ctx, dropout_p >= 0.f && dropout_p < 1.f, "fd_score_forward_train: dropout_p=%f", dropout_p);
+    if (!m->prepared) return fd_fail(ctx, FD_ERR_STATE, "fd_score_forward_train: call fd_score_prepare first");
+    int rc = fd_score_forward_f32(m, x, t, out, B, (hipStream_t)stream, true, dropout_p, seed, offset);
+    if (rc == FD_OK) {
+        m->have_saved = true;
+        m->saved_B = B;
+        m->saved_p = dropout_p;
+        m->saved_seed = seed;
+        m->saved_offset = offset;
+        m->saved_x = x;
+        m->saved_t = t;
+    }
+    return rc;
+}

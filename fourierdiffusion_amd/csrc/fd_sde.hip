@@ -1,0 +1,269 @@
+// fd_sde.hip -- HBM-bound elementwise kernels of the SDE (reference: src/fdiff/schedulers/sde.py,
+// src/fdiff/utils/losses.py).  The reference spells its row scalings as diag_embed + (T,T)@(B,T,C)
+// matmuls; here every one is a fused per-element multiply by G[t] with on-device Philox noise.
+//
+// Layout: (B,T,C) float32 row-major; thread i owns the 16-byte group of elements [4i, 4i+4) so that
+// every access is a coalesced dwordx4 and one Philox counter feeds exactly one group.
+#include "fd_common.h"
+#include "fd_philox.h"
+#include "fd_sde.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float4 ld4(const float* p, size_t e, size_t n) {
+    if (e + 4 <= n) return *reinterpret_cast<const float4*>(p + e);
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    float* f = reinterpret_cast<float*>(&v);
+    for (size_t i = e; i < n; ++i) f[i - e] = p[i];
+    return v;
+}
+__device__ __forceinline__ void st4(float* p, size_t e, size_t n, float4 v) {
+    if (e + 4 <= n) {
+        *reinterpret_cast<float4*>(p + e) = v;
+        return;
+    }
+    const float* f = reinterpret_cast<const float*>(&v);
+    for (size_t i = e; i < n; ++i) p[i] = f[i - e];
+}
+
+__global__ __launch_bounds__(kBlock) void k_randn(float* __restrict__ out, size_t n, uint64_t seed,
+                                                    uint64_t offset) {
+    const size_t ngroups = (n + 3) / 4;
+    for (size_t g = blockIdx.x * (size_t)kBlock + threadIdx.x; g < ngroups; g += (size_t)gridDim.x * kBlock) {
+        float z[4];
+        fd_randn4(offset + g, seed, z);
+        st4(out, g * 4, n, float4{z[0], z[1], z[2], z[3]});
+    }
+}
+
+// out = scale * G[t] * z
+__global__ __launch_bounds__(kBlock) void k_prior(const float* __restrict__ G, const float* __restrict__ zin,
+                                                    float* __restrict__ out, size_t n, int T, int C,
+                                                    float scale, uint64_t seed, uint64_t offset) {
+    const size_t ngroups = (n + 3) / 4;
+    for (size_t g = blockIdx.x * (size_t)kBlock + threadIdx.x; g < ngroups; g += (size_t)gridDim.x * kBlock) {
+        const size_t e = g * 4;
+        float z[4];
+        if (zin) {
+            const float4 v = ld4(zin, e, n);
+            z[0] = v.x; z[1] = v.y; z[2] = v.z; z[3] = v.w;
+        } else {
+            fd_randn4(offset + g, seed, z);
+        }
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t ei = e + i;
+            const int t = (int)((ei / (size_t)C) % (size_t)T);
+            o[i] = (ei < n) ? scale * (G[t] * z[i]) : 0.f;
+        }
+        st4(out, e, n, float4{o[0], o[1], o[2], o[3]});
+    }
+}
+
+// Euler-Maruyama reverse step (sde.py:129-165, 215-246), one pass.
+__global__ __launch_bounds__(kBlock) void k_sde_step(const float* __restrict__ G, const float* __restrict__ x,
+                                                       const float* __restrict__ score,
+                                                       const float* __restrict__ zin, float* __restrict__ out,
+                                                       size_t n, int T, int C, SdeCoef cf, uint64_t seed,
+                                                       uint64_t offset) {
+    const size_t ngroups = (n + 3) / 4;
+    for (size_t g = blockIdx.x * (size_t)kBlock + threadIdx.x; g < ngroups; g += (size_t)gridDim.x * kBlock) {
+        const size_t e = g * 4;
+        const float4 xv = ld4(x, e, n), sv = ld4(score, e, n);
+        float z[4];
+        if (zin) {
+            const float4 v = ld4(zin, e, n);
+            z[0] = v.x; z[1] = v.y; z[2] = v.z; z[3] = v.w;
+        } else {
+            fd_randn4(offset + g, seed, z);
+        }
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        const float ss[4] = {sv.x, sv.y, sv.z, sv.w};
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t ei = e + i;
+            const int t = (int)((ei / (size_t)C) % (size_t)T);
+            o[i] = fd_sde_apply(xs[i], ss[i], z[i], G[t], cf);
+        }
+        st4(out, e, n, float4{o[0], o[1], o[2], o[3]});
+    }
+}
+
+// Perturbation kernel of the loss (losses.py:66-85): per-sample t.
+__global__ __launch_bounds__(kBlock) void k_perturb(const float* __restrict__ G, const float* __restrict__ x,
+                                                      const float* __restrict__ tvec,
+                                                      const float* __restrict__ zin, float* __restrict__ xn,
+                                                      float* __restrict__ target, float* __restrict__ std_out,
+                                                      size_t n, int T, int C, int kind, float p0, float p1,
+                                                      uint64_t seed, uint64_t offset) {
+    const size_t ngroups = (n + 3) / 4;
+    const size_t per_b = (size_t)T * C;
+    for (size_t g = blockIdx.x * (size_t)kBlock + threadIdx.x; g < ngroups; g += (size_t)gridDim.x * kBlock) {
+        const size_t e = g * 4;
+        const float4 xv = ld4(x, e, n);
+        float z[4];
+        if (zin) {
+            const float4 v = ld4(zin, e, n);
+            z[0] = v.x; z[1] = v.y; z[2] = v.z; z[3] = v.w;
+        } else {
+            fd_randn4(offset + g, seed, z);
+        }
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        float o[4], tg[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t ei = (e + i < n) ? e + i : n - 1;
+            const int b = (int)(ei / per_b);
+            const int t = (int)((ei / (size_t)C) % (size_t)T);
+            const float tt = tvec[b];
+            float mcoef, s;
+            if (kind == 0) {
+                const float lmc = -0.25f * tt * tt * (p1 - p0) - 0.5f * tt * p0;   // sde.py:195-197
+                mcoef = expf(lmc);
+                s = sqrtf(1.0f - expf(2.0f * lmc));                                 // sde.py:203-205
+            } else {
+                mcoef = 1.0f;
+                s = p0 * powf(p1 / p0, tt);                                         // sde.py:117
+            }
+            const float sd = s * G[t];
+            o[i] = mcoef * xs[i] + sd * z[i];
+            tg[i] = z[i] / sd;
+            if (std_out && (ei % (size_t)C) == 0 && e + i < n) std_out[(size_t)b * T + t] = sd;
+        }
+        st4(xn, e, n, float4{o[0], o[1], o[2], o[3]});
+        if (target) st4(target, e, n, float4{tg[0], tg[1], tg[2], tg[3]});
+    }
+}
+
+// Denoising score-matching loss (losses.py:92-124) + gradient wrt score.
+// One block per sample b: w_b from std row, then sum over (t,c).
+__global__ __launch_bounds__(kBlock) void k_dsm_loss(const float* __restrict__ score,
+                                                       const float* __restrict__ target,
+                                                       const float* __restrict__ stdv, int lw,
+                                                       float* __restrict__ loss_out, float* __restrict__ dscore,
+                                                       int B, int T, int C) {
+    __shared__ float red[kBlock / 64];
+    __shared__ float w_sh;
+    const int b = blockIdx.x;
+    const float* sd = stdv + (size_t)b * T;
+    // w_b = 1 / sum_k std^-2   (losses.py:96)
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < T; k += kBlock) acc += 1.0f / (sd[k] * sd[k]);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < kBlock / 64; ++i) s += red[i];
+        w_sh = 1.0f / s;
+    }
+    __syncthreads();
+    const float w = w_sh;
+    const size_t per_b = (size_t)T * C;
+    const float inv_cnt = 1.0f / ((float)per_b * (float)B);
+    float part = 0.f;
+    for (size_t i = threadIdx.x; i < per_b; i += kBlock) {
+        const size_t e = (size_t)b * per_b + i;
+        const int k = (int)(i / C);
+        const float d = score[e] + target[e];
+        float coef;                       // loss element = coef * d^2
+        if (lw) coef = sd[k] * sd[k];     // (std*(s+target))^2, losses.py:115-121
+        else coef = w;                    // w_b (s+target)^2,   losses.py:100-102
+        part += coef * d * d;
+        if (dscore) dscore[e] = 2.0f * coef * d * inv_cnt;
+    }
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < kBlock / 64; ++i) s += red[i];
+        atomicAdd(loss_out, s * inv_cnt);
+    }
+}
+
+inline int grid_for(size_t ngroups, int num_cu) {
+    size_t blocks = (ngroups + kBlock - 1) / kBlock;
+    size_t cap = (size_t)num_cu * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int check_btc(fd_ctx* ctx, int B, int T, int C) {
+    FD_REQUIRE(ctx, B > 0 && T > 0 && C > 0, "bad shape B=%d T=%d C=%d", B, T, C);
+    return FD_OK;
+}
+
+}  // namespace
+
+extern "C" int fd_randn(fd_ctx* ctx, float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, out && n > 0, "fd_randn: null output or n == 0");
+    const size_t ng = (n + 3) / 4;
+    hipLaunchKernelGGL(k_randn, dim3(grid_for(ng, ctx->num_cu)), dim3(kBlock), 0, (hipStream_t)stream, out, n,
+                       seed, offset);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
+extern "C" int fd_prior_sample(fd_ctx* ctx, const fd_sde_params* sde, const float* G, const float* z,
+                               uint64_t seed, uint64_t offset, float* out, int B, int T, int C, void* stream) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, sde && G && out, "fd_prior_sample: null pointer");
+    if (int rc = check_btc(ctx, B, T, C)) return rc;
+    const size_t n = (size_t)B * T * C;
+    const float scale = (sde->kind == 1) ? sde->p1 : 1.0f;   // sde.py:125-127
+    hipLaunchKernelGGL(k_prior, dim3(grid_for((n + 3) / 4, ctx->num_cu)), dim3(kBlock), 0, (hipStream_t)stream,
+                       G, z, out, n, T, C, scale, seed, offset);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
+extern "C" int fd_sde_step(fd_ctx* ctx, const fd_sde_params* sde, const float* G, const float* x,
+                           const float* score, const float* z, uint64_t seed, uint64_t offset, double t,
+                           float dt, float* out, int B, int T, int C, void* stream) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, sde && G && x && score && out, "fd_sde_step: null pointer");
+    FD_REQUIRE(ctx, sde->kind == 0 || sde->kind == 1, "fd_sde_step: unknown SDE kind %d", sde->kind);
+    FD_REQUIRE(ctx, dt > 0.f, "fd_sde_step: step size must be > 0 (sde.py:158)");
+    if (int rc = check_btc(ctx, B, T, C)) return rc;
+    const size_t n = (size_t)B * T * C;
+    const SdeCoef cf = fd_sde_coef(*sde, t, dt);
+    hipLaunchKernelGGL(k_sde_step, dim3(grid_for((n + 3) / 4, ctx->num_cu)), dim3(kBlock), 0,
+                       (hipStream_t)stream, G, x, score, z, out, n, T, C, cf, seed, offset);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
+extern "C" int fd_perturb(fd_ctx* ctx, const fd_sde_params* sde, const float* G, const float* x, const float* t,
+                          const float* z, uint64_t seed, uint64_t offset, float* x_noisy, float* target,
+                          float* std_out, int B, int T, int C, void* stream) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, sde && G && x && t && x_noisy, "fd_perturb: null pointer");
+    FD_REQUIRE(ctx, sde->kind == 0 || sde->kind == 1, "fd_perturb: unknown SDE kind %d", sde->kind);
+    if (int rc = check_btc(ctx, B, T, C)) return rc;
+    const size_t n = (size_t)B * T * C;
+    hipLaunchKernelGGL(k_perturb, dim3(grid_for((n + 3) / 4, ctx->num_cu)), dim3(kBlock), 0, (hipStream_t)stream,
+                       G, x, t, z, x_noisy, target, std_out, n, T, C, sde->kind, sde->p0, sde->p1, seed, offset);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
+extern "C" int fd_dsm_loss(fd_ctx* ctx, const float* score, const float* target, const float* std,
+                           int likelihood_weighting, float* loss_out, float* dscore, int B, int T, int C,
+                           void* stream) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, score && target && std && loss_out, "fd_dsm_loss: null pointer");
+    if (int rc = check_btc(ctx, B, T, C)) return rc;
+    FD_HIP(ctx, hipMemsetAsync(loss_out, 0, sizeof(float), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_dsm_loss, dim3(B), dim3(kBlock), 0, (hipStream_t)stream, score, target, std,
+                       likelihood_weighting, loss_out, dscore, B, T, C);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}

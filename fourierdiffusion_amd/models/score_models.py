@@ -1,0 +1,309 @@
+"""ScoreModule on the HIP engine -- same surface as fdiff.models.score_models.ScoreModule
+(reference: src/fdiff/models/score_models.py:22-166).
+
+The network (Linear embed + learned positional table with max_norm + Gaussian-Fourier time
+embedding -> L x post-LN transformer encoder layer (relu, dim_ff 2048) -> Linear unembed) lives in
+ONE flat fp32 device buffer whose layout is defined by the engine (``fd_score_layout``); the
+reference's state_dict keys are views into it, so checkpoints interchange, the optimizer is one
+fused pass and the data-parallel gradient exchange is one flat RCCL all-reduce.
+
+No autograd graph is built: ``forward`` in training mode keeps activations inside the engine and
+``backward(dscore)`` accumulates into ``self.grads`` (same flat layout).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from collections import OrderedDict
+from typing import Any, Callable, Dict, Iterator, Optional, Tuple
+
+import torch
+
+from .. import _C, _rng
+from ..schedulers.sde import SDE
+from ..utils.dataclasses import DiffusableBatch
+from ..utils.losses import get_sde_loss_fn
+
+_PRECISIONS = {"fp32": _C.FD_MODE_F32, "bf16": _C.FD_MODE_BF16}
+
+
+def _default_precision() -> str:
+    return os.environ.get("FDIFF_PRECISION", "bf16")
+
+
+class ScoreModule:
+    # torch.nn.TransformerEncoderLayer defaults the reference relies on (score_models.py:57-59)
+    dim_feedforward = 2048
+    dropout = 0.1
+
+    def __init__(
+        self,
+        n_channels: int,
+        max_len: int,
+        noise_scheduler: SDE,
+        fourier_noise_scaling: bool = True,
+        d_model: int = 60,
+        num_layers: int = 3,
+        n_head: int = 12,
+        num_training_steps: int = 1000,
+        lr_max: float = 1e-3,
+        likelihood_weighting: bool = False,
+    ) -> None:
+        self.max_len = int(max_len)
+        self.n_channels = int(n_channels)
+        self.noise_scheduler = noise_scheduler
+        self.num_warmup_steps = num_training_steps // 10
+        self.num_training_steps = num_training_steps
+        self.lr_max = lr_max
+        self.d_model = int(d_model)
+        self.num_layers = int(num_layers)
+        self.n_head = int(n_head)
+        self.scale_noise = fourier_noise_scaling
+        self.likelihood_weighting = likelihood_weighting
+        self.training = True
+        self.precision = _default_precision()      # eval/sampling arithmetic: "bf16" (MFMA) or "fp32" (parity)
+        self.hparams: Dict[str, Any] = dict(
+            n_channels=n_channels, max_len=max_len, noise_scheduler=noise_scheduler,
+            fourier_noise_scaling=fourier_noise_scaling, d_model=d_model, num_layers=num_layers, n_head=n_head,
+            num_training_steps=num_training_steps, lr_max=lr_max, likelihood_weighting=likelihood_weighting)
+
+        self.training_loss_fn, self.validation_loss_fn = self.set_loss_fn()
+
+        if self.d_model % self.n_head != 0:
+            raise AssertionError("embed_dim must be divisible by num_heads")
+        self._dims = _C.model_dims(self.n_channels, self.max_len, self.d_model, self.n_head, self.num_layers,
+                                   self.dim_feedforward)
+        self._layout, self._nparams = _C.score_layout(self._dims)
+        self._flat = torch.zeros(self._nparams, dtype=torch.float32)
+        self.grads: Optional[torch.Tensor] = None
+        self._views: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        self._trainable: Dict[str, bool] = {}
+        self._bind_views()
+        self._init_parameters()
+        self._handle: Optional[int] = None
+        self._dirty = True
+
+    # ------------------------------------------------------------------ parameters
+    def _bind_views(self) -> None:
+        self._views.clear()
+        for name, off, numel, shape, trainable in self._layout:
+            self._views[name] = self._flat[off:off + numel].view(*shape)
+            self._trainable[name] = trainable
+
+    def _init_parameters(self) -> None:
+        """Same initialisers, drawn from torch's global generator in the same order as the reference's
+        constructor (score_models.py:52-62), so that ``torch.manual_seed(s)`` gives the reference's weights:
+        Embedding N(0,1); randn*30; Linear = kaiming_uniform(a=sqrt 5) + U(+-1/sqrt(fan_in)) bias;
+        MHA: out_proj Linear init, then xavier_uniform in_proj, zero in_proj_bias / out_proj.bias;
+        one encoder layer is drawn and copied into all L layers (nn.TransformerEncoder deep-copies)."""
+        v = self._views
+        init = torch.nn.init
+
+        def linear(prefix: str) -> None:
+            w, b = v[prefix + ".weight"], v[prefix + ".bias"]
+            init.kaiming_uniform_(w, a=math.sqrt(5))
+            bound = 1.0 / math.sqrt(w.shape[1]) if w.shape[1] > 0 else 0.0
+            init.uniform_(b, -bound, bound)
+
+        init.normal_(v["pos_encoder.embedding.weight"])
+        v["time_encoder.W"].copy_(torch.randn((self.d_model + 1) // 2) * 30.0)
+        linear("time_encoder.dense")
+        linear("embedder")
+        linear("unembedder")
+        if self.num_layers > 0:
+            p = "backbone.layers.0."
+            linear(p + "self_attn.out_proj")
+            init.xavier_uniform_(v[p + "self_attn.in_proj_weight"])
+            v[p + "self_attn.in_proj_bias"].zero_()
+            v[p + "self_attn.out_proj.bias"].zero_()
+            linear(p + "linear1")
+            linear(p + "linear2")
+            for nm in ("norm1", "norm2"):
+                v[p + nm + ".weight"].fill_(1.0)
+                v[p + nm + ".bias"].zero_()
+            for i in range(1, self.num_layers):
+                q = f"backbone.layers.{i}."
+                for k in list(v):
+                    if k.startswith(p):
+                        v[q + k[len(p):]].copy_(v[k])
+
+    def parameters(self) -> Iterator[torch.Tensor]:
+        return iter(self._views.values())
+
+    def named_parameters(self) -> Iterator[Tuple[str, torch.Tensor]]:
+        return iter(self._views.items())
+
+    def trainable_mask(self) -> Dict[str, bool]:
+        return dict(self._trainable)
+
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        return OrderedDict((k, t.detach().clone()) for k, t in self._views.items())
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        missing = [k for k in self._views if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in self._views]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {unexpected}")
+        for k, dst in self._views.items():
+            if k in state_dict:
+                src = state_dict[k]
+                if tuple(src.shape) != tuple(dst.shape):
+                    raise RuntimeError(f"size mismatch for {k}: {tuple(src.shape)} vs {tuple(dst.shape)}")
+                dst.copy_(src.to(device=dst.device, dtype=torch.float32))
+        self._dirty = True
+
+    @property
+    def flat_parameters(self) -> torch.Tensor:
+        return self._flat
+
+    def mark_parameters_changed(self) -> None:
+        """Call after writing into ``flat_parameters`` / the views (e.g. an optimizer step)."""
+        self._dirty = True
+
+    # ------------------------------------------------------------------ device / mode
+    @property
+    def device(self) -> torch.device:
+        return self._flat.device
+
+    def to(self, device=None, **kwargs) -> "ScoreModule":
+        device = torch.device(device if device is not None else kwargs.get("device"))
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if device != self._flat.device:
+            self._release()
+            self._flat = self._flat.to(device)
+            self.grads = None
+            self._bind_views()
+            self._dirty = True
+        return self
+
+    def cuda(self) -> "ScoreModule":
+        return self.to("cuda")
+
+    def cpu(self) -> "ScoreModule":
+        return self.to("cpu")
+
+    def eval(self) -> "ScoreModule":
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True) -> "ScoreModule":
+        self.training = bool(mode)
+        return self
+
+    def _release(self) -> None:
+        if self._handle is not None:
+            _C.lib().fd_score_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _engine(self) -> Tuple[int, int]:
+        """(ctx, model handle); creates the engine object and refreshes derived weights when dirty."""
+        if self._flat.device.type != "cuda":
+            raise _C.FdError("ScoreModule is on the CPU: move it to the GPU with .to('cuda') -- the score network "
+                             "runs only on the HIP engine (no CPU fallback)")
+        ctx = _C.ctx(self._flat.device)
+        if self._handle is None:
+            h = C.c_void_p()
+            rc = _C.lib().fd_score_create(ctx, C.byref(self._dims), C.byref(h))
+            _C.check(rc, ctx)
+            self._handle = h
+            self._dirty = True
+        if self._dirty:
+            rc = _C.lib().fd_score_prepare(self._handle, self._flat.data_ptr(), _C.stream_of(self._flat))
+            _C.check(rc, ctx)
+            self._dirty = False
+        return ctx, self._handle
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, batch: DiffusableBatch) -> torch.Tensor:
+        X = batch.X
+        assert X.size()[1:] == (self.max_len, self.n_channels), (
+            f"X has wrong shape, should be {(X.size(0), self.max_len, self.n_channels)}, but is {X.size()}")
+        timesteps = batch.timesteps
+        assert timesteps is not None and timesteps.size(0) == len(batch)
+        ctx, h = self._engine()
+        Xd = _C.dev_f32(X.to(self.device), "batch.X")
+        td = _C.dev_f32(timesteps.to(self.device), "batch.timesteps")
+        out = torch.empty_like(Xd)
+        B = Xd.shape[0]
+        if self.training:
+            p = float(self.dropout)
+            key, off = _rng.stream()
+            rc = _C.lib().fd_score_forward_train(h, Xd.data_ptr(), td.data_ptr(), out.data_ptr(), B, p,
+                                                 key, off, _C.stream_of(Xd))
+            self._train_inputs = (Xd, td)       # the engine reads them again in backward
+        else:
+            mode = _PRECISIONS[self.precision]
+            rc = _C.lib().fd_score_forward(h, Xd.data_ptr(), td.data_ptr(), out.data_ptr(), B, mode,
+                                           _C.stream_of(Xd))
+        _C.check(rc, ctx)
+        return out
+
+    __call__ = forward
+
+    def zero_grad(self) -> None:
+        if self.grads is not None:
+            self.grads.zero_()
+
+    def backward(self, dscore: torch.Tensor, accumulate: bool = True) -> torch.Tensor:
+        """d loss / d params for the last training-mode forward; accumulates into ``self.grads``."""
+        ctx, h = self._engine()
+        if self.grads is None or self.grads.device != self.device:
+            self.grads = torch.zeros_like(self._flat)
+        d = _C.dev_f32(dscore, "dscore")
+        rc = _C.lib().fd_score_backward(h, d.data_ptr(), self.grads.data_ptr(), 1 if accumulate else 0,
+                                        _C.stream_of(d))
+        _C.check(rc, ctx)
+        return self.grads
+
+    def grad_views(self) -> "OrderedDict[str, torch.Tensor]":
+        assert self.grads is not None
+        return OrderedDict((name, self.grads[off:off + numel].view(*shape))
+                           for name, off, numel, shape, _ in self._layout)
+
+    # ------------------------------------------------------------------ Lightning-style hooks
+    def training_step(self, batch: DiffusableBatch, batch_idx: int = 0, dataloader_idx: int = 0) -> torch.Tensor:
+        return self.training_loss_fn(self, batch)
+
+    def validation_step(self, batch: DiffusableBatch, batch_idx: int = 0, dataloader_idx: int = 0) -> torch.Tensor:
+        return self.validation_loss_fn(self, batch)
+
+    def configure_optimizers(self):
+        """AdamW(lr_max) + cosine schedule with warmup = num_training_steps // 10, stepped per batch
+        (score_models.py:122-130)."""
+        from ..optim import FusedAdamW, cosine_schedule_with_warmup
+        opt = FusedAdamW(self, lr=self.lr_max)
+        sched = cosine_schedule_with_warmup(self.num_warmup_steps, self.num_training_steps)
+        return {"optimizer": opt, "lr_scheduler": {"scheduler": sched, "interval": "step"}}
+
+    def set_loss_fn(self) -> Tuple[Callable, Callable]:
+        if isinstance(self.noise_scheduler, SDE):
+            return (get_sde_loss_fn(self.noise_scheduler, train=True, likelihood_weighting=self.likelihood_weighting),
+                    get_sde_loss_fn(self.noise_scheduler, train=False, likelihood_weighting=self.likelihood_weighting))
+        raise NotImplementedError(
+            f"Scheduler {self.noise_scheduler} not implemented yet, cannot set loss function.")
+
+    # ------------------------------------------------------------------ checkpoints (Lightning layout)
+    def save_checkpoint(self, path, **extra) -> None:
+        ckpt = {"state_dict": OrderedDict((k, t.cpu()) for k, t in self.state_dict().items()),
+                "hyper_parameters": dict(self.hparams), "engine": "fourierdiffusion_amd"}
+        ckpt.update(extra)
+        torch.save(ckpt, path)
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, **overrides) -> "ScoreModule":
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        hp = dict(ckpt["hyper_parameters"])
+        hp.update(overrides)
+        model = cls(**hp)
+        model.load_state_dict(ckpt["state_dict"])
+        if map_location is not None:
+            model.to(map_location)
+        return model

@@ -1,0 +1,60 @@
+"""Denoising score-matching loss on the HIP engine -- same surface as fdiff.utils.losses.get_sde_loss_fn
+(reference: src/fdiff/utils/losses.py:12-127).
+
+loss_fn(model, batch): t ~ U[eps, T], z ~ N(0, I), x_t = mean + diag(std) z, target = -z/std,
+weight 1/tr(Sigma^-1) (default) or the Mahalanobis form (likelihood weighting).  The reference
+materialises two (B,T,T) diagonal matrices and four matmuls for what are row scalings; here it is
+fd_perturb -> score network -> fd_dsm_loss, and in training mode the same call also runs the backward
+pass (there is no autograd graph): the parameter gradients are ACCUMULATED into ``model.grads``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional
+
+import torch
+
+from .. import _C
+from ..schedulers.sde import SDE
+from .dataclasses import DiffusableBatch
+
+
+def get_sde_loss_fn(
+    scheduler: SDE,
+    train: bool,
+    reduce_mean: bool = True,
+    likelihood_weighting: bool = False,
+) -> Callable[..., torch.Tensor]:
+    if not reduce_mean:
+        raise NotImplementedError("reduce_mean=False (0.5 * sum) is never used by the reference's callers")
+
+    def loss_fn(model, batch: DiffusableBatch, noise: Optional[torch.Tensor] = None,
+                backward: Optional[bool] = None) -> torch.Tensor:
+        """Scalar loss tensor (device).  noise= injects z (parity tests); backward=None means "iff train"."""
+        if train:
+            model.train()
+        else:
+            model.eval()
+        do_bwd = train if backward is None else bool(backward)
+        dev = model.device
+        X = _C.dev_f32(batch.X.to(dev), "batch.X")
+        timesteps = batch.timesteps
+        if timesteps is None:
+            # t ~ U[eps, T] per sample (losses.py:59-63); host-side draw from torch's generator is plumbing
+            timesteps = torch.rand(X.shape[0]) * (scheduler.T - scheduler.eps) + scheduler.eps
+        timesteps = _C.dev_f32(timesteps.to(dev), "timesteps")
+        x_noisy, target, std = scheduler.perturb(X, timesteps, noise=noise)
+        score = model(DiffusableBatch(X=x_noisy, y=batch.y, timesteps=timesteps))
+        B, T, Cn = X.shape
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        dscore = torch.empty_like(score) if do_bwd else None
+        h = _C.ctx(dev)
+        rc = _C.lib().fd_dsm_loss(h, score.data_ptr(), target.data_ptr(), std.data_ptr(),
+                                  1 if likelihood_weighting else 0, loss.data_ptr(), _C.ptr(dscore), B, T, Cn,
+                                  _C.stream_of(score))
+        _C.check(rc, h)
+        if do_bwd:
+            model.backward(dscore, accumulate=True)
+        return loss[0]
+
+    return loss_fn

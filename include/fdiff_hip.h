@@ -1,0 +1,194 @@
+/*
+ * fdiff_hip.h -- C ABI of libfdiff_hip.so, the MI355X (gfx950) engine for the
+ * score-matching hot path of JonathanCrabbe/FourierDiffusion.
+ *
+ * The reference has no FFI of its own for this path: it sits behind plain Python
+ * classes.  Each entry point below therefore names the reference
+ * *Python* interface it replaces (file:line relative to /root/reference); the
+ * ctypes binding a maintainer would add is shown in INTEGRATION.md and lives in
+ * fourierdiffusion_amd/_C.py.
+ *
+ * Conventions
+ *   - extern "C"; plain pointers and sizes only (no torch types).
+ *   - every function returns 0 on success, <0 on error (FD_ERR_*); the message is
+ *     available from fd_last_error(ctx).
+ *   - all data pointers are CALLER-OWNED DEVICE pointers (float32, row-major,
+ *     contiguous (B,T,C)) unless marked "host".  bf16 exists only inside the engine.
+ *   - asynchronous on the passed hipStream_t (void* to keep the header toolchain-free);
+ *     no host synchronisation inside any call unless stated.
+ *   - one fd_ctx per (process, device); a ctx and the models created from it are
+ *     not thread-safe.
+ */
+#ifndef FDIFF_HIP_H
+#define FDIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FD_OK 0
+#define FD_ERR_ARG (-1)      /* bad argument (shape, null pointer, unsupported size) */
+#define FD_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define FD_ERR_STATE (-3)    /* call order violated (e.g. forward before prepare) */
+#define FD_ERR_COMM (-4)     /* RCCL failure */
+#define FD_ERR_UNSUPPORTED (-5)
+
+typedef struct fd_ctx fd_ctx;
+typedef struct fd_score fd_score;
+
+/* ---------------------------------------------------------------- context */
+int fd_version(void);
+int fd_ctx_create(int device, fd_ctx** out);
+int fd_ctx_destroy(fd_ctx* ctx);
+const char* fd_last_error(fd_ctx* ctx);   /* host string, valid until the next call on ctx */
+/* number of bytes currently held by the ctx workspace (activations, scratch) */
+size_t fd_ctx_workspace_bytes(fd_ctx* ctx);
+
+/* --------------------------------------------- a1/a2 spectral representation
+ * replaces fdiff.utils.fourier.dft   (src/fdiff/utils/fourier.py:8-45)
+ *      and fdiff.utils.fourier.idft  (src/fdiff/utils/fourier.py:48-87)
+ * y[b, 0:T/2+1, c] = Re X_k ; y[b, T/2+1:T, c] = Im X_k (k=1..), ortho norm.
+ * In place (x == y) is NOT allowed. */
+int fd_rfft_pack(fd_ctx* ctx, const float* x, float* y, int B, int T, int C, void* stream);
+int fd_irfft_unpack(fd_ctx* ctx, const float* x, float* y, int B, int T, int C, void* stream);
+/* fused dataset front-end (src/fdiff/dataloaders/datamodules.py:61-62, cmd/sample.py:76-82):
+ *   fd_rfft_pack_standardize : y = (dft(x) - mean) / std      mean,std (T,C)
+ *   fd_destandardize_irfft   : y = idft(x * std + mean)                              */
+int fd_rfft_pack_standardize(fd_ctx* ctx, const float* x, const float* mean, const float* std,
+                             float* y, int B, int T, int C, void* stream);
+int fd_destandardize_irfft(fd_ctx* ctx, const float* x, const float* mean, const float* std,
+                           float* y, int B, int T, int C, void* stream);
+
+/* ------------------------------------------------------------ a3..a8 SDE
+ * kind 0 = VP  (p0 = beta_min,  p1 = beta_max)   fdiff.schedulers.sde.VPScheduler (sde.py:168-246)
+ * kind 1 = VE  (p0 = sigma_min, p1 = sigma_max)  fdiff.schedulers.sde.VEScheduler (sde.py:90-165) */
+typedef struct fd_sde_params {
+    int kind;
+    float p0, p1;
+} fd_sde_params;
+
+/* Standard normals from the engine's Philox4x32-10 stream: element i of the call uses
+ * counter (offset + i/4), key = seed.  Used for the prior, the per-step noise and tests. */
+int fd_randn(fd_ctx* ctx, float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* replaces SDE.prior_sampling (sde.py:79-87) + VE override (sde.py:125-127):
+ *   out = G[t] * z (VE: * sigma_max).  z == NULL -> z drawn on device (seed, offset). */
+int fd_prior_sample(fd_ctx* ctx, const fd_sde_params* sde, const float* G, const float* z,
+                    uint64_t seed, uint64_t offset, float* out, int B, int T, int C, void* stream);
+
+/* replaces VPScheduler.step (sde.py:215-246) / VEScheduler.step (sde.py:129-165):
+ *   VP: out = x + (0.5*beta*x + beta*G^2*score)*dt + sqrt(dt*beta)*G*z
+ *   VE: out = x + g^2*G^2*score*dt + sqrt(dt)*g*G*z
+ * One fused pass (reads x, score [, z]; writes out; out may alias x).
+ * z == NULL -> on-device Philox noise (seed, offset). t is the Python float the reference passes. */
+int fd_sde_step(fd_ctx* ctx, const fd_sde_params* sde, const float* G, const float* x,
+                const float* score, const float* z, uint64_t seed, uint64_t offset, double t,
+                float dt, float* out, int B, int T, int C, void* stream);
+
+/* replaces the perturbation half of loss_fn (src/fdiff/utils/losses.py:66-85) with
+ * marginal_prob (sde.py:108-123,187-210) and add_noise (sde.py:66-77) fused:
+ *   std[b,k] = s(t_b)*G[k];  x_noisy = m(t_b)*x + std*z;  target = z/std
+ * z == NULL -> Philox noise.  std_out (B,T) and target (B,T,C) may be NULL. */
+int fd_perturb(fd_ctx* ctx, const fd_sde_params* sde, const float* G, const float* x,
+               const float* t, const float* z, uint64_t seed, uint64_t offset, float* x_noisy,
+               float* target, float* std_out, int B, int T, int C, void* stream);
+
+/* replaces the reduction half of loss_fn (losses.py:92-124, reduce_mean=True):
+ *   likelihood_weighting == 0: mean_b mean_{t,c} w_b (score+target)^2, w_b = 1/sum_k std^-2
+ *   likelihood_weighting == 1: mean_b mean_{t,c} (std (score+target))^2
+ * loss_out: device float[1].  dscore (nullable): d loss / d score, (B,T,C). */
+int fd_dsm_loss(fd_ctx* ctx, const float* score, const float* target, const float* std,
+                int likelihood_weighting, float* loss_out, float* dscore, int B, int T, int C,
+                void* stream);
+
+/* ------------------------------------------------------- a9 score network
+ * replaces fdiff.models.score_models.ScoreModule (score_models.py:22-166): transformer
+ * encoder (post-LN, relu, dim_ff) between Linear embed/unembed, learned positional table
+ * with max_norm, Gaussian-Fourier time embedding.                                       */
+typedef struct fd_model_dims {
+    int n_channels;   /* C */
+    int max_len;      /* T */
+    int d_model;      /* D */
+    int n_head;       /* H, D % H == 0 */
+    int num_layers;   /* L */
+    int dim_ff;       /* F (torch default 2048) */
+} fd_model_dims;
+
+/* Flat fp32 parameter buffer layout.  Order = the reference's state_dict order
+ * (SURVEY.md A.4); every tensor starts on a 16-byte boundary.  name uses the reference's
+ * state_dict key.  Call with entries == NULL to get the count. */
+typedef struct fd_param_entry {
+    char name[96];
+    int64_t offset;   /* in floats */
+    int64_t numel;
+    int32_t rows, cols;   /* cols == 0 for vectors */
+    int32_t trainable;    /* 0 for time_encoder.W (requires_grad=False, transformer.py:72-74) */
+} fd_param_entry;
+int64_t fd_score_param_count(const fd_model_dims* dims);
+int fd_score_layout(const fd_model_dims* dims, fd_param_entry* entries, int* n_entries);
+
+int fd_score_create(fd_ctx* ctx, const fd_model_dims* dims, fd_score** out);
+int fd_score_destroy(fd_score* m);
+
+/* Derive the engine-side weight images from the flat fp32 parameters (device pointer):
+ * max_norm-renormed positional table (the reference renorms in place inside forward,
+ * transformer.py:13-15,27), bf16 MFMA-fragment-ordered matrices, folded biases.
+ * Must be called after every change of params (load, optimizer step) before forward.
+ * The engine keeps the pointer `params` (no copy of the fp32 masters). */
+int fd_score_prepare(fd_score* m, const float* params, void* stream);
+
+#define FD_MODE_F32 0    /* fp32 parity path (exact-f32 arithmetic) */
+#define FD_MODE_BF16 1   /* bf16 MFMA operands, fp32 accumulate / residual / LN / softmax */
+
+/* ScoreModule.forward (score_models.py:67-94), eval mode: x (B,T,C), t (B) -> out (B,T,C) */
+int fd_score_forward(fd_score* m, const float* x, const float* t, float* out, int B, int mode,
+                     void* stream);
+
+/* Training forward: keeps activations in the ctx workspace for fd_score_backward.
+ * dropout_p > 0 applies the four dropout sites of nn.TransformerEncoderLayer with masks
+ * from Philox(seed, offset) (regenerated in backward). */
+int fd_score_forward_train(fd_score* m, const float* x, const float* t, float* out, int B,
+                           float dropout_p, uint64_t seed, uint64_t offset, void* stream);
+/* dout (B,T,C) -> grads (flat, same layout as params; ACCUMULATED into if accumulate != 0) */
+int fd_score_backward(fd_score* m, const float* dout, float* grads, int accumulate, void* stream);
+
+/* ----------------------------------------------------------- a12 sampler
+ * replaces the inner loop of DiffusionSampler.sample (src/fdiff/sampling/sampler.py:83-104):
+ * for i in range(n_steps): score = model(x, t_i); x = sde.step(score, t_i, x).
+ * timesteps: HOST float[n_steps] (the scheduler's linspace grid, sde.py:62-64).
+ * x: device (B,T,C), in/out.  z_steps: device (n_steps,B,T,C) injected noise or NULL for
+ * on-device Philox (seed; step i, element e uses offset + i*ceil(BTC/4) + e/4).
+ * The whole loop is enqueued on `stream` without any host synchronisation. */
+int fd_sampler_run(fd_score* m, const fd_sde_params* sde, const float* G, const float* timesteps,
+                   int n_steps, float dt, float* x, const float* z_steps, uint64_t seed,
+                   uint64_t offset, int B, int mode, void* stream);
+
+/* ------------------------------------------------------------ a11 optimiser
+ * torch.optim.AdamW defaults + diffusers cosine-warmup + Lightning global-norm clip
+ * (score_models.py:122-130, cmd/conf/trainer/default.yaml:4), fused over the flat buffer.
+ * fd_grad_sqnorm: norm2_out[0] = sum(grads^2) (device float[1], fp32 accumulated in fp64 blocks).
+ * fd_adamw_step : clip_coef is read from device: coef = min(1, max_norm/(sqrt(*sqnorm)+1e-6))
+ *                 when sqnorm != NULL, else 1.  frozen [frozen_begin, frozen_end) is skipped. */
+int fd_grad_sqnorm(fd_ctx* ctx, const float* grads, int64_t n, float* sqnorm_out, void* stream);
+int fd_adamw_step(fd_ctx* ctx, float* params, const float* grads, float* exp_avg,
+                  float* exp_avg_sq, int64_t n, int step, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, const float* sqnorm, float max_norm,
+                  float grad_scale, int64_t frozen_begin, int64_t frozen_end, void* stream);
+
+/* ----------------------------------------------------- (e) multi-GPU exchange
+ * Data-parallel gradient all-reduce over RCCL/xGMI on ONE flat fp32 buffer.
+ * unique_id: host bytes from fd_comm_unique_id on rank 0, broadcast by the launcher. */
+#define FD_COMM_ID_BYTES 128
+int fd_comm_unique_id(void* id_out /* host, FD_COMM_ID_BYTES */);
+int fd_comm_init(fd_ctx* ctx, int rank, int nranks, const void* unique_id);
+int fd_comm_destroy(fd_ctx* ctx);
+/* buf = sum over ranks (buf) * scale, in place */
+int fd_allreduce_grads(fd_ctx* ctx, float* buf, int64_t n, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDIFF_HIP_H */

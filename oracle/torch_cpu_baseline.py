@@ -1,0 +1,89 @@
+"""CPU baseline leg of bench.py: the reference's CPU path re-expressed as the same torch-op sequence.
+
+TEST/BENCH INFRASTRUCTURE ONLY (kind = "port": /root/reference does not exist on the GPU box).  What the
+reference executes per reverse-diffusion step on CPU:
+  nn.Linear embed -> + nn.Embedding(max_norm) rows -> + Linear(cat[sin,cos](2 pi t W)) ->
+  nn.TransformerEncoder(L x post-LN relu layer, eval/no-grad fused fast path) -> nn.Linear unembed
+  (src/fdiff/models/score_models.py:67-94), then the scheduler step written with torch.diag_embed and
+  two (T,T)@(B,T,C) matmuls plus torch.randn_like (src/fdiff/schedulers/sde.py:215-246).
+fp32, torch.set_num_threads(all host cores).
+"""
+from __future__ import annotations
+
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+class _CpuScoreNet(nn.Module):
+    def __init__(self, C, T, d_model, num_layers, n_head):
+        super().__init__()
+        self.d_model = d_model
+        self.pos = nn.Embedding(T, d_model, max_norm=math.sqrt(d_model))
+        self.W = nn.Parameter(torch.randn((d_model + 1) // 2) * 30.0, requires_grad=False)
+        self.dense = nn.Linear(d_model, d_model)
+        self.embedder = nn.Linear(C, d_model)
+        self.unembedder = nn.Linear(d_model, C)
+        layer = nn.TransformerEncoderLayer(d_model=d_model, nhead=n_head, batch_first=True)
+        self.backbone = nn.TransformerEncoder(encoder_layer=layer, num_layers=num_layers)
+
+    def forward(self, X, t):
+        h = self.embedder(X)
+        h = h + self.pos(torch.arange(X.size(1)).unsqueeze(0))
+        proj = t[:, None] * self.W[None, :] * 2 * np.pi
+        emb = torch.cat([torch.sin(proj), torch.cos(proj)], dim=-1)[:, : self.d_model].unsqueeze(1)
+        h = h + self.dense(emb)
+        return self.unembedder(self.backbone(h))
+
+
+def _vp_step(score, t, x, G, step_size, beta0=0.1, beta1=20.0):
+    beta = beta0 + t * (beta1 - beta0)
+    diffusion = torch.diag_embed(math.sqrt(beta) * G)
+    drift = -0.5 * beta * x - torch.matmul(diffusion * diffusion, score)
+    z = torch.randn_like(x)
+    return x - drift * step_size + torch.sqrt(step_size) * torch.matmul(diffusion, z)
+
+
+def time_sampler_steps(batch=512, T=100, C=12, d_model=72, num_layers=10, n_head=12, n_timed=3, n_warm=2,
+                       num_diffusion_steps=1000):
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(42)
+    net = _CpuScoreNet(C, T, d_model, num_layers, n_head).eval()
+    G = torch.ones(T) / math.sqrt(2)
+    G[0] = 1.0
+    if T % 2 == 0:
+        G[T // 2] = 1.0
+    ts = torch.linspace(1.0, 1e-5, num_diffusion_steps)
+    step_size = ts[0] - ts[1]
+    x = torch.randn(batch, T, C)
+    times = []
+    with torch.no_grad():
+        for i in range(n_warm + n_timed):
+            t0 = time.perf_counter()
+            tb = torch.full((batch,), float(ts[i]))
+            score = net(x, tb)
+            x = _vp_step(score, float(ts[i]), x, G, step_size)
+            dt = time.perf_counter() - t0
+            if i >= n_warm:
+                times.append(dt)
+    step_s = float(np.mean(times))
+    return {
+        "value": batch / (step_s * num_diffusion_steps),
+        "unit": "series/s",
+        "cores": cores,
+        "kind": "port",
+        "step_ms": step_s * 1e3,
+        "sample": f"{n_timed} timed reverse-diffusion steps (after {n_warm} warm-up) at batch={batch}, T={T}, C={C}, "
+                  f"default transformer, fp32, torch {torch.__version__} CPU with {cores} threads; series/s "
+                  f"extrapolated to {num_diffusion_steps} identical-cost steps",
+    }
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(time_sampler_steps()))
