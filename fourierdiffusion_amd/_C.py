@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfdiff_hip.so")
+LIB_PATH = os.environ.get("FDIFF_LIB", os.path.join(_HERE, "libfdiff_hip.so"))   # FDIFF_LIB: kernel-ablation builds
 
 FD_MODE_F32 = 0
 FD_MODE_BF16 = 1

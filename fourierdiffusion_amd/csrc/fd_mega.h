@@ -1,0 +1,51 @@
+// fd_mega.h -- parameter block of the persistent series-resident kernel (fd_mega.hip).
+#pragma once
+#include "fd_common.h"
+
+#define FD_MEGA_FORWARD 0   // one score-network forward: x, tvec -> score_out
+#define FD_MEGA_SAMPLE 1    // nsteps x {forward, reverse-SDE step}, x updated in place
+
+struct fd_sde_step_coef {
+    float a_x, g, dt, sqrt_dt, t;   // SdeCoef of fd_sde.h + the timestep itself (time embedding)
+};
+
+struct fd_mega_layer_f32 {          // offsets (floats) into the flat fp32 parameter buffer
+    long long out_b, l2_b, n1_w, n1_b, n2_w, n2_b;
+};
+
+struct fd_mega_params {
+    // shapes
+    int B, T, KT /* ceil(T/16) */, C, D, H, hd, L, F;
+    int S;        // series per workgroup
+    int NPG;      // head pairs per attention group (K/V buffers hold one group)
+    int KSE;      // k-steps of the embed GEMM  (ceil((C+1)/32))
+    int CT;       // 16-row tiles of the unembed GEMM (ceil(C/16))
+    int rot;      // rotation of the second wave set (SIMD load balance)
+    int mode, nsteps;
+    int lds_temb; // byte offset of the time-embedding scratch in LDS
+    int lds_afr;  // byte offset of the attention-output fragments in LDS
+    int dbg;      // debugging aid (FDIFF_MEGA_DBG): bit0 zero the attention output, bit1 skip the FFN
+    unsigned* dbg_out;   // debugging aid: LDS image of workgroup 0 after layer 0's attention
+    int dbg_bytes;
+    // tensors
+    float* x;
+    float* score_out;
+    const float* tvec;
+    const float* params;
+    long long pos, tW, td_w, td_b;
+    const fd_mega_layer_f32* layers;     // device array [L]
+    // bf16 fragment images
+    const char* img_emb;
+    const char* img_unemb;
+    const char* img_layers;
+    size_t layer_stride;
+    size_t off_wk, off_wv, off_wq, off_wo, off_ffn;
+    // sampler
+    const float* G;
+    const fd_sde_step_coef* steps;       // device array [nsteps]
+    const float* z_steps;                // injected noise (nsteps, B, T, C) or null
+    unsigned long long seed, offset, ctr_per_step, n_elem;
+};
+
+int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int kso, int mt, int grid, size_t lds,
+                   hipStream_t s);

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void k_fill(float* __restrict__ p, int n, floa
 }
 }  // namespace
 
-int fd_sampler_run_bf16(fd_score* m, const fd_sde_params* sde, const float* G, const float* timesteps, int n_steps,
+int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, const float* timesteps, int n_steps,
                         float dt, float* x, const float* z_steps, uint64_t seed, uint64_t offset, int B,
                         hipStream_t s);
 
@@ -29,9 +29,11 @@ extern "C" int fd_sampler_run(fd_score* m, const fd_sde_params* sde, const float
     FD_REQUIRE(ctx, dt > 0.f, "fd_sampler_run: step size must be > 0 (sde.py:158)");
     if (!m->prepared) return fd_fail(ctx, FD_ERR_STATE, "fd_sampler_run: call fd_score_prepare first");
     hipStream_t s = (hipStream_t)stream;
-    if (mode == FD_MODE_BF16)
-        return fd_sampler_run_bf16(m, sde, G, timesteps, n_steps, dt, x, z_steps, seed, offset, B, s);
-    FD_REQUIRE(ctx, mode == FD_MODE_F32, "fd_sampler_run: unknown mode %d", mode);
+    FD_REQUIRE(ctx, mode == FD_MODE_F32 || mode == FD_MODE_BF16, "fd_sampler_run: unknown mode %d", mode);
+    if (mode == FD_MODE_BF16) {
+        const int rc = fd_sampler_run_mega(m, sde, G, timesteps, n_steps, dt, x, z_steps, seed, offset, B, s);
+        if (rc != FD_ERR_UNSUPPORTED) return rc;     // ran (or failed loudly); else: step-by-step fallback below
+    }
 
     const int T = m->d.max_len, C = m->d.n_channels;
     const size_t n = (size_t)B * T * C;
@@ -43,7 +45,9 @@ extern "C" int fd_sampler_run(fd_score* m, const fd_sde_params* sde, const float
     const uint64_t per_step = (uint64_t)((n + 3) / 4);
     for (int i = 0; i < n_steps; ++i) {
         hipLaunchKernelGGL(k_fill, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, timesteps[i]);
-        if (int rc = fd_score_forward_f32(m, x, tvec, score, B, s, false, 0.f, 0, 0)) return rc;
+        const int rc_f = (mode == FD_MODE_BF16) ? fd_score_forward_bf16(m, x, tvec, score, B, s)
+                                                : fd_score_forward_f32(m, x, tvec, score, B, s, false, 0.f, 0, 0);
+        if (rc_f) return rc_f;
         const float* z = z_steps ? z_steps + (size_t)i * n : nullptr;
         if (int rc = fd_sde_step(ctx, sde, G, x, score, z, seed, offset + (uint64_t)i * per_step,
                                  (double)timesteps[i], dt, x, B, T, C, stream))

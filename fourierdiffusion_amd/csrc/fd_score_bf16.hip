@@ -1,25 +1,705 @@
-// fd_score_bf16.hip -- bf16 MFMA inference path (placeholder until the fused kernels land).
+// fd_score_bf16.hip -- bf16 MFMA inference path of the score network (gfx950).
+//
+// Operand convention shared by every kernel here (v_mfma_f32_16x16x32_bf16, one wave = one 16x16 tile):
+//   * the TOKEN index always rides on lane&15; lane>>4 (= g) selects an 8-wide k-slot group, so an
+//     activation fragment is "for token lane&15: 8 consecutive features starting at 32*ks + 8*g".
+//   * weights are the A operand (rows = output features), activations the B operand (columns = tokens):
+//     every GEMM is computed TRANSPOSED (out^T = W . x^T), so the C tile comes out as
+//     C[row = 4*g + r (feature), col = lane&15 (token)] -- again token-on-lane.  A C tile can therefore be
+//     fed straight back as the next GEMM's B operand after a register-local relu/convert, with the k
+//     order of the next weight matrix permuted to match (done once in fd_bf16_prepare): the 2048-wide
+//     FFN hidden never leaves registers.
+//   * biases ride in the zero padding of K (an extra "1.0" activation row), so padding FLOPs do work.
+//   * weight images are stored in HBM in exact fragment order (1 KiB = 64 lanes x 16 B per block) and
+//     streamed L2 -> LDS with global_load_lds (16 B/lane), double buffered, shared by all waves of the WG.
+//
+// Reference arithmetic: nn.TransformerEncoderLayer (post-LN, relu) as built at
+// src/fdiff/models/score_models.py:57-62; SURVEY.md A.3.  fp32 everywhere except the MFMA operands.
+#include <algorithm>
+#include <cmath>
+
+#include "fd_gemm_f32.h"
+#include "fd_mega.h"
 #include "fd_score.h"
+#include "fd_sde.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// fd_score_f32.hip
+void fd_attention_f32(const float* qkv, float* out, float* lse, int B, int T, int H, int hd, float drop_p,
+                      uint64_t seed, uint64_t offset, hipStream_t s);
 
 struct fd_bf16_images {
-    int dummy;
+    bool supported = false;     // fused FFN kernel available (hybrid path)
+    bool mega = false;          // persistent series-resident kernel available
+    int ks1 = 0, dt = 0;        // k-steps of GEMM1 (incl. bias slot), 16-row tiles of d_model
+    int kso = 0, kse = 0, ct = 0, np = 0;
+    size_t ffn_layer_bytes = 0;
+    char* ffn = nullptr;        // [L][fh 2][chunk F/64][NB blocks][64 lanes][8 bf16]
+    // persistent-kernel images: emb | unemb | per layer {wk, wv, wq, wo} (FFN image shared with `ffn`)
+    char* mimg = nullptr;
+    size_t off_emb = 0, off_unemb = 0, off_layers = 0, layer_stride = 0;
+    size_t off_wk = 0, off_wv = 0, off_wq = 0, off_wo = 0, off_ffn = 0;
+    fd_mega_layer_f32* layer_tab = nullptr;   // device [L]
 };
 
+namespace {
+
+// ------------------------------------------------------------------ weight images
+// FFN image of one layer.  Block order inside a (F-half, chunk) group: W1 [ft 0..1][ks 0..KS1-1], W2 [dt].
+//   W1 block (ft, ks): lane (row=l&15, g): k = 32ks+8g+j -> W1[f = fbase+16ft+row][k], k==D -> b1[f], else 0
+//   W2 block (dt)    : lane (row=l&15, g): slot j<4 -> f = fbase+4g+j ; j>=4 -> f = fbase+16+4g+(j-4)
+//                                          value W2[d = 16dt+row][f] (0 when d >= D)
+// The W2 k-permutation is exactly the (token, 4g+r) register layout of the two 16x16 hidden tiles.
+__global__ __launch_bounds__(64) void k_build_ffn_image(const float* __restrict__ W1, const float* __restrict__ b1,
+                                                         const float* __restrict__ W2, __bf16* __restrict__ img,
+                                                         int D, int F, int KS1, int DT) {
+    const int NB = 2 * KS1 + DT;
+    const int NC = F / 64;                      // 32-wide chunks per F-half
+    const int blk = blockIdx.x;                 // ((fh*NC + c)*NB + j)
+    const int j = blk % NB;
+    const int c = (blk / NB) % NC;
+    const int fh = blk / (NB * NC);
+    const int lane = threadIdx.x, row = lane & 15, g = lane >> 4;
+    const int fbase = fh * (F / 2) + c * 32;
+    __bf16* dst = img + ((size_t)blk * 64 + lane) * 8;
+    if (j < 2 * KS1) {
+        const int ft = j / KS1, ks = j % KS1;
+        const int f = fbase + 16 * ft + row;
+        for (int e = 0; e < 8; ++e) {
+            const int k = 32 * ks + 8 * g + e;
+            float v = 0.f;
+            if (k < D) v = W1[(size_t)f * D + k];
+            else if (k == D) v = b1[f];
+            dst[e] = (__bf16)v;
+        }
+    } else {
+        const int dt = j - 2 * KS1;
+        const int d = 16 * dt + row;
+        for (int e = 0; e < 8; ++e) {
+            const int f = fbase + ((e < 4) ? (4 * g + e) : (16 + 4 * g + (e - 4)));
+            dst[e] = (__bf16)((d < D) ? W2[(size_t)d * F + f] : 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ persistent-kernel weight images
+// One 64-lane block = one 1 KiB MFMA fragment: lane (row = l&15, g = l>>4) holds 8 bf16 = k-slots 8g..8g+7 of
+// k-step ks for matrix row `row` of row tile rt.  kind selects how (rt, row, k) maps onto the fp32 weights.
+enum { IMG_EMB = 0, IMG_UNEMB = 1, IMG_Q = 2, IMG_K = 3, IMG_V = 4, IMG_WO = 5 };
+__global__ __launch_bounds__(64) void k_build_image(int kind, const float* __restrict__ W, const float* __restrict__ bias,
+                                                     __bf16* __restrict__ img, int KS, int rows, int K, int H, int hd,
+                                                     int D, float scale) {
+    const int blk = blockIdx.x;
+    const int rt = blk / KS, ks = blk - rt * KS;
+    const int lane = threadIdx.x, row = lane & 15, g = lane >> 4;
+    __bf16* dst = img + ((size_t)blk * 64 + lane) * 8;
+    for (int e = 0; e < 8; ++e) {
+        const int k = 32 * ks + 8 * g + e;
+        float v = 0.f;
+        if (kind == IMG_EMB || kind == IMG_UNEMB) {
+            // rows of W (rows x K) with the bias in k-slot K
+            const int r = 16 * rt + row;
+            if (r < rows) v = (k < K) ? W[(size_t)r * K + k] : (k == K ? bias[r] : 0.f);
+        } else if (kind == IMG_Q || kind == IMG_K || kind == IMG_V) {
+            // in_proj rows regrouped pair-major: row tile = head pair, 8 rows per head (hd real + zero pad)
+            const int head = 2 * rt + (row >> 3), j = row & 7;
+            if (head < H && j < hd) {
+                const int src = (kind - IMG_Q) * D + hd * head + j;          // row of in_proj_weight (3D x D)
+                v = (k < D) ? W[(size_t)src * D + k] : (k == D ? bias[src] : 0.f);
+                v *= scale;
+            }
+        } else {   // IMG_WO: k-slot group (ks, g) = head 4ks+g, slot e = head dim
+            const int d = 16 * rt + row, head = 4 * ks + g;
+            if (d < D && head < H && e < hd) v = W[(size_t)d * D + hd * head + e];
+        }
+        dst[e] = (__bf16)v;
+    }
+}
+
+// ------------------------------------------------------------------ fused FFN + residual + LayerNorm
+// out[m,:] = LN(x[m,:] + relu(x[m,:] W1^T + b1) W2^T + b2)   for the tokens of one workgroup.
+//
+// 8 waves = (2 token halves: mh) x (4 quarters of F: fq), two waves per SIMD; waves 0-3 (one per SIMD)
+// take the first MT token tiles, waves 4-7 the rest, so every SIMD carries the same tile count.
+// Each wave keeps DT x MT accumulator tiles in registers and walks its quarter of F in 32-wide chunks:
+//   hidden^T(32 x 16 tokens) = W1 chunk . x^T      (2*KS1 MFMAs per token tile, bias through the K padding)
+//   relu + bf16 in registers                         (the C tiles ARE the next B fragment)
+//   out^T(D x 16 tokens)   += W2 chunk . hidden^T   (DT MFMAs per token tile)
+// x^T B-fragments live in LDS (bf16, fragment order); the weight stream for all four F quarters is
+// double-buffered in LDS by global_load_lds; one barrier per chunk step.
+__device__ __forceinline__ float relu_bits(float x) {
+    int i = __builtin_bit_cast(int, x);        // v_max_i32: relu on the IEEE bit pattern, no canonicalise
+    i = i > 0 ? i : 0;
+    return __builtin_bit_cast(float, i);
+}
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    // vector fptrunc selects v_cvt_pk_bf16_f32 AND lets hipcc place the MFMA->VALU wait states itself
+    // (an inline-asm cvt reading an MFMA result directly is not padded by the compiler: measured wrong data)
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ bf16x8 relu_pack(f32x4 a, f32x4 b) {
+    u32x4 r;
+    r[0] = cvt_pk_bf16(relu_bits(a[0]), relu_bits(a[1]));
+    r[1] = cvt_pk_bf16(relu_bits(a[2]), relu_bits(a[3]));
+    r[2] = cvt_pk_bf16(relu_bits(b[0]), relu_bits(b[1]));
+    r[3] = cvt_pk_bf16(relu_bits(b[2]), relu_bits(b[3]));
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// Wave roles: 8 waves = 4 token quarters (mq) x 2 halves of F (fh), two waves per SIMD.  The token tiles of
+// the workgroup are dealt to the quarters as evenly as possible (e.g. 13 tiles -> 4,3,3,3) and the second
+// set of waves is rotated by one quarter, so the two waves sharing a SIMD carry (4+3, 3+3, 3+3, 3+4) tiles.
+template <int KS1, int DT, int MT>
+__global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, float* __restrict__ out,
+                                                    const char* __restrict__ wimg, const float* __restrict__ b2,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int M, int D, int F,
+                                                    int tok_per_wg) {
+    constexpr int NB = 2 * KS1 + DT;            // 1 KiB fragment blocks per (F-half, 32-wide chunk)
+    constexpr int SUB = 2;                      // chunks per barrier step
+    constexpr int WBUF = 2 * SUB * NB * 1024;   // both F-halves of one step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fh = wave >> 2;
+    const int mq = (wave + fh) & 3;
+    const int tok = lane & 15, g = lane >> 4;
+    const int NS = F / (64 * SUB);              // barrier steps per F-half
+    const int m_wg = blockIdx.x * tok_per_wg;
+    const int m_end = min(M, m_wg + tok_per_wg);
+    const int tiles = (m_end - m_wg + 15) >> 4;
+    const int tbase = tiles >> 2, trem = tiles & 3;
+    const int ntile = tbase + (mq < trem ? 1 : 0);                 // this wave's token tiles (<= MT)
+    const int tile0 = mq * tbase + (mq < trem ? mq : trem);
+
+    // ---- weight stream: L2 -> LDS, 1 KiB per wave-instruction, blocks dealt round-robin to the 8 waves.
+    // image order: [fh][step][sub][NB]  ->  LDS buffer [fh][sub][NB]
+    auto issue_dma = [&](int st, int buf) {
+#pragma unroll
+        for (int i = 0; i < (2 * SUB * NB + 7) / 8; ++i) {
+            const int b = wave + 8 * i;
+            if (b < 2 * SUB * NB) {
+                const int h = b / (SUB * NB);
+                const int j = b - h * (SUB * NB);
+                const char* src = wimg + ((((size_t)h * NS + st) * SUB * NB + j) * 64 + lane) * 16;
+                char* dst = smem + buf * WBUF + b * 1024;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst), 16, 0, 0);
+            }
+        }
+    };
+    issue_dma(0, 0);
+
+    // ---- activations -> bf16 B fragments in registers (token on lane&15, 8 features per lane, "1.0" in slot D)
+    bf16x8 xf[MT][KS1];
+#pragma unroll
+    for (int tt = 0; tt < MT; ++tt) {
+        const int m = m_wg + (tile0 + tt) * 16 + tok;
+        const bool valid = (tt < ntile) && (m < m_end);
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            const int k0 = 32 * ks + 8 * g;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            if (valid) {
+                if (k0 + 8 <= D) {
+                    const float4 a = *reinterpret_cast<const float4*>(x + (size_t)m * D + k0);
+                    const float4 b = *reinterpret_cast<const float4*>(x + (size_t)m * D + k0 + 4);
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+                    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = k0 + e;
+                        if (k < D) v[e] = x[(size_t)m * D + k];
+                        else if (k == D) v[e] = 1.0f;          // bias row of the K padding
+                    }
+                }
+            }
+            u32x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
+            xf[tt][ks] = __builtin_bit_cast(bf16x8, pk);
+        }
+    }
+
+    f32x4 acc[DT][MT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int tt = 0; tt < MT; ++tt) acc[dt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int buf = 0;
+    for (int st = 0; st < NS; ++st) {
+#ifndef FD_ABLATE_NODMA
+        if (st + 1 < NS) issue_dma(st + 1, buf ^ 1);
+#endif
+#pragma unroll
+        for (int sub = 0; sub < SUB; ++sub) {
+#ifdef FD_ABLATE_NOMFMA
+            if (st > 0) continue;
+#endif
+            const char* wb = smem + buf * WBUF + (fh * SUB + sub) * NB * 1024 + lane * 16;
+            bf16x8 w1[2][KS1], w2[DT];
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks)
+                    w1[ft][ks] = *reinterpret_cast<const bf16x8*>(wb + (ft * KS1 + ks) * 1024);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                w2[dt] = *reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024);
+#pragma unroll
+            for (int tt = 0; tt < MT; ++tt) {
+                if (tt < ntile) {
+                    f32x4 h0 = f32x4{0.f, 0.f, 0.f, 0.f}, h1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks) {
+                        h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[0][ks], xf[tt][ks], h0, 0, 0, 0);
+                        h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[1][ks], xf[tt][ks], h1, 0, 0, 0);
+                    }
+#ifdef FD_ABLATE_NORELU
+                    u32x4 hraw = {__builtin_bit_cast(unsigned, h0[0]), __builtin_bit_cast(unsigned, h0[1]),
+                                  __builtin_bit_cast(unsigned, h1[0]), __builtin_bit_cast(unsigned, h1[1])};
+                    const bf16x8 hb = __builtin_bit_cast(bf16x8, hraw);
+#else
+                    const bf16x8 hb = relu_pack(h0, h1);
+#endif
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+                        acc[dt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[dt], hb, acc[dt][tt], 0, 0, 0);
+                }
+            }
+        }
+#ifndef FD_ABLATE_NOBAR
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+#endif
+    }
+
+#ifdef FD_ABLATE_NOEPI
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
+    // ---- combine the two F-halves through LDS; tile tt is finalised by the wave with (tt & 1) == fh
+    f32x4* xch = reinterpret_cast<f32x4*>(smem);       // [mq][tt][dt][lane]
+#pragma unroll
+    for (int tt = 0; tt < MT; ++tt) {
+        if (tt < ntile && (tt & 1) != fh) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) xch[((mq * MT + tt) * DT + dt) * 64 + lane] = acc[dt][tt];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < MT; ++tt) {
+        if (tt >= ntile || (tt & 1) != fh) continue;
+        const int m = m_wg + (tile0 + tt) * 16 + tok;
+        const bool valid = m < m_end;
+        float v[DT][4];
+        float s = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const f32x4 tot = acc[dt][tt] + xch[((mq * MT + tt) * DT + dt) * 64 + lane];
+            const int d0 = 16 * dt + 4 * g;
+            const bool dv = d0 < D;                          // D % 4 == 0: a 4-group is all-valid or all-pad
+            float4 res = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
+            if (dv) {
+                bb = *reinterpret_cast<const float4*>(b2 + d0);
+                if (valid) res = *reinterpret_cast<const float4*>(x + (size_t)m * D + d0);
+            }
+            v[dt][0] = dv ? tot[0] + bb.x + res.x : 0.f;
+            v[dt][1] = dv ? tot[1] + bb.y + res.y : 0.f;
+            v[dt][2] = dv ? tot[2] + bb.z + res.z : 0.f;
+            v[dt][3] = dv ? tot[3] + bb.w + res.w : 0.f;
+            s += (v[dt][0] + v[dt][1]) + (v[dt][2] + v[dt][3]);
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const float mean = s / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            if (16 * dt + 4 * g < D) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float cdev = v[dt][r] - mean;
+                    q += cdev * cdev;
+                }
+            }
+        }
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        const float rstd = rsqrtf(q / (float)D + 1e-5f);
+        if (valid) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d0 = 16 * dt + 4 * g;
+                if (d0 < D) {
+                    const float4 gm = *reinterpret_cast<const float4*>(gamma + d0);
+                    const float4 bt = *reinterpret_cast<const float4*>(beta + d0);
+                    float4 o;
+                    o.x = (v[dt][0] - mean) * rstd * gm.x + bt.x;
+                    o.y = (v[dt][1] - mean) * rstd * gm.y + bt.y;
+                    o.z = (v[dt][2] - mean) * rstd * gm.z + bt.z;
+                    o.w = (v[dt][3] - mean) * rstd * gm.w + bt.w;
+                    *reinterpret_cast<float4*>(out + (size_t)m * D + d0) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int KS1, int DT, int MT>
+int launch_ffn(fd_ctx* ctx, const float* x, float* out, const char* wimg, const float* b2, const float* gamma,
+               const float* beta, int M, int D, int F, int tok_per_wg, hipStream_t s) {
+    constexpr int NB = 2 * KS1 + DT;
+    constexpr size_t lds_main = 2 * (size_t)2 * 2 * NB * 1024;         // 2 buffers x 2 F-halves x SUB chunks
+    constexpr size_t lds_xch = (size_t)4 * MT * DT * 1024;
+    const size_t lds = lds_main > lds_xch ? lds_main : lds_xch;
+    auto kern = k_ffn_ln<KS1, DT, MT>;
+    static bool attr = false;
+    if (!attr) {
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const int grid = (M + tok_per_wg - 1) / tok_per_wg;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, x, out, wimg, b2, gamma, beta, M, D, F, tok_per_wg);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
+// tokens per workgroup: whole "rounds" of one workgroup per CU, each WG at most 4*MT tiles (256 tokens)
+template <int KS1, int DT>
+int dispatch_ffn(fd_ctx* ctx, const float* x, float* out, const char* wimg, const float* b2, const float* gamma,
+                 const float* beta, int M, int D, int F, hipStream_t s) {
+    const long long cap = 256LL * ctx->num_cu;
+    const int rounds = (int)((M + cap - 1) / cap);
+    int tok = (int)((M + (long long)rounds * ctx->num_cu - 1) / ((long long)rounds * ctx->num_cu));
+    if (tok > 256) tok = 256;
+    if (tok < 16) tok = 16;
+    const int mt = ((tok + 15) / 16 + 3) / 4;       // tiles of the fullest token quarter
+    switch (mt) {
+        case 1: return launch_ffn<KS1, DT, 1>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, s);
+        case 2: return launch_ffn<KS1, DT, 2>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, s);
+        case 3: return launch_ffn<KS1, DT, 3>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, s);
+        default: return launch_ffn<KS1, DT, 4>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, s);
+    }
+}
+
+int run_ffn(fd_score* m, const float* x, float* out, int layer, int M, hipStream_t s) {
+    fd_ctx* ctx = m->ctx;
+    const fd_bf16_images* im = m->bf16;
+    const fd_layer_off& lo = m->layers[layer];
+    const float* P = m->params;
+    const char* wimg = im->ffn + (size_t)layer * im->ffn_layer_bytes;
+    const int D = m->d.d_model, F = m->d.dim_ff;
+#define FD_FFN_CASE(K, T_)                                                                                     \
+    if (im->ks1 == K && im->dt == T_)                                                                          \
+        return dispatch_ffn<K, T_>(ctx, x, out, wimg, P + lo.l2_b, P + lo.n2_w, P + lo.n2_b, M, D, F, s);
+    FD_FFN_CASE(3, 5)   // d_model 72 (hydra default)
+    FD_FFN_CASE(2, 4)   // d_model 60 (class default)
+    FD_FFN_CASE(1, 2)   // d_model 24
+    FD_FFN_CASE(1, 1)   // d_model 8
+#undef FD_FFN_CASE
+    return fd_fail(ctx, FD_ERR_UNSUPPORTED, "bf16 FFN kernel not instantiated for d_model=%d", D);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ object plumbing
 int fd_bf16_create(fd_score* m) {
+    fd_bf16_images* im = new fd_bf16_images();
+    const int D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, C = m->d.n_channels, L = m->d.num_layers;
+    const int hd = D / H;
+    im->ks1 = (D + 1 + 31) / 32;
+    im->dt = (D + 15) / 16;
+    im->kso = (8 * H + 31) / 32;
+    im->kse = (C + 1 + 31) / 32;
+    im->ct = (C + 15) / 16;
+    im->np = (H + 1) / 2;
+    const bool inst = (im->ks1 == 3 && im->dt == 5) || (im->ks1 == 2 && im->dt == 4) ||
+                      (im->ks1 == 1 && im->dt == 2) || (im->ks1 == 1 && im->dt == 1);
+    im->supported = inst && (D % 4 == 0) && (F % 128 == 0) && L > 0;
+    const bool inst_mega = (im->ks1 == 3 && im->dt == 5 && im->kso == 3) || (im->ks1 == 2 && im->dt == 4 && im->kso == 3) ||
+                           (im->ks1 == 1 && im->dt == 2 && im->kso == 1) || (im->ks1 == 1 && im->dt == 1 && im->kso == 1);
+    im->mega = im->supported && inst_mega && hd <= 8 && D < 16 * im->dt && C <= 40;
+    m->bf16 = im;
+    if (!im->supported) return FD_OK;
+    const int NB = 2 * im->ks1 + im->dt;
+    im->ffn_layer_bytes = (size_t)2 * (F / 64) * NB * 1024;
+    if (hipMalloc((void**)&im->ffn, im->ffn_layer_bytes * L) != hipSuccess) {
+        delete im;
+        m->bf16 = nullptr;
+        return fd_fail(m->ctx, FD_ERR_HIP, "fd_bf16_create: hipMalloc of the FFN weight images failed");
+    }
+    if (im->mega) {
+        const size_t KB = 1024;
+        im->off_emb = 0;
+        im->off_unemb = im->off_emb + (size_t)im->dt * im->kse * KB;
+        im->off_layers = im->off_unemb + (size_t)im->ct * im->ks1 * KB;
+        im->off_wk = 0;
+        im->off_wv = im->off_wk + (size_t)im->np * im->ks1 * KB;
+        im->off_wq = im->off_wv + (size_t)im->np * im->ks1 * KB;
+        im->off_wo = im->off_wq + (size_t)im->np * im->ks1 * KB;
+        im->off_ffn = im->off_wo + (size_t)im->dt * im->kso * KB;
+        im->layer_stride = im->off_ffn + im->ffn_layer_bytes;
+        const size_t total = im->off_layers + im->layer_stride * L;
+        if (hipMalloc((void**)&im->mimg, total) != hipSuccess ||
+            hipMalloc((void**)&im->layer_tab, sizeof(fd_mega_layer_f32) * L) != hipSuccess) {
+            fd_bf16_destroy(m);
+            return fd_fail(m->ctx, FD_ERR_HIP, "fd_bf16_create: hipMalloc of the persistent-kernel images failed");
+        }
+        std::vector<fd_mega_layer_f32> tab(L);
+        for (int i = 0; i < L; ++i) {
+            const fd_layer_off& lo = m->layers[i];
+            tab[i] = fd_mega_layer_f32{lo.out_b, lo.l2_b, lo.n1_w, lo.n1_b, lo.n2_w, lo.n2_b};
+        }
+        if (hipMemcpy(im->layer_tab, tab.data(), sizeof(fd_mega_layer_f32) * L, hipMemcpyHostToDevice) != hipSuccess) {
+            fd_bf16_destroy(m);
+            return fd_fail(m->ctx, FD_ERR_HIP, "fd_bf16_create: upload of the layer table failed");
+        }
+    }
+    return FD_OK;
+}
+
+void fd_bf16_destroy(fd_score* m) {
+    if (!m->bf16) return;
+    if (m->bf16->ffn) (void)hipFree(m->bf16->ffn);
+    if (m->bf16->mimg) (void)hipFree(m->bf16->mimg);
+    if (m->bf16->layer_tab) (void)hipFree(m->bf16->layer_tab);
+    delete m->bf16;
     m->bf16 = nullptr;
-    return FD_OK;
 }
-void fd_bf16_destroy(fd_score* m) { (void)m; }
+
 int fd_bf16_prepare(fd_score* m, hipStream_t s) {
-    (void)m;
-    (void)s;
+    fd_bf16_images* im = m->bf16;
+    if (!im || !im->supported) return FD_OK;
+    const int D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, C = m->d.n_channels, hd = D / H;
+    const int NB = 2 * im->ks1 + im->dt;
+    const int nblk = 2 * (F / 64) * NB;
+    const float* P = m->params;
+    for (int i = 0; i < m->d.num_layers; ++i) {
+        const fd_layer_off& lo = m->layers[i];
+        hipLaunchKernelGGL(k_build_ffn_image, dim3(nblk), dim3(64), 0, s, P + lo.l1_w, P + lo.l1_b, P + lo.l2_w,
+                           (__bf16*)(im->ffn + (size_t)i * im->ffn_layer_bytes), D, F, im->ks1, im->dt);
+    }
+    if (im->mega) {
+        auto build = [&](int kind, const float* W, const float* b, size_t off, int ntiles, int KS, int rows, int K,
+                         float scale) {
+            hipLaunchKernelGGL(k_build_image, dim3(ntiles * KS), dim3(64), 0, s, kind, W, b, (__bf16*)(im->mimg + off), KS,
+                               rows, K, H, hd, D, scale);
+        };
+        build(IMG_EMB, P + m->emb_w, P + m->emb_b, im->off_emb, im->dt, im->kse, D, C, 1.f);
+        build(IMG_UNEMB, P + m->un_w, P + m->un_b, im->off_unemb, im->ct, im->ks1, C, D, 1.f);
+        // softmax scale and log2(e) folded into W_q / b_q: the kernel's softmax is exp2(s - max)
+        const float qscale = (float)(1.4426950408889634 / std::sqrt((double)hd));
+        for (int i = 0; i < m->d.num_layers; ++i) {
+            const fd_layer_off& lo = m->layers[i];
+            const size_t base = im->off_layers + (size_t)i * im->layer_stride;
+            build(IMG_K, P + lo.in_w, P + lo.in_b, base + im->off_wk, im->np, im->ks1, 0, D, 1.f);
+            build(IMG_V, P + lo.in_w, P + lo.in_b, base + im->off_wv, im->np, im->ks1, 0, D, 1.f);
+            build(IMG_Q, P + lo.in_w, P + lo.in_b, base + im->off_wq, im->np, im->ks1, 0, D, qscale);
+            build(IMG_WO, P + lo.out_w, nullptr, base + im->off_wo, im->dt, im->kso, 0, D, 1.f);
+            FD_HIP(m->ctx, hipMemcpyAsync(im->mimg + base + im->off_ffn, im->ffn + (size_t)i * im->ffn_layer_bytes,
+                                          im->ffn_layer_bytes, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    FD_LAUNCH_CHECK(m->ctx);
     return FD_OK;
 }
-int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* out, int B, hipStream_t s) {
-    (void)x; (void)t; (void)out; (void)B; (void)s;
-    return fd_fail(m->ctx, FD_ERR_UNSUPPORTED, "bf16 path not built yet");
+
+// ------------------------------------------------------------------ persistent-kernel planning
+struct MegaPlan {
+    bool ok = false;
+    int S = 1, KT = 1, mt = 1, rot = 1, grid = 0, npg = 1;
+    size_t lds = 0;
+    int lds_temb = 0, lds_afr = 0;
+};
+
+static MegaPlan plan_mega(const fd_score* m, int B) {
+    MegaPlan pl;
+    const fd_bf16_images* im = m->bf16;
+    if (!im || !im->mega) return pl;
+    const int T = m->d.max_len, D = m->d.d_model;
+    const int KT = (T + 15) / 16;
+    if (KT > 16) return pl;                                   // one series must fit 16 token tiles
+    const int NB = 2 * im->ks1 + im->dt;
+    const int NP = im->np;
+    const size_t ring = (size_t)2 * 2 * 2 * NB * 1024;            // 2 buffers x 2 F-halves x SUB(2) chunks
+    const size_t half_ring = ring / 2;
+    const int want = std::max(1, (B + m->ctx->num_cu - 1) / m->ctx->num_cu);   // series per WG for one WG per CU
+    for (int S = std::min(want, 16 / KT); S >= 1; --S) {
+        const int NTILE = S * KT, NTOK = NTILE * 16, NJ = (KT + 1) / 2;
+        const int mt = (NTILE + 3) / 4;
+        const size_t xfr = (size_t)NTILE * im->ks1 * 1024;
+        const size_t afr = (size_t)NTILE * im->kso * 1024;
+        const size_t xch = (size_t)4 * mt * im->dt * 1024;
+        for (int ng = 1; ng <= NP; ++ng) {                        // head-pair groups: fewer pairs -> smaller K/V
+            const int npg = (NP + ng - 1) / ng;
+            const size_t wkv = (size_t)npg * im->ks1 * 1024 + (size_t)npg * NTOK * 32 + (size_t)npg * S * NJ * 4 * 16 * 16;
+            // FFN ring buffer 0 is filled while the out-proj still reads afr: it must fit in front of afr
+            const size_t front = std::max(wkv, half_ring);
+            const size_t mid = std::max(front + afr, std::max(ring, xch));
+            const size_t temb = ((size_t)2 * S * D * sizeof(float) + 15) & ~size_t(15);
+            const size_t total = xfr + mid + temb;
+            if (total > 160 * 1024) continue;
+            pl.ok = true;
+            pl.S = S; pl.KT = KT; pl.mt = mt; pl.npg = npg;
+            pl.lds = total;
+            pl.lds_afr = (int)(xfr + front);
+            pl.lds_temb = (int)(xfr + mid);
+            pl.grid = (B + S - 1) / S;
+            // rotation of the second wave set: minimise the heaviest SIMD (tiles of the two waves sharing it)
+            int best = 1 << 30;
+            const int tb = NTILE / 4, tr = NTILE % 4;
+            for (int rot = 1; rot <= 3; ++rot) {
+                int worst = 0;
+                for (int q = 0; q < 4; ++q) {
+                    const int a = tb + (q < tr), b = tb + (((q + rot) & 3) < tr);
+                    worst = std::max(worst, a + b);
+                }
+                if (worst < best) { best = worst; pl.rot = rot; }
+            }
+            return pl;
+        }
+    }
+    return pl;
 }
-int fd_sampler_run_bf16(fd_score* m, const fd_sde_params*, const float*, const float*, int, float, float*,
-                        const float*, uint64_t, uint64_t, int, hipStream_t) {
-    return fd_fail(m->ctx, FD_ERR_UNSUPPORTED, "bf16 path not built yet");
+
+static void fill_mega_params(const fd_score* m, const MegaPlan& pl, int B, fd_mega_params& P) {
+    const fd_bf16_images* im = m->bf16;
+    memset(&P, 0, sizeof P);
+    P.B = B; P.T = m->d.max_len; P.KT = pl.KT; P.C = m->d.n_channels; P.D = m->d.d_model; P.H = m->d.n_head;
+    P.hd = P.D / P.H; P.L = m->d.num_layers; P.F = m->d.dim_ff;
+    if (const char* d2 = getenv("FDIFF_MEGA_DBG")) P.dbg = atoi(d2);
+    if (const char* dbg = getenv("FDIFF_MEGA_LAYERS")) P.L = std::min(P.L, atoi(dbg));   // debugging aid
+    P.S = pl.S; P.NPG = pl.npg; P.KSE = im->kse; P.CT = im->ct; P.rot = pl.rot;
+    P.lds_temb = pl.lds_temb; P.lds_afr = pl.lds_afr;
+    P.params = m->params;
+    P.pos = m->pos; P.tW = m->tW; P.td_w = m->td_w; P.td_b = m->td_b;
+    P.layers = im->layer_tab;
+    P.img_emb = im->mimg + im->off_emb;
+    P.img_unemb = im->mimg + im->off_unemb;
+    P.img_layers = im->mimg + im->off_layers;
+    P.layer_stride = im->layer_stride;
+    P.off_wk = im->off_wk; P.off_wv = im->off_wv; P.off_wq = im->off_wq; P.off_wo = im->off_wo; P.off_ffn = im->off_ffn;
+}
+
+// fd_score_f32.hip kernels reused by the hybrid path
+namespace fdf32 {
+void time_embed(const float* t, const float* W, const float* Wd, const float* bd, float* temb, int B, int D,
+                hipStream_t s);
+void embed(const float* x, const float* We, const float* be, const float* pe, const float* temb, float* h, int M,
+           int T, int C, int D, hipStream_t s);
+void add_layernorm(const float* a, const float* r, const float* gamma, const float* beta, float* y, int M, int D,
+                   hipStream_t s);
+}  // namespace fdf32
+
+int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* out, int B, hipStream_t s) {
+    fd_ctx* ctx = m->ctx;
+    if (!m->bf16 || !m->bf16->supported)
+        return fd_fail(ctx, FD_ERR_UNSUPPORTED,
+                       "bf16 MFMA path supports d_model in {8,24,60,72} with dim_ff %% 128 == 0; use FD_MODE_F32");
+    {
+        const MegaPlan pl = plan_mega(m, B);
+        if (pl.ok && !getenv("FDIFF_NO_MEGA")) {
+            fd_mega_params MP;
+            fill_mega_params(m, pl, B, MP);
+            MP.mode = FD_MEGA_FORWARD;
+            MP.nsteps = 1;
+            MP.x = const_cast<float*>(x);
+            MP.score_out = out;
+            MP.tvec = t;
+            if (const char* dump = getenv("FDIFF_MEGA_DUMP")) {      // debugging aid: LDS image of workgroup 0
+                unsigned* dbuf = nullptr;
+                FD_HIP(ctx, hipMalloc((void**)&dbuf, pl.lds));
+                MP.dbg_out = dbuf;
+                MP.dbg_bytes = (int)pl.lds;
+                int rc = fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.grid, pl.lds, s);
+                FD_HIP(ctx, hipStreamSynchronize(s));
+                std::vector<char> hostbuf(pl.lds);
+                FD_HIP(ctx, hipMemcpy(hostbuf.data(), dbuf, pl.lds, hipMemcpyDeviceToHost));
+                if (FILE* f = fopen(dump, "wb")) {
+                    fwrite(hostbuf.data(), 1, pl.lds, f);
+                    fclose(f);
+                }
+                (void)hipFree(dbuf);
+                fprintf(stderr, "[fdiff] LDS dump: S=%d KT=%d mt=%d rot=%d npg=%d lds=%zu afr@%d temb@%d\n", pl.S, pl.KT, pl.mt,
+                        pl.rot, pl.npg, pl.lds, pl.lds_afr, pl.lds_temb);
+                return rc;
+            }
+            return fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.grid, pl.lds, s);
+        }
+    }
+    const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model, H = m->d.n_head;
+    const int L = m->d.num_layers, hd = D / H;
+    const int M = B * T;
+    const float* P = m->params;
+    if (int rc = fd_ws_reserve(ctx, fd_score_f32_workspace(m, B, false))) return rc;
+    fd_ws ws(ctx);
+    float* temb = ws.take<float>((size_t)B * D);
+    float* h0 = ws.take<float>((size_t)M * D);
+    float* h1 = ws.take<float>((size_t)M * D);
+    float* qkv = ws.take<float>((size_t)M * 3 * D);
+    float* att = ws.take<float>((size_t)M * D);
+    float* tmp = ws.take<float>((size_t)M * D);
+    fdf32::time_embed(t, P + m->tW, P + m->td_w, P + m->td_b, temb, B, D, s);
+    fdf32::embed(x, P + m->emb_w, P + m->emb_b, P + m->pos, temb, h0, M, T, C, D, s);
+    for (int i = 0; i < L; ++i) {
+        const fd_layer_off& lo = m->layers[i];
+        fdgemm::linear_fwd(h0, P + lo.in_w, P + lo.in_b, qkv, M, 3 * D, D, false, s);
+        fd_attention_f32(qkv, att, nullptr, B, T, H, hd, 0.f, 0, 0, s);
+        fdgemm::linear_fwd(att, P + lo.out_w, P + lo.out_b, tmp, M, D, D, false, s);
+        fdf32::add_layernorm(h0, tmp, P + lo.n1_w, P + lo.n1_b, h1, M, D, s);
+        if (int rc = run_ffn(m, h1, h0, i, M, s)) return rc;
+    }
+    fdgemm::linear_fwd(h0, P + m->un_w, P + m->un_b, out, M, C, D, false, s);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
+// Whole reverse-diffusion loop in the persistent kernel.  Returns FD_ERR_UNSUPPORTED (without touching x)
+// when the shape does not fit, so that fd_sampler_run can fall back to the step-by-step loop.
+int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, const float* timesteps, int n_steps,
+                        float dt, float* x, const float* z_steps, uint64_t seed, uint64_t offset, int B,
+                        hipStream_t s) {
+    fd_ctx* ctx = m->ctx;
+    const MegaPlan pl = plan_mega(m, B);
+    if (!pl.ok || (m->d.n_channels % 4) != 0 || getenv("FDIFF_NO_MEGA")) return FD_ERR_UNSUPPORTED;
+    const size_t tab_bytes = fd_ws::padded(sizeof(fd_sde_step_coef) * (size_t)n_steps);
+    if (int rc = fd_ws_reserve(ctx, tab_bytes)) return rc;
+    std::vector<fd_sde_step_coef> tab(n_steps);
+    for (int i = 0; i < n_steps; ++i) {
+        const SdeCoef c = fd_sde_coef(*sde, (double)timesteps[i], dt);
+        tab[i] = fd_sde_step_coef{c.a_x, c.g, c.dt, c.sqrt_dt, timesteps[i]};
+    }
+    // pageable source: the runtime stages the copy before returning, so `tab` may go out of scope
+    FD_HIP(ctx, hipMemcpyAsync(ctx->ws, tab.data(), sizeof(fd_sde_step_coef) * (size_t)n_steps, hipMemcpyHostToDevice, s));
+    fd_mega_params MP;
+    fill_mega_params(m, pl, B, MP);
+    MP.mode = FD_MEGA_SAMPLE;
+    MP.nsteps = n_steps;
+    MP.x = x;
+    MP.G = G;
+    MP.steps = reinterpret_cast<const fd_sde_step_coef*>(ctx->ws);
+    MP.z_steps = z_steps;
+    MP.seed = seed;
+    MP.offset = offset;
+    MP.n_elem = (unsigned long long)B * m->d.max_len * m->d.n_channels;
+    MP.ctr_per_step = (MP.n_elem + 3) / 4;
+    return fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.grid, pl.lds, s);
 }

@@ -333,6 +333,26 @@ uint64_t fd_dropout_site_offset(uint64_t base, int layer, int site) {
     return base + (((uint64_t)layer * 4 + (uint64_t)site) << 40);
 }
 
+// thin launch wrappers reused by the bf16 hybrid path (fd_score_bf16.hip)
+namespace fdf32 {
+void time_embed(const float* t, const float* W, const float* Wd, const float* bd, float* temb, int B, int D,
+                hipStream_t s) {
+    hipLaunchKernelGGL(k_time_embed, dim3(B), dim3(128), D * sizeof(float), s, t, W, Wd, bd, (float*)nullptr, temb,
+                       D);
+}
+void embed(const float* x, const float* We, const float* be, const float* pe, const float* temb, float* h, int M,
+           int T, int C, int D, hipStream_t s) {
+    const size_t n = (size_t)M * D;
+    hipLaunchKernelGGL(k_embed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, We, be, pe, temb, h, M, T, C,
+                       D);
+}
+void add_layernorm(const float* a, const float* r, const float* gamma, const float* beta, float* y, int M, int D,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(k_add_layernorm, dim3((M + 3) / 4), dim3(256), 0, s, a, r, gamma, beta, (float*)nullptr,
+                       (float*)nullptr, y, M, D);
+}
+}  // namespace fdf32
+
 // ------------------------------------------------------------------ workspace
 namespace {
 inline size_t fl(size_t n) { return fd_ws::padded(n * sizeof(float)); }
