@@ -25,8 +25,10 @@ struct fd_mega_params {
     int lds_temb; // byte offset of the time-embedding scratch in LDS
     int lds_afr;  // byte offset of the attention-output fragments in LDS
     int dbg;      // debugging aid (FDIFF_MEGA_DBG): bit0 zero the attention output, bit1 skip the FFN
+    unsigned long long* prof;   // profiling aid (FDIFF_MEGA_PROF): (phase, s_memtime) pairs of WG 0 / wave 0, steps 0-3
     unsigned* dbg_out;   // debugging aid: LDS image of workgroup 0 after layer 0's attention
     int dbg_bytes;
+    float* stash;        // global scratch [grid][8 waves][2][DT][64 lanes] float4: residual tiles parked during the FFN
     // tensors
     float* x;
     float* score_out;

@@ -19,6 +19,8 @@
 //
 // Reference arithmetic: src/fdiff/models/score_models.py:67-94 (+ torch TransformerEncoderLayer),
 // src/fdiff/sampling/sampler.py:83-104, src/fdiff/schedulers/sde.py:129-165,215-246.
+#include <type_traits>
+
 #include "fd_mega.h"
 #include "fd_philox.h"
 
@@ -30,6 +32,13 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+#ifndef FD_XF_REGS
+#define FD_XF_REGS 0     // FFN activation fragments: 1 = registers for the whole phase, 0 = LDS read per use
+#endif
+#ifndef FD_FOLD_RES
+#define FD_FOLD_RES 1    // start the owner's FFN accumulators from the residual (no extra live registers in the loop)
+#endif
 
 namespace {
 
@@ -73,8 +82,24 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
+// Shape policies: ShapeDyn reads every dimension from the parameter block (any supported model/shape);
+// a ShapeStatic instantiation bakes the dimensions of one workload in, which removes the index arithmetic,
+// the runtime loop guards (each guard splits a basic block and stops hipcc interleaving independent MFMA /
+// VALU chains) and ~40 live scalars -- PMC showed 6.5 VALU + 3.2 SALU instructions per MFMA in the generic build.
+struct ShapeDyn {
+    static constexpr bool kStatic = false;
+    static constexpr int T = 0, KT = 0, D = 0, C = 0, H = 0, hd = 0, S = 0, NPG = 0, KSE = 0, CT = 0, rot = 0, L = 0, F = 0;
+};
+template <int T_, int D_, int C_, int H_, int S_, int NPG_, int ROT_, int L_, int F_>
+struct ShapeStatic {
+    static constexpr bool kStatic = true;
+    static constexpr int T = T_, KT = (T_ + 15) / 16, D = D_, C = C_, H = H_, hd = D_ / H_, S = S_, NPG = NPG_;
+    static constexpr int KSE = (C_ + 1 + 31) / 32, CT = (C_ + 15) / 16, rot = ROT_, L = L_, F = F_;
+};
+#define SHP(name) (SH::kStatic ? SH::name : P.name)
+
 // ---------------------------------------------------------------------------------------------------
-template <int KS1, int DT, int KSO, int MT>
+template <int KS1, int DT, int KSO, int MT, class SH>
 __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
     constexpr int KSX = KS1;                     // x-fragment blocks per token tile
     constexpr int NBF = 2 * KS1 + DT;            // FFN blocks per (F-half, 32-wide chunk)
@@ -82,14 +107,25 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
     constexpr int WBUF = 2 * SUB * NBF * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int lane = threadIdx.x & 63;
+    // lane / tok / g are re-derived from an opaque (asm volatile) lane id at every phase boundary: otherwise
+    // hipcc hoists every lane-dependent address of every phase out of the step/layer loops, keeps them live
+    // across the FFN loop and spills them INSIDE it (a scratch reload forces s_waitcnt vmcnt(0), which also
+    // drains the in-flight weight DMA and serialises stream and compute -- measured).
+    int lane, tok, g;
+    auto refresh_lane = [&]() {
+        unsigned l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        lane = (int)l;
+        tok = lane & 15;
+        g = lane >> 4;
+    };
+    refresh_lane();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tok = lane & 15, g = lane >> 4;
-    const int T = P.T, KT = P.KT, D = P.D, C = P.C, H = P.H, hd = P.hd, S = P.S;
+    const int T = SHP(T), KT = SHP(KT), D = SHP(D), C = SHP(C), H = SHP(H), hd = SHP(hd), S = SHP(S);
     const int NTILE = S * KT;                    // token tiles of this workgroup (16 slots each)
     const int NTOK = NTILE * 16;
     const int NP = (H + 1) >> 1;                 // head pairs
-    const int NPG = P.NPG;                       // head pairs per attention group
+    const int NPG = SHP(NPG);                    // head pairs per attention group
     const int NJ = (KT + 1) >> 1;                // 32-key blocks per series
     const int b0 = blockIdx.x * S;               // first series of this workgroup
 
@@ -101,15 +137,30 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
     char* const afr = smem + P.lds_afr;                       // [NTILE][KSO][64][16 B]  attention-output fragments
     char* const ring = wsl;                                   // FFN weight ring + exchange alias W/K/V(/afr)
     float* const temb = reinterpret_cast<float*>(smem + P.lds_temb);   // [S][D] + emb scratch [S][D]
+    float* const lpar = temb + 2 * S * D;                              // [6][D] bo, b2, g1, b1, g2, b2 of the layer
 
     // ---- token-tile ownership (same split as the FFN: quarters mq, F-halves fh; fh waves rotated)
     const int fh = wave >> 2;
-    const int mq = (wave + fh * P.rot) & 3;
+    const int mq = (wave + fh * SHP(rot)) & 3;
     const int tbase = NTILE >> 2, trem = NTILE & 3;
     const int ntile = tbase + (mq < trem ? 1 : 0);
     const int tile0 = mq * tbase + (mq < trem ? mq : trem);
     // owned tiles (residual stream lives in this wave's registers): tt = fh, fh + 2
+    // fp32 residual stream of the owned tiles (tt = fh, fh + 2).  It stays in registers except during the FFN
+    // loop, where it IS the initial value of the owner's accumulator tiles (out = res + b2 + W2 relu(..)), so the
+    // hot loop carries no extra live registers.
     f32x4 res[2][DT];
+    int prof_cnt = 0;
+    auto mark = [&](int phase, int step) {
+        if (P.prof && blockIdx.x == 0 && wave == 0 && step < 4) {
+            const unsigned long long tm = __builtin_readcyclecounter();
+            if (lane == 0) {
+                P.prof[2 * prof_cnt] = (unsigned long long)phase;
+                P.prof[2 * prof_cnt + 1] = tm;
+            }
+            ++prof_cnt;
+        }
+    };
 
     auto tile_token = [&](int tile, int& ser, int& t, bool& valid) {
         ser = tile / KT;
@@ -187,6 +238,8 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
 
     const int nsteps = (P.mode == FD_MEGA_SAMPLE) ? P.nsteps : 1;
     for (int step = 0; step < nsteps; ++step) {
+        mark(0, step);
+        refresh_lane();
         // ============================ time embedding (transformer.py:80-89), one wave per series
         if (wave < S) {
             const int b = b0 + wave;
@@ -223,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) acc[dt] = f4zero();
                 const float* xrow = P.x + ((size_t)(b0 + ser) * T + t) * C;
-                for (int ks = 0; ks < P.KSE; ++ks) {
+                for (int ks = 0; ks < SHP(KSE); ++ks) {
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -236,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                                 cvt_pk_bf16(v[6], v[7])};
                     const bf16x8 xb = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(gfrag(P.img_emb, dt * P.KSE + ks), xb, acc[dt]);
+                    for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(gfrag(P.img_emb, dt * SHP(KSE) + ks), xb, acc[dt]);
                 }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
@@ -252,18 +305,27 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                     } else {
                         acc[dt] = f4zero();
                     }
-                    res[oi][dt] = acc[dt];
                 }
-                write_xfrags(tile, res[oi]);
+                write_xfrags(tile, acc);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) res[oi][dt] = acc[dt];
             }
         }
-        // first layer's W_k for group 0 can stream while the embed finishes
         __syncthreads();
+        mark(1, step);
+        refresh_lane();
 
         // ============================ encoder layers
-        for (int l = 0; l < P.L; ++l) {
+        for (int l = 0; l < SHP(L); ++l) {
             const char* limg = layer_ptr(l);
-            const fd_mega_layer_f32 lp = P.layers[l];
+            refresh_lane();
+            if (wave == 7) {   // small fp32 vectors of this layer -> LDS (first read after several barriers)
+                const fd_mega_layer_f32 lp = P.layers[l];
+                const long long offs[6] = {lp.out_b, lp.l2_b, lp.n1_w, lp.n1_b, lp.n2_w, lp.n2_b};
+#pragma unroll
+                for (int v = 0; v < 6; ++v)
+                    for (int d = lane; d < D; d += 64) lpar[v * D + d] = P.params[offs[v] + d];
+            }
 
             // -------- attention, one group of head pairs at a time
             for (int pg = 0; pg < NP; pg += NPG) {
@@ -283,6 +345,8 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                     *reinterpret_cast<u32x2*>(kbf + ((size_t)(pr * NTOK + tile * 16 + tok) * 4 + g) * 8) = pk;
                 }
                 __syncthreads();
+                mark(2, step);
+                refresh_lane();
                 // ---- V projection (non-transposed: C rows = tokens) -> vbf as V^T A-fragments
                 dma_blocks(limg + P.off_wv + (size_t)pg * KS1 * 1024, wsl, npg * KS1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -302,6 +366,8 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                     if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
                 }
                 __syncthreads();
+                mark(3, step);
+                refresh_lane();
                 // ---- W_q, then the attention units (query tile x head pair)
                 dma_blocks(limg + P.off_wq + (size_t)pg * KS1 * 1024, wsl, npg * KS1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -318,20 +384,32 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                     const bf16x8 qb = __builtin_bit_cast(bf16x8, qpk);   // both heads: even in g<2, odd in g>=2
                     float o_sel[4] = {0.f, 0.f, 0.f, 0.f};
                     float l_sel = 1.f;
+                    float m2[2] = {kNegBig, kNegBig}, lsum2[2] = {0.f, 0.f};
+                    f32x4 o2[2] = {f4zero(), f4zero()};
+                    const bool lo_grp = (g >> 1) == 0;               // lane groups 0-1: even head, 2-3: odd head
+                    for (int kb = 0; kb < KT; kb += 8) {
+                        // K and V fragments of this 128-key block: one read serves both heads of the pair
+                        u32x2 kr[8];
+                        bf16x8 vf[4];
 #pragma unroll
-                    for (int hs = 0; hs < 2; ++hs) {
-                        const bool mine = ((g >> 1) == hs);         // lane groups carrying this head's k-slots
-                        float m = kNegBig, lsum = 0.f;
-                        f32x4 o = f4zero();
-                        for (int kb = 0; kb < KT; kb += 8) {
+                        for (int j = 0; j < 8; ++j)
+                            if (kb + j < KT)
+                                kr[j] = *reinterpret_cast<const u32x2*>(
+                                    kbf + ((size_t)(pr * NTOK + (ser * KT + kb + j) * 16 + tok) * 4 + g) * 8);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+                            if ((kb >> 1) + jj < NJ)
+                                vf[jj] = *reinterpret_cast<const bf16x8*>(
+                                    vbf + ((size_t)(((pr * S + ser) * NJ + (kb >> 1) + jj) * 4 + g) * 16 + tok) * 16);
+#pragma unroll
+                        for (int hs = 0; hs < 2; ++hs) {
+                            const bool mine = (hs == 0) ? lo_grp : !lo_grp;
                             f32x4 s[8];
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
                                 const int kt = kb + j;
                                 if (kt < KT) {
-                                    const u32x2 kr = *reinterpret_cast<const u32x2*>(
-                                        kbf + ((size_t)(pr * NTOK + (ser * KT + kt) * 16 + tok) * 4 + g) * 8);
-                                    u32x4 kk = {mine ? kr[0] : 0u, mine ? kr[1] : 0u, 0u, 0u};
+                                    u32x4 kk = {mine ? kr[j][0] : 0u, mine ? kr[j][1] : 0u, 0u, 0u};
                                     s[j] = MFMA(__builtin_bit_cast(bf16x8, kk), qb, f4zero());
                                     if (kt == KT - 1) {             // keys beyond T in the ragged last tile
 #pragma unroll
@@ -347,11 +425,11 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                             for (int j = 0; j < 8; ++j)
                                 bm = fmaxf(bm, fmaxf(fmaxf(s[j][0], s[j][1]), fmaxf(s[j][2], s[j][3])));
                             bm = group_max(bm);
-                            const float mnew = fmaxf(m, bm);
-                            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-                            lsum *= alpha;
-                            o *= alpha;
-                            m = mnew;
+                            const float mnew = fmaxf(m2[hs], bm);
+                            const float alpha = __builtin_amdgcn_exp2f(m2[hs] - mnew);
+                            float lsum = lsum2[hs] * alpha;
+                            f32x4 o = o2[hs] * alpha;
+                            m2[hs] = mnew;
 #pragma unroll
                             for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -361,20 +439,17 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                                     lsum += p;
                                 }
 #pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) {
-                                const int jb = (kb >> 1) + jj;
-                                if (jb < NJ) {
-                                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(
-                                        vbf + ((size_t)(((pr * S + ser) * NJ + jb) * 4 + g) * 16 + tok) * 16);
-                                    o = MFMA(vf, pack8(s[2 * jj], s[2 * jj + 1]), o);
-                                }
-                            }
+                            for (int jj = 0; jj < 4; ++jj)
+                                if ((kb >> 1) + jj < NJ) o = MFMA(vf[jj], pack8(s[2 * jj], s[2 * jj + 1]), o);
+                            lsum2[hs] = lsum;
+                            o2[hs] = o;
                         }
-                        lsum = group_sum(lsum);
-                        if (mine) {                                  // rows 8*hs + [0,8) of O^T live in these lanes
-                            o_sel[0] = o[0]; o_sel[1] = o[1]; o_sel[2] = o[2]; o_sel[3] = o[3];
-                            l_sel = lsum;
-                        }
+                    }
+                    {
+                        const float l0 = group_sum(lsum2[0]), l1 = group_sum(lsum2[1]);
+                        l_sel = lo_grp ? l0 : l1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o_sel[r] = lo_grp ? o2[0][r] : o2[1][r];
                     }
                     const float inv = 1.0f / l_sel;
                     // head = 2*(pg+pr) + (g>>1); its 8 dims are one 16-B k-slot group of the out-proj B fragment
@@ -388,14 +463,22 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                 __syncthreads();
             }
 
+            mark(4, step);
+            refresh_lane();
             if (P.dbg_out && blockIdx.x == 0 && l == 0 && step == 0) {      // debugging aid: dump LDS
                 for (int i = threadIdx.x; i < P.dbg_bytes / 4; i += 512) P.dbg_out[i] = reinterpret_cast<unsigned*>(smem)[i];
                 __syncthreads();
             }
             // -------- FFN weight stream: buffer 0 overlays W/K/V only (afr is still read by the out-proj);
             //          buffer 1 (first used at step 0 of the FFN loop) may overlay afr
-            const int NS = P.F / (64 * SUB);
-            auto issue_ffn = [&](int st, int buf) {
+            const int NS = SHP(F) / (64 * SUB);
+            // Every CU streams the SAME weights; marching through them in lockstep makes all 32 CUs of an XCD hit
+            // the same L2 channel at the same time (measured: the stream ran at ~25 GB/s per CU and bounded the FFN
+            // loop).  The F chunks are summed, so each workgroup walks them in its own rotated order.
+            const int st_rot = (blockIdx.x >> 3) % NS;
+            auto issue_ffn = [&](int st_seq, int buf) {
+                int st = st_seq + st_rot;
+                st -= (st >= NS) ? NS : 0;
                 for (int b = wave; b < 2 * SUB * NBF; b += 8) {
                     const int h = b / (SUB * NBF);
                     const int j = b - h * (SUB * NBF);
@@ -405,7 +488,12 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
             };
             issue_ffn(0, 0);
 
-            // -------- out-proj + residual + LayerNorm1 on the owned tiles
+            // -------- out-proj + residual + LayerNorm1 on the owned tiles (W_o fragments: one L2 round trip)
+            bf16x8 wo[DT][KSO];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int ks = 0; ks < KSO; ++ks) wo[dt][ks] = gfrag(limg + P.off_wo, dt * KSO + ks);
 #pragma unroll
             for (int oi = 0; oi < 2; ++oi) {
                 const int tt = fh + 2 * oi;
@@ -418,73 +506,92 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                     for (int ks = 0; ks < KSO; ++ks) {
                         const bf16x8 af = *reinterpret_cast<const bf16x8*>(afr + ((tile * KSO + ks) * 64 + lane) * 16);
 #pragma unroll
-                        for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(gfrag(limg + P.off_wo, dt * KSO + ks), af, acc[dt]);
+                        for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(wo[dt][ks], af, acc[dt]);
                     }
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) {
                         const int d0 = 16 * dt + 4 * g;
                         if (d0 < D) {
-                            const float4 bo = *reinterpret_cast<const float4*>(P.params + lp.out_b + d0);
+                            const float4 bo = *reinterpret_cast<const float4*>(lpar + 0 * D + d0);
                             res[oi][dt][0] += acc[dt][0] + bo.x;
                             res[oi][dt][1] += acc[dt][1] + bo.y;
                             res[oi][dt][2] += acc[dt][2] + bo.z;
                             res[oi][dt][3] += acc[dt][3] + bo.w;
                         }
                     }
-                    layer_norm(res[oi], P.params + lp.n1_w, P.params + lp.n1_b);
+                    layer_norm(res[oi], lpar + 2 * D, lpar + 3 * D);
                     write_xfrags(tile, res[oi]);
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
 
+            mark(5, step);
+            refresh_lane();
             // -------- FFN: hidden never leaves registers (see fd_score_bf16.hip)
             {
-                bf16x8 xf[MT][KS1];
-#pragma unroll
-                for (int tt = 0; tt < MT; ++tt)
-#pragma unroll
-                    for (int ks = 0; ks < KS1; ++ks) xf[tt][ks] = (tt < ntile) ? xfrag(tile0 + tt, ks) : frag_zero();
                 f32x4 acc[DT][MT];
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int tt = 0; tt < MT; ++tt) acc[dt][tt] = f4zero();
-                int buf = 0;
-                for (int st = 0; st < NS; ++st) {
-                    if (st + 1 < NS) issue_ffn(st + 1, buf ^ 1);
-                    if (P.dbg & 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); buf ^= 1; continue; }
+                    for (int tt = 0; tt < MT; ++tt) {
+                        // owned tiles (tt & 1) == fh start from the residual (tile index tt>>1 of res), others from 0
+                        const f32x4 r = res[(tt >> 1) & 1][dt];
+                        acc[dt][tt] = ((tt & 1) == fh) ? r : f4zero();
+                    }
+                // The chunk body is instantiated per tile count so that it is ONE basic block: with a runtime
+                // `tt < ntile` guard every tile becomes its own block and hipcc cannot interleave the tiles'
+                // LDS reads / MFMAs / relu (measured: 45 % MFMA-pipe occupancy in this loop, fully serialised).
+                auto ffn_loop = [&](auto ntc) {
+                    constexpr int NTT = decltype(ntc)::value;
+                    bf16x8 xf[FD_XF_REGS ? NTT : 1][KS1];           // activation fragments kept in registers (optional)
+                    if (FD_XF_REGS) {
 #pragma unroll
-                    for (int sub = 0; sub < SUB; ++sub) {
-                        const char* wb = ring + buf * WBUF + (fh * SUB + sub) * NBF * 1024 + lane * 16;
-                        bf16x8 w1[2][KS1], w2[DT];
+                        for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-                        for (int ft = 0; ft < 2; ++ft)
+                            for (int ks = 0; ks < KS1; ++ks) xf[tt][ks] = xfrag(tile0 + tt, ks);
+                    }
+                    int buf = 0;
+                    for (int st = 0; st < NS; ++st) {
+                        if (st + 1 < NS && !(P.dbg & 4)) issue_ffn(st + 1, buf ^ 1);
 #pragma unroll
-                            for (int ks = 0; ks < KS1; ++ks)
-                                w1[ft][ks] = *reinterpret_cast<const bf16x8*>(wb + (ft * KS1 + ks) * 1024);
+                        for (int sub = 0; sub < SUB; ++sub) {
+                            const char* wb = ring + buf * WBUF + (fh * SUB + sub) * NBF * 1024 + lane * 16;
+                            bf16x8 w1[2][KS1], w2[DT];
 #pragma unroll
-                        for (int dt = 0; dt < DT; ++dt)
-                            w2[dt] = *reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024);
+                            for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-                        for (int tt = 0; tt < MT; ++tt) {
-                            if (tt < ntile) {
+                                for (int ks = 0; ks < KS1; ++ks)
+                                    w1[ft][ks] = *reinterpret_cast<const bf16x8*>(wb + (ft * KS1 + ks) * 1024);
+#pragma unroll
+                            for (int dt = 0; dt < DT; ++dt)
+                                w2[dt] = *reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024);
+#pragma unroll
+                            for (int tt = 0; tt < NTT; ++tt) {
                                 f32x4 h0 = f4zero(), h1 = f4zero();
 #pragma unroll
                                 for (int ks = 0; ks < KS1; ++ks) {
-                                    h0 = MFMA(w1[0][ks], xf[tt][ks], h0);
-                                    h1 = MFMA(w1[1][ks], xf[tt][ks], h1);
+                                    const bf16x8 xv = FD_XF_REGS ? xf[FD_XF_REGS ? tt : 0][ks] : xfrag(tile0 + tt, ks);
+                                    h0 = MFMA(w1[0][ks], xv, h0);
+                                    h1 = MFMA(w1[1][ks], xv, h1);
                                 }
                                 const bf16x8 hb = relu_pack(h0, h1);
 #pragma unroll
                                 for (int dt = 0; dt < DT; ++dt) acc[dt][tt] = MFMA(w2[dt], hb, acc[dt][tt]);
                             }
                         }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        buf ^= 1;
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    buf ^= 1;
+                };
+                if (ntile == MT) ffn_loop(std::integral_constant<int, MT>{});
+                else if (MT > 1 && ntile == MT - 1) ffn_loop(std::integral_constant<int, (MT > 1 ? MT - 1 : 1)>{});
+                else {   // fewer tiles only happens for tiny workgroups: run the full width (extra tiles are zeros)
+                    ffn_loop(std::integral_constant<int, MT>{});
                 }
+                mark(6, step);
+                refresh_lane();
                 // combine the two F halves: tile tt is finalised by its owner wave ((tt & 1) == fh)
                 f32x4* xch = reinterpret_cast<f32x4*>(ring);       // [mq][tt][dt][lane]
 #pragma unroll
@@ -507,19 +614,21 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                                 const f32x4 mine = (fh == 0) ? acc[dt][(2 * oi) < MT ? 2 * oi : 0]
                                                              : acc[dt][(2 * oi + 1) < MT ? 2 * oi + 1 : 0];
                                 const f32x4 other = xch[((mq * MT + tt) * DT + dt) * 64 + lane];
-                                const float4 b2 = *reinterpret_cast<const float4*>(P.params + lp.l2_b + d0);
-                                res[oi][dt][0] += mine[0] + other[0] + b2.x;
-                                res[oi][dt][1] += mine[1] + other[1] + b2.y;
-                                res[oi][dt][2] += mine[2] + other[2] + b2.z;
-                                res[oi][dt][3] += mine[3] + other[3] + b2.w;
+                                const float4 b2 = *reinterpret_cast<const float4*>(lpar + 1 * D + d0);
+                                res[oi][dt][0] = mine[0] + other[0] + b2.x;      // `mine` already contains the residual
+                                res[oi][dt][1] = mine[1] + other[1] + b2.y;
+                                res[oi][dt][2] = mine[2] + other[2] + b2.z;
+                                res[oi][dt][3] = mine[3] + other[3] + b2.w;
                             }
                         }
-                        layer_norm(res[oi], P.params + lp.n2_w, P.params + lp.n2_b);
+                        layer_norm(res[oi], lpar + 4 * D, lpar + 5 * D);
                         write_xfrags(tile0 + tt, res[oi]);
                     }
                 }
                 __syncthreads();
             }
+            mark(7, step);
+            refresh_lane();
         }   // layers
 
         // ============================ unembed (score_models.py:90) + output / reverse SDE step
@@ -532,7 +641,7 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                 int ser, t;
                 bool valid;
                 tile_token(tile, ser, t, valid);
-                for (int ct = 0; ct < P.CT; ++ct) {
+                for (int ct = 0; ct < SHP(CT); ++ct) {
                     f32x4 sc = f4zero();
 #pragma unroll
                     for (int ks = 0; ks < KS1; ++ks) sc = MFMA(gfrag(P.img_unemb, ct * KS1 + ks), xfrag(tile, ks), sc);
@@ -566,6 +675,7 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                 }
             }
         }
+        mark(8, step);
         __syncthreads();   // x of this step is complete before the next step's embed reads it (same wave, but
                            // also fences the fragment region against the next embed's writes)
     }
@@ -574,9 +684,9 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ host side
-template <int KS1, int DT, int KSO, int MT>
+template <int KS1, int DT, int KSO, int MT, class SH>
 static int launch_mega_t(fd_ctx* ctx, const fd_mega_params& P, int grid, size_t lds, hipStream_t s) {
-    auto kern = k_mega<KS1, DT, KSO, MT>;
+    auto kern = k_mega<KS1, DT, KSO, MT, SH>;
     static bool attr = false;
     if (!attr) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -587,10 +697,17 @@ static int launch_mega_t(fd_ctx* ctx, const fd_mega_params& P, int grid, size_t 
     return FD_OK;
 }
 
+// BASELINE.json configs[1]: ecg-synth (T=100, C=12), default transformer, 2 series per workgroup, 2 head groups
+using ShapeEcg = ShapeStatic<100, 72, 12, 12, 2, 3, 2, 10, 2048>;
+
 int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int kso, int mt, int grid, size_t lds,
                    hipStream_t s) {
+    if (!getenv("FDIFF_MEGA_GENERIC") && ks1 == 3 && dt == 5 && kso == 3 && mt == 4 && P.T == ShapeEcg::T &&
+        P.D == ShapeEcg::D && P.C == ShapeEcg::C && P.H == ShapeEcg::H && P.S == ShapeEcg::S && P.NPG == ShapeEcg::NPG &&
+        P.rot == ShapeEcg::rot && P.L == ShapeEcg::L && P.F == ShapeEcg::F)
+        return launch_mega_t<3, 5, 3, 4, ShapeEcg>(ctx, P, grid, lds, s);
 #define FD_MEGA_CASE(K, T_, O, M_)                                                                 \
-    if (ks1 == K && dt == T_ && kso == O && mt == M_) return launch_mega_t<K, T_, O, M_>(ctx, P, grid, lds, s);
+    if (ks1 == K && dt == T_ && kso == O && mt == M_) return launch_mega_t<K, T_, O, M_, ShapeDyn>(ctx, P, grid, lds, s);
 #define FD_MEGA_MT(K, T_, O) FD_MEGA_CASE(K, T_, O, 1) FD_MEGA_CASE(K, T_, O, 2) FD_MEGA_CASE(K, T_, O, 3) FD_MEGA_CASE(K, T_, O, 4)
     FD_MEGA_MT(3, 5, 3)   // d_model 72, 12 heads (hydra default)
     FD_MEGA_MT(2, 4, 3)   // d_model 60, 12 heads (class default)

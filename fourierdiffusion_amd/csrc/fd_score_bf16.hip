@@ -46,6 +46,8 @@ struct fd_bf16_images {
     size_t off_emb = 0, off_unemb = 0, off_layers = 0, layer_stride = 0;
     size_t off_wk = 0, off_wv = 0, off_wq = 0, off_wo = 0, off_ffn = 0;
     fd_mega_layer_f32* layer_tab = nullptr;   // device [L]
+    float* stash = nullptr;                   // residual stash of the persistent kernel (grown on demand)
+    size_t stash_bytes = 0;
 };
 
 namespace {
@@ -481,6 +483,7 @@ void fd_bf16_destroy(fd_score* m) {
     if (m->bf16->ffn) (void)hipFree(m->bf16->ffn);
     if (m->bf16->mimg) (void)hipFree(m->bf16->mimg);
     if (m->bf16->layer_tab) (void)hipFree(m->bf16->layer_tab);
+    if (m->bf16->stash) (void)hipFree(m->bf16->stash);
     delete m->bf16;
     m->bf16 = nullptr;
 }
@@ -554,7 +557,7 @@ static MegaPlan plan_mega(const fd_score* m, int B) {
             // FFN ring buffer 0 is filled while the out-proj still reads afr: it must fit in front of afr
             const size_t front = std::max(wkv, half_ring);
             const size_t mid = std::max(front + afr, std::max(ring, xch));
-            const size_t temb = ((size_t)2 * S * D * sizeof(float) + 15) & ~size_t(15);
+            const size_t temb = ((size_t)(2 * S + 6) * D * sizeof(float) + 15) & ~size_t(15);
             const size_t total = xfr + mid + temb;
             if (total > 160 * 1024) continue;
             pl.ok = true;
@@ -580,9 +583,17 @@ static MegaPlan plan_mega(const fd_score* m, int B) {
     return pl;
 }
 
-static void fill_mega_params(const fd_score* m, const MegaPlan& pl, int B, fd_mega_params& P) {
-    const fd_bf16_images* im = m->bf16;
+static int fill_mega_params(const fd_score* m, const MegaPlan& pl, int B, fd_mega_params& P) {
+    fd_bf16_images* im = m->bf16;
     memset(&P, 0, sizeof P);
+    const size_t need = (size_t)pl.grid * 8 * 2 * im->dt * 64 * sizeof(float) * 4;
+    if (need > im->stash_bytes) {
+        if (im->stash) { (void)hipDeviceSynchronize(); (void)hipFree(im->stash); im->stash = nullptr; im->stash_bytes = 0; }
+        if (hipMalloc((void**)&im->stash, need) != hipSuccess)
+            return fd_fail(m->ctx, FD_ERR_HIP, "persistent kernel: hipMalloc of the residual stash (%zu B) failed", need);
+        im->stash_bytes = need;
+    }
+    P.stash = im->stash;
     P.B = B; P.T = m->d.max_len; P.KT = pl.KT; P.C = m->d.n_channels; P.D = m->d.d_model; P.H = m->d.n_head;
     P.hd = P.D / P.H; P.L = m->d.num_layers; P.F = m->d.dim_ff;
     if (const char* d2 = getenv("FDIFF_MEGA_DBG")) P.dbg = atoi(d2);
@@ -597,6 +608,7 @@ static void fill_mega_params(const fd_score* m, const MegaPlan& pl, int B, fd_me
     P.img_layers = im->mimg + im->off_layers;
     P.layer_stride = im->layer_stride;
     P.off_wk = im->off_wk; P.off_wv = im->off_wv; P.off_wq = im->off_wq; P.off_wo = im->off_wo; P.off_ffn = im->off_ffn;
+    return FD_OK;
 }
 
 // fd_score_f32.hip kernels reused by the hybrid path
@@ -618,7 +630,7 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
         const MegaPlan pl = plan_mega(m, B);
         if (pl.ok && !getenv("FDIFF_NO_MEGA")) {
             fd_mega_params MP;
-            fill_mega_params(m, pl, B, MP);
+            if (int rc = fill_mega_params(m, pl, B, MP)) return rc;
             MP.mode = FD_MEGA_FORWARD;
             MP.nsteps = 1;
             MP.x = const_cast<float*>(x);
@@ -690,7 +702,7 @@ int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, c
     // pageable source: the runtime stages the copy before returning, so `tab` may go out of scope
     FD_HIP(ctx, hipMemcpyAsync(ctx->ws, tab.data(), sizeof(fd_sde_step_coef) * (size_t)n_steps, hipMemcpyHostToDevice, s));
     fd_mega_params MP;
-    fill_mega_params(m, pl, B, MP);
+    if (int rc = fill_mega_params(m, pl, B, MP)) return rc;
     MP.mode = FD_MEGA_SAMPLE;
     MP.nsteps = n_steps;
     MP.x = x;
@@ -701,5 +713,39 @@ int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, c
     MP.offset = offset;
     MP.n_elem = (unsigned long long)B * m->d.max_len * m->d.n_channels;
     MP.ctr_per_step = (MP.n_elem + 3) / 4;
+    if (getenv("FDIFF_MEGA_PROF")) {      // profiling aid: per-phase cycle breakdown of workgroup 0 / wave 0
+        const size_t nent = 4096;
+        unsigned long long* pb = nullptr;
+        FD_HIP(ctx, hipMalloc((void**)&pb, nent * 16));
+        FD_HIP(ctx, hipMemsetAsync(pb, 0xff, nent * 16, s));
+        MP.prof = pb;
+        int rc = fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.grid, pl.lds, s);
+        FD_HIP(ctx, hipStreamSynchronize(s));
+        std::vector<unsigned long long> hb(nent * 2);
+        FD_HIP(ctx, hipMemcpy(hb.data(), pb, nent * 16, hipMemcpyDeviceToHost));
+        (void)hipFree(pb);
+        static const char* names[] = {"step begin->", "time-embed+embed", "K proj (+DMA)", "V proj (+DMA)", "Q DMA + attention",
+                                      "out-proj + LN1", "FFN loop", "FFN combine + LN2", "unembed + SDE",
+                                      " op: ->tile0 start", " op: unpark+MFMA+add", " op: layer_norm", " op: write frags+park", " op: tile1 (all)"};
+        double acc[14] = {0};
+        unsigned long long prev = 0, first = 0, last = 0;
+        size_t n = 0;
+        for (; n < nent && hb[2 * n] != ~0ull; ++n) {
+            const int ph = (int)hb[2 * n];
+            const unsigned long long tm = hb[2 * n + 1];
+            if (n == 0) first = tm;
+            else if (ph >= 1 && ph <= 13) acc[ph] += (double)(tm - prev);
+            prev = tm;
+            last = tm;
+        }
+        int steps_seen = 0;
+        for (size_t i = 0; i < n; ++i) steps_seen += (hb[2 * i] == 0);
+        fprintf(stderr, "[fdiff prof] S=%d npg=%d mt=%d rot=%d lds=%zu: %d steps, %.0f cycles/step\n", pl.S, pl.npg, pl.mt, pl.rot,
+                pl.lds, steps_seen, (double)(last - first) / std::max(1, steps_seen));
+        for (int ph = 1; ph <= 13; ++ph)
+            fprintf(stderr, "[fdiff prof]   %-22s %10.0f cycles/step  %5.1f%%\n", names[ph], acc[ph] / std::max(1, steps_seen),
+                    100.0 * acc[ph] / std::max(1.0, (double)(last - first)));
+        return rc;
+    }
     return fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.grid, pl.lds, s);
 }
