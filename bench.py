@@ -34,6 +34,18 @@ def flops_per_series_forward(T=T, C=CH, D=D, L=L, F=F):
     return T * (L * (2 * D * 3 * D + 2 * D * D + 4 * D * F + 4 * T * D) + 4 * C * D) + 2 * D * D
 
 
+def hbm_traffic_per_launch():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_hbm_traffic.json,
+    collected with separate rocprofv3 --pmc runs of this same command; FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md).  None when no measurement is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def cpu_baseline(batch: int, n_timed: int = 3):
     """The reference's CPU path = the same torch-op sequence it executes (nn.TransformerEncoder eval fast path +
     diag_embed/matmul scheduler step), timed on this host's cores by oracle/torch_cpu_baseline.py on a bounded
@@ -110,9 +122,8 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     barrier()
-    prof = hasattr(lib, "fd_prof_begin")
-    if prof:
-        lib.fd_prof_begin(ctx, 16)
+    prof = True
+    _C.check(lib.fd_prof_begin(ctx), ctx)
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
@@ -156,11 +167,11 @@ def main():
             flops = C.c_double(0)
             name = C.create_string_buffer(128)
             if lib.fd_prof_end(ctx, name, C.byref(avg_us), C.byref(cnt), C.byref(flops)) == 0 and cnt.value > 0:
-                peak = 2500.0 if args.precision == "bf16" else 157.3
+                peak = 2500.0 if args.precision == "bf16" else 157.3     # dense MFMA peak, MI355X_MICROARCH.md
                 ach = flops.value / (avg_us.value * 1e-6) / 1e12
                 roof = {"bound": "mfma", "kernel": name.value.decode(), "achieved": ach, "peak": peak,
-                        "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                        "avg_kernel_us": avg_us.value, "launches_sampled": cnt.value,
+                        "unit": "TFLOP/s", "frac": ach / peak, "traffic": hbm_traffic_per_launch(),
+                        "avg_kernel_us": avg_us.value, "launches_timed": cnt.value,
                         "flops_per_launch": flops.value}
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/fdiff_hip.h"
@@ -21,6 +22,30 @@ struct fd_ctx {
     void* comm = nullptr;   // ncclComm_t when fd_comm_init succeeded
     int rank = 0, nranks = 1;
     int num_cu = 256;
+    // measurement hooks (fd_prof_begin / fd_prof_end)
+    bool prof_on = false;
+    std::string prof_name;
+    double prof_flops = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+};
+
+// Bracket one launch of the dominant kernel with events on its stream (no-op unless profiling is on).
+struct fd_prof_scope {
+    fd_ctx* ctx;
+    hipStream_t s;
+    hipEvent_t a = nullptr, b = nullptr;
+    fd_prof_scope(fd_ctx* c, hipStream_t st, const char* name, double flops) : ctx(c), s(st) {
+        if (!ctx->prof_on || ctx->prof_events.size() >= 4096) { ctx = nullptr; return; }
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { ctx = nullptr; return; }
+        ctx->prof_name = name;
+        ctx->prof_flops = flops;
+        (void)hipEventRecord(a, s);
+    }
+    ~fd_prof_scope() {
+        if (!ctx) return;
+        (void)hipEventRecord(b, s);
+        ctx->prof_events.emplace_back(a, b);
+    }
 };
 
 inline int fd_fail(fd_ctx* ctx, int code, const char* fmt, ...) {

@@ -45,3 +45,39 @@ int fd_ws_reserve(fd_ctx* ctx, size_t bytes) {
     ctx->ws_bytes = want;
     return FD_OK;
 }
+
+extern "C" int fd_prof_begin(fd_ctx* ctx) {
+    if (!ctx) return FD_ERR_ARG;
+    for (auto& e : ctx->prof_events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    ctx->prof_events.clear();
+    ctx->prof_name.clear();
+    ctx->prof_flops = 0.0;
+    ctx->prof_on = true;
+    return FD_OK;
+}
+
+extern "C" int fd_prof_end(fd_ctx* ctx, char* name_out, double* avg_us, int* launches, double* flops_per_launch) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, name_out && avg_us && launches && flops_per_launch, "fd_prof_end: null output");
+    ctx->prof_on = false;
+    double total_ms = 0.0;
+    int n = 0;
+    for (auto& e : ctx->prof_events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+            total_ms += ms;
+            ++n;
+        }
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    ctx->prof_events.clear();
+    snprintf(name_out, 128, "%s", ctx->prof_name.c_str());
+    *launches = n;
+    *avg_us = n ? 1e3 * total_ms / n : 0.0;
+    *flops_per_launch = ctx->prof_flops;
+    return FD_OK;
+}

@@ -747,5 +747,11 @@ int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, c
                     100.0 * acc[ph] / std::max(1.0, (double)(last - first)));
         return rc;
     }
-    return fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.grid, pl.lds, s);
+    {
+        // algorithmic flops of this launch: per series per forward x B x n_steps
+        const double T = m->d.max_len, D = m->d.d_model, F = m->d.dim_ff, C = m->d.n_channels, L = m->d.num_layers;
+        const double per_fwd = T * (L * (2 * D * 3 * D + 2 * D * D + 4 * D * F + 4 * T * D) + 4 * C * D) + 2 * D * D;
+        fd_prof_scope scope(ctx, s, "k_mega (persistent score-net + reverse-SDE loop)", per_fwd * B * n_steps);
+        return fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.grid, pl.lds, s);
+    }
 }

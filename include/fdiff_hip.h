@@ -47,6 +47,16 @@ const char* fd_last_error(fd_ctx* ctx);   /* host string, valid until the next c
 /* number of bytes currently held by the ctx workspace (activations, scratch) */
 size_t fd_ctx_workspace_bytes(fd_ctx* ctx);
 
+/* ---------------------------------------------------------- measurement hooks
+ * bench.py's roofline leg: between fd_prof_begin and fd_prof_end the engine brackets every launch of its
+ * dominant kernel (the persistent score-network/sampler kernel; the fused FFN kernel on the step-by-step
+ * fallback path) with HIP events on the launch stream.  fd_prof_end synchronises those events and returns
+ * the kernel name, the average launch duration, the launch count and the ALGORITHMIC flops of one launch
+ * (SURVEY.md 8d formula x series x diffusion steps in the launch; padding flops are not counted). */
+int fd_prof_begin(fd_ctx* ctx);
+int fd_prof_end(fd_ctx* ctx, char* name_out /* >= 128 bytes */, double* avg_us, int* launches,
+                double* flops_per_launch);
+
 /* --------------------------------------------- a1/a2 spectral representation
  * replaces fdiff.utils.fourier.dft   (src/fdiff/utils/fourier.py:8-45)
  *      and fdiff.utils.fourier.idft  (src/fdiff/utils/fourier.py:48-87)
