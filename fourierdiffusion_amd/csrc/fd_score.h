@@ -55,6 +55,7 @@ int fd_score_forward_f32(fd_score* m, const float* x, const float* t, float* out
                          bool train, float dropout_p, uint64_t seed, uint64_t offset);
 size_t fd_score_f32_workspace(const fd_score* m, int B, bool train);
 void fd_score_carve_saved(const fd_score* m, int B, fd_ws& ws, fd_saved& sv);
+size_t fd_score_bwd_workspace(const fd_score* m, int B);   // fd_score_bwd.hip
 
 // fd_score_bf16.hip
 int fd_bf16_create(fd_score* m);

@@ -1,8 +1,386 @@
-// fd_score_bwd.hip -- backward pass of the score network (placeholder).
+// fd_score_bwd.hip -- backward pass of the score network (exact-f32 training path).
+//
+// The reference trains through torch autograd (Lightning `training_step`, src/fdiff/models/score_models.py:96-108);
+// here the gradient of every op of SURVEY.md A.3 is written out: GEMM-shaped pieces reuse fd_gemm_f32.h with
+// transposed strides, the rest (LayerNorm, attention, dropout/relu masks, bias/positional/time-embedding reductions)
+// are the kernels below.  Activations come from the ctx workspace filled by fd_score_forward_train; dropout masks
+// are regenerated from the same Philox counters (never stored).  Gradients accumulate into ONE flat fp32 buffer
+// with the parameter layout (so the data-parallel exchange is one all-reduce).
+#include "fd_gemm_f32.h"
+#include "fd_philox.h"
 #include "fd_score.h"
 
+void fd_dropout_inplace(fd_ctx* ctx, float* x, size_t n, float p, uint64_t seed, uint64_t offset, hipStream_t s);
+uint64_t fd_dropout_site_offset(uint64_t base, int layer, int site);
+
+namespace {
+
+// out[n] += sum_m x[m, n]      (bias gradients)
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, float* __restrict__ out, int M, int N,
+                                                 int rows_per_block) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;                 // 4 row-strands per block
+    const int m0 = blockIdx.y * rows_per_block;
+    const int m1 = min(M, m0 + rows_per_block);
+    float acc = 0.f;
+    if (n < N)
+        for (int m = m0 + sub; m < m1; m += 4) acc += x[(size_t)m * N + n];
+    __shared__ float red[4][64];
+    red[sub][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (sub == 0 && n < N) atomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// LayerNorm backward.  y = (x - mean) * rstd * gamma + beta, x = pre-norm sum saved by the forward.
+//   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+//   dgamma += sum_tokens dy * xhat ; dbeta += sum_tokens dy
+// One wave per token, 4 tokens per block pass; per-block partial parameter gradients go through LDS.
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ x,
+                                                 const float* __restrict__ mr, const float* __restrict__ gamma,
+                                                 float* __restrict__ dx, float* __restrict__ dgamma,
+                                                 float* __restrict__ dbeta, int M, int D, int tokens_per_block) {
+    extern __shared__ float sh[];          // [2][D] partial dgamma, dbeta
+    for (int i = threadIdx.x; i < 2 * D; i += 256) sh[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * tokens_per_block;
+    const int m1 = min(M, m0 + tokens_per_block);
+    for (int m = m0 + w; m < m1; m += 4) {
+        const float mean = mr[(size_t)m * 2], rstd = mr[(size_t)m * 2 + 1];
+        float g[16], xh[16];
+        float sg = 0.f, sgx = 0.f;
+        int n = 0;
+        for (int d = lane; d < D; d += 64, ++n) {
+            const float dyv = dy[(size_t)m * D + d];
+            xh[n] = (x[(size_t)m * D + d] - mean) * rstd;
+            g[n] = dyv * gamma[d];
+            sg += g[n];
+            sgx += g[n] * xh[n];
+            atomicAdd(&sh[d], dyv * xh[n]);
+            atomicAdd(&sh[D + d], dyv);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            sg += __shfl_xor(sg, o);
+            sgx += __shfl_xor(sgx, o);
+        }
+        const float mg = sg / (float)D, mgx = sgx / (float)D;
+        n = 0;
+        for (int d = lane; d < D; d += 64, ++n) dx[(size_t)m * D + d] = rstd * (g[n] - mg - xh[n] * mgx);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += 256) {
+        atomicAdd(dgamma + i, sh[i]);
+        atomicAdd(dbeta + i, sh[D + i]);
+    }
+}
+
+// d(relu + inverted dropout): g *= (act != 0) / (1 - p)  (act = drop(relu(.)): nonzero <=> kept and positive)
+__global__ __launch_bounds__(256) void k_relu_drop_bwd(float* __restrict__ g, const float* __restrict__ act, size_t n,
+                                                        float inv_keep) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        g[i] = (act[i] != 0.f) ? g[i] * inv_keep : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_add_inplace(float* __restrict__ a, const float* __restrict__ b, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a[i] += b[i];
+}
+
+// Dq[b,h,q] = sum_d dO[q, h, d] * O[q, h, d]   (row term of the softmax Jacobian)
+__global__ __launch_bounds__(256) void k_attn_rowdot(const float* __restrict__ dO, const float* __restrict__ O,
+                                                      float* __restrict__ Dq, int B, int T, int H, int hd) {
+    const size_t id = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (id >= (size_t)B * H * T) return;
+    const int q = (int)(id % T), h = (int)((id / T) % H), b = (int)(id / ((size_t)T * H));
+    const size_t base = ((size_t)b * T + q) * (H * hd) + h * hd;
+    float a = 0.f;
+    for (int d = 0; d < hd; ++d) a = fmaf(dO[base + d], O[base + d], a);
+    Dq[id] = a;
+}
+
+__device__ __forceinline__ float drop_keep(float drop_p, uint64_t seed, uint64_t offset, int bh, int T, int q, int key,
+                                           float keep_scale) {
+    if (drop_p <= 0.f) return 1.0f;
+    const int groups_per_row = (T + 3) / 4;
+    const uint64_t grp = (((uint64_t)bh * T + q) * groups_per_row) + key / 4;
+    const fd_u4 r = fd_philox4x32_10(offset + grp, seed);
+    const uint32_t rv = (key & 3) == 0 ? r.x : (key & 3) == 1 ? r.y : (key & 3) == 2 ? r.z : r.w;
+    return (fd_u01(rv) >= drop_p) ? keep_scale : 0.f;
+}
+
+// dq: thread per query, keys/values streamed through LDS.  dS = P * (dP - Dq), dq = scale * dS . K
+template <int HDP>
+__global__ __launch_bounds__(64) void k_attn_bwd_q(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                                    const float* __restrict__ lse, const float* __restrict__ Dq,
+                                                    float* __restrict__ dqkv, int T, int H, int hd, float scale,
+                                                    float drop_p, uint64_t seed, uint64_t offset) {
+    constexpr int KT = 32;
+    __shared__ float Ks[KT][HDP];
+    __shared__ float Vs[KT][HDP];
+    const int D = H * hd;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    const bool active = q < T;
+    const size_t row0 = (size_t)b * T;
+    float qr[HDP], dor[HDP], dq[HDP];
+#pragma unroll
+    for (int d = 0; d < HDP; ++d) { qr[d] = 0.f; dor[d] = 0.f; dq[d] = 0.f; }
+    float L = 0.f, Dv = 0.f;
+    if (active) {
+        const float* qp = qkv + (row0 + q) * 3 * D + h * hd;
+        const float* dp = dO + (row0 + q) * D + h * hd;
+        for (int d = 0; d < hd; ++d) { qr[d] = qp[d] * scale; dor[d] = dp[d]; }
+        L = lse[((size_t)b * H + h) * T + q];
+        Dv = Dq[((size_t)b * H + h) * T + q];
+    }
+    const float keep_scale = (drop_p > 0.f) ? 1.0f / (1.0f - drop_p) : 1.0f;
+    for (int k0 = 0; k0 < T; k0 += KT) {
+        const int kn = min(KT, T - k0);
+        __syncthreads();
+        for (int id = threadIdx.x; id < KT * HDP; id += 64) {
+            const int j = id / HDP, d = id % HDP;
+            float kv = 0.f, vv = 0.f;
+            if (j < kn && d < hd) {
+                const float* base = qkv + (row0 + k0 + j) * 3 * D + h * hd + d;
+                kv = base[D];
+                vv = base[2 * D];
+            }
+            Ks[j][d] = kv;
+            Vs[j][d] = vv;
+        }
+        __syncthreads();
+        for (int j = 0; j < kn; ++j) {
+            float s = 0.f, dpd = 0.f;
+#pragma unroll
+            for (int d = 0; d < HDP; ++d) {
+                s = fmaf(qr[d], Ks[j][d], s);
+                dpd = fmaf(dor[d], Vs[j][d], dpd);
+            }
+            const float p = expf(s - L);
+            const float keep = drop_keep(drop_p, seed, offset, b * H + h, T, active ? q : 0, k0 + j, keep_scale);
+            const float ds = p * (keep * dpd - Dv);
+#pragma unroll
+            for (int d = 0; d < HDP; ++d) dq[d] = fmaf(ds, Ks[j][d], dq[d]);
+        }
+    }
+    if (active) {
+        float* out = dqkv + (row0 + q) * 3 * D + h * hd;
+        for (int d = 0; d < hd; ++d) out[d] = dq[d] * scale;
+    }
+}
+
+// dk, dv: thread per key, queries streamed through LDS.
+template <int HDP>
+__global__ __launch_bounds__(64) void k_attn_bwd_kv(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                                     const float* __restrict__ lse, const float* __restrict__ Dq,
+                                                     float* __restrict__ dqkv, int T, int H, int hd, float scale,
+                                                     float drop_p, uint64_t seed, uint64_t offset) {
+    constexpr int QT = 32;
+    __shared__ float Qs[QT][HDP];
+    __shared__ float dOs[QT][HDP];
+    __shared__ float Ls[QT], Ds[QT];
+    const int D = H * hd;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int key = blockIdx.x * 64 + threadIdx.x;
+    const bool active = key < T;
+    const size_t row0 = (size_t)b * T;
+    float kr[HDP], vr[HDP], dk[HDP], dv[HDP];
+#pragma unroll
+    for (int d = 0; d < HDP; ++d) { kr[d] = 0.f; vr[d] = 0.f; dk[d] = 0.f; dv[d] = 0.f; }
+    if (active) {
+        const float* kp = qkv + (row0 + key) * 3 * D + h * hd;
+        for (int d = 0; d < hd; ++d) { kr[d] = kp[D + d]; vr[d] = kp[2 * D + d]; }
+    }
+    const float keep_scale = (drop_p > 0.f) ? 1.0f / (1.0f - drop_p) : 1.0f;
+    for (int q0 = 0; q0 < T; q0 += QT) {
+        const int qn = min(QT, T - q0);
+        __syncthreads();
+        for (int id = threadIdx.x; id < QT * HDP; id += 64) {
+            const int j = id / HDP, d = id % HDP;
+            float qv = 0.f, dv_ = 0.f;
+            if (j < qn && d < hd) {
+                qv = qkv[(row0 + q0 + j) * 3 * D + h * hd + d] * scale;
+                dv_ = dO[(row0 + q0 + j) * D + h * hd + d];
+            }
+            Qs[j][d] = qv;
+            dOs[j][d] = dv_;
+        }
+        if (threadIdx.x < QT) {
+            const int j = threadIdx.x;
+            Ls[j] = (j < qn) ? lse[((size_t)b * H + h) * T + q0 + j] : 0.f;
+            Ds[j] = (j < qn) ? Dq[((size_t)b * H + h) * T + q0 + j] : 0.f;
+        }
+        __syncthreads();
+        for (int j = 0; j < qn; ++j) {
+            float s = 0.f, dpd = 0.f;
+#pragma unroll
+            for (int d = 0; d < HDP; ++d) {
+                s = fmaf(Qs[j][d], kr[d], s);
+                dpd = fmaf(dOs[j][d], vr[d], dpd);
+            }
+            const float p = expf(s - Ls[j]);
+            const float keep = drop_keep(drop_p, seed, offset, b * H + h, T, q0 + j, active ? key : 0, keep_scale);
+            const float pd = p * keep;                        // dropped / rescaled probability
+            const float ds = p * (keep * dpd - Ds[j]);
+#pragma unroll
+            for (int d = 0; d < HDP; ++d) {
+                dv[d] = fmaf(pd, dOs[j][d], dv[d]);
+                dk[d] = fmaf(ds, Qs[j][d], dk[d]);          // Qs already carries the softmax scale
+            }
+        }
+    }
+    if (active) {
+        float* out = dqkv + (row0 + key) * 3 * D + h * hd;
+        for (int d = 0; d < hd; ++d) {
+            out[D + d] = dk[d];
+            out[2 * D + d] = dv[d];
+        }
+    }
+}
+
+// dpos[t, :] += sum_b dh[b, t, :] ; dtemb[b, :] = sum_t dh[b, t, :]
+__global__ __launch_bounds__(256) void k_embed_reduce(const float* __restrict__ dh, float* __restrict__ dpos,
+                                                       float* __restrict__ dtemb, int B, int T, int D) {
+    const size_t id = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (id < (size_t)T * D) {
+        const int t = (int)(id / D), d = (int)(id % D);
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += dh[((size_t)b * T + t) * D + d];
+        dpos[id] += a;
+    }
+    if (id < (size_t)B * D) {
+        const int b = (int)(id / D), d = (int)(id % D);
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += dh[((size_t)b * T + t) * D + d];
+        dtemb[id] = a;
+    }
+}
+
+inline unsigned ew_grid(fd_ctx* ctx, size_t n) {
+    size_t b = (n + 255) / 256;
+    const size_t cap = (size_t)ctx->num_cu * 8;
+    return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+void colsum(fd_ctx* ctx, const float* x, float* out, int M, int N, hipStream_t s) {
+    const int rows_per_block = 512;
+    dim3 grid((N + 63) / 64, (M + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL(k_colsum, grid, dim3(256), 0, s, x, out, M, N, rows_per_block);
+    (void)ctx;
+}
+
+void ln_bwd(fd_ctx* ctx, const float* dy, const float* x, const float* mr, const float* gamma, float* dx, float* dgamma,
+            float* dbeta, int M, int D, hipStream_t s) {
+    const int tokens_per_block = 64;
+    hipLaunchKernelGGL(k_ln_bwd, dim3((M + tokens_per_block - 1) / tokens_per_block), dim3(256), 2 * D * sizeof(float), s,
+                       dy, x, mr, gamma, dx, dgamma, dbeta, M, D, tokens_per_block);
+    (void)ctx;
+}
+
+template <int HDP>
+void attn_bwd_t(const float* qkv, const float* dO, const float* lse, const float* Dq, float* dqkv, int B, int T, int H,
+                int hd, float p, uint64_t seed, uint64_t offset, hipStream_t s) {
+    dim3 grid((T + 63) / 64, H, B);
+    const float scale = 1.0f / sqrtf((float)hd);
+    hipLaunchKernelGGL((k_attn_bwd_q<HDP>), grid, dim3(64), 0, s, qkv, dO, lse, Dq, dqkv, T, H, hd, scale, p, seed, offset);
+    hipLaunchKernelGGL((k_attn_bwd_kv<HDP>), grid, dim3(64), 0, s, qkv, dO, lse, Dq, dqkv, T, H, hd, scale, p, seed, offset);
+}
+
+}  // namespace
+
+size_t fd_score_bwd_workspace(const fd_score* m, int B) {
+    const size_t M = (size_t)B * m->d.max_len, D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, T = m->d.max_len;
+    auto fl = [](size_t n) { return fd_ws::padded(n * sizeof(float)); };
+    return 3 * fl(M * D) + fl(M * F) + fl(M * 3 * D) + fl((size_t)B * H * T) + fl((size_t)B * D) + 4096;
+}
+
 extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, int accumulate, void* stream) {
-    (void)dout; (void)grads; (void)accumulate; (void)stream;
     if (!m) return FD_ERR_ARG;
-    return fd_fail(m->ctx, FD_ERR_UNSUPPORTED, "backward not built yet");
+    fd_ctx* ctx = m->ctx;
+    FD_REQUIRE(ctx, dout && grads, "fd_score_backward: null pointer");
+    if (!m->have_saved) return fd_fail(ctx, FD_ERR_STATE, "fd_score_backward: no training forward to differentiate");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = m->saved_B;
+    const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model, H = m->d.n_head, F = m->d.dim_ff;
+    const int L = m->d.num_layers, hd = D / H;
+    const int M = B * T;
+    const float p = m->saved_p;
+    const float* P = m->params;
+    // the training forward reserved room for both carve-outs; re-derive the same pointers
+    const size_t fwd_bytes = fd_score_f32_workspace(m, B, true);
+    if (ctx->ws_bytes < fwd_bytes + fd_score_bwd_workspace(m, B))
+        return fd_fail(ctx, FD_ERR_STATE, "fd_score_backward: workspace was resized since the training forward");
+    fd_ws ws(ctx);
+    fd_saved sv;
+    fd_score_carve_saved(m, B, ws, sv);
+    ws.off = fwd_bytes;
+    float* dh = ws.take<float>((size_t)M * D);
+    float* ds = ws.take<float>((size_t)M * D);
+    float* tmp = ws.take<float>((size_t)M * D);
+    float* dact = ws.take<float>((size_t)M * F);
+    float* dqkv = ws.take<float>((size_t)M * 3 * D);
+    float* Dq = ws.take<float>((size_t)B * H * T);
+    float* dtemb = ws.take<float>((size_t)B * D);
+
+    if (!accumulate) FD_HIP(ctx, hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->nparams, s));
+    const float inv_keep = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
+
+    // ---- unembedder: out = hL Wu^T + bu
+    fdgemm::linear_bwd_weight(dout, sv.hL, grads + m->un_w, M, C, D, true, s);
+    colsum(ctx, dout, grads + m->un_b, M, C, s);
+    fdgemm::linear_bwd_input(dout, P + m->un_w, dh, M, C, D, false, s);
+
+    for (int i = L - 1; i >= 0; --i) {
+        const fd_layer_off& lo = m->layers[i];
+        const fd_saved_layer& A = sv.layers[i];
+        // x_next = LN2(s2): dh -> ds (= d s2)
+        ln_bwd(ctx, dh, A.s2, A.mr2, P + lo.n2_w, ds, grads + lo.n2_w, grads + lo.n2_b, M, D, s);
+        // s2 = x1 + drop(f2), f2 = hact W2^T + b2
+        FD_HIP(ctx, hipMemcpyAsync(tmp, ds, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, s));
+        fd_dropout_inplace(ctx, tmp, (size_t)M * D, p, m->saved_seed, fd_dropout_site_offset(m->saved_offset, i, 3), s);
+        fdgemm::linear_bwd_weight(tmp, A.hact, grads + lo.l2_w, M, D, F, true, s);
+        colsum(ctx, tmp, grads + lo.l2_b, M, D, s);
+        fdgemm::linear_bwd_input(tmp, P + lo.l2_w, dact, M, D, F, false, s);
+        // hact = drop(relu(x1 W1^T + b1))
+        hipLaunchKernelGGL(k_relu_drop_bwd, dim3(ew_grid(ctx, (size_t)M * F)), dim3(256), 0, s, dact, A.hact, (size_t)M * F,
+                           inv_keep);
+        fdgemm::linear_bwd_weight(dact, A.x1, grads + lo.l1_w, M, F, D, true, s);
+        colsum(ctx, dact, grads + lo.l1_b, M, F, s);
+        fdgemm::linear_bwd_input(dact, P + lo.l1_w, ds, M, F, D, true, s);        // ds = d x1 (residual + FFN branch)
+        // x1 = LN1(s1): ds -> dh (= d s1)
+        ln_bwd(ctx, ds, A.s1, A.mr1, P + lo.n1_w, dh, grads + lo.n1_w, grads + lo.n1_b, M, D, s);
+        // s1 = x0 + drop(proj), proj = att Wo^T + bo
+        FD_HIP(ctx, hipMemcpyAsync(tmp, dh, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, s));
+        fd_dropout_inplace(ctx, tmp, (size_t)M * D, p, m->saved_seed, fd_dropout_site_offset(m->saved_offset, i, 1), s);
+        fdgemm::linear_bwd_weight(tmp, A.att, grads + lo.out_w, M, D, D, true, s);
+        colsum(ctx, tmp, grads + lo.out_b, M, D, s);
+        fdgemm::linear_bwd_input(tmp, P + lo.out_w, ds, M, D, D, false, s);      // ds = d att
+        // attention core
+        {
+            const size_t n = (size_t)B * H * T;
+            hipLaunchKernelGGL(k_attn_rowdot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ds, A.att, Dq, B, T, H, hd);
+            const uint64_t off0 = fd_dropout_site_offset(m->saved_offset, i, 0);
+            if (hd <= 8) attn_bwd_t<8>(A.qkv, ds, A.lse, Dq, dqkv, B, T, H, hd, p, m->saved_seed, off0, s);
+            else if (hd <= 16) attn_bwd_t<16>(A.qkv, ds, A.lse, Dq, dqkv, B, T, H, hd, p, m->saved_seed, off0, s);
+            else if (hd <= 32) attn_bwd_t<32>(A.qkv, ds, A.lse, Dq, dqkv, B, T, H, hd, p, m->saved_seed, off0, s);
+            else attn_bwd_t<64>(A.qkv, ds, A.lse, Dq, dqkv, B, T, H, hd, p, m->saved_seed, off0, s);
+        }
+        // qkv = x0 Win^T + bin
+        fdgemm::linear_bwd_weight(dqkv, A.x0, grads + lo.in_w, M, 3 * D, D, true, s);
+        colsum(ctx, dqkv, grads + lo.in_b, M, 3 * D, s);
+        fdgemm::linear_bwd_input(dqkv, P + lo.in_w, dh, M, 3 * D, D, true, s);   // dh = d x0 (residual + attention branch)
+    }
+
+    // ---- embed: h0 = X We^T + be + pe[t] + temb[b]
+    fdgemm::linear_bwd_weight(dh, m->saved_x, grads + m->emb_w, M, D, C, true, s);
+    colsum(ctx, dh, grads + m->emb_b, M, D, s);
+    {
+        const size_t n = std::max((size_t)T * D, (size_t)B * D);
+        hipLaunchKernelGGL(k_embed_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dh, grads + m->pos, dtemb, B, T,
+                           D);
+    }
+    // temb = emb Wd^T + bd   (time_encoder.W is frozen: transformer.py:72-74)
+    fdgemm::linear_bwd_weight(dtemb, sv.emb, grads + m->td_w, B, D, D, true, s);
+    colsum(ctx, dtemb, grads + m->td_b, B, D, s);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
 }

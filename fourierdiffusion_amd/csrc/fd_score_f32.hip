@@ -412,7 +412,9 @@ int fd_score_forward_f32(fd_score* m, const float* x, const float* t, float* out
     const int L = m->d.num_layers, hd = D / H;
     const int M = B * T;
     const float* P = m->params;
-    if (int rc = fd_ws_reserve(ctx, fd_score_f32_workspace(m, B, train))) return rc;
+    // a training forward also reserves the backward pass's scratch: growing the arena later would move it
+    if (int rc = fd_ws_reserve(ctx, fd_score_f32_workspace(m, B, train) + (train ? fd_score_bwd_workspace(m, B) : 0)))
+        return rc;
     fd_ws ws(ctx);
     fd_saved sv;
     fd_saved_layer scratch{};
