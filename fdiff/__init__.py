@@ -1,0 +1,26 @@
+"""`fdiff` -- alias of `fourierdiffusion_amd` so that the reference's dotted paths keep working
+(hydra `_target_: fdiff.models.score_models.ScoreModule`, `fdiff.schedulers.sde.VPScheduler`,
+`fdiff.sampling.sampler.DiffusionSampler`, ... )."""
+import importlib
+import sys
+
+import fourierdiffusion_amd as _pkg
+
+_SUBMODULES = [
+    "utils", "utils.dataclasses", "utils.fourier", "utils.losses", "utils.extraction", "utils.callbacks",
+    "schedulers", "schedulers.sde",
+    "models", "models.score_models", "models.transformer",
+    "sampling", "sampling.sampler",
+    "dataloaders", "dataloaders.datamodules",
+]
+for _name in _SUBMODULES:
+    try:
+        _mod = importlib.import_module(f"fourierdiffusion_amd.{_name}")
+    except ModuleNotFoundError:      # optional pieces
+        continue
+    sys.modules[f"fdiff.{_name}"] = _mod
+    _parent, _, _leaf = _name.rpartition(".")
+    if not _parent:
+        globals()[_leaf] = _mod
+
+__version__ = _pkg.__version__
