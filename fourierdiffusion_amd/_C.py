@@ -60,6 +60,8 @@ _PROTOS = {
     "fd_perturb": (C.c_int, [_vp, C.POINTER(SdeParams), _vp, _vp, _vp, _vp, C.c_uint64, C.c_uint64,
                              _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "fd_dsm_loss": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "fd_positional_add": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
+    "fd_time_embed_add": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "fd_score_param_count": (C.c_int64, [C.POINTER(ModelDims)]),
     "fd_score_layout": (C.c_int, [C.POINTER(ModelDims), C.POINTER(ParamEntry), C.POINTER(C.c_int)]),
     "fd_score_create": (C.c_int, [_vp, C.POINTER(ModelDims), C.POINTER(_vp)]),

@@ -4,6 +4,8 @@
 // (src/fdiff/models/transformer.py:8-29), GaussianFourierProjection (transformer.py:61-91) and
 // torch's nn.TransformerEncoderLayer(batch_first, post-LN, relu, dim_ff) built at
 // score_models.py:57-62.  SURVEY.md A.3 is the op-by-op specification this file follows.
+#include <algorithm>
+
 #include "fd_gemm_f32.h"
 #include "fd_philox.h"
 #include "fd_score.h"
@@ -524,4 +526,46 @@ extern "C" int fd_score_forward_train(fd_score* m, const float* x, const float* 
         m->saved_t = t;
     }
     return rc;
+}
+
+// ------------------------------------------------------------------ stand-alone encoders (transformer.py)
+namespace {
+__global__ __launch_bounds__(256) void k_bcast_add(const float* __restrict__ x, const float* __restrict__ v,
+                                                    float* __restrict__ out, size_t n, int T, int D, int mode) {
+    // mode 0: v is (T,D) indexed by the time position; mode 1: v is (B,D) indexed by the batch element
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int d = (int)(i % D);
+        const size_t row = i / D;
+        const size_t vr = (mode == 0) ? (row % (size_t)T) : (T > 0 ? row / (size_t)T : row);
+        out[i] = x[i] + v[vr * D + d];
+    }
+}
+}  // namespace
+
+extern "C" int fd_positional_add(fd_ctx* ctx, const float* x, float* table, float* out, int B, int T, int D,
+                                 float max_norm, void* stream) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, x && table && out && B > 0 && T > 0 && D > 0, "fd_positional_add: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_renorm_rows, dim3(T), dim3(64), 0, s, table, T, D, max_norm);
+    const size_t n = (size_t)B * T * D;
+    size_t blocks = std::min((n + 255) / 256, (size_t)ctx->num_cu * 8);
+    hipLaunchKernelGGL(k_bcast_add, dim3((unsigned)blocks), dim3(256), 0, s, x, table, out, n, T, D, 0);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
+extern "C" int fd_time_embed_add(fd_ctx* ctx, const float* x, const float* t, const float* W, const float* Wd,
+                                 const float* bd, float* out, int B, int T, int D, void* stream) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, x && t && W && Wd && bd && out && B > 0 && T >= 0 && D > 0, "fd_time_embed_add: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = fd_ws_reserve(ctx, fd_ws::padded((size_t)B * D * sizeof(float)))) return rc;
+    float* temb = (float*)ctx->ws;
+    hipLaunchKernelGGL(k_time_embed, dim3(B), dim3(128), D * sizeof(float), s, t, W, Wd, bd, (float*)nullptr, temb, D);
+    const size_t n = (size_t)B * (T > 0 ? T : 1) * D;
+    size_t blocks = std::min((n + 255) / 256, (size_t)ctx->num_cu * 8);
+    hipLaunchKernelGGL(k_bcast_add, dim3((unsigned)blocks), dim3(256), 0, s, x, temb, out, n, T, D, 1);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
 }

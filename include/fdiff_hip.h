@@ -137,6 +137,17 @@ typedef struct fd_param_entry {
     int32_t rows, cols;   /* cols == 0 for vectors */
     int32_t trainable;    /* 0 for time_encoder.W (requires_grad=False, transformer.py:72-74) */
 } fd_param_entry;
+/* Stand-alone encoders of src/fdiff/models/transformer.py (the fused score network does not call these; they
+ * back the PositionalEncoding / GaussianFourierProjection classes of the fdiff surface):
+ *   fd_positional_add: renorm rows of table (T,D) IN PLACE to max_norm (nn.Embedding(max_norm), :13-15), then
+ *                      out[b,t,:] = x[b,t,:] + table[t,:]                                   (:17-29)
+ *   fd_time_embed_add: e = cat[sin,cos](2*pi*t*W)[:D]; p = e Wd^T + bd; out = x + p (broadcast over the time
+ *                      axis when T > 0; T == 0 means x is (B,D))                            (:77-91) */
+int fd_positional_add(fd_ctx* ctx, const float* x, float* table, float* out, int B, int T, int D, float max_norm,
+                      void* stream);
+int fd_time_embed_add(fd_ctx* ctx, const float* x, const float* t, const float* W, const float* Wd,
+                      const float* bd, float* out, int B, int T, int D, void* stream);
+
 int64_t fd_score_param_count(const fd_model_dims* dims);
 int fd_score_layout(const fd_model_dims* dims, fd_param_entry* entries, int* n_entries);
 
