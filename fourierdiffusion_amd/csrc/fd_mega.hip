@@ -34,7 +34,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 #ifndef FD_XF_REGS
-#define FD_XF_REGS 0     // FFN activation fragments: 1 = registers for the whole phase, 0 = LDS read per use
+#define FD_XF_REGS 1     // FFN activation fragments: 1 = registers for the whole phase, 0 = LDS read per use
 #endif
 #ifndef FD_FOLD_RES
 #define FD_FOLD_RES 1    // start the owner's FFN accumulators from the residual (no extra live registers in the loop)
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
 
     // ---- LDS map
     char* const xfr = smem;                                   // [NTILE][KSX][64][16 B]  activation B fragments
-    char* const wsl = xfr + NTILE * KSX * 1024;               // [NPG][KS1][1 KiB]        W_k / W_v / W_q slot
-    char* const kbf = wsl + NPG * KS1 * 1024;                 // [NPG][NTOK][4][8 B]      K (both heads per pair)
+    char* const wsl = xfr + NTILE * KSX * 1024;               // [3][NPG][KS1][1 KiB]     W_k | W_v | W_q of the group
+    char* const kbf = wsl + 3 * NPG * KS1 * 1024;             // [NPG][NTOK][4][8 B]      K (both heads per pair)
     char* const vbf = kbf + NPG * NTOK * 32;                  // [NPG][S][NJ][4][16][16 B] V^T
     char* const afr = smem + P.lds_afr;                       // [NTILE][KSO][64][16 B]  attention-output fragments
     char* const ring = wsl;                                   // FFN weight ring + exchange alias W/K/V(/afr)
@@ -330,128 +330,126 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
             // -------- attention, one group of head pairs at a time
             for (int pg = 0; pg < NP; pg += NPG) {
                 const int npg = min(NPG, NP - pg);
-                // ---- K projection: K^T rows (pair-major, 8 rows per head) x all token tiles -> kbf
-                dma_blocks(limg + P.off_wk + (size_t)pg * KS1 * 1024, wsl, npg * KS1);
+                // W_k | W_v | W_q of this group in ONE stream (one exposed L2->LDS round trip per group)
+                char* const wk = wsl;
+                char* const wv = wsl + NPG * KS1 * 1024;
+                char* const wq = wsl + 2 * NPG * KS1 * 1024;
+                dma_blocks(limg + P.off_wk + (size_t)pg * KS1 * 1024, wk, npg * KS1);
+                dma_blocks(limg + P.off_wv + (size_t)pg * KS1 * 1024, wv, npg * KS1);
+                dma_blocks(limg + P.off_wq + (size_t)pg * KS1 * 1024, wq, npg * KS1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                // ---- K projection (K^T rows pair-major, 8 rows per head) and V projection (non-transposed, so the
+                //      C tile is already the V^T A-fragment) for every token tile -> kbf / vbf
                 for (int u = wave; u < npg * NTILE; u += 8) {
                     const int pr = u / NTILE, tile = u - pr * NTILE;
-                    f32x4 a = f4zero();
+                    f32x4 a = f4zero(), b = f4zero();
 #pragma unroll
-                    for (int ks = 0; ks < KS1; ++ks)
-                        a = MFMA(*reinterpret_cast<const bf16x8*>(wsl + ((pr * KS1 + ks) * 64 + lane) * 16),
-                                 xfrag(tile, ks), a);
+                    for (int ks = 0; ks < KS1; ++ks) {
+                        const bf16x8 xf = xfrag(tile, ks);
+                        a = MFMA(*reinterpret_cast<const bf16x8*>(wk + ((pr * KS1 + ks) * 64 + lane) * 16), xf, a);
+                        b = MFMA(xf, *reinterpret_cast<const bf16x8*>(wv + ((pr * KS1 + ks) * 64 + lane) * 16), b);
+                    }
                     u32x2 pk = {cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
                     *reinterpret_cast<u32x2*>(kbf + ((size_t)(pr * NTOK + tile * 16 + tok) * 4 + g) * 8) = pk;
-                }
-                __syncthreads();
-                mark(2, step);
-                refresh_lane();
-                // ---- V projection (non-transposed: C rows = tokens) -> vbf as V^T A-fragments
-                dma_blocks(limg + P.off_wv + (size_t)pg * KS1 * 1024, wsl, npg * KS1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                for (int u = wave; u < npg * NTILE; u += 8) {
-                    const int pr = u / NTILE, tile = u - pr * NTILE;
-                    f32x4 a = f4zero();
-#pragma unroll
-                    for (int ks = 0; ks < KS1; ++ks)
-                        a = MFMA(xfrag(tile, ks),
-                                 *reinterpret_cast<const bf16x8*>(wsl + ((pr * KS1 + ks) * 64 + lane) * 16), a);
-                    // lane (col = lane&15, g) holds 4 consecutive tokens (keys) 4g+r of this tile
+                    // V: lane (col = lane&15, g) holds 4 consecutive tokens (keys) 4g+r of this tile
                     const int ser = tile / KT, kt = tile - ser * KT;
-                    u32x2 pk = {cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
+                    u32x2 pv = {cvt_pk_bf16(b[0], b[1]), cvt_pk_bf16(b[2], b[3])};
                     char* dst = vbf + ((size_t)(((pr * S + ser) * NJ + (kt >> 1)) * 4 + g) * 16 + tok) * 16;
-                    *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = pk;
+                    *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = pv;
                     if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
                 }
                 __syncthreads();
                 mark(3, step);
                 refresh_lane();
-                // ---- W_q, then the attention units (query tile x head pair)
-                dma_blocks(limg + P.off_wq + (size_t)pg * KS1 * 1024, wsl, npg * KS1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                // ---- attention units (query tile x head pair)
                 for (int u = wave; u < npg * NTILE; u += 8) {
                     const int pr = u / NTILE, qt = u - pr * NTILE;
                     const int ser = qt / KT;
                     f32x4 qa = f4zero();
 #pragma unroll
                     for (int ks = 0; ks < KS1; ++ks)
-                        qa = MFMA(*reinterpret_cast<const bf16x8*>(wsl + ((pr * KS1 + ks) * 64 + lane) * 16),
+                        qa = MFMA(*reinterpret_cast<const bf16x8*>(wq + ((pr * KS1 + ks) * 64 + lane) * 16),
                                   xfrag(qt, ks), qa);
-                    u32x4 qpk = {cvt_pk_bf16(qa[0], qa[1]), cvt_pk_bf16(qa[2], qa[3]), 0u, 0u};
-                    const bf16x8 qb = __builtin_bit_cast(bf16x8, qpk);   // both heads: even in g<2, odd in g>=2
-                    float o_sel[4] = {0.f, 0.f, 0.f, 0.f};
-                    float l_sel = 1.f;
-                    float m2[2] = {kNegBig, kNegBig}, lsum2[2] = {0.f, 0.f};
+                    // The C tile holds both heads of the pair (even head in lane groups 0-1, odd in 2-3).  Masking
+                    // Q once per unit (instead of every K fragment) selects the head: the K fragment then serves
+                    // both heads unmodified because the other head's k-slots meet zeros.
+                    const bool lo_grp = (g >> 1) == 0;
+                    const unsigned q01 = cvt_pk_bf16(qa[0], qa[1]), q23 = cvt_pk_bf16(qa[2], qa[3]);
+                    const u32x4 qe = {lo_grp ? q01 : 0u, lo_grp ? q23 : 0u, 0u, 0u};
+                    const u32x4 qo = {lo_grp ? 0u : q01, lo_grp ? 0u : q23, 0u, 0u};
+                    const bf16x8 qb[2] = {__builtin_bit_cast(bf16x8, qe), __builtin_bit_cast(bf16x8, qo)};
+                    float m2[2] = {kNegBig, kNegBig};
                     f32x4 o2[2] = {f4zero(), f4zero()};
-                    const bool lo_grp = (g >> 1) == 0;               // lane groups 0-1: even head, 2-3: odd head
                     for (int kb = 0; kb < KT; kb += 8) {
                         // K and V fragments of this 128-key block: one read serves both heads of the pair
-                        u32x2 kr[8];
-                        bf16x8 vf[4];
+                        bf16x8 kf[8], vf[4];
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
-                            if (kb + j < KT)
-                                kr[j] = *reinterpret_cast<const u32x2*>(
+                            if (kb + j < KT) {
+                                const u32x2 kr = *reinterpret_cast<const u32x2*>(
                                     kbf + ((size_t)(pr * NTOK + (ser * KT + kb + j) * 16 + tok) * 4 + g) * 8);
+                                const u32x4 kk = {kr[0], kr[1], 0u, 0u};
+                                kf[j] = __builtin_bit_cast(bf16x8, kk);
+                            }
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj)
                             if ((kb >> 1) + jj < NJ)
                                 vf[jj] = *reinterpret_cast<const bf16x8*>(
                                     vbf + ((size_t)(((pr * S + ser) * NJ + (kb >> 1) + jj) * 4 + g) * 16 + tok) * 16);
+                        f32x4 s[2][8];
 #pragma unroll
-                        for (int hs = 0; hs < 2; ++hs) {
-                            const bool mine = (hs == 0) ? lo_grp : !lo_grp;
-                            f32x4 s[8];
+                        for (int j = 0; j < 8; ++j) {
+                            const int kt = kb + j;
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const int kt = kb + j;
+                            for (int hs = 0; hs < 2; ++hs) {
                                 if (kt < KT) {
-                                    u32x4 kk = {mine ? kr[j][0] : 0u, mine ? kr[j][1] : 0u, 0u, 0u};
-                                    s[j] = MFMA(__builtin_bit_cast(bf16x8, kk), qb, f4zero());
+                                    s[hs][j] = MFMA(kf[j], qb[hs], f4zero());
                                     if (kt == KT - 1) {             // keys beyond T in the ragged last tile
 #pragma unroll
                                         for (int r = 0; r < 4; ++r)
-                                            if (kt * 16 + 4 * g + r >= T) s[j][r] = kNegBig;
+                                            if (kt * 16 + 4 * g + r >= T) s[hs][j][r] = kNegBig;
                                     }
                                 } else {
-                                    s[j] = f32x4{kNegBig, kNegBig, kNegBig, kNegBig};
+                                    s[hs][j] = f32x4{kNegBig, kNegBig, kNegBig, kNegBig};
                                 }
                             }
+                        }
+#pragma unroll
+                        for (int hs = 0; hs < 2; ++hs) {
                             float bm = kNegBig;
 #pragma unroll
                             for (int j = 0; j < 8; ++j)
-                                bm = fmaxf(bm, fmaxf(fmaxf(s[j][0], s[j][1]), fmaxf(s[j][2], s[j][3])));
+                                bm = fmaxf(bm, fmaxf(fmaxf(s[hs][j][0], s[hs][j][1]), fmaxf(s[hs][j][2], s[hs][j][3])));
                             bm = group_max(bm);
                             const float mnew = fmaxf(m2[hs], bm);
                             const float alpha = __builtin_amdgcn_exp2f(m2[hs] - mnew);
-                            float lsum = lsum2[hs] * alpha;
                             f32x4 o = o2[hs] * alpha;
                             m2[hs] = mnew;
 #pragma unroll
                             for (int j = 0; j < 8; ++j)
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const float p = __builtin_amdgcn_exp2f(s[j][r] - mnew);
-                                    s[j][r] = p;
-                                    lsum += p;
-                                }
+                                for (int r = 0; r < 4; ++r) s[hs][j][r] = __builtin_amdgcn_exp2f(s[hs][j][r] - mnew);
+                            // the row sum of P comes out of the same MFMAs: V^T carries a row of ones (dim slot hd)
 #pragma unroll
                             for (int jj = 0; jj < 4; ++jj)
-                                if ((kb >> 1) + jj < NJ) o = MFMA(vf[jj], pack8(s[2 * jj], s[2 * jj + 1]), o);
-                            lsum2[hs] = lsum;
+                                if ((kb >> 1) + jj < NJ) o = MFMA(vf[jj], pack8(s[hs][2 * jj], s[hs][2 * jj + 1]), o);
                             o2[hs] = o;
                         }
                     }
-                    {
-                        const float l0 = group_sum(lsum2[0]), l1 = group_sum(lsum2[1]);
-                        l_sel = lo_grp ? l0 : l1;
+                    // O^T rows 8*hs + [0,8) live in lane groups 2hs, 2hs+1; row 8*hs + hd is sum_j P (ones row)
+                    float o_sel[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o_sel[r] = lo_grp ? o2[0][r] : o2[1][r];
-                    }
-                    const float inv = 1.0f / l_sel;
+                    for (int r = 0; r < 4; ++r) o_sel[r] = lo_grp ? o2[0][r] : o2[1][r];
+                    // hd in [4,7]: the ones row is register hd-4 of the odd lane group; hd < 4: register hd of the even one
+                    // (the shuffle must run with all lanes active: a lane cannot read an exec-masked neighbour)
+                    float cand = o_sel[0];
+#pragma unroll
+                    for (int r = 1; r < 4; ++r) cand = ((hd & 3) == r) ? o_sel[r] : cand;
+                    const float other = __shfl_xor(cand, 16);
+                    const bool holds = (hd >= 4) ? ((g & 1) != 0) : ((g & 1) == 0);
+                    const float lrow = holds ? cand : other;
+                    const float inv = 1.0f / lrow;
                     // head = 2*(pg+pr) + (g>>1); its 8 dims are one 16-B k-slot group of the out-proj B fragment
                     const int head = 2 * (pg + pr) + (g >> 1);
                     u32x2 pk = {cvt_pk_bf16(o_sel[0] * inv, o_sel[1] * inv), cvt_pk_bf16(o_sel[2] * inv, o_sel[3] * inv)};

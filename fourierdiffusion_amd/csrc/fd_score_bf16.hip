@@ -115,6 +115,10 @@ __global__ __launch_bounds__(64) void k_build_image(int kind, const float* __res
                 const int src = (kind - IMG_Q) * D + hd * head + j;          // row of in_proj_weight (3D x D)
                 v = (k < D) ? W[(size_t)src * D + k] : (k == D ? bias[src] : 0.f);
                 v *= scale;
+            } else if (kind == IMG_V && head < H && j == hd) {
+                // "ones" feature: V[token][head, hd] = 1 (through the bias slot), so that the P.V MFMAs also
+                // deliver sum_j P[q, j] (the softmax denominator) in row hd of the head's O^T block
+                v = (k == D) ? 1.f : 0.f;
             }
         } else {   // IMG_WO: k-slot group (ks, g) = head 4ks+g, slot e = head dim
             const int d = 16 * rt + row, head = 4 * ks + g;
@@ -438,7 +442,7 @@ int fd_bf16_create(fd_score* m) {
     im->supported = inst && (D % 4 == 0) && (F % 128 == 0) && L > 0;
     const bool inst_mega = (im->ks1 == 3 && im->dt == 5 && im->kso == 3) || (im->ks1 == 2 && im->dt == 4 && im->kso == 3) ||
                            (im->ks1 == 1 && im->dt == 2 && im->kso == 1) || (im->ks1 == 1 && im->dt == 1 && im->kso == 1);
-    im->mega = im->supported && inst_mega && hd <= 8 && D < 16 * im->dt && C <= 40;
+    im->mega = im->supported && inst_mega && hd <= 7 && D < 16 * im->dt && C <= 40;   // hd <= 7: a free V slot holds the ones row
     m->bf16 = im;
     if (!im->supported) return FD_OK;
     const int NB = 2 * im->ks1 + im->dt;
@@ -553,7 +557,7 @@ static MegaPlan plan_mega(const fd_score* m, int B) {
         const size_t xch = (size_t)4 * mt * im->dt * 1024;
         for (int ng = 1; ng <= NP; ++ng) {                        // head-pair groups: fewer pairs -> smaller K/V
             const int npg = (NP + ng - 1) / ng;
-            const size_t wkv = (size_t)npg * im->ks1 * 1024 + (size_t)npg * NTOK * 32 + (size_t)npg * S * NJ * 4 * 16 * 16;
+            const size_t wkv = (size_t)3 * npg * im->ks1 * 1024 + (size_t)npg * NTOK * 32 + (size_t)npg * S * NJ * 4 * 16 * 16;
             // FFN ring buffer 0 is filled while the out-proj still reads afr: it must fit in front of afr
             const size_t front = std::max(wkv, half_ring);
             const size_t mid = std::max(front + afr, std::max(ring, xch));

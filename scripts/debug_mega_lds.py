@@ -27,7 +27,7 @@ def bf16(u16):
 KT = (T + 15) // 16; S = 1; NTILE = S * KT; NTOK = NTILE * 16; KS1 = 3; KSX = 3; NP = 6; NJ = (KT + 1) // 2
 off_xfr = 0
 off_wsl = NTILE * KSX * 1024
-off_kbf = off_wsl + NP * KS1 * 1024
+off_kbf = off_wsl + 3 * NP * KS1 * 1024
 off_vbf = off_kbf + NP * NTOK * 32
 _, hidden = O.score_forward(sd, X, t, H, return_hidden=True)
 h0 = hidden[0][0]                                  # (T, D) layer-0 input of series 0
@@ -74,7 +74,10 @@ for pair in range(NP):
                     elif key >= KT * 16 and got != 0:
                         print("nonzero V pad", pair, jb, g, d16, e, got)
 print("V max err", verr, "nan in V", np.isnan(vb).sum(), "inf", np.isinf(vb).sum())
-xf = bf16(raw[off_xfr:off_xfr + NTILE * KSX * 1024].view(np.uint16)).reshape(NTILE, KSX, 4, 16, 8)
+off_afr = off_vbf + NP * S * NJ * 4 * 16 * 16
+half_ring = 2 * 2 * 11 * 1024
+off_afr = max(off_afr, off_wsl + half_ring)
+xf = bf16(raw[off_afr:off_afr + NTILE * KSX * 1024].view(np.uint16)).reshape(NTILE, KSX, 4, 16, 8)
 qh = q.reshape(T, H, hd).transpose(1, 0, 2); kh = k.reshape(T, H, hd).transpose(1, 0, 2); vh = v.reshape(T, H, hd).transpose(1, 0, 2)
 sc = qh @ kh.transpose(0, 2, 1) / np.sqrt(hd)
 sc = sc - sc.max(-1, keepdims=True); p = np.exp(sc); p /= p.sum(-1, keepdims=True)
