@@ -527,16 +527,17 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
             mark(5, step);
             refresh_lane();
             // -------- FFN: hidden never leaves registers (see fd_score_bf16.hip)
-            {
+            // The whole phase is instantiated per F-half (FH): which accumulator tiles a wave owns then is a
+            // compile-time fact -- no per-element selects, and accumulators die as soon as they are exchanged
+            // (with a runtime fh hipcc kept all 80 accumulator registers plus both candidates live and spilled).
+            auto ffn_phase = [&](auto fhc) {
+                constexpr int FH = decltype(fhc)::value;
                 f32x4 acc[DT][MT];
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int tt = 0; tt < MT; ++tt) {
-                        // owned tiles (tt & 1) == fh start from the residual (tile index tt>>1 of res), others from 0
-                        const f32x4 r = res[(tt >> 1) & 1][dt];
-                        acc[dt][tt] = ((tt & 1) == fh) ? r : f4zero();
-                    }
+                    for (int tt = 0; tt < MT; ++tt)
+                        acc[dt][tt] = ((tt & 1) == FH) ? res[(tt >> 1) & 1][dt] : f4zero();   // owner tiles start from the residual
                 // The chunk body is instantiated per tile count so that it is ONE basic block: with a runtime
                 // `tt < ntile` guard every tile becomes its own block and hipcc cannot interleave the tiles'
                 // LDS reads / MFMAs / relu (measured: 45 % MFMA-pipe occupancy in this loop, fully serialised).
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                         if (st + 1 < NS && !(P.dbg & 4)) issue_ffn(st + 1, buf ^ 1);
 #pragma unroll
                         for (int sub = 0; sub < SUB; ++sub) {
-                            const char* wb = ring + buf * WBUF + (fh * SUB + sub) * NBF * 1024 + lane * 16;
+                            const char* wb = ring + buf * WBUF + (FH * SUB + sub) * NBF * 1024 + lane * 16;
                             bf16x8 w1[2][KS1], w2[DT];
 #pragma unroll
                             for (int ft = 0; ft < 2; ++ft)
@@ -590,41 +591,40 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                 }
                 mark(6, step);
                 refresh_lane();
-                // combine the two F halves: tile tt is finalised by its owner wave ((tt & 1) == fh)
+                // combine the two F halves: tile tt is finalised by its owner wave ((tt & 1) == FH)
                 f32x4* xch = reinterpret_cast<f32x4*>(ring);       // [mq][tt][dt][lane]
 #pragma unroll
                 for (int tt = 0; tt < MT; ++tt)
-                    if (tt < ntile && (tt & 1) != fh) {
+                    if ((tt & 1) != FH && tt < ntile) {
 #pragma unroll
                         for (int dt = 0; dt < DT; ++dt) xch[((mq * MT + tt) * DT + dt) * 64 + lane] = acc[dt][tt];
                     }
                 __syncthreads();
 #pragma unroll
                 for (int oi = 0; oi < 2; ++oi) {
-                    // owned tile index is a compile-time function of oi only through fh (runtime): select
-                    const int tt = fh + 2 * oi;
-                    if (tt < ntile) {
+                    const int ttc = FH + 2 * oi;                     // owned tile: a constant after unrolling
+                    if (ttc < MT && ttc < ntile) {
 #pragma unroll
                         for (int dt = 0; dt < DT; ++dt) {
                             const int d0 = 16 * dt + 4 * g;
                             if (d0 < D) {
-                                // acc index must be compile-time: tt is 2*oi or 2*oi+1
-                                const f32x4 mine = (fh == 0) ? acc[dt][(2 * oi) < MT ? 2 * oi : 0]
-                                                             : acc[dt][(2 * oi + 1) < MT ? 2 * oi + 1 : 0];
-                                const f32x4 other = xch[((mq * MT + tt) * DT + dt) * 64 + lane];
+                                const f32x4 mine = acc[dt][ttc < MT ? ttc : 0];      // already contains the residual
+                                const f32x4 other = xch[((mq * MT + ttc) * DT + dt) * 64 + lane];
                                 const float4 b2 = *reinterpret_cast<const float4*>(lpar + 1 * D + d0);
-                                res[oi][dt][0] = mine[0] + other[0] + b2.x;      // `mine` already contains the residual
+                                res[oi][dt][0] = mine[0] + other[0] + b2.x;
                                 res[oi][dt][1] = mine[1] + other[1] + b2.y;
                                 res[oi][dt][2] = mine[2] + other[2] + b2.z;
                                 res[oi][dt][3] = mine[3] + other[3] + b2.w;
                             }
                         }
                         layer_norm(res[oi], lpar + 4 * D, lpar + 5 * D);
-                        write_xfrags(tile0 + tt, res[oi]);
+                        write_xfrags(tile0 + ttc, res[oi]);
                     }
                 }
                 __syncthreads();
-            }
+            };
+            if (fh == 0) ffn_phase(std::integral_constant<int, 0>{});
+            else ffn_phase(std::integral_constant<int, 1>{});
             mark(7, step);
             refresh_lane();
         }   // layers
