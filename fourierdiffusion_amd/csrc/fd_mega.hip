@@ -28,10 +28,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
 
 #ifndef FD_XF_REGS
 #define FD_XF_REGS 1     // FFN activation fragments: 1 = registers for the whole phase, 0 = LDS read per use
@@ -71,15 +73,34 @@ __device__ __forceinline__ bf16x8 frag_zero() {
     return __builtin_bit_cast(bf16x8, z);
 }
 __device__ __forceinline__ f32x4 f4zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+// Exchanges between the 4 lane groups (rows of 16 lanes) that hold one token: gfx950's row-swap instructions run at
+// VALU latency; ds_bpermute (what __shfl_xor lowers to) is an LDS round trip of >100 cycles on the critical path
+// of every softmax / LayerNorm.  swap16: a = value of the even row of each row pair, b = of the odd row.
+__device__ __forceinline__ void swap32(float v, float& a, float& b) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned r0 = r.x, r1 = r.y;
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void swap16(float v, float& a, float& b) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned r0 = r.x, r1 = r.y;
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
 __device__ __forceinline__ float group_sum(float v) {      // sum over the 4 lane groups holding one token
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    float a, b;
+    swap32(v, a, b);
+    swap16(a + b, a, b);
+    return a + b;
 }
 __device__ __forceinline__ float group_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
+    float a, b;
+    swap32(v, a, b);
+    swap16(fmaxf(a, b), a, b);
+    return fmaxf(a, b);
 }
 
 // Shape policies: ShapeDyn reads every dimension from the parameter block (any supported model/shape);
@@ -339,6 +360,7 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                 dma_blocks(limg + P.off_wq + (size_t)pg * KS1 * 1024, wq, npg * KS1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                mark(2, step);
                 // ---- K projection (K^T rows pair-major, 8 rows per head) and V projection (non-transposed, so the
                 //      C tile is already the V^T A-fragment) for every token tile -> kbf / vbf
                 for (int u = wave; u < npg * NTILE; u += 8) {
@@ -362,101 +384,182 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                 __syncthreads();
                 mark(3, step);
                 refresh_lane();
-                // ---- attention units (query tile x head pair)
-                for (int u = wave; u < npg * NTILE; u += 8) {
-                    const int pr = u / NTILE, qt = u - pr * NTILE;
-                    const int ser = qt / KT;
-                    f32x4 qa = f4zero();
+                // ---- attention units: (head pair) x (series) x (NQ consecutive query tiles).  The NQ query tiles
+                //      share every K / V fragment read and give each wave NQ independent dependency chains (one
+                //      wave has only one partner on its SIMD to hide MFMA / exp / LDS latency behind).
+                constexpr int NQ = 2;
+                const int DUS = (KT + NQ - 1) / NQ;                 // units per (pair, series)
+                const unsigned long long tw0 = P.prof ? __builtin_readcyclecounter() : 0ull;
+                for (int u = wave; u < npg * S * DUS; u += 8) {
+                    const int pr = u / (S * DUS), ur = u - pr * (S * DUS);
+                    const int ser = ur / DUS, du = ur - ser * DUS;
+                    int qt[NQ];
+                    bool qv[NQ];
 #pragma unroll
-                    for (int ks = 0; ks < KS1; ++ks)
-                        qa = MFMA(*reinterpret_cast<const bf16x8*>(wq + ((pr * KS1 + ks) * 64 + lane) * 16),
-                                  xfrag(qt, ks), qa);
+                    for (int q = 0; q < NQ; ++q) {                  // a ragged last unit recomputes its first tile
+                        qv[q] = du * NQ + q < KT;
+                        qt[q] = ser * KT + (qv[q] ? du * NQ + q : du * NQ);
+                    }
+                    mark(9, step);
+                    f32x4 qa[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) qa[q] = f4zero();
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks) {
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wq + ((pr * KS1 + ks) * 64 + lane) * 16);
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) qa[q] = MFMA(wf, xfrag(qt[q], ks), qa[q]);
+                    }
                     // The C tile holds both heads of the pair (even head in lane groups 0-1, odd in 2-3).  Masking
                     // Q once per unit (instead of every K fragment) selects the head: the K fragment then serves
                     // both heads unmodified because the other head's k-slots meet zeros.
+                    // S^T tiles contract over 16 k-slots (8 dims x 2 heads): the K=16 MFMA takes the 8-byte K rows
+                    // as they lie in LDS (no zero-padded upper half to materialise)
                     const bool lo_grp = (g >> 1) == 0;
-                    const unsigned q01 = cvt_pk_bf16(qa[0], qa[1]), q23 = cvt_pk_bf16(qa[2], qa[3]);
-                    const u32x4 qe = {lo_grp ? q01 : 0u, lo_grp ? q23 : 0u, 0u, 0u};
-                    const u32x4 qo = {lo_grp ? 0u : q01, lo_grp ? 0u : q23, 0u, 0u};
-                    const bf16x8 qb[2] = {__builtin_bit_cast(bf16x8, qe), __builtin_bit_cast(bf16x8, qo)};
-                    float m2[2] = {kNegBig, kNegBig};
-                    f32x4 o2[2] = {f4zero(), f4zero()};
+                    s16x4 qb[NQ][2];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const unsigned q01 = cvt_pk_bf16(qa[q][0], qa[q][1]), q23 = cvt_pk_bf16(qa[q][2], qa[q][3]);
+                        const u32x2 qe = {lo_grp ? q01 : 0u, lo_grp ? q23 : 0u};
+                        const u32x2 qo = {lo_grp ? 0u : q01, lo_grp ? 0u : q23};
+                        qb[q][0] = __builtin_bit_cast(s16x4, qe);
+                        qb[q][1] = __builtin_bit_cast(s16x4, qo);
+                    }
+                    // keys beyond T in the ragged last tile: masked through the MFMA's C operand
+                    f32x4 cmask;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cmask[r] = ((KT - 1) * 16 + 4 * g + r >= T) ? kNegBig : 0.f;
+                    float m2[NQ][2];
+                    f32x4 o2[NQ][2];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int hs = 0; hs < 2; ++hs) {
+                            m2[q][hs] = kNegBig;
+                            o2[q][hs] = f4zero();
+                        }
                     for (int kb = 0; kb < KT; kb += 8) {
-                        // K and V fragments of this 128-key block: one read serves both heads of the pair
-                        bf16x8 kf[8], vf[4];
+                        // K and V fragments of this 128-key block: one read serves both heads and all NQ query tiles
+                        s16x4 kf[8];
+                        bf16x8 vf[4];
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
-                            if (kb + j < KT) {
-                                const u32x2 kr = *reinterpret_cast<const u32x2*>(
+                            if (kb + j < KT)
+                                kf[j] = *reinterpret_cast<const s16x4*>(
                                     kbf + ((size_t)(pr * NTOK + (ser * KT + kb + j) * 16 + tok) * 4 + g) * 8);
-                                const u32x4 kk = {kr[0], kr[1], 0u, 0u};
-                                kf[j] = __builtin_bit_cast(bf16x8, kk);
-                            }
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj)
                             if ((kb >> 1) + jj < NJ)
                                 vf[jj] = *reinterpret_cast<const bf16x8*>(
                                     vbf + ((size_t)(((pr * S + ser) * NJ + (kb >> 1) + jj) * 4 + g) * 16 + tok) * 16);
-                        f32x4 s[2][8];
+                        // pass 1: row maxima only (the VALU, not the matrix pipe, bounds this phase: the scores are
+                        // recomputed in pass 2 with -max riding in the C operand, which removes one v_sub per score).
+                        // Both passes are software-pipelined by hand, a few MFMAs ahead of their consumers, and
+                        // fenced per stage: left alone hipcc issues MFMA -> s_nop 7 -> 4 exps strictly in sequence.
+                        // Tile index k = ((hs * 4 + jj) * NQ + q) * 2 + jl with key tile j = 2 jj + jl.
+                        const int nk = min(8, KT - kb);                 // key tiles in this block
+                        constexpr int NKT = 16 * NQ;                    // score tiles per block
+                        mark(10, step);
+                        float bm[NQ][2];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int kt = kb + j;
+                        for (int q = 0; q < NQ; ++q) bm[q][0] = bm[q][1] = kNegBig;
+                        {
+                            constexpr int LAG = 3;
+                            f32x4 t4[NKT];
 #pragma unroll
-                            for (int hs = 0; hs < 2; ++hs) {
-                                if (kt < KT) {
-                                    s[hs][j] = MFMA(kf[j], qb[hs], f4zero());
-                                    if (kt == KT - 1) {             // keys beyond T in the ragged last tile
-#pragma unroll
-                                        for (int r = 0; r < 4; ++r)
-                                            if (kt * 16 + 4 * g + r >= T) s[hs][j][r] = kNegBig;
-                                    }
-                                } else {
-                                    s[hs][j] = f32x4{kNegBig, kNegBig, kNegBig, kNegBig};
+                            for (int k = 0; k < NKT + LAG; ++k) {
+                                if (k < NKT) {
+                                    const int jl = k & 1, q = (k >> 1) % NQ, jj = ((k >> 1) / NQ) & 3, hs = (k >> 1) / NQ >> 2;
+                                    const int j = 2 * jj + jl;
+                                    if (j < nk) t4[k] = MFMA16(kf[j], qb[q][hs], (kb + j == KT - 1) ? cmask : f4zero());
                                 }
+                                if (k >= LAG) {
+                                    const int e = k - LAG;
+                                    const int jl = e & 1, q = (e >> 1) % NQ, jj = ((e >> 1) / NQ) & 3, hs = (e >> 1) / NQ >> 2;
+                                    if (2 * jj + jl < nk) {
+                                        const f32x4 v = t4[e];
+                                        float bb = bm[q][hs];
+                                        bb = fmaxf(fmaxf(bb, v[0]), v[1]);
+                                        bb = fmaxf(fmaxf(bb, v[2]), v[3]);
+                                        bm[q][hs] = bb;
+                                    }
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
                             }
                         }
+                        mark(11, step);
+                        f32x4 negm[NQ][2], clast[NQ][2];
 #pragma unroll
-                        for (int hs = 0; hs < 2; ++hs) {
-                            float bm = kNegBig;
+                        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                bm = fmaxf(bm, fmaxf(fmaxf(s[hs][j][0], s[hs][j][1]), fmaxf(s[hs][j][2], s[hs][j][3])));
-                            bm = group_max(bm);
-                            const float mnew = fmaxf(m2[hs], bm);
-                            const float alpha = __builtin_amdgcn_exp2f(m2[hs] - mnew);
-                            f32x4 o = o2[hs] * alpha;
-                            m2[hs] = mnew;
+                            for (int hs = 0; hs < 2; ++hs) {
+                                const float mnew = fmaxf(m2[q][hs], group_max(bm[q][hs]));
+                                const float alpha = __builtin_amdgcn_exp2f(m2[q][hs] - mnew);
+                                o2[q][hs] = o2[q][hs] * alpha;
+                                m2[q][hs] = mnew;
+                                negm[q][hs] = f32x4{-mnew, -mnew, -mnew, -mnew};
+                                clast[q][hs] = cmask - mnew;
+                            }
+                        mark(12, step);
+                        // pass 2: P = exp2(S - max) tile by tile, packed to bf16 B fragments, then P V.  The row sum of
+                        // P comes out of the same MFMAs: V^T carries a row of ones (dim slot hd).
+                        {
+                            constexpr int LAG = 2;
+                            f32x4 pe[NKT];
+                            bf16x8 pk[NKT / 2];
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)
+                            for (int k = 0; k < NKT + 2 * LAG; ++k) {
+                                if (k < NKT) {
+                                    const int jl = k & 1, q = (k >> 1) % NQ, jj = ((k >> 1) / NQ) & 3, hs = (k >> 1) / NQ >> 2;
+                                    const int j = 2 * jj + jl;
+                                    if (j < nk) pe[k] = MFMA16(kf[j], qb[q][hs], (kb + j == KT - 1) ? clast[q][hs] : negm[q][hs]);
+                                    else pe[k] = f4zero();
+                                }
+                                if (k >= LAG && k - LAG < NKT) {
+                                    const int e = k - LAG;
+                                    const int jl = e & 1, jj = ((e >> 1) / NQ) & 3;
+                                    if (2 * jj + jl < nk) {
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) s[hs][j][r] = __builtin_amdgcn_exp2f(s[hs][j][r] - mnew);
-                            // the row sum of P comes out of the same MFMAs: V^T carries a row of ones (dim slot hd)
-#pragma unroll
-                            for (int jj = 0; jj < 4; ++jj)
-                                if ((kb >> 1) + jj < NJ) o = MFMA(vf[jj], pack8(s[hs][2 * jj], s[hs][2 * jj + 1]), o);
-                            o2[hs] = o;
+                                        for (int r = 0; r < 4; ++r) pe[e][r] = __builtin_amdgcn_exp2f(pe[e][r]);
+                                    }
+                                    if (jl) pk[e >> 1] = pack8(pe[e - 1], pe[e]);
+                                }
+                                if (k >= 2 * LAG && ((k - 2 * LAG) & 1)) {
+                                    const int e = k - 2 * LAG;
+                                    const int q = (e >> 1) % NQ, jj = ((e >> 1) / NQ) & 3, hs = (e >> 1) / NQ >> 2;
+                                    if (2 * jj < nk) o2[q][hs] = MFMA(vf[jj], pk[e >> 1], o2[q][hs]);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                     }
-                    // O^T rows 8*hs + [0,8) live in lane groups 2hs, 2hs+1; row 8*hs + hd is sum_j P (ones row)
-                    float o_sel[4];
+                    mark(13, step);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o_sel[r] = lo_grp ? o2[0][r] : o2[1][r];
-                    // hd in [4,7]: the ones row is register hd-4 of the odd lane group; hd < 4: register hd of the even one
-                    // (the shuffle must run with all lanes active: a lane cannot read an exec-masked neighbour)
-                    float cand = o_sel[0];
+                    for (int q = 0; q < NQ; ++q) {
+                        // O^T rows 8*hs + [0,8) live in lane groups 2hs, 2hs+1; row 8*hs + hd is sum_j P (ones row)
+                        float o_sel[4];
 #pragma unroll
-                    for (int r = 1; r < 4; ++r) cand = ((hd & 3) == r) ? o_sel[r] : cand;
-                    const float other = __shfl_xor(cand, 16);
-                    const bool holds = (hd >= 4) ? ((g & 1) != 0) : ((g & 1) == 0);
-                    const float lrow = holds ? cand : other;
-                    const float inv = 1.0f / lrow;
-                    // head = 2*(pg+pr) + (g>>1); its 8 dims are one 16-B k-slot group of the out-proj B fragment
-                    const int head = 2 * (pg + pr) + (g >> 1);
-                    u32x2 pk = {cvt_pk_bf16(o_sel[0] * inv, o_sel[1] * inv), cvt_pk_bf16(o_sel[2] * inv, o_sel[3] * inv)};
-                    if (head >= H || (P.dbg & 1)) pk = u32x2{0u, 0u};
-                    if (head < 4 * KSO)
-                        *reinterpret_cast<u32x2*>(afr + ((qt * KSO + (head >> 2)) * 64 + (head & 3) * 16 + tok) * 16 +
-                                                  8 * (g & 1)) = pk;
+                        for (int r = 0; r < 4; ++r) o_sel[r] = lo_grp ? o2[q][0][r] : o2[q][1][r];
+                        // hd in [4,7]: the ones row is register hd-4 of the odd lane group; hd < 4: register hd of the even one
+                        float cand = o_sel[0];
+#pragma unroll
+                        for (int r = 1; r < 4; ++r) cand = ((hd & 3) == r) ? o_sel[r] : cand;
+                        float row_even, row_odd;
+                        swap16(cand, row_even, row_odd);
+                        const float lrow = (hd >= 4) ? row_odd : row_even;
+                        const float inv = 1.0f / lrow;
+                        // head = 2*(pg+pr) + (g>>1); its 8 dims are one 16-B k-slot group of the out-proj B fragment
+                        const int head = 2 * (pg + pr) + (g >> 1);
+                        u32x2 pk = {cvt_pk_bf16(o_sel[0] * inv, o_sel[1] * inv), cvt_pk_bf16(o_sel[2] * inv, o_sel[3] * inv)};
+                        if (head >= H || (P.dbg & 1)) pk = u32x2{0u, 0u};
+                        if (head < 4 * KSO && qv[q])
+                            *reinterpret_cast<u32x2*>(afr + ((qt[q] * KSO + (head >> 2)) * 64 + (head & 3) * 16 + tok) * 16 +
+                                                      8 * (g & 1)) = pk;
+                    }
+                }
+                if (P.prof && blockIdx.x == 0 && step == 1 && l == 1 && lane == 0) {   // per-wave unit-loop time
+                    P.prof[2 * (4000 + 8 * (pg / NPG) + wave)] = 100 + wave;
+                    P.prof[2 * (4000 + 8 * (pg / NPG) + wave) + 1] = __builtin_readcyclecounter() - tw0;
                 }
                 __syncthreads();
             }

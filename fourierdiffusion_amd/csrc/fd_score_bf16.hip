@@ -728,13 +728,13 @@ int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, c
         std::vector<unsigned long long> hb(nent * 2);
         FD_HIP(ctx, hipMemcpy(hb.data(), pb, nent * 16, hipMemcpyDeviceToHost));
         (void)hipFree(pb);
-        static const char* names[] = {"step begin->", "time-embed+embed", "K proj (+DMA)", "V proj (+DMA)", "Q DMA + attention",
+        static const char* names[] = {"step begin->", "time-embed+embed", "QKV weight DMA wait", "K/V projection", "att: last epilogue + barrier",
                                       "out-proj + LN1", "FFN loop", "FFN combine + LN2", "unembed + SDE",
-                                      " op: ->tile0 start", " op: unpark+MFMA+add", " op: layer_norm", " op: write frags+park", " op: tile1 (all)"};
+                                      " att: prev epilogue/loop", " att: Q proj + frag loads", " att: pass 1 (max)", " att: softmax stats", " att: pass 2 + PV"};
         double acc[14] = {0};
         unsigned long long prev = 0, first = 0, last = 0;
         size_t n = 0;
-        for (; n < nent && hb[2 * n] != ~0ull; ++n) {
+        for (; n < 4000 && hb[2 * n] != ~0ull; ++n) {
             const int ph = (int)hb[2 * n];
             const unsigned long long tm = hb[2 * n + 1];
             if (n == 0) first = tm;
@@ -742,6 +742,9 @@ int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, c
             prev = tm;
             last = tm;
         }
+        for (size_t i = 4000; i < 4032 && i < nent; ++i)
+            if (hb[2 * i] != ~0ull)
+                fprintf(stderr, "[fdiff prof]   unit loop, group %zu wave %zu: %llu cycles\n", (i - 4000) / 8, (i - 4000) % 8, hb[2 * i + 1]);
         int steps_seen = 0;
         for (size_t i = 0; i < n; ++i) steps_seen += (hb[2 * i] == 0);
         fprintf(stderr, "[fdiff prof] S=%d npg=%d mt=%d rot=%d lds=%zu: %d steps, %.0f cycles/step\n", pl.S, pl.npg, pl.mt, pl.rot,

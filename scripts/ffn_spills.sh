@@ -1,6 +1,6 @@
 #!/bin/bash
 # compile fd_mega.hip (extra flags in $@) and report spills + scratch ops inside the FFN hot loop of the ecg-static kernel
-cd /tmp/t && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -save-temps "$@" -c /root/repo/fourierdiffusion_amd/csrc/fd_mega.hip -o x.o 2>/dev/null
+cd /tmp/t && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-honor-nans -save-temps "$@" -c /root/repo/fourierdiffusion_amd/csrc/fd_mega.hip -o x.o 2>/dev/null
 S=fd_mega-hip-amdgcn-amd-amdhsa-gfx950.s
 awk 'NR>=7{print} /s_endpgm/{exit}' $S > megas.s
 grep -E "^; (ScratchSize|NumVgprs|VGPRs spill|SGPRS spill|.vgpr_spill|codeLenInByte)" megas.s $S 2>/dev/null | head -0
