@@ -21,6 +21,7 @@ struct fd_mega_params {
     int KSE;      // k-steps of the embed GEMM  (ceil((C+1)/32))
     int CT;       // 16-row tiles of the unembed GEMM (ceil(C/16))
     int rot;      // rotation of the second wave set (SIMD load balance)
+    int num_cu;   // CUs of the device (co-resident 4-wave workgroups alternate their tile split)
     int mode, nsteps;
     int lds_temb; // byte offset of the time-embedding scratch in LDS
     int lds_afr;  // byte offset of the attention-output fragments in LDS
@@ -49,5 +50,5 @@ struct fd_mega_params {
     unsigned long long seed, offset, ctr_per_step, n_elem;
 };
 
-int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int kso, int mt, int grid, size_t lds,
+int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int kso, int mt, int nw, int grid, size_t lds,
                    hipStream_t s);

@@ -64,9 +64,12 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
     return __builtin_bit_cast(bf16x8, r);
 }
 __device__ __forceinline__ bf16x8 relu_pack(f32x4 a, f32x4 b) {
-    u32x4 r = {cvt_pk_bf16(relu_bits(a[0]), relu_bits(a[1])), cvt_pk_bf16(relu_bits(a[2]), relu_bits(a[3])),
-               cvt_pk_bf16(relu_bits(b[0]), relu_bits(b[1])), cvt_pk_bf16(relu_bits(b[2]), relu_bits(b[3]))};
-    return __builtin_bit_cast(bf16x8, r);
+    // convert first, then relu on the packed bf16 pairs: a negative bf16 is a negative int16, so one
+    // v_pk_max_i16 against 0 clamps two values (8 VALU per 8 values instead of 12)
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_bit_cast(s16x8, pack8(a, b));
+    const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(bf16x8, __builtin_elementwise_max(v, z));
 }
 __device__ __forceinline__ bf16x8 frag_zero() {
     u32x4 z = {0u, 0u, 0u, 0u};
@@ -120,11 +123,17 @@ struct ShapeStatic {
 #define SHP(name) (SH::kStatic ? SH::name : P.name)
 
 // ---------------------------------------------------------------------------------------------------
-template <int KS1, int DT, int KSO, int MT, class SH>
-__global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
+// NW waves per workgroup: 8 (one workgroup per CU, up to 16 token tiles, SUB = 2) or 4 (two co-resident workgroups per
+// CU, up to 8 token tiles each, <= 80 KiB LDS, SUB = 1).  The 4-wave form keeps the same per-wave work but the two
+// workgroups of a CU drift apart, so one's VALU-bound attention / LayerNorm / barrier waits overlap the other's
+// MFMA-bound FFN instead of all 8 waves stalling in lockstep.
+template <int KS1, int DT, int KSO, int MT, class SH, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
     constexpr int KSX = KS1;                     // x-fragment blocks per token tile
     constexpr int NBF = 2 * KS1 + DT;            // FFN blocks per (F-half, 32-wide chunk)
-    constexpr int SUB = 2;                       // FFN chunks per barrier step
+    constexpr int SUB = NW / 4;                  // FFN chunks per barrier step
+    constexpr int MQ = NW / 2;                   // token-tile shares ("quarters" when NW = 8)
+    constexpr int NTH = NW * 64;
     constexpr int WBUF = 2 * SUB * NBF * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -161,9 +170,11 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
     float* const lpar = temb + 2 * S * D;                              // [6][D] bo, b2, g1, b1, g2, b2 of the layer
 
     // ---- token-tile ownership (same split as the FFN: quarters mq, F-halves fh; fh waves rotated)
-    const int fh = wave >> 2;
-    const int mq = (wave + fh * SHP(rot)) & 3;
-    const int tbase = NTILE >> 2, trem = NTILE & 3;
+    const int fh = wave / MQ;
+    // the two 4-wave workgroups sharing a CU (blocks i and i + num_cu under in-order dispatch) mirror their split
+    const int wgpar = (NW == 4) ? (int)((blockIdx.x / (unsigned)P.num_cu) & 1u) : 0;
+    const int mq = (wave + fh * SHP(rot) + wgpar) % MQ;
+    const int tbase = NTILE / MQ, trem = NTILE % MQ;
     const int ntile = tbase + (mq < trem ? 1 : 0);
     const int tile0 = mq * tbase + (mq < trem ? mq : trem);
     // owned tiles (residual stream lives in this wave's registers): tt = fh, fh + 2
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
     f32x4 res[2][DT];
     int prof_cnt = 0;
     auto mark = [&](int phase, int step) {
-        if (P.prof && blockIdx.x == 0 && wave == 0 && step < 4) {
+        if (P.prof && blockIdx.x == 0 && wave == 0 && (step < 4 || phase == 0) && prof_cnt < 3990) {
             const unsigned long long tm = __builtin_readcyclecounter();
             if (lane == 0) {
                 P.prof[2 * prof_cnt] = (unsigned long long)phase;
@@ -248,26 +259,34 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
         return *reinterpret_cast<const bf16x8*>(img + ((size_t)blk * 64 + lane) * 16);
     };
     auto dma_blocks = [&](const char* src, char* dst, int nblk) {   // nblk KiB, dealt round-robin to the 8 waves
-        for (int b = wave; b < nblk; b += 8)
+        for (int b = wave; b < nblk; b += NW)
             __builtin_amdgcn_global_load_lds(GLB_PTR(src + ((size_t)b * 64 + lane) * 16), LDS_PTR(dst + b * 1024), 16,
                                              0, 0);
     };
 
     // ---- zero the fragment region once (k padding beyond the written slots must read as 0)
-    for (int i = threadIdx.x; i < NTILE * KSX * 64; i += 512) reinterpret_cast<u32x4*>(xfr)[i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = threadIdx.x; i < NTILE * KSX * 64; i += NTH) reinterpret_cast<u32x4*>(xfr)[i] = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
 
     const int nsteps = (P.mode == FD_MEGA_SAMPLE) ? P.nsteps : 1;
+    if (P.prof && wave == 0 && lane == 0 && blockIdx.x < 2048) {     // residency trace: start time + hardware id
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        P.prof[2 * (4100 + blockIdx.x)] = wall_clock64();
+        P.prof[2 * (4100 + 2048 + blockIdx.x)] = ((unsigned long long)xcc << 32) | hwid;
+    }
     for (int step = 0; step < nsteps; ++step) {
         mark(0, step);
         refresh_lane();
         // ============================ time embedding (transformer.py:80-89), one wave per series
-        if (wave < S) {
-            const int b = b0 + wave;
+        for (int sw = wave; sw < S; sw += NW) {
+            const int b = b0 + sw;
             float tv = 0.f;
             if (b < P.B) tv = (P.mode == FD_MEGA_SAMPLE) ? P.steps[step].t : P.tvec[b];
             const int half = (D + 1) / 2;
-            float* emb = temb + (S + wave) * D;
+            float* emb = temb + (S + sw) * D;
             for (int j = lane; j < D; j += 64) {
                 const int jj = (j < half) ? j : j - half;
                 const float ph = ((tv * P.params[P.tW + jj]) * 2.0f) * 3.14159274101257324f;
@@ -279,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                 float a = P.params[P.td_b + d];
                 const float* w = P.params + P.td_w + (size_t)d * D;
                 for (int j = 0; j < D; ++j) a = fmaf(w[j], emb[j], a);
-                temb[wave * D + d] = a;
+                temb[sw * D + d] = a;
             }
         }
         __syncthreads();
@@ -340,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
         for (int l = 0; l < SHP(L); ++l) {
             const char* limg = layer_ptr(l);
             refresh_lane();
-            if (wave == 7) {   // small fp32 vectors of this layer -> LDS (first read after several barriers)
+            if (wave == NW - 1) {   // small fp32 vectors of this layer -> LDS (first read after several barriers)
                 const fd_mega_layer_f32 lp = P.layers[l];
                 const long long offs[6] = {lp.out_b, lp.l2_b, lp.n1_w, lp.n1_b, lp.n2_w, lp.n2_b};
 #pragma unroll
@@ -363,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                 mark(2, step);
                 // ---- K projection (K^T rows pair-major, 8 rows per head) and V projection (non-transposed, so the
                 //      C tile is already the V^T A-fragment) for every token tile -> kbf / vbf
-                for (int u = wave; u < npg * NTILE; u += 8) {
+                for (int u = wave; u < npg * NTILE; u += NW) {
                     const int pr = u / NTILE, tile = u - pr * NTILE;
                     f32x4 a = f4zero(), b = f4zero();
 #pragma unroll
@@ -390,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
                 constexpr int NQ = 2;
                 const int DUS = (KT + NQ - 1) / NQ;                 // units per (pair, series)
                 const unsigned long long tw0 = P.prof ? __builtin_readcyclecounter() : 0ull;
-                for (int u = wave; u < npg * S * DUS; u += 8) {
+                for (int u = wave; u < npg * S * DUS; u += NW) {
                     const int pr = u / (S * DUS), ur = u - pr * (S * DUS);
                     const int ser = ur / DUS, du = ur - ser * DUS;
                     int qt[NQ];
@@ -567,7 +586,7 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
             mark(4, step);
             refresh_lane();
             if (P.dbg_out && blockIdx.x == 0 && l == 0 && step == 0) {      // debugging aid: dump LDS
-                for (int i = threadIdx.x; i < P.dbg_bytes / 4; i += 512) P.dbg_out[i] = reinterpret_cast<unsigned*>(smem)[i];
+                for (int i = threadIdx.x; i < P.dbg_bytes / 4; i += NTH) P.dbg_out[i] = reinterpret_cast<unsigned*>(smem)[i];
                 __syncthreads();
             }
             // -------- FFN weight stream: buffer 0 overlays W/K/V only (afr is still read by the out-proj);
@@ -580,11 +599,14 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
             auto issue_ffn = [&](int st_seq, int buf) {
                 int st = st_seq + st_rot;
                 st -= (st >= NS) ? NS : 0;
-                for (int b = wave; b < 2 * SUB * NBF; b += 8) {
-                    const int h = b / (SUB * NBF);
-                    const int j = b - h * (SUB * NBF);
-                    const char* src = limg + P.off_ffn + ((((size_t)h * NS + st) * SUB * NBF + j) * 64 + lane) * 16;
-                    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(ring + buf * WBUF + b * 1024), 16, 0, 0);
+                // the image is chunk-major ([32-wide chunk][F-half][block]) and so is the ring: one linear copy
+                const char* src = limg + P.off_ffn + (size_t)st * (2 * SUB * NBF * 1024) + lane * 16;
+                char* dst = ring + buf * WBUF;
+#pragma unroll
+                for (int i = 0; i < (2 * SUB * NBF + NW - 1) / NW; ++i) {
+                    const int b = wave + i * NW;
+                    if (b < 2 * SUB * NBF)
+                        __builtin_amdgcn_global_load_lds(GLB_PTR(src + b * 1024), LDS_PTR(dst + b * 1024), 16, 0, 0);
                 }
             };
             issue_ffn(0, 0);
@@ -653,38 +675,81 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
 #pragma unroll
                             for (int ks = 0; ks < KS1; ++ks) xf[tt][ks] = xfrag(tile0 + tt, ks);
                     }
+                    // One step = SUB chunks x NTT tiles = NI items; item i: H (2 K-chains of KS1 MFMAs: the two
+                    // 16-wide hidden tiles), relu+pack (VALU), W2 (DT MFMAs into the tile's accumulators).
+                    // The schedule is pinned by hand (sched_barrier between stages), one item ahead:
+                    //   H(i+1) | relu(i) | W2(i)
+                    // so the VALU of item i and the MFMA latency of H(i) hide behind H(i+1)'s MFMAs; left alone hipcc
+                    // emits H(i), s_nop, relu(i), W2(i) strictly in sequence and waits for ALL weight fragments of a
+                    // chunk (lgkmcnt(0)) before its first MFMA.  W1 / W2 fragment registers are refilled for the next
+                    // chunk as soon as their last reader has issued; the last item's relu + W2 run after the barrier,
+                    // behind the first LDS reads of the next step.
+                    constexpr int NI = SUB * NTT;
+                    bf16x8 w1[2][KS1], w2[DT];
+                    f32x4 h0, h1;                                     // hidden tiles of the item in flight
+                    auto load_w1 = [&](int buf, int sub) {
+                        const char* wb = ring + buf * WBUF + (sub * 2 + FH) * NBF * 1024 + lane * 16;
+#pragma unroll
+                        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                            for (int ks = 0; ks < KS1; ++ks)
+                                w1[ft][ks] = *reinterpret_cast<const bf16x8*>(wb + (ft * KS1 + ks) * 1024);
+                    };
+                    auto load_w2 = [&](int buf, int sub) {
+                        const char* wb = ring + buf * WBUF + (sub * 2 + FH) * NBF * 1024 + lane * 16;
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt)
+                            w2[dt] = *reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024);
+                    };
+                    auto do_h = [&](int tt) {
+                        h0 = f4zero();
+                        h1 = f4zero();
+#pragma unroll
+                        for (int ks = 0; ks < KS1; ++ks) {
+                            const bf16x8 xv = FD_XF_REGS ? xf[FD_XF_REGS ? tt : 0][ks] : xfrag(tile0 + tt, ks);
+                            h0 = MFMA(w1[0][ks], xv, h0);
+                            h1 = MFMA(w1[1][ks], xv, h1);
+                        }
+                    };
                     int buf = 0;
                     for (int st = 0; st < NS; ++st) {
                         if (st + 1 < NS && !(P.dbg & 4)) issue_ffn(st + 1, buf ^ 1);
+                        bf16x8 hb_prev;
+                        if (st > 0) hb_prev = relu_pack(h0, h1);      // tail of the previous step (item NI-1)
+                        load_w1(buf, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (st > 0) {
 #pragma unroll
-                        for (int sub = 0; sub < SUB; ++sub) {
-                            const char* wb = ring + buf * WBUF + (FH * SUB + sub) * NBF * 1024 + lane * 16;
-                            bf16x8 w1[2][KS1], w2[DT];
+                            for (int dt = 0; dt < DT; ++dt) acc[dt][NTT - 1] = MFMA(w2[dt], hb_prev, acc[dt][NTT - 1]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_w2(buf, 0);
+                        do_h(0);
+                        if (NTT == 1 && SUB > 1) load_w1(buf, 1);     // H(0) was the only reader of chunk 0's W1
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int ft = 0; ft < 2; ++ft)
+                        for (int i = 0; i + 1 < NI; ++i) {
+                            const int sub = i / NTT, tt = i - sub * NTT;
+                            const int sub1 = (i + 1) / NTT, tt1 = (i + 1) - sub1 * NTT;
+                            const f32x4 g0 = h0, g1 = h1;             // H(i): complete by the time H(i+1) has issued
+                            do_h(tt1);
+                            if (tt1 == NTT - 1 && sub1 + 1 < SUB) load_w1(buf, sub1 + 1);   // W1 of the next chunk
+                            __builtin_amdgcn_sched_barrier(0);
+                            const bf16x8 hb = relu_pack(g0, g1);
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                                for (int ks = 0; ks < KS1; ++ks)
-                                    w1[ft][ks] = *reinterpret_cast<const bf16x8*>(wb + (ft * KS1 + ks) * 1024);
-#pragma unroll
-                            for (int dt = 0; dt < DT; ++dt)
-                                w2[dt] = *reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024);
-#pragma unroll
-                            for (int tt = 0; tt < NTT; ++tt) {
-                                f32x4 h0 = f4zero(), h1 = f4zero();
-#pragma unroll
-                                for (int ks = 0; ks < KS1; ++ks) {
-                                    const bf16x8 xv = FD_XF_REGS ? xf[FD_XF_REGS ? tt : 0][ks] : xfrag(tile0 + tt, ks);
-                                    h0 = MFMA(w1[0][ks], xv, h0);
-                                    h1 = MFMA(w1[1][ks], xv, h1);
-                                }
-                                const bf16x8 hb = relu_pack(h0, h1);
-#pragma unroll
-                                for (int dt = 0; dt < DT; ++dt) acc[dt][tt] = MFMA(w2[dt], hb, acc[dt][tt]);
-                            }
+                            for (int dt = 0; dt < DT; ++dt) acc[dt][tt] = MFMA(w2[dt], hb, acc[dt][tt]);
+                            if (tt == NTT - 1 && sub + 1 < SUB) load_w2(buf, sub + 1);      // W2 of the next chunk
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __syncthreads();
                         buf ^= 1;
+                    }
+                    {   // tail of the last step
+                        const bf16x8 hb = relu_pack(h0, h1);
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) acc[dt][NTT - 1] = MFMA(w2[dt], hb, acc[dt][NTT - 1]);
                     }
                 };
                 if (ntile == MT) ffn_loop(std::integral_constant<int, MT>{});
@@ -777,6 +842,8 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
             }
         }
         mark(8, step);
+        if (P.prof && step == nsteps - 1 && wave == 0 && lane == 0 && blockIdx.x < 2048)
+            P.prof[2 * (4100 + blockIdx.x) + 1] = wall_clock64();
         __syncthreads();   // x of this step is complete before the next step's embed reads it (same wave, but
                            // also fences the fragment region against the next embed's writes)
     }
@@ -785,24 +852,40 @@ __global__ __launch_bounds__(512, 2) void k_mega(const fd_mega_params P) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ host side
-template <int KS1, int DT, int KSO, int MT, class SH>
+template <int KS1, int DT, int KSO, int MT, class SH, int NW = 8>
 static int launch_mega_t(fd_ctx* ctx, const fd_mega_params& P, int grid, size_t lds, hipStream_t s) {
-    auto kern = k_mega<KS1, DT, KSO, MT, SH>;
+    auto kern = k_mega<KS1, DT, KSO, MT, SH, NW>;
     static bool attr = false;
     if (!attr) {
-        FD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (NW == 8 ? 160 : 80) * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, P);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, P);
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }
 
 // BASELINE.json configs[1]: ecg-synth (T=100, C=12), default transformer, 2 series per workgroup, 2 head groups
 using ShapeEcg = ShapeStatic<100, 72, 12, 12, 2, 3, 2, 10, 2048>;
+// the same workload as two 4-wave workgroups per CU: 1 series per workgroup, 3 head groups of 2 pairs
+using ShapeEcg4 = ShapeStatic<100, 72, 12, 12, 1, 2, 1, 10, 2048>;
 
-int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int kso, int mt, int grid, size_t lds,
+bool fd_mega_has_nw4(int ks1, int dt, int kso) { return ks1 == 3 && dt == 5 && kso == 3; }
+
+int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int kso, int mt, int nw, int grid, size_t lds,
                    hipStream_t s) {
+    if (nw == 4) {
+        if (!getenv("FDIFF_MEGA_GENERIC") && ks1 == 3 && dt == 5 && kso == 3 && mt == 4 && P.T == ShapeEcg4::T &&
+            P.D == ShapeEcg4::D && P.C == ShapeEcg4::C && P.H == ShapeEcg4::H && P.S == ShapeEcg4::S &&
+            P.NPG == ShapeEcg4::NPG && P.rot == ShapeEcg4::rot && P.L == ShapeEcg4::L && P.F == ShapeEcg4::F)
+            return launch_mega_t<3, 5, 3, 4, ShapeEcg4, 4>(ctx, P, grid, lds, s);
+#define FD_MEGA_CASE4(M_) \
+    if (ks1 == 3 && dt == 5 && kso == 3 && mt == M_) return launch_mega_t<3, 5, 3, M_, ShapeDyn, 4>(ctx, P, grid, lds, s);
+        FD_MEGA_CASE4(1) FD_MEGA_CASE4(2) FD_MEGA_CASE4(3) FD_MEGA_CASE4(4)
+#undef FD_MEGA_CASE4
+        return fd_fail(ctx, FD_ERR_UNSUPPORTED, "4-wave persistent kernel not instantiated for ks1=%d dt=%d kso=%d mt=%d",
+                       ks1, dt, kso, mt);
+    }
     if (!getenv("FDIFF_MEGA_GENERIC") && ks1 == 3 && dt == 5 && kso == 3 && mt == 4 && P.T == ShapeEcg::T &&
         P.D == ShapeEcg::D && P.C == ShapeEcg::C && P.H == ShapeEcg::H && P.S == ShapeEcg::S && P.NPG == ShapeEcg::NPG &&
         P.rot == ShapeEcg::rot && P.L == ShapeEcg::L && P.F == ShapeEcg::F)

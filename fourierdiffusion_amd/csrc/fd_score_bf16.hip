@@ -17,6 +17,7 @@
 // src/fdiff/models/score_models.py:57-62; SURVEY.md A.3.  fp32 everywhere except the MFMA operands.
 #include <algorithm>
 #include <cmath>
+#include <map>
 
 #include "fd_gemm_f32.h"
 #include "fd_mega.h"
@@ -60,7 +61,7 @@ namespace {
 // The W2 k-permutation is exactly the (token, 4g+r) register layout of the two 16x16 hidden tiles.
 __global__ __launch_bounds__(64) void k_build_ffn_image(const float* __restrict__ W1, const float* __restrict__ b1,
                                                          const float* __restrict__ W2, __bf16* __restrict__ img,
-                                                         int D, int F, int KS1, int DT) {
+                                                         int D, int F, int KS1, int DT, int chunk_major) {
     const int NB = 2 * KS1 + DT;
     const int NC = F / 64;                      // 32-wide chunks per F-half
     const int blk = blockIdx.x;                 // ((fh*NC + c)*NB + j)
@@ -69,7 +70,10 @@ __global__ __launch_bounds__(64) void k_build_ffn_image(const float* __restrict_
     const int fh = blk / (NB * NC);
     const int lane = threadIdx.x, row = lane & 15, g = lane >> 4;
     const int fbase = fh * (F / 2) + c * 32;
-    __bf16* dst = img + ((size_t)blk * 64 + lane) * 8;
+    // chunk_major: [chunk][F-half][block] (the persistent kernel streams whole chunk pairs linearly);
+    // otherwise [F-half][chunk][block] (k_ffn_ln: each workgroup half walks its own F-half)
+    const int oblk = chunk_major ? (c * 2 + fh) * NB + j : blk;
+    __bf16* dst = img + ((size_t)oblk * 64 + lane) * 8;
     if (j < 2 * KS1) {
         const int ft = j / KS1, ks = j % KS1;
         const int f = fbase + 16 * ft + row;
@@ -502,7 +506,7 @@ int fd_bf16_prepare(fd_score* m, hipStream_t s) {
     for (int i = 0; i < m->d.num_layers; ++i) {
         const fd_layer_off& lo = m->layers[i];
         hipLaunchKernelGGL(k_build_ffn_image, dim3(nblk), dim3(64), 0, s, P + lo.l1_w, P + lo.l1_b, P + lo.l2_w,
-                           (__bf16*)(im->ffn + (size_t)i * im->ffn_layer_bytes), D, F, im->ks1, im->dt);
+                           (__bf16*)(im->ffn + (size_t)i * im->ffn_layer_bytes), D, F, im->ks1, im->dt, 0);
     }
     if (im->mega) {
         auto build = [&](int kind, const float* W, const float* b, size_t off, int ntiles, int KS, int rows, int K,
@@ -521,8 +525,8 @@ int fd_bf16_prepare(fd_score* m, hipStream_t s) {
             build(IMG_V, P + lo.in_w, P + lo.in_b, base + im->off_wv, im->np, im->ks1, 0, D, 1.f);
             build(IMG_Q, P + lo.in_w, P + lo.in_b, base + im->off_wq, im->np, im->ks1, 0, D, qscale);
             build(IMG_WO, P + lo.out_w, nullptr, base + im->off_wo, im->dt, im->kso, 0, D, 1.f);
-            FD_HIP(m->ctx, hipMemcpyAsync(im->mimg + base + im->off_ffn, im->ffn + (size_t)i * im->ffn_layer_bytes,
-                                          im->ffn_layer_bytes, hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(k_build_ffn_image, dim3(nblk), dim3(64), 0, s, P + lo.l1_w, P + lo.l1_b, P + lo.l2_w,
+                               (__bf16*)(im->mimg + base + im->off_ffn), D, F, im->ks1, im->dt, 1);
         }
     }
     FD_LAUNCH_CHECK(m->ctx);
@@ -532,29 +536,38 @@ int fd_bf16_prepare(fd_score* m, hipStream_t s) {
 // ------------------------------------------------------------------ persistent-kernel planning
 struct MegaPlan {
     bool ok = false;
-    int S = 1, KT = 1, mt = 1, rot = 1, grid = 0, npg = 1;
+    int S = 1, KT = 1, mt = 1, rot = 1, grid = 0, npg = 1, nw = 8;
     size_t lds = 0;
     int lds_temb = 0, lds_afr = 0;
 };
 
-static MegaPlan plan_mega(const fd_score* m, int B) {
+bool fd_mega_has_nw4(int ks1, int dt, int kso);   // fd_mega.hip
+
+// One plan per workgroup shape.  nw = 8: one 8-wave workgroup per CU (<= 160 KiB LDS, <= 16 token tiles);
+// nw = 4: two co-resident 4-wave workgroups per CU (<= 80 KiB LDS each, <= 8 token tiles each).
+static MegaPlan plan_mega_nw(const fd_score* m, int B, int nw) {
     MegaPlan pl;
+    pl.nw = nw;
     const fd_bf16_images* im = m->bf16;
     if (!im || !im->mega) return pl;
     const int T = m->d.max_len, D = m->d.d_model;
     const int KT = (T + 15) / 16;
-    if (KT > 16) return pl;                                   // one series must fit 16 token tiles
+    const int MQ = nw / 2, SUBc = nw / 4, max_tiles = MQ * 4;
+    if (KT > max_tiles) return pl;                            // one series must fit the workgroup's token tiles
     const int NB = 2 * im->ks1 + im->dt;
     const int NP = im->np;
-    const size_t ring = (size_t)2 * 2 * 2 * NB * 1024;            // 2 buffers x 2 F-halves x SUB(2) chunks
+    const size_t ring = (size_t)2 * 2 * SUBc * NB * 1024;         // 2 buffers x 2 F-halves x SUB chunks
     const size_t half_ring = ring / 2;
-    const int want = std::max(1, (B + m->ctx->num_cu - 1) / m->ctx->num_cu);   // series per WG for one WG per CU
-    for (int S = std::min(want, 16 / KT); S >= 1; --S) {
+    const size_t lds_cap = (size_t)(nw == 8 ? 160 : 80) * 1024;
+    const int wg_per_cu = nw == 8 ? 1 : 2;
+    const int slots = m->ctx->num_cu * wg_per_cu;
+    const int want = std::max(1, (B + slots - 1) / slots);        // series per WG for one round of workgroups
+    for (int S = std::min(want, max_tiles / KT); S >= 1; --S) {
         const int NTILE = S * KT, NTOK = NTILE * 16, NJ = (KT + 1) / 2;
-        const int mt = (NTILE + 3) / 4;
+        const int mt = (NTILE + MQ - 1) / MQ;
         const size_t xfr = (size_t)NTILE * im->ks1 * 1024;
         const size_t afr = (size_t)NTILE * im->kso * 1024;
-        const size_t xch = (size_t)4 * mt * im->dt * 1024;
+        const size_t xch = (size_t)MQ * mt * im->dt * 1024;
         for (int ng = 1; ng <= NP; ++ng) {                        // head-pair groups: fewer pairs -> smaller K/V
             const int npg = (NP + ng - 1) / ng;
             const size_t wkv = (size_t)3 * npg * im->ks1 * 1024 + (size_t)npg * NTOK * 32 + (size_t)npg * S * NJ * 4 * 16 * 16;
@@ -563,7 +576,7 @@ static MegaPlan plan_mega(const fd_score* m, int B) {
             const size_t mid = std::max(front + afr, std::max(ring, xch));
             const size_t temb = ((size_t)(2 * S + 6) * D * sizeof(float) + 15) & ~size_t(15);
             const size_t total = xfr + mid + temb;
-            if (total > 160 * 1024) continue;
+            if (total > lds_cap) continue;
             pl.ok = true;
             pl.S = S; pl.KT = KT; pl.mt = mt; pl.npg = npg;
             pl.lds = total;
@@ -572,11 +585,11 @@ static MegaPlan plan_mega(const fd_score* m, int B) {
             pl.grid = (B + S - 1) / S;
             // rotation of the second wave set: minimise the heaviest SIMD (tiles of the two waves sharing it)
             int best = 1 << 30;
-            const int tb = NTILE / 4, tr = NTILE % 4;
-            for (int rot = 1; rot <= 3; ++rot) {
+            const int tb = NTILE / MQ, tr = NTILE % MQ;
+            for (int rot = 1; rot < std::max(2, MQ); ++rot) {
                 int worst = 0;
-                for (int q = 0; q < 4; ++q) {
-                    const int a = tb + (q < tr), b = tb + (((q + rot) & 3) < tr);
+                for (int q = 0; q < MQ; ++q) {
+                    const int a = tb + (q < tr), b = tb + (((q + rot) % MQ) < tr);
                     worst = std::max(worst, a + b);
                 }
                 if (worst < best) { best = worst; pl.rot = rot; }
@@ -585,6 +598,19 @@ static MegaPlan plan_mega(const fd_score* m, int B) {
         }
     }
     return pl;
+}
+
+static MegaPlan plan_mega(const fd_score* m, int B) {
+    const fd_bf16_images* im = m->bf16;
+    if (!im || !im->mega) return MegaPlan{};
+    int force = 0;
+    if (const char* e = getenv("FDIFF_MEGA_NW")) force = atoi(e);
+    // two 4-wave workgroups per CU once the batch can fill them; small batches keep 8 waves per series
+    if (force != 8 && fd_mega_has_nw4(im->ks1, im->dt, im->kso) && (force == 4 || B > m->ctx->num_cu)) {
+        MegaPlan p4 = plan_mega_nw(m, B, 4);
+        if (p4.ok) return p4;
+    }
+    return plan_mega_nw(m, B, 8);
 }
 
 static int fill_mega_params(const fd_score* m, const MegaPlan& pl, int B, fd_mega_params& P) {
@@ -603,7 +629,7 @@ static int fill_mega_params(const fd_score* m, const MegaPlan& pl, int B, fd_meg
     if (const char* d2 = getenv("FDIFF_MEGA_DBG")) P.dbg = atoi(d2);
     if (const char* dbg = getenv("FDIFF_MEGA_LAYERS")) P.L = std::min(P.L, atoi(dbg));   // debugging aid
     P.S = pl.S; P.NPG = pl.npg; P.KSE = im->kse; P.CT = im->ct; P.rot = pl.rot;
-    P.lds_temb = pl.lds_temb; P.lds_afr = pl.lds_afr;
+    P.lds_temb = pl.lds_temb; P.lds_afr = pl.lds_afr; P.num_cu = m->ctx->num_cu;
     P.params = m->params;
     P.pos = m->pos; P.tW = m->tW; P.td_w = m->td_w; P.td_b = m->td_b;
     P.layers = im->layer_tab;
@@ -645,7 +671,7 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
                 FD_HIP(ctx, hipMalloc((void**)&dbuf, pl.lds));
                 MP.dbg_out = dbuf;
                 MP.dbg_bytes = (int)pl.lds;
-                int rc = fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.grid, pl.lds, s);
+                int rc = fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.nw, pl.grid, pl.lds, s);
                 FD_HIP(ctx, hipStreamSynchronize(s));
                 std::vector<char> hostbuf(pl.lds);
                 FD_HIP(ctx, hipMemcpy(hostbuf.data(), dbuf, pl.lds, hipMemcpyDeviceToHost));
@@ -658,7 +684,7 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
                         pl.rot, pl.npg, pl.lds, pl.lds_afr, pl.lds_temb);
                 return rc;
             }
-            return fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.grid, pl.lds, s);
+            return fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.nw, pl.grid, pl.lds, s);
         }
     }
     const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model, H = m->d.n_head;
@@ -718,12 +744,12 @@ int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, c
     MP.n_elem = (unsigned long long)B * m->d.max_len * m->d.n_channels;
     MP.ctr_per_step = (MP.n_elem + 3) / 4;
     if (getenv("FDIFF_MEGA_PROF")) {      // profiling aid: per-phase cycle breakdown of workgroup 0 / wave 0
-        const size_t nent = 4096;
+        const size_t nent = 8300;
         unsigned long long* pb = nullptr;
         FD_HIP(ctx, hipMalloc((void**)&pb, nent * 16));
         FD_HIP(ctx, hipMemsetAsync(pb, 0xff, nent * 16, s));
         MP.prof = pb;
-        int rc = fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.grid, pl.lds, s);
+        int rc = fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.nw, pl.grid, pl.lds, s);
         FD_HIP(ctx, hipStreamSynchronize(s));
         std::vector<unsigned long long> hb(nent * 2);
         FD_HIP(ctx, hipMemcpy(hb.data(), pb, nent * 16, hipMemcpyDeviceToHost));
@@ -738,20 +764,60 @@ int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, c
             const int ph = (int)hb[2 * n];
             const unsigned long long tm = hb[2 * n + 1];
             if (n == 0) first = tm;
-            else if (ph >= 1 && ph <= 13) acc[ph] += (double)(tm - prev);
+            else if (ph >= 1 && ph <= 13) acc[ph] += (double)(tm - prev);   // (ph == 0 intervals = unprofiled steps)
             prev = tm;
             last = tm;
         }
         for (size_t i = 4000; i < 4032 && i < nent; ++i)
             if (hb[2 * i] != ~0ull)
                 fprintf(stderr, "[fdiff prof]   unit loop, group %zu wave %zu: %llu cycles\n", (i - 4000) / 8, (i - 4000) % 8, hb[2 * i + 1]);
+        {   // residency of every workgroup: start / end (100 MHz wall clock), XCC and CU it ran on
+            unsigned long long t0 = ~0ull, t1 = 0;
+            const int ng = std::min(pl.grid, 2048);
+            for (int i = 0; i < ng; ++i) { t0 = std::min(t0, hb[2 * (4100 + i)]); t1 = std::max(t1, hb[2 * (4100 + i) + 1]); }
+            int late = 0;
+            std::map<unsigned long long, int> per_cu;
+            for (int i = 0; i < ng; ++i) {
+                const unsigned long long st = hb[2 * (4100 + i)] - t0;
+                if (st > (t1 - t0) / 10) ++late;
+                const unsigned long long id = hb[2 * (4100 + 2048 + i)];
+                const unsigned hw = (unsigned)id, xcc = (unsigned)(id >> 32) & 0xf;
+                // HW_ID: [3:0] wave, [5:4] simd, [7:6] pipe, [11:8] cu, [12] sh, [15:13] se
+                const unsigned long long key = ((unsigned long long)xcc << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15);
+                per_cu[key]++;
+            }
+            std::vector<double> dur;
+            for (int i = 0; i < ng; ++i) dur.push_back((hb[2 * (4100 + i) + 1] - hb[2 * (4100 + i)]) / 1e5);
+            std::vector<double> sd = dur;
+            std::sort(sd.begin(), sd.end());
+            fprintf(stderr, "[fdiff prof] workgroup durations (ms): wg0 %.3f min %.3f p10 %.3f median %.3f p90 %.3f max %.3f\n", dur[0],
+                    sd.front(), sd[sd.size() / 10], sd[sd.size() / 2], sd[sd.size() * 9 / 10], sd.back());
+            int hist[8] = {0};
+            for (auto& kv : per_cu) hist[std::min(7, kv.second)]++;
+            fprintf(stderr, "[fdiff prof] %d workgroups, launch span %.3f ms, %d started after 10%% of the span; distinct CUs %zu, "
+                    "workgroups per CU histogram 1:%d 2:%d 3:%d 4+:%d\n", ng, (t1 - t0) / 1e5, late, per_cu.size(), hist[1], hist[2], hist[3],
+                    hist[4] + hist[5] + hist[6] + hist[7]);
+        }
+        {   // duration of every step (workgroup 0): shows drift / clock changes after the profiled first steps
+            unsigned long long pt = 0;
+            int k = 0;
+            for (size_t i = 0; i < n; ++i)
+                if (hb[2 * i] == 0) {
+                    if (pt && (k % 8 == 0)) fprintf(stderr, "[fdiff prof]   step %d: %llu cycles\n", k, hb[2 * i + 1] - pt);
+                    pt = hb[2 * i + 1];
+                    ++k;
+                }
+        }
         int steps_seen = 0;
         for (size_t i = 0; i < n; ++i) steps_seen += (hb[2 * i] == 0);
-        fprintf(stderr, "[fdiff prof] S=%d npg=%d mt=%d rot=%d lds=%zu: %d steps, %.0f cycles/step\n", pl.S, pl.npg, pl.mt, pl.rot,
+        fprintf(stderr, "[fdiff prof] nw=%d S=%d npg=%d mt=%d rot=%d lds=%zu: %d steps, %.0f cycles/step\n", pl.nw, pl.S, pl.npg, pl.mt, pl.rot,
                 pl.lds, steps_seen, (double)(last - first) / std::max(1, steps_seen));
+        const int steps_prof = std::max(1, std::min(4, steps_seen));      // phases are recorded for the first 4 steps
+        double acc_all = 0;
+        for (int ph = 1; ph <= 13; ++ph) acc_all += acc[ph];
         for (int ph = 1; ph <= 13; ++ph)
-            fprintf(stderr, "[fdiff prof]   %-22s %10.0f cycles/step  %5.1f%%\n", names[ph], acc[ph] / std::max(1, steps_seen),
-                    100.0 * acc[ph] / std::max(1.0, (double)(last - first)));
+            fprintf(stderr, "[fdiff prof]   %-22s %10.0f cycles/step  %5.1f%%\n", names[ph], acc[ph] / steps_prof,
+                    100.0 * acc[ph] / std::max(1.0, acc_all));
         return rc;
     }
     {
@@ -759,6 +825,6 @@ int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, c
         const double T = m->d.max_len, D = m->d.d_model, F = m->d.dim_ff, C = m->d.n_channels, L = m->d.num_layers;
         const double per_fwd = T * (L * (2 * D * 3 * D + 2 * D * D + 4 * D * F + 4 * T * D) + 4 * C * D) + 2 * D * D;
         fd_prof_scope scope(ctx, s, "k_mega (persistent score-net + reverse-SDE loop)", per_fwd * B * n_steps);
-        return fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.grid, pl.lds, s);
+        return fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.nw, pl.grid, pl.lds, s);
     }
 }
