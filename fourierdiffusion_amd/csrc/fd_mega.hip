@@ -123,18 +123,18 @@ struct ShapeStatic {
 #define SHP(name) (SH::kStatic ? SH::name : P.name)
 
 // ---------------------------------------------------------------------------------------------------
-// NW waves per workgroup: 8 (one workgroup per CU, up to 16 token tiles, SUB = 2) or 4 (two co-resident workgroups per
-// CU, up to 8 token tiles each, <= 80 KiB LDS, SUB = 1).  The 4-wave form keeps the same per-wave work but the two
-// workgroups of a CU drift apart, so one's VALU-bound attention / LayerNorm / barrier waits overlap the other's
-// MFMA-bound FFN instead of all 8 waves stalling in lockstep.
+// NW = waves per workgroup (8: one workgroup per CU, up to 16 token tiles).  A 4-wave form (two co-resident
+// workgroups per CU, one series each) was measured: the younger workgroup of each CU loses issue arbitration and
+// finishes 25 % later than the older one, 0.65 vs 0.565 ms per diffusion step -- only NW = 8 is instantiated.
 template <int KS1, int DT, int KSO, int MT, class SH, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
     constexpr int KSX = KS1;                     // x-fragment blocks per token tile
     constexpr int NBF = 2 * KS1 + DT;            // FFN blocks per (F-half, 32-wide chunk)
-    constexpr int SUB = NW / 4;                  // FFN chunks per barrier step
+    constexpr int NBUF = 4;                      // FFN weight ring: 4 buffers of one 32-wide chunk per F-half
+    constexpr int WB1 = 2 * NBF * 1024;          // bytes per ring buffer ([F-half][block])
+    constexpr int NDMA = (2 * NBF + NW - 1) / NW;   // DMA instructions per wave per buffer (padded: uniform vmcnt)
     constexpr int MQ = NW / 2;                   // token-tile shares ("quarters" when NW = 8)
     constexpr int NTH = NW * 64;
-    constexpr int WBUF = 2 * SUB * NBF * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // lane / tok / g are re-derived from an opaque (asm volatile) lane id at every phase boundary: otherwise
@@ -481,8 +481,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         mark(10, step);
                         float bm[NQ][2];
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) bm[q][0] = bm[q][1] = kNegBig;
-                        {
+                        for (int q = 0; q < NQ; ++q) bm[q][0] = bm[q][1] = (P.dbg & 32) ? 0.f : kNegBig;
+                        if (!(P.dbg & 32)) {
                             constexpr int LAG = 3;
                             f32x4 t4[NKT];
 #pragma unroll
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                                     const int jl = e & 1, jj = ((e >> 1) / NQ) & 3;
                                     if (2 * jj + jl < nk) {
 #pragma unroll
-                                        for (int r = 0; r < 4; ++r) pe[e][r] = __builtin_amdgcn_exp2f(pe[e][r]);
+                                        for (int r = 0; r < 4; ++r) pe[e][r] = (P.dbg & 64) ? pe[e][r] : __builtin_amdgcn_exp2f(pe[e][r]);
                                     }
                                     if (jl) pk[e >> 1] = pack8(pe[e - 1], pe[e]);
                                 }
@@ -589,27 +589,31 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                 for (int i = threadIdx.x; i < P.dbg_bytes / 4; i += NTH) P.dbg_out[i] = reinterpret_cast<unsigned*>(smem)[i];
                 __syncthreads();
             }
-            // -------- FFN weight stream: buffer 0 overlays W/K/V only (afr is still read by the out-proj);
-            //          buffer 1 (first used at step 0 of the FFN loop) may overlay afr
-            const int NS = SHP(F) / (64 * SUB);
+            // -------- FFN weight stream: a ring of NBUF chunk buffers filled 3 steps ahead of their use.  Buffers 0-1
+            //          overlay W/K/V only (afr is still read by the out-proj) and are filled during the out-proj;
+            //          buffers 2-3 overlay afr and are first filled after the barrier that ends the out-proj.
+            const int NS = SHP(F) / 64;
             // Every CU streams the SAME weights; marching through them in lockstep makes all 32 CUs of an XCD hit
             // the same L2 channel at the same time (measured: the stream ran at ~25 GB/s per CU and bounded the FFN
             // loop).  The F chunks are summed, so each workgroup walks them in its own rotated order.
             const int st_rot = (blockIdx.x >> 3) % NS;
-            auto issue_ffn = [&](int st_seq, int buf) {
+            auto issue_ffn = [&](int st_seq) {
                 int st = st_seq + st_rot;
                 st -= (st >= NS) ? NS : 0;
-                // the image is chunk-major ([32-wide chunk][F-half][block]) and so is the ring: one linear copy
-                const char* src = limg + P.off_ffn + (size_t)st * (2 * SUB * NBF * 1024) + lane * 16;
-                char* dst = ring + buf * WBUF;
+                // the image is chunk-major ([32-wide chunk][F-half][block]) and so is a ring buffer: one linear copy.
+                // Every wave issues exactly NDMA instructions (the last ones repeat a block) so that
+                // `s_waitcnt vmcnt(NDMA)` means "everything but the newest buffer has landed" for all waves.
+                const char* src = limg + P.off_ffn + (size_t)st * WB1 + lane * 16;
+                char* dst = ring + (st_seq % NBUF) * WB1;
 #pragma unroll
-                for (int i = 0; i < (2 * SUB * NBF + NW - 1) / NW; ++i) {
-                    const int b = wave + i * NW;
-                    if (b < 2 * SUB * NBF)
-                        __builtin_amdgcn_global_load_lds(GLB_PTR(src + b * 1024), LDS_PTR(dst + b * 1024), 16, 0, 0);
+                for (int i = 0; i < NDMA; ++i) {
+                    int b = wave + i * NW;
+                    b -= (b >= 2 * NBF) ? NW : 0;
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(src + b * 1024), LDS_PTR(dst + b * 1024), 16, 0, 0);
                 }
             };
-            issue_ffn(0, 0);
+            issue_ffn(0);
+            if (NS > 1) issue_ffn(1);
 
             // -------- out-proj + residual + LayerNorm1 on the owned tiles (W_o fragments: one L2 round trip)
             bf16x8 wo[DT][KSO];
@@ -648,6 +652,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if (NS > 2) issue_ffn(2);                // afr is dead now: the buffers overlaying it may fill
 
             mark(5, step);
             refresh_lane();
@@ -675,28 +680,29 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
 #pragma unroll
                             for (int ks = 0; ks < KS1; ++ks) xf[tt][ks] = xfrag(tile0 + tt, ks);
                     }
-                    // One step = SUB chunks x NTT tiles = NI items; item i: H (2 K-chains of KS1 MFMAs: the two
-                    // 16-wide hidden tiles), relu+pack (VALU), W2 (DT MFMAs into the tile's accumulators).
-                    // The schedule is pinned by hand (sched_barrier between stages), one item ahead:
-                    //   H(i+1) | relu(i) | W2(i)
-                    // so the VALU of item i and the MFMA latency of H(i) hide behind H(i+1)'s MFMAs; left alone hipcc
-                    // emits H(i), s_nop, relu(i), W2(i) strictly in sequence and waits for ALL weight fragments of a
-                    // chunk (lgkmcnt(0)) before its first MFMA.  W1 / W2 fragment registers are refilled for the next
-                    // chunk as soon as their last reader has issued; the last item's relu + W2 run after the barrier,
-                    // behind the first LDS reads of the next step.
-                    constexpr int NI = SUB * NTT;
+                    // One step = one 32-wide chunk per F-half x NTT tiles; item (s, i): H (2 K-chains of KS1 MFMAs:
+                    // the two 16-wide hidden tiles), relu+pack (VALU), W2 (DT MFMAs into the tile's accumulators).
+                    // The schedule is pinned by hand (sched_barrier between stages), one item ahead and straight
+                    // across the step boundary:
+                    //   H(next item) | relu(item) | W2(item)
+                    // so the VALU of an item and the MFMA latency of its H hide behind the next H's MFMAs; left
+                    // alone hipcc emits H, s_nop, relu, W2 strictly in sequence and waits for ALL weight fragments
+                    // of a chunk (lgkmcnt(0)) before its first MFMA.  The W1 / W2 fragment registers are refilled for
+                    // the NEXT step as soon as their last reader has issued: with the ring filled 3 steps ahead, the
+                    // next step's buffer became visible one barrier ago, so no LDS read ever waits on the barrier
+                    // it follows, and the barrier only keeps the waves within one step of each other (buffer reuse).
                     bf16x8 w1[2][KS1], w2[DT];
                     f32x4 h0, h1;                                     // hidden tiles of the item in flight
-                    auto load_w1 = [&](int buf, int sub) {
-                        const char* wb = ring + buf * WBUF + (sub * 2 + FH) * NBF * 1024 + lane * 16;
+                    auto load_w1 = [&](int s) {
+                        const char* wb = ring + (s % NBUF) * WB1 + FH * NBF * 1024 + lane * 16;
 #pragma unroll
                         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
                             for (int ks = 0; ks < KS1; ++ks)
                                 w1[ft][ks] = *reinterpret_cast<const bf16x8*>(wb + (ft * KS1 + ks) * 1024);
                     };
-                    auto load_w2 = [&](int buf, int sub) {
-                        const char* wb = ring + buf * WBUF + (sub * 2 + FH) * NBF * 1024 + lane * 16;
+                    auto load_w2 = [&](int s) {
+                        const char* wb = ring + (s % NBUF) * WB1 + FH * NBF * 1024 + lane * 16;
 #pragma unroll
                         for (int dt = 0; dt < DT; ++dt)
                             w2[dt] = *reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024);
@@ -711,45 +717,36 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             h1 = MFMA(w1[1][ks], xv, h1);
                         }
                     };
-                    int buf = 0;
+                    load_w1(0);
+                    load_w2(0);
+                    do_h(0);
+                    __builtin_amdgcn_sched_barrier(0);
                     for (int st = 0; st < NS; ++st) {
-                        if (st + 1 < NS && !(P.dbg & 4)) issue_ffn(st + 1, buf ^ 1);
-                        bf16x8 hb_prev;
-                        if (st > 0) hb_prev = relu_pack(h0, h1);      // tail of the previous step (item NI-1)
-                        load_w1(buf, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (st > 0) {
+                        if (st + 3 < NS && !(P.dbg & 4)) issue_ffn(st + 3);
+                        // NTT == 1: H(0) of this step issued during the previous step, before this step's successor
+                        // buffer was visible -- its W1 can only be fetched now
+                        if (NTT == 1 && st + 1 < NS) load_w1(st + 1);
 #pragma unroll
-                            for (int dt = 0; dt < DT; ++dt) acc[dt][NTT - 1] = MFMA(w2[dt], hb_prev, acc[dt][NTT - 1]);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        load_w2(buf, 0);
-                        do_h(0);
-                        if (NTT == 1 && SUB > 1) load_w1(buf, 1);     // H(0) was the only reader of chunk 0's W1
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int i = 0; i + 1 < NI; ++i) {
-                            const int sub = i / NTT, tt = i - sub * NTT;
-                            const int sub1 = (i + 1) / NTT, tt1 = (i + 1) - sub1 * NTT;
-                            const f32x4 g0 = h0, g1 = h1;             // H(i): complete by the time H(i+1) has issued
-                            do_h(tt1);
-                            if (tt1 == NTT - 1 && sub1 + 1 < SUB) load_w1(buf, sub1 + 1);   // W1 of the next chunk
+                        for (int i = 0; i < NTT; ++i) {
+                            const f32x4 g0 = h0, g1 = h1;             // H(st, i): complete by the time the next H issued
+                            if (i + 1 < NTT) {
+                                do_h(i + 1);
+                                if (i + 1 == NTT - 1 && st + 1 < NS) load_w1(st + 1);   // last reader of W1(st) issued
+                            } else if (st + 1 < NS) {
+                                do_h(0);                              // first item of the next step
+                            }
                             __builtin_amdgcn_sched_barrier(0);
                             const bf16x8 hb = relu_pack(g0, g1);
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int dt = 0; dt < DT; ++dt) acc[dt][tt] = MFMA(w2[dt], hb, acc[dt][tt]);
-                            if (tt == NTT - 1 && sub + 1 < SUB) load_w2(buf, sub + 1);      // W2 of the next chunk
+                            for (int dt = 0; dt < DT; ++dt) acc[dt][i] = MFMA(w2[dt], hb, acc[dt][i]);
+                            if (i == NTT - 1 && st + 1 < NS) load_w2(st + 1);
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        // buffer st+2 must have landed before anyone reads it in step st+1 (own DMA, then barrier)
+                        if (st + 3 < NS && !(P.dbg & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __syncthreads();
-                        buf ^= 1;
-                    }
-                    {   // tail of the last step
-                        const bf16x8 hb = relu_pack(h0, h1);
-#pragma unroll
-                        for (int dt = 0; dt < DT; ++dt) acc[dt][NTT - 1] = MFMA(w2[dt], hb, acc[dt][NTT - 1]);
                     }
                 };
                 if (ntile == MT) ffn_loop(std::integral_constant<int, MT>{});
@@ -867,25 +864,9 @@ static int launch_mega_t(fd_ctx* ctx, const fd_mega_params& P, int grid, size_t 
 
 // BASELINE.json configs[1]: ecg-synth (T=100, C=12), default transformer, 2 series per workgroup, 2 head groups
 using ShapeEcg = ShapeStatic<100, 72, 12, 12, 2, 3, 2, 10, 2048>;
-// the same workload as two 4-wave workgroups per CU: 1 series per workgroup, 3 head groups of 2 pairs
-using ShapeEcg4 = ShapeStatic<100, 72, 12, 12, 1, 2, 1, 10, 2048>;
-
-bool fd_mega_has_nw4(int ks1, int dt, int kso) { return ks1 == 3 && dt == 5 && kso == 3; }
-
 int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int kso, int mt, int nw, int grid, size_t lds,
                    hipStream_t s) {
-    if (nw == 4) {
-        if (!getenv("FDIFF_MEGA_GENERIC") && ks1 == 3 && dt == 5 && kso == 3 && mt == 4 && P.T == ShapeEcg4::T &&
-            P.D == ShapeEcg4::D && P.C == ShapeEcg4::C && P.H == ShapeEcg4::H && P.S == ShapeEcg4::S &&
-            P.NPG == ShapeEcg4::NPG && P.rot == ShapeEcg4::rot && P.L == ShapeEcg4::L && P.F == ShapeEcg4::F)
-            return launch_mega_t<3, 5, 3, 4, ShapeEcg4, 4>(ctx, P, grid, lds, s);
-#define FD_MEGA_CASE4(M_) \
-    if (ks1 == 3 && dt == 5 && kso == 3 && mt == M_) return launch_mega_t<3, 5, 3, M_, ShapeDyn, 4>(ctx, P, grid, lds, s);
-        FD_MEGA_CASE4(1) FD_MEGA_CASE4(2) FD_MEGA_CASE4(3) FD_MEGA_CASE4(4)
-#undef FD_MEGA_CASE4
-        return fd_fail(ctx, FD_ERR_UNSUPPORTED, "4-wave persistent kernel not instantiated for ks1=%d dt=%d kso=%d mt=%d",
-                       ks1, dt, kso, mt);
-    }
+    if (nw != 8) return fd_fail(ctx, FD_ERR_UNSUPPORTED, "persistent kernel: only 8-wave workgroups are instantiated");
     if (!getenv("FDIFF_MEGA_GENERIC") && ks1 == 3 && dt == 5 && kso == 3 && mt == 4 && P.T == ShapeEcg::T &&
         P.D == ShapeEcg::D && P.C == ShapeEcg::C && P.H == ShapeEcg::H && P.S == ShapeEcg::S && P.NPG == ShapeEcg::NPG &&
         P.rot == ShapeEcg::rot && P.L == ShapeEcg::L && P.F == ShapeEcg::F)

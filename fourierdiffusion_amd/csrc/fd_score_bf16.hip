@@ -541,10 +541,8 @@ struct MegaPlan {
     int lds_temb = 0, lds_afr = 0;
 };
 
-bool fd_mega_has_nw4(int ks1, int dt, int kso);   // fd_mega.hip
-
-// One plan per workgroup shape.  nw = 8: one 8-wave workgroup per CU (<= 160 KiB LDS, <= 16 token tiles);
-// nw = 4: two co-resident 4-wave workgroups per CU (<= 80 KiB LDS each, <= 8 token tiles each).
+// Workgroup shape: nw = 8 waves, one workgroup per CU (<= 160 KiB LDS, <= 16 token tiles).  (nw = 4, two co-resident
+// workgroups per CU, was measured slower and is not instantiated; the arithmetic below stays general.)
 static MegaPlan plan_mega_nw(const fd_score* m, int B, int nw) {
     MegaPlan pl;
     pl.nw = nw;
@@ -552,11 +550,11 @@ static MegaPlan plan_mega_nw(const fd_score* m, int B, int nw) {
     if (!im || !im->mega) return pl;
     const int T = m->d.max_len, D = m->d.d_model;
     const int KT = (T + 15) / 16;
-    const int MQ = nw / 2, SUBc = nw / 4, max_tiles = MQ * 4;
+    const int MQ = nw / 2, max_tiles = MQ * 4;
     if (KT > max_tiles) return pl;                            // one series must fit the workgroup's token tiles
     const int NB = 2 * im->ks1 + im->dt;
     const int NP = im->np;
-    const size_t ring = (size_t)2 * 2 * SUBc * NB * 1024;         // 2 buffers x 2 F-halves x SUB chunks
+    const size_t ring = (size_t)4 * 2 * NB * 1024;                // 4 chunk buffers x 2 F-halves (fd_mega.hip NBUF)
     const size_t half_ring = ring / 2;
     const size_t lds_cap = (size_t)(nw == 8 ? 160 : 80) * 1024;
     const int wg_per_cu = nw == 8 ? 1 : 2;
@@ -603,13 +601,6 @@ static MegaPlan plan_mega_nw(const fd_score* m, int B, int nw) {
 static MegaPlan plan_mega(const fd_score* m, int B) {
     const fd_bf16_images* im = m->bf16;
     if (!im || !im->mega) return MegaPlan{};
-    int force = 0;
-    if (const char* e = getenv("FDIFF_MEGA_NW")) force = atoi(e);
-    // two 4-wave workgroups per CU once the batch can fill them; small batches keep 8 waves per series
-    if (force != 8 && fd_mega_has_nw4(im->ks1, im->dt, im->kso) && (force == 4 || B > m->ctx->num_cu)) {
-        MegaPlan p4 = plan_mega_nw(m, B, 4);
-        if (p4.ok) return p4;
-    }
     return plan_mega_nw(m, B, 8);
 }
 

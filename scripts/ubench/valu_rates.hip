@@ -28,6 +28,7 @@
         }                                                                                                   \
         unsigned long long t1 = __builtin_readcyclecounter();                                               \
         if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                                          \
+        if ((threadIdx.x & 63) == 0) atomicMax(&out[2], t1 - t0);                                          \
         if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + c0[0] + c1[0] + c2[0] + c3[0] + p0[0] + p1[0] + p2[0] + p3[0] == 12345.f) out[1] = 1;    \
     }
 
@@ -42,6 +43,10 @@ TIMED(k_exp_fma2, "v_exp_f32 %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_exp_f32 %2, %
 TIMED(k_mfma16, "v_mfma_f32_16x16x16_bf16 %8, %16, %16, %8\n v_mfma_f32_16x16x16_bf16 %9, %16, %16, %9\n v_mfma_f32_16x16x16_bf16 %10, %16, %16, %10\n v_mfma_f32_16x16x16_bf16 %11, %16, %16, %11")
 TIMED(k_mfma32, "v_mfma_f32_16x16x32_bf16 %8, %17, %17, %8\n v_mfma_f32_16x16x32_bf16 %9, %17, %17, %9\n v_mfma_f32_16x16x32_bf16 %10, %17, %17, %10\n v_mfma_f32_16x16x32_bf16 %11, %17, %17, %11")
 TIMED(k_mfma16_exp, "v_mfma_f32_16x16x16_bf16 %8, %16, %16, %8\n v_exp_f32 %0, %0\n v_mfma_f32_16x16x16_bf16 %9, %16, %16, %9\n v_exp_f32 %1, %1")
+TIMED(k_mfma32_d1, "v_mfma_f32_16x16x32_bf16 %8, %17, %17, %8\n v_mfma_f32_16x16x32_bf16 %8, %17, %17, %8\n v_mfma_f32_16x16x32_bf16 %8, %17, %17, %8\n v_mfma_f32_16x16x32_bf16 %8, %17, %17, %8")
+TIMED(k_mfma32_d2, "v_mfma_f32_16x16x32_bf16 %8, %17, %17, %8\n v_mfma_f32_16x16x32_bf16 %9, %17, %17, %9\n v_mfma_f32_16x16x32_bf16 %8, %17, %17, %8\n v_mfma_f32_16x16x32_bf16 %9, %17, %17, %9")
+TIMED(k_mfma32_d2v, "v_mfma_f32_16x16x32_bf16 %8, %17, %17, %8\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_mfma_f32_16x16x32_bf16 %9, %17, %17, %9\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3")
+TIMED(k_mfma32_d4v, "v_mfma_f32_16x16x32_bf16 %8, %17, %17, %8\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_mfma_f32_16x16x32_bf16 %9, %17, %17, %9\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n v_mfma_f32_16x16x32_bf16 %10, %17, %17, %10\n v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_mfma_f32_16x16x32_bf16 %11, %17, %17, %11\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7")
 TIMED(k_ldexp, "v_ldexp_f32 %0, %0, %1\n v_ldexp_f32 %2, %2, %3\n v_ldexp_f32 %4, %4, %5\n v_ldexp_f32 %6, %6, %7")
 TIMED(k_cvti, "v_cvt_i32_f32 %0, %0\n v_cvt_i32_f32 %1, %1\n v_cvt_i32_f32 %2, %2\n v_cvt_i32_f32 %3, %3")
 TIMED(k_pkmul, "v_pk_mul_f32 %12, %12, %12\n v_pk_mul_f32 %13, %13, %13\n v_pk_mul_f32 %14, %14, %14\n v_pk_mul_f32 %15, %15, %15")
@@ -55,6 +60,7 @@ int main() {
         {"v_exp_f32", k_exp}, {"v_fma_f32", k_fma}, {"v_max3_f32", k_max3}, {"v_cvt_pk_bf16_f32", k_cvt},
         {"v_pk_fma_f32", k_pkfma}, {"v_pk_mul_f32", k_pkmul}, {"1 exp + 3 fma", k_exp_fma}, {"2 exp + 2 fma", k_exp_fma2},
         {"mfma 16x16x16 bf16", k_mfma16}, {"mfma 16x16x32 bf16", k_mfma32}, {"2 mfma16 + 2 exp", k_mfma16_exp},
+        {"mfma32 dependent d=1 (x4)", k_mfma32_d1}, {"mfma32 dependent d=2 (x4)", k_mfma32_d2}, {"2 mfma32 d=2 + 4 fma", k_mfma32_d2v}, {"4 mfma32 d=4 + 8 fma", k_mfma32_d4v},
         {"v_ldexp_f32", k_ldexp}, {"v_cvt_i32_f32", k_cvti}, {"v_exp_f16", k_exp16}, {"v_rcp_f32", k_rcp}};
     for (int threads : {256, 512}) {
         printf("--- %d threads per CU (%d wave(s) per SIMD), 1 workgroup\n", threads, threads / 256);
@@ -62,11 +68,10 @@ int main() {
             hipMemset(d, 0, 64);
             hipLaunchKernelGGL(e.k, dim3(1), dim3(threads), 0, 0, d, 0.5f);
             hipLaunchKernelGGL(e.k, dim3(1), dim3(threads), 0, 0, d, 0.5f);
-            unsigned long long h[2];
-            hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+            unsigned long long h[3];
+            hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
             // s_memtime ticks at a constant 100 MHz on gfx9: convert through the shader clock measured by a reference
-            printf("%-22s %8.2f ticks per 4-instruction group (raw counter / %d groups)\n", e.n, (double)h[0] / (16.0 * REP),
-                   16 * REP);
+            printf("%-28s wave0 %8.2f  slowest wave %8.2f cycles per group\n", e.n, (double)h[0] / (16.0 * REP), (double)h[2] / (16.0 * REP));
         }
     }
     return 0;
