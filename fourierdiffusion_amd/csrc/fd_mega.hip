@@ -33,6 +33,11 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#ifdef FD_ABL_NOEXP   // ablation build: a full-rate VALU op in place of the half-rate transcendental (wrong results)
+#define FD_EXP2(x) ((x) * 1.0001f)
+#else
+#define FD_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
 
 #ifndef FD_XF_REGS
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                                     const int jl = e & 1, jj = ((e >> 1) / NQ) & 3;
                                     if (2 * jj + jl < nk) {
 #pragma unroll
-                                        for (int r = 0; r < 4; ++r) pe[e][r] = (P.dbg & 64) ? pe[e][r] : __builtin_amdgcn_exp2f(pe[e][r]);
+                                        for (int r = 0; r < 4; ++r) pe[e][r] = FD_EXP2(pe[e][r]);
                                     }
                                     if (jl) pk[e >> 1] = pack8(pe[e - 1], pe[e]);
                                 }
@@ -772,18 +777,22 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
 #pragma unroll
                         for (int dt = 0; dt < DT; ++dt) {
                             const int d0 = 16 * dt + 4 * g;
-                            if (d0 < D) {
-                                const f32x4 mine = acc[dt][ttc < MT ? ttc : 0];      // already contains the residual
-                                const f32x4 other = xch[((mq * MT + ttc) * DT + dt) * 64 + lane];
-                                const float4 b2 = *reinterpret_cast<const float4*>(lpar + 1 * D + d0);
-                                res[oi][dt][0] = mine[0] + other[0] + b2.x;
-                                res[oi][dt][1] = mine[1] + other[1] + b2.y;
-                                res[oi][dt][2] = mine[2] + other[2] + b2.z;
-                                res[oi][dt][3] = mine[3] + other[3] + b2.w;
-                            }
+                            // every path below overwrites res[oi] completely: a partial / conditional update would
+                            // keep the pre-FFN residual live across the whole loop (it cost 32 spilled registers)
+                            const int dr = (d0 < D) ? d0 : 0;
+                            const f32x4 mine = acc[dt][ttc < MT ? ttc : 0];          // already contains the residual
+                            const f32x4 other = xch[((mq * MT + ttc) * DT + dt) * 64 + lane];
+                            const float4 b2 = *reinterpret_cast<const float4*>(lpar + 1 * D + dr);
+                            res[oi][dt][0] = mine[0] + other[0] + b2.x;              // lanes with d0 >= D: zeroed by layer_norm
+                            res[oi][dt][1] = mine[1] + other[1] + b2.y;
+                            res[oi][dt][2] = mine[2] + other[2] + b2.z;
+                            res[oi][dt][3] = mine[3] + other[3] + b2.w;
                         }
                         layer_norm(res[oi], lpar + 4 * D, lpar + 5 * D);
                         write_xfrags(tile0 + ttc, res[oi]);
+                    } else {
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) res[oi][dt] = f4zero();
                     }
                 }
                 __syncthreads();

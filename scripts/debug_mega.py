@@ -8,7 +8,10 @@ from tests.gpu_util import make_model, dev, host
 from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
 
 name = sys.argv[1] if len(sys.argv) > 1 else "default"
-cfg = {"default": CFG_DEFAULT, "tiny": CFG_TINY, "odd": CFG_ODD}[name]
+cfgs = {"default": CFG_DEFAULT, "tiny": CFG_TINY, "odd": CFG_ODD,
+        "nasdaq": dict(T=252, C=6, D=72, L=10, H=12), "mimic": dict(T=256, C=28, D=72, L=10, H=12),
+        "long": dict(T=1024, C=16, D=72, L=10, H=12)}
+cfg = cfgs[name]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 nl = int(os.environ.get("FDIFF_MEGA_LAYERS", cfg["L"]))
 m, _, sd = make_model(cfg, precision="bf16")
