@@ -98,6 +98,18 @@ __device__ __forceinline__ void swap16(float v, float& a, float& b) {
     a = __builtin_bit_cast(float, r0);
     b = __builtin_bit_cast(float, r1);
 }
+// max over the 16 lanes of a row (DPP row rotations: VALU latency, no LDS)
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_max16(float v) {
+    v = fmaxf(v, row_ror<8>(v));
+    v = fmaxf(v, row_ror<4>(v));
+    v = fmaxf(v, row_ror<2>(v));
+    v = fmaxf(v, row_ror<1>(v));
+    return v;
+}
 __device__ __forceinline__ float group_sum(float v) {      // sum over the 4 lane groups holding one token
     float a, b;
     swap32(v, a, b);
@@ -173,6 +185,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
     char* const ring = wsl;                                   // FFN weight ring + exchange alias W/K/V(/afr)
     float* const temb = reinterpret_cast<float*>(smem + P.lds_temb);   // [S][D] + emb scratch [S][D]
     float* const lpar = temb + 2 * S * D;                              // [6][D] bo, b2, g1, b1, g2, b2 of the layer
+    unsigned* const kmax = reinterpret_cast<unsigned*>(lpar + 6 * D);  // [NPG][S][2] max_j |k_j|^2 per head of the group (bits)
 
     // ---- token-tile ownership (same split as the FFN: quarters mq, F-halves fh; fh waves rotated)
     const int fh = wave / MQ;
@@ -382,6 +395,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                 dma_blocks(limg + P.off_wk + (size_t)pg * KS1 * 1024, wk, npg * KS1);
                 dma_blocks(limg + P.off_wv + (size_t)pg * KS1 * 1024, wv, npg * KS1);
                 dma_blocks(limg + P.off_wq + (size_t)pg * KS1 * 1024, wq, npg * KS1);
+                for (int i = threadIdx.x; i < NPG * S * 2; i += NTH) kmax[i] = 0u;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 mark(2, step);
@@ -398,8 +412,19 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     }
                     u32x2 pk = {cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
                     *reinterpret_cast<u32x2*>(kbf + ((size_t)(pr * NTOK + tile * 16 + tok) * 4 + g) * 8) = pk;
-                    // V: lane (col = lane&15, g) holds 4 consecutive tokens (keys) 4g+r of this tile
                     const int ser = tile / KT, kt = tile - ser * KT;
+                    // max_j |k_j|^2 per (series, head) over the keys (softmax shift bound of the attention units):
+                    // rows 4g+r are the dims (head g>>1), the 16 lanes of a row are this tile's tokens
+                    {
+                        float n2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+                        float ea, eb;
+                        swap16(n2, ea, eb);                           // the two lane groups of a head
+                        n2 = row_max16(ea + eb);
+                        if (tok == 0 && (g & 1) == 0)
+                            __hip_atomic_fetch_max(&kmax[(pr * S + ser) * 2 + (g >> 1)], __builtin_bit_cast(unsigned, n2),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    // V: lane (col = lane&15, g) holds 4 consecutive tokens (keys) 4g+r of this tile
                     u32x2 pv = {cvt_pk_bf16(b[0], b[1]), cvt_pk_bf16(b[2], b[3])};
                     char* dst = vbf + ((size_t)(((pr * S + ser) * NJ + (kt >> 1)) * 4 + g) * 16 + tok) * 16;
                     *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = pv;
@@ -453,13 +478,32 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     f32x4 cmask;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) cmask[r] = ((KT - 1) * 16 + 4 * g + r >= T) ? kNegBig : 0.f;
+                    // Softmax shift.  Fast path: the bound  |q| max_j |k_j|  >= max_j q.k_j  (2 % headroom for
+                    // the bf16 rounding of q and k) replaces the row maximum -- any shift cancels in P V / sum P as long
+                    // as nothing overflows (bound >= max) or flushes to zero; P keeps the fp32 exponent range in bf16.
+                    // If a row sum comes out below 2^-100 (bound > max + ~100: not seen with real weights) the unit is
+                    // redone with the exact two-pass maximum.
+                    float bq[NQ][2];
+                    {
+                        const float k2 = reinterpret_cast<const float*>(kmax)[(pr * S + ser) * 2 + (g >> 1)];
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            const float part = qa[q][0] * qa[q][0] + qa[q][1] * qa[q][1] + qa[q][2] * qa[q][2] + qa[q][3] * qa[q][3];
+                            float ea, eb;
+                            swap16(part, ea, eb);                     // the two lane groups of a head
+                            const float bnd = __builtin_sqrtf((ea + eb) * k2) * 1.02f;
+                            swap32(bnd, bq[q][0], bq[q][1]);          // head 0 bound | head 1 bound, in every lane
+                        }
+                    }
                     float m2[NQ][2];
                     f32x4 o2[NQ][2];
+                    auto run_unit = [&](auto exact_c) {
+                    constexpr bool EXACT = decltype(exact_c)::value;
 #pragma unroll
                     for (int q = 0; q < NQ; ++q)
 #pragma unroll
                         for (int hs = 0; hs < 2; ++hs) {
-                            m2[q][hs] = kNegBig;
+                            m2[q][hs] = EXACT ? kNegBig : bq[q][hs];
                             o2[q][hs] = f4zero();
                         }
                     for (int kb = 0; kb < KT; kb += 8) {
@@ -476,18 +520,18 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             if ((kb >> 1) + jj < NJ)
                                 vf[jj] = *reinterpret_cast<const bf16x8*>(
                                     vbf + ((size_t)(((pr * S + ser) * NJ + (kb >> 1) + jj) * 4 + g) * 16 + tok) * 16);
-                        // pass 1: row maxima only (the VALU, not the matrix pipe, bounds this phase: the scores are
-                        // recomputed in pass 2 with -max riding in the C operand, which removes one v_sub per score).
                         // Both passes are software-pipelined by hand, a few MFMAs ahead of their consumers, and
                         // fenced per stage: left alone hipcc issues MFMA -> s_nop 7 -> 4 exps strictly in sequence.
                         // Tile index k = ((hs * 4 + jj) * NQ + q) * 2 + jl with key tile j = 2 jj + jl.
                         const int nk = min(8, KT - kb);                 // key tiles in this block
                         constexpr int NKT = 16 * NQ;                    // score tiles per block
                         mark(10, step);
-                        float bm[NQ][2];
+                        if (EXACT) {
+                            // pass 1 (exact path only): row maxima; the scores are recomputed in pass 2 with -max
+                            // riding in the C operand, which removes one v_sub per score
+                            float bm[NQ][2];
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) bm[q][0] = bm[q][1] = (P.dbg & 32) ? 0.f : kNegBig;
-                        if (!(P.dbg & 32)) {
+                            for (int q = 0; q < NQ; ++q) bm[q][0] = bm[q][1] = kNegBig;
                             constexpr int LAG = 3;
                             f32x4 t4[NKT];
 #pragma unroll
@@ -510,6 +554,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
                             }
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                                for (int hs = 0; hs < 2; ++hs) {
+                                    const float mnew = fmaxf(m2[q][hs], group_max(bm[q][hs]));
+                                    const float alpha = __builtin_amdgcn_exp2f(m2[q][hs] - mnew);
+                                    o2[q][hs] = o2[q][hs] * alpha;
+                                    m2[q][hs] = mnew;
+                                }
                         }
                         mark(11, step);
                         f32x4 negm[NQ][2], clast[NQ][2];
@@ -517,15 +570,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         for (int q = 0; q < NQ; ++q)
 #pragma unroll
                             for (int hs = 0; hs < 2; ++hs) {
-                                const float mnew = fmaxf(m2[q][hs], group_max(bm[q][hs]));
-                                const float alpha = __builtin_amdgcn_exp2f(m2[q][hs] - mnew);
-                                o2[q][hs] = o2[q][hs] * alpha;
-                                m2[q][hs] = mnew;
-                                negm[q][hs] = f32x4{-mnew, -mnew, -mnew, -mnew};
-                                clast[q][hs] = cmask - mnew;
+                                const float mm = m2[q][hs];
+                                negm[q][hs] = f32x4{-mm, -mm, -mm, -mm};
+                                clast[q][hs] = cmask - mm;
                             }
                         mark(12, step);
-                        // pass 2: P = exp2(S - max) tile by tile, packed to bf16 B fragments, then P V.  The row sum of
+                        // pass 2: P = exp2(S - shift) tile by tile, packed to bf16 B fragments, then P V.  The row sum of
                         // P comes out of the same MFMAs: V^T carries a row of ones (dim slot hd).
                         {
                             constexpr int LAG = 2;
@@ -557,21 +607,43 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             }
                         }
                     }
+                    };
+                    // row sums of P: O^T rows 8*hs + [0,8) live in lane groups 2hs, 2hs+1; row 8*hs + hd is the ones row.
+                    // hd in [4,7]: register hd-4 of the odd lane group; hd < 4: register hd of the even one
+                    float lrow[NQ];
+                    auto row_sums = [&]() -> bool {
+                        bool bad = false;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            float cand = lo_grp ? o2[q][0][0] : o2[q][1][0];
+#pragma unroll
+                            for (int r = 1; r < 4; ++r) cand = ((hd & 3) == r) ? (lo_grp ? o2[q][0][r] : o2[q][1][r]) : cand;
+                            float row_even, row_odd;
+                            swap16(cand, row_even, row_odd);
+                            lrow[q] = (hd >= 4) ? row_odd : row_even;
+                            bad |= !(lrow[q] > 7.8e-31f);                 // 2^-100; also catches NaN
+                        }
+                        return bad;
+                    };
+                    if (P.dbg & 32) {
+                        run_unit(std::true_type{});
+                        (void)row_sums();
+                    } else {
+                        run_unit(std::false_type{});
+                        const bool bad = row_sums();
+                        // (dbg bit 64 suppresses the fallback: lets the tests prove that it is what rescues such rows)
+                        if (__builtin_amdgcn_ballot_w64(bad) != 0ull && !(P.dbg & 64)) {   // wave-uniform: redo with the exact maximum
+                            run_unit(std::true_type{});
+                            (void)row_sums();
+                        }
+                    }
                     mark(13, step);
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
-                        // O^T rows 8*hs + [0,8) live in lane groups 2hs, 2hs+1; row 8*hs + hd is sum_j P (ones row)
                         float o_sel[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o_sel[r] = lo_grp ? o2[q][0][r] : o2[q][1][r];
-                        // hd in [4,7]: the ones row is register hd-4 of the odd lane group; hd < 4: register hd of the even one
-                        float cand = o_sel[0];
-#pragma unroll
-                        for (int r = 1; r < 4; ++r) cand = ((hd & 3) == r) ? o_sel[r] : cand;
-                        float row_even, row_odd;
-                        swap16(cand, row_even, row_odd);
-                        const float lrow = (hd >= 4) ? row_odd : row_even;
-                        const float inv = 1.0f / lrow;
+                        const float inv = 1.0f / lrow[q];
                         // head = 2*(pg+pr) + (g>>1); its 8 dims are one 16-B k-slot group of the out-proj B fragment
                         const int head = 2 * (pg + pr) + (g >> 1);
                         u32x2 pk = {cvt_pk_bf16(o_sel[0] * inv, o_sel[1] * inv), cvt_pk_bf16(o_sel[2] * inv, o_sel[3] * inv)};

@@ -572,7 +572,8 @@ static MegaPlan plan_mega_nw(const fd_score* m, int B, int nw) {
             // FFN ring buffer 0 is filled while the out-proj still reads afr: it must fit in front of afr
             const size_t front = std::max(wkv, half_ring);
             const size_t mid = std::max(front + afr, std::max(ring, xch));
-            const size_t temb = ((size_t)(2 * S + 6) * D * sizeof(float) + 15) & ~size_t(15);
+            // time embedding + its scratch, the layer's fp32 vectors, max|K| table of the attention group
+            const size_t temb = (((size_t)(2 * S + 6) * D + (size_t)npg * S * 16) * sizeof(float) + 15) & ~size_t(15);
             const size_t total = xfr + mid + temb;
             if (total > lds_cap) continue;
             pl.ok = true;

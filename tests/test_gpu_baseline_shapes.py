@@ -1,0 +1,131 @@
+"""GPU parity at the series shapes of BASELINE.json configs[2..4] (nasdaq T=252 C=6, mimiciii T=256 C=28, long-horizon
+T=1024 C=16; default transformer d_model=72, 10 layers, 12 heads), against the float64 oracle at batch sizes it
+finishes in seconds, plus size-independent properties at the full per-GPU batch.
+
+Tolerances as in test_gpu_score.py: fp32 mode 5e-6 abs... at T=1024 the fp32 attention sums 1024 terms, 2e-5;
+bf16 MFMA mode <= 2e-2 of the output scale (max) and <= 1e-2 rms."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fdiff_oracle as O
+from oracle import weights as W
+
+from .gpu_util import DEV, dev, host, make_model, oracle_sde
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    "nasdaq": dict(T=252, C=6, D=72, L=10, H=12),
+    "mimic": dict(T=256, C=28, D=72, L=10, H=12),
+    "long": dict(T=1024, C=16, D=72, L=10, H=12),
+}
+
+
+def run(model, X, t):
+    from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
+    model.eval()
+    return host(model(DiffusableBatch(X=dev(X), y=None, timesteps=dev(t))))
+
+
+@pytest.mark.parametrize("name,B", [("nasdaq", 2), ("mimic", 2), ("long", 1)])
+def test_forward_f32_vs_oracle(name, B):
+    cfg = SHAPES[name]
+    m, _, sd = make_model(cfg, precision="fp32")
+    X = W.randn(f"bs_x_{name}", (B, cfg["T"], cfg["C"]), 2)
+    t = W.uniform(f"bs_t_{name}", (B,), 2, 1e-5, 1.0)
+    out = run(m, X, t)
+    ref = O.score_forward(sd, X, t, cfg["H"])
+    np.testing.assert_allclose(out, ref, atol=2e-5 if cfg["T"] > 256 else 5e-6, rtol=0)
+
+
+@pytest.mark.parametrize("name,B", [("nasdaq", 3), ("mimic", 3), ("long", 2)])
+def test_forward_bf16_vs_oracle(name, B):
+    cfg = SHAPES[name]
+    m, _, sd = make_model(cfg, precision="bf16")
+    X = W.randn(f"bs_x_{name}", (B, cfg["T"], cfg["C"]), 2)
+    t = W.uniform(f"bs_t_{name}", (B,), 2, 1e-5, 1.0)
+    out = run(m, X, t)
+    ref = O.score_forward(sd, X, t, cfg["H"])
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    rms = np.sqrt(((out - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())
+    assert err <= 2e-2 and rms <= 1e-2, (err, rms)
+
+
+@pytest.mark.parametrize("name,kind,p", [("nasdaq", "vp", (0.1, 20.0)), ("mimic", "ve", (0.01, 2.0))])
+def test_short_trajectory_f32_vs_oracle(name, kind, p):
+    """8-step reverse diffusion with injected normals (prior + per step), fp32 engine vs the oracle's sampler loop."""
+    from fourierdiffusion_amd.sampling.sampler import DiffusionSampler
+    cfg = SHAPES[name]
+    B, N = 2, 8
+    m, sch, sd = make_model(cfg, kind=kind, p=p, precision="fp32")
+    zp = W.randn(f"bs_zp_{name}", (B, cfg["T"], cfg["C"]), 3)
+    zs = np.stack([W.randn(f"bs_zs_{name}_{i}", (B, cfg["T"], cfg["C"]), 3) for i in range(N)])
+    ref, _ = O.sample_trajectory(sd, oracle_sde(kind, p, True, cfg["T"]), zp, list(zs), cfg["H"])
+    smp = DiffusionSampler(score_model=m, sample_batch_size=B)
+    out = smp.sample(num_samples=B, num_diffusion_steps=N, prior_noise=[dev(zp)], step_noise=[dev(zs)]).numpy()
+    scale = max(1.0, np.abs(ref).max())
+    assert np.abs(out - ref).max() <= 1e-4 * scale, (np.abs(out - ref).max(), scale)
+
+
+def test_mimic_full_batch_properties_bf16():
+    """512 series per GPU at T=256, C=28 (configs[3] per-GPU shard): finite, deterministic, rows independent."""
+    from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
+    cfg = SHAPES["mimic"]
+    m, _, _ = make_model(cfg, precision="bf16")
+    m.eval()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    X = torch.randn(512, cfg["T"], cfg["C"], generator=g).to(DEV)
+    t = torch.rand(512, generator=g).to(DEV)
+    a = m(DiffusableBatch(X=X, timesteps=t))
+    b = m(DiffusableBatch(X=X, timesteps=t))
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    idx = torch.tensor([0, 129, 255, 511], device=DEV)
+    sub = m(DiffusableBatch(X=X[idx].contiguous(), timesteps=t[idx].contiguous()))
+    # a different batch changes the workgroup shape and the fp32 summation order; in bf16 mode a 1e-7 change can flip
+    # an activation rounding (2^-9 relative), so rows agree to bf16 noise, not bitwise (fp32 mode: test_gpu_score.py)
+    assert (sub - a[idx]).abs().max() <= 2e-2 * a.abs().max()
+
+
+def test_softmax_shift_fallback_equals_exact_path():
+    """The persistent kernel shifts the softmax by the bound |q| max|k| and redoes a unit with the exact row maximum
+    when a row sum underflows.  With the attention input projection scaled up (logits of several hundred) the bound
+    overshoots by more than 2^100, so the fallback must trigger; its result must equal the always-exact path
+    (FDIFF_MEGA_DBG=32) -- both are bf16, the only difference allowed is the rounding of the shift."""
+    from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
+    from oracle.make_golden import CFG_DEFAULT
+    cfg = dict(CFG_DEFAULT, L=2)
+    outs = {}
+    for scale in (1.0, 40.0):
+        m, _, sd = make_model(cfg, precision="bf16")
+        st = m.state_dict()
+        for k in list(st):
+            if k.endswith("self_attn.in_proj_weight"):
+                st[k] = st[k] * scale
+        m.load_state_dict(st)
+        m.eval()
+        X = dev(W.randn("fb_x", (6, cfg["T"], cfg["C"]), 2))
+        t = dev(W.uniform("fb_t", (6,), 2, 1e-5, 1.0))
+        old = os.environ.get("FDIFF_MEGA_DBG")
+        try:
+            os.environ.pop("FDIFF_MEGA_DBG", None)
+            fast = host(m(DiffusableBatch(X=X, timesteps=t)))
+            os.environ["FDIFF_MEGA_DBG"] = "32"
+            exact = host(m(DiffusableBatch(X=X, timesteps=t)))
+            os.environ["FDIFF_MEGA_DBG"] = "64"                      # bound only, fallback suppressed
+            nofb = host(m(DiffusableBatch(X=X, timesteps=t)))
+        finally:
+            if old is None:
+                os.environ.pop("FDIFF_MEGA_DBG", None)
+            else:
+                os.environ["FDIFF_MEGA_DBG"] = old
+        assert np.isfinite(fast).all() and np.isfinite(exact).all()
+        if scale > 1.0:   # the fixture really drives rows into underflow: without the fallback the result is wrong
+            assert (not np.isfinite(nofb).all()) or np.abs(nofb - exact).max() > 0.1 * np.abs(exact).max()
+        else:
+            np.testing.assert_allclose(nofb, exact, atol=2e-3 * np.abs(exact).max(), rtol=0)
+        outs[scale] = (fast, exact)
+        np.testing.assert_allclose(fast, exact, atol=2e-3 * np.abs(exact).max(), rtol=0)
+    assert np.abs(outs[40.0][1] - outs[1.0][1]).max() > 1e-2, "scaled projection must change the output"
