@@ -71,13 +71,20 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
                          f"(WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; the modulo only matters for the single-GPU rehearsal of the multi-rank path
+    # (FDIFF_BENCH_BACKEND=gloo, tests/test_gpu_entrypoints.py), where two ranks share cuda:0
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
+    backend = os.environ.get("FDIFF_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist_mod.init_process_group(backend=backend)
         dist = dist_mod
 
     from fourierdiffusion_amd import _C, _rng
@@ -131,7 +138,7 @@ def main():
     elapsed = time.perf_counter() - t0
     assert torch.isfinite(X).all(), "sampler produced non-finite values"
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

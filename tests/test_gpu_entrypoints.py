@@ -58,3 +58,28 @@ def test_fourier_datamodule_roundtrip_and_standardisation():
     torch.manual_seed(0)
     tr = torch.cat([b.X for b in dm.train_dataloader()])
     assert tr.shape == (60, 20, 3) and abs(float(tr.mean())) < 0.05 and abs(float(tr.std()) - 1.0) < 0.05
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's multi-rank path (one process per rank under torch.distributed.run, barrier-bracketed timing, MAX over
+    ranks, rank 0 prints ONE JSON line with the whole-job value).  The box has one GPU, so both ranks share cuda:0 and
+    rendezvous over gloo (FDIFF_BENCH_BACKEND); on the 8-GPU node the same code runs with backend "nccl" (= RCCL)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, FDIFF_BENCH_BACKEND="gloo", PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--batch", "64", "--diffusion-steps", "20"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
