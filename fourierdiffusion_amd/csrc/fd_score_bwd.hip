@@ -287,10 +287,13 @@ void attn_bwd_t(const float* qkv, const float* dO, const float* lse, const float
 
 }  // namespace
 
+// split-K partial sums of the weight-gradient GEMMs (dW = dY^T X reduces over all B*T tokens): 16 x the largest dW
+constexpr size_t kSplitKFloats = (size_t)4 << 20;
+
 size_t fd_score_bwd_workspace(const fd_score* m, int B) {
     const size_t M = (size_t)B * m->d.max_len, D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, T = m->d.max_len;
     auto fl = [](size_t n) { return fd_ws::padded(n * sizeof(float)); };
-    return 3 * fl(M * D) + fl(M * F) + fl(M * 3 * D) + fl((size_t)B * H * T) + fl((size_t)B * D) + 4096;
+    return 3 * fl(M * D) + fl(M * F) + fl(M * 3 * D) + fl((size_t)B * H * T) + fl((size_t)B * D) + fl(kSplitKFloats) + 4096;
 }
 
 extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, int accumulate, void* stream) {
@@ -320,12 +323,13 @@ extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, i
     float* dqkv = ws.take<float>((size_t)M * 3 * D);
     float* Dq = ws.take<float>((size_t)B * H * T);
     float* dtemb = ws.take<float>((size_t)B * D);
+    float* skp = ws.take<float>(kSplitKFloats);
 
     if (!accumulate) FD_HIP(ctx, hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->nparams, s));
     const float inv_keep = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
 
     // ---- unembedder: out = hL Wu^T + bu
-    fdgemm::linear_bwd_weight(dout, sv.hL, grads + m->un_w, M, C, D, true, s);
+    fdgemm::linear_bwd_weight(dout, sv.hL, grads + m->un_w, M, C, D, true, s, skp, kSplitKFloats);
     colsum(ctx, dout, grads + m->un_b, M, C, s);
     fdgemm::linear_bwd_input(dout, P + m->un_w, dh, M, C, D, false, s);
 
@@ -337,13 +341,13 @@ extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, i
         // s2 = x1 + drop(f2), f2 = hact W2^T + b2
         FD_HIP(ctx, hipMemcpyAsync(tmp, ds, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, s));
         fd_dropout_inplace(ctx, tmp, (size_t)M * D, p, m->saved_seed, fd_dropout_site_offset(m->saved_offset, i, 3), s);
-        fdgemm::linear_bwd_weight(tmp, A.hact, grads + lo.l2_w, M, D, F, true, s);
+        fdgemm::linear_bwd_weight(tmp, A.hact, grads + lo.l2_w, M, D, F, true, s, skp, kSplitKFloats);
         colsum(ctx, tmp, grads + lo.l2_b, M, D, s);
         fdgemm::linear_bwd_input(tmp, P + lo.l2_w, dact, M, D, F, false, s);
         // hact = drop(relu(x1 W1^T + b1))
         hipLaunchKernelGGL(k_relu_drop_bwd, dim3(ew_grid(ctx, (size_t)M * F)), dim3(256), 0, s, dact, A.hact, (size_t)M * F,
                            inv_keep);
-        fdgemm::linear_bwd_weight(dact, A.x1, grads + lo.l1_w, M, F, D, true, s);
+        fdgemm::linear_bwd_weight(dact, A.x1, grads + lo.l1_w, M, F, D, true, s, skp, kSplitKFloats);
         colsum(ctx, dact, grads + lo.l1_b, M, F, s);
         fdgemm::linear_bwd_input(dact, P + lo.l1_w, ds, M, F, D, true, s);        // ds = d x1 (residual + FFN branch)
         // x1 = LN1(s1): ds -> dh (= d s1)
@@ -351,7 +355,7 @@ extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, i
         // s1 = x0 + drop(proj), proj = att Wo^T + bo
         FD_HIP(ctx, hipMemcpyAsync(tmp, dh, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, s));
         fd_dropout_inplace(ctx, tmp, (size_t)M * D, p, m->saved_seed, fd_dropout_site_offset(m->saved_offset, i, 1), s);
-        fdgemm::linear_bwd_weight(tmp, A.att, grads + lo.out_w, M, D, D, true, s);
+        fdgemm::linear_bwd_weight(tmp, A.att, grads + lo.out_w, M, D, D, true, s, skp, kSplitKFloats);
         colsum(ctx, tmp, grads + lo.out_b, M, D, s);
         fdgemm::linear_bwd_input(tmp, P + lo.out_w, ds, M, D, D, false, s);      // ds = d att
         // attention core
@@ -365,13 +369,13 @@ extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, i
             else attn_bwd_t<64>(A.qkv, ds, A.lse, Dq, dqkv, B, T, H, hd, p, m->saved_seed, off0, s);
         }
         // qkv = x0 Win^T + bin
-        fdgemm::linear_bwd_weight(dqkv, A.x0, grads + lo.in_w, M, 3 * D, D, true, s);
+        fdgemm::linear_bwd_weight(dqkv, A.x0, grads + lo.in_w, M, 3 * D, D, true, s, skp, kSplitKFloats);
         colsum(ctx, dqkv, grads + lo.in_b, M, 3 * D, s);
         fdgemm::linear_bwd_input(dqkv, P + lo.in_w, dh, M, 3 * D, D, true, s);   // dh = d x0 (residual + attention branch)
     }
 
     // ---- embed: h0 = X We^T + be + pe[t] + temb[b]
-    fdgemm::linear_bwd_weight(dh, m->saved_x, grads + m->emb_w, M, D, C, true, s);
+    fdgemm::linear_bwd_weight(dh, m->saved_x, grads + m->emb_w, M, D, C, true, s, skp, kSplitKFloats);
     colsum(ctx, dh, grads + m->emb_b, M, D, s);
     {
         const size_t n = std::max((size_t)T * D, (size_t)B * D);
@@ -379,7 +383,7 @@ extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, i
                            D);
     }
     // temb = emb Wd^T + bd   (time_encoder.W is frozen: transformer.py:72-74)
-    fdgemm::linear_bwd_weight(dtemb, sv.emb, grads + m->td_w, B, D, D, true, s);
+    fdgemm::linear_bwd_weight(dtemb, sv.emb, grads + m->td_w, B, D, D, true, s, skp, kSplitKFloats);
     colsum(ctx, dtemb, grads + m->td_b, B, D, s);
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
