@@ -1,0 +1,269 @@
+// fd_attn_bf16.hip -- bf16 MFMA self-attention for the step-by-step path (series too long for the persistent
+// kernel: T > 256).  Same formulation as the attention units of fd_mega.hip, as a standalone kernel:
+//   * one workgroup = (series, head pair, slice of the query tiles); K and V^T of the pair for the WHOLE series are
+//     converted to bf16 fragments in LDS once (T = 1024: 64 KiB) and every wave then walks 128-key blocks from LDS;
+//   * unit = 2 consecutive query tiles x both heads of the pair: S^T = K Q^T by the K=16 MFMA (two heads share each K
+//     fragment, Q masked per head), exact two-pass online softmax per key block (row max, then exp2(S - max) with -max
+//     riding in the MFMA C operand), P re-packed in registers as the B operand of O^T = V^T P^T; the softmax
+//     denominator is the ones row V^T carries in the free dim slot hd (so head_dim <= 7 here).
+// Reference arithmetic: torch.nn.MultiheadAttention inside nn.TransformerEncoderLayer
+// (src/fdiff/models/score_models.py:57-62), eval mode, softmax(q k^T / sqrt(hd)) v per head.
+#include <hip/hip_runtime.h>
+
+#include "fd_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
+
+namespace {
+
+constexpr float kNegBig = -1.0e30f;
+constexpr int NW = 8, NTH = NW * 64, NQ = 2;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
+    u32x4 r = {cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3]), cvt_pk_bf16(b[0], b[1]), cvt_pk_bf16(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ f32x4 f4zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void swap32(float v, float& a, float& b) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned r0 = r.x, r1 = r.y;
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void swap16(float v, float& a, float& b) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned r0 = r.x, r1 = r.y;
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ float group_max(float v) {      // over the 4 lane groups (rows of 16 lanes) of one query
+    float a, b;
+    swap32(v, a, b);
+    swap16(fmaxf(a, b), a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ unsigned short bf16_bits(float v) {
+    return __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+
+// qkv (B*T, 3D) fp32 rows [q | k | v]; out (B*T, D) fp32.  grid (query slices, head pairs, B), 512 threads.
+__global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restrict__ qkv, float* __restrict__ out, int T,
+                                                           int H, int hd, int D, float qscale, int du_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KT = (T + 15) >> 4, NJ = (KT + 1) >> 1, NTOK = KT * 16;
+    const int pair = blockIdx.y, b = blockIdx.z;
+    char* const kbf = smem;                       // [NTOK][4 g][8 B]: lane group g = 2*hs + (d >> 2), element d & 3
+    char* const vbf = smem + (size_t)NTOK * 32;   // [NJ][4 g][16 dim slots][16 B]: (half, r) -> token (2jj+half)*16 + 4g + r
+    const float* base = qkv + (size_t)b * T * 3 * D;
+
+    // ---- stage K and V^T of this (series, pair): zero, then scatter the valid entries
+    for (int i = threadIdx.x; i < (NTOK * 32 + NJ * 1024) / 16; i += NTH) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += NTH) {
+        const float* row = base + (size_t)t * 3 * D;
+        const int jj = t >> 5, half = (t >> 4) & 1, gg = (t & 15) >> 2, r = t & 3;
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+            const int head = 2 * pair + hs;
+            if (head >= H) continue;
+            for (int d = 0; d < hd; ++d) {
+                const float kv = row[D + head * hd + d], vv = row[2 * D + head * hd + d];
+                *reinterpret_cast<unsigned short*>(kbf + ((size_t)t * 4 + 2 * hs + (d >> 2)) * 8 + (d & 3) * 2) = bf16_bits(kv);
+                *reinterpret_cast<unsigned short*>(vbf + ((size_t)(jj * 4 + gg) * 16 + hs * 8 + d) * 16 + half * 8 + r * 2) =
+                    bf16_bits(vv);
+            }
+            // ones row: the P V MFMAs then also produce sum_j P (softmax denominator)
+            *reinterpret_cast<unsigned short*>(vbf + ((size_t)(jj * 4 + gg) * 16 + hs * 8 + hd) * 16 + half * 8 + r * 2) = 0x3F80;
+        }
+    }
+    __syncthreads();
+
+    const bool lo_grp = (g >> 1) == 0;
+    const int myhead = 2 * pair + (g >> 1);
+    f32x4 cmask;                                                     // keys beyond T in the ragged last tile
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cmask[r] = ((KT - 1) * 16 + 4 * g + r >= T) ? kNegBig : 0.f;
+    const int DUS = (KT + NQ - 1) / NQ;
+    const int du0 = blockIdx.x * du_per_block, du1 = min(DUS, du0 + du_per_block);
+    for (int du = du0 + wave; du < du1; du += NW) {
+        int qt[NQ];
+        bool qv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            qv[q] = du * NQ + q < KT;
+            qt[q] = qv[q] ? du * NQ + q : du * NQ;
+        }
+        // Q^T B operands: lane (query tok, g) holds dims 4(g&1)..+3 of head g>>1, pre-scaled by log2(e)/sqrt(hd)
+        s16x4 qb[NQ][2];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int t = qt[q] * 16 + tok;
+            float qvv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = 4 * (g & 1) + r;
+                qvv[r] = (t < T && d < hd && myhead < H) ? base[(size_t)t * 3 * D + myhead * hd + d] * qscale : 0.f;
+            }
+            const unsigned q01 = cvt_pk_bf16(qvv[0], qvv[1]), q23 = cvt_pk_bf16(qvv[2], qvv[3]);
+            const u32x2 qe = {lo_grp ? q01 : 0u, lo_grp ? q23 : 0u};
+            const u32x2 qo = {lo_grp ? 0u : q01, lo_grp ? 0u : q23};
+            qb[q][0] = __builtin_bit_cast(s16x4, qe);
+            qb[q][1] = __builtin_bit_cast(s16x4, qo);
+        }
+        float m2[NQ][2];
+        f32x4 o2[NQ][2];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int hs = 0; hs < 2; ++hs) {
+                m2[q][hs] = kNegBig;
+                o2[q][hs] = f4zero();
+            }
+        for (int kb = 0; kb < KT; kb += 8) {
+            s16x4 kf[8];
+            bf16x8 vf[4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (kb + j < KT) kf[j] = *reinterpret_cast<const s16x4*>(kbf + ((size_t)((kb + j) * 16 + tok) * 4 + g) * 8);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if ((kb >> 1) + jj < NJ)
+                    vf[jj] = *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(((kb >> 1) + jj) * 4 + g) * 16 + tok) * 16);
+            const int nk = min(8, KT - kb);
+            constexpr int NKT = 16 * NQ;          // score tiles per block: k = ((hs*4 + jj)*NQ + q)*2 + jl, key tile 2jj+jl
+            // pass 1: row maxima of this key block (software-pipelined by hand, see fd_mega.hip)
+            float bm[NQ][2];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) bm[q][0] = bm[q][1] = kNegBig;
+            {
+                constexpr int LAG = 3;
+                f32x4 t4[NKT];
+#pragma unroll
+                for (int k = 0; k < NKT + LAG; ++k) {
+                    if (k < NKT) {
+                        const int jl = k & 1, q = (k >> 1) % NQ, jj = ((k >> 1) / NQ) & 3, hs = (k >> 1) / NQ >> 2;
+                        const int j = 2 * jj + jl;
+                        if (j < nk) t4[k] = MFMA16(kf[j], qb[q][hs], (kb + j == KT - 1) ? cmask : f4zero());
+                    }
+                    if (k >= LAG) {
+                        const int e = k - LAG;
+                        const int jl = e & 1, q = (e >> 1) % NQ, jj = ((e >> 1) / NQ) & 3, hs = (e >> 1) / NQ >> 2;
+                        if (2 * jj + jl < nk) {
+                            const f32x4 v = t4[e];
+                            float bb = bm[q][hs];
+                            bb = fmaxf(fmaxf(bb, v[0]), v[1]);
+                            bb = fmaxf(fmaxf(bb, v[2]), v[3]);
+                            bm[q][hs] = bb;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            f32x4 negm[NQ][2], clast[NQ][2];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int hs = 0; hs < 2; ++hs) {
+                    const float mnew = fmaxf(m2[q][hs], group_max(bm[q][hs]));
+                    const float alpha = __builtin_amdgcn_exp2f(m2[q][hs] - mnew);
+                    o2[q][hs] = o2[q][hs] * alpha;
+                    m2[q][hs] = mnew;
+                    negm[q][hs] = f32x4{-mnew, -mnew, -mnew, -mnew};
+                    clast[q][hs] = cmask - mnew;
+                }
+            // pass 2: P = exp2(S - max), packed to bf16 B fragments, then P V
+            {
+                constexpr int LAG = 2;
+                f32x4 pe[NKT];
+                bf16x8 pk[NKT / 2];
+#pragma unroll
+                for (int k = 0; k < NKT + 2 * LAG; ++k) {
+                    if (k < NKT) {
+                        const int jl = k & 1, q = (k >> 1) % NQ, jj = ((k >> 1) / NQ) & 3, hs = (k >> 1) / NQ >> 2;
+                        const int j = 2 * jj + jl;
+                        if (j < nk) pe[k] = MFMA16(kf[j], qb[q][hs], (kb + j == KT - 1) ? clast[q][hs] : negm[q][hs]);
+                        else pe[k] = f4zero();
+                    }
+                    if (k >= LAG && k - LAG < NKT) {
+                        const int e = k - LAG;
+                        const int jl = e & 1, jj = ((e >> 1) / NQ) & 3;
+                        if (2 * jj + jl < nk) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) pe[e][r] = __builtin_amdgcn_exp2f(pe[e][r]);
+                        }
+                        if (jl) pk[e >> 1] = pack8(pe[e - 1], pe[e]);
+                    }
+                    if (k >= 2 * LAG && ((k - 2 * LAG) & 1)) {
+                        const int e = k - 2 * LAG;
+                        const int q = (e >> 1) % NQ, jj = ((e >> 1) / NQ) & 3, hs = (e >> 1) / NQ >> 2;
+                        if (2 * jj < nk) o2[q][hs] = MFMA(vf[jj], pk[e >> 1], o2[q][hs]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // O^T rows 8*hs + [0,8) live in lane groups 2hs, 2hs+1; row 8*hs + hd is sum_j P (the ones row):
+        // hd in [4,7]: register hd-4 of the odd lane group; hd < 4: register hd of the even one
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float o_sel[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o_sel[r] = lo_grp ? o2[q][0][r] : o2[q][1][r];
+            float cand = o_sel[0];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) cand = ((hd & 3) == r) ? o_sel[r] : cand;
+            float row_even, row_odd;
+            swap16(cand, row_even, row_odd);
+            const float inv = 1.0f / ((hd >= 4) ? row_odd : row_even);
+            const int t = qt[q] * 16 + tok;
+            if (qv[q] && t < T && myhead < H) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = 4 * (g & 1) + r;
+                    if (d < hd) out[((size_t)b * T + t) * D + myhead * hd + d] = o_sel[r] * inv;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// bf16 MFMA attention over packed projections.  Returns FD_ERR_UNSUPPORTED when the shape does not fit (head_dim > 7,
+// or K/V^T of one series exceed the LDS): the caller then runs the exact-f32 kernel.
+int fd_attention_bf16(fd_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int hd, hipStream_t s) {
+    const int KT = (T + 15) / 16, NJ = (KT + 1) / 2, D = H * hd;
+    const size_t lds = (size_t)KT * 16 * 32 + (size_t)NJ * 1024;
+    if (hd > 7 || lds > 160 * 1024) return FD_ERR_UNSUPPORTED;
+    static bool attr = false;
+    if (!attr) {
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_attention_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const int NP = (H + 1) / 2, DUS = (KT + NQ - 1) / NQ;
+    // enough workgroups to fill the chip, but each one restages K/V: at most 4 slices, at least NW units per slice
+    int slices = 1;
+    while (slices < 4 && (size_t)B * NP * slices < 2 * (size_t)ctx->num_cu && DUS / (slices * 2) >= NW) slices *= 2;
+    const int du_per_block = (DUS + slices - 1) / slices;
+    const float qscale = 1.4426950408889634f / sqrtf((float)hd);
+    hipLaunchKernelGGL(k_attention_bf16, dim3(slices, NP, B), dim3(NTH), lds, s, qkv, out, T, H, hd, D, qscale, du_per_block);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}

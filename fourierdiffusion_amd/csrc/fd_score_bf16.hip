@@ -696,7 +696,9 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
     for (int i = 0; i < L; ++i) {
         const fd_layer_off& lo = m->layers[i];
         fdgemm::linear_fwd(h0, P + lo.in_w, P + lo.in_b, qkv, M, 3 * D, D, false, s);
-        fd_attention_f32(qkv, att, nullptr, B, T, H, hd, 0.f, 0, 0, s);
+        const int arc = getenv("FDIFF_ATTN_F32") ? FD_ERR_UNSUPPORTED : fd_attention_bf16(ctx, qkv, att, B, T, H, hd, s);
+        if (arc == FD_ERR_UNSUPPORTED) fd_attention_f32(qkv, att, nullptr, B, T, H, hd, 0.f, 0, 0, s);
+        else if (arc != FD_OK) return arc;
         fdgemm::linear_fwd(att, P + lo.out_w, P + lo.out_b, tmp, M, D, D, false, s);
         fdf32::add_layernorm(h0, tmp, P + lo.n1_w, P + lo.n1_b, h1, M, D, s);
         if (int rc = run_ffn(m, h1, h0, i, M, s)) return rc;
