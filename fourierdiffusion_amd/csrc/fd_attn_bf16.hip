@@ -10,6 +10,8 @@
 // (src/fdiff/models/score_models.py:57-62), eval mode, softmax(q k^T / sqrt(hd)) v per head.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "fd_common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -57,9 +59,6 @@ __device__ __forceinline__ float group_max(float v) {      // over the 4 lane gr
     swap16(fmaxf(a, b), a, b);
     return fmaxf(a, b);
 }
-__device__ __forceinline__ unsigned short bf16_bits(float v) {
-    return __builtin_bit_cast(unsigned short, (__bf16)v);
-}
 
 // qkv (B*T, 3D) fp32 rows [q | k | v]; out (B*T, D) fp32.  grid (query slices, head pairs, B), 512 threads.
 __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restrict__ qkv, float* __restrict__ out, int T,
@@ -73,25 +72,33 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
     char* const vbf = smem + (size_t)NTOK * 32;   // [NJ][4 g][16 dim slots][16 B]: (half, r) -> token (2jj+half)*16 + 4g + r
     const float* base = qkv + (size_t)b * T * 3 * D;
 
-    // ---- stage K and V^T of this (series, pair): zero, then scatter the valid entries
-    for (int i = threadIdx.x; i < (NTOK * 32 + NJ * 1024) / 16; i += NTH) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
-    __syncthreads();
-    for (int t = threadIdx.x; t < T; t += NTH) {
-        const float* row = base + (size_t)t * 3 * D;
-        const int jj = t >> 5, half = (t >> 4) & 1, gg = (t & 15) >> 2, r = t & 3;
+    // ---- stage K and V^T of this (series, pair) as bf16 fragments; every byte of both regions is written here
+    // K: one thread per (token, lane group gq): the 4 dims 4(gq&1)..+3 of head gq>>1 -> one 8-byte row
+    for (int i = threadIdx.x; i < NTOK * 4; i += NTH) {
+        const int t = i >> 2, gq = i & 3, head = 2 * pair + (gq >> 1);
+        float kv[4];
 #pragma unroll
-        for (int hs = 0; hs < 2; ++hs) {
-            const int head = 2 * pair + hs;
-            if (head >= H) continue;
-            for (int d = 0; d < hd; ++d) {
-                const float kv = row[D + head * hd + d], vv = row[2 * D + head * hd + d];
-                *reinterpret_cast<unsigned short*>(kbf + ((size_t)t * 4 + 2 * hs + (d >> 2)) * 8 + (d & 3) * 2) = bf16_bits(kv);
-                *reinterpret_cast<unsigned short*>(vbf + ((size_t)(jj * 4 + gg) * 16 + hs * 8 + d) * 16 + half * 8 + r * 2) =
-                    bf16_bits(vv);
-            }
-            // ones row: the P V MFMAs then also produce sum_j P (softmax denominator)
-            *reinterpret_cast<unsigned short*>(vbf + ((size_t)(jj * 4 + gg) * 16 + hs * 8 + hd) * 16 + half * 8 + r * 2) = 0x3F80;
+        for (int r = 0; r < 4; ++r) {
+            const int d = 4 * (gq & 1) + r;
+            kv[r] = (t < T && d < hd && head < H) ? base[(size_t)t * 3 * D + D + head * hd + d] : 0.f;
         }
+        *reinterpret_cast<u32x2*>(kbf + (size_t)i * 8) = u32x2{cvt_pk_bf16(kv[0], kv[1]), cvt_pk_bf16(kv[2], kv[3])};
+    }
+    // V^T: one thread per (32-key block jj, lane group gg, dim slot row): 8 keys (half, r) of that dim -> one 16-byte
+    // vector.  Slot hd of each head is the ones row: the P V MFMAs then also produce sum_j P (softmax denominator).
+    for (int i = threadIdx.x; i < NJ * 64; i += NTH) {
+        const int row = i & 15, gg = (i >> 4) & 3, jj = i >> 6;
+        const int hs = row >> 3, d = row & 7, head = 2 * pair + hs;
+        float vv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int t = (2 * jj + (e >> 2)) * 16 + 4 * gg + (e & 3);
+            float x = 0.f;
+            if (t < T && head < H) x = (d < hd) ? base[(size_t)t * 3 * D + 2 * D + head * hd + d] : (d == hd ? 1.0f : 0.f);
+            vv[e] = x;
+        }
+        *reinterpret_cast<u32x4*>(vbf + (size_t)i * 16) = u32x4{cvt_pk_bf16(vv[0], vv[1]), cvt_pk_bf16(vv[2], vv[3]),
+                                                               cvt_pk_bf16(vv[4], vv[5]), cvt_pk_bf16(vv[6], vv[7])};
     }
     __syncthreads();
 
@@ -136,17 +143,21 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
                 m2[q][hs] = kNegBig;
                 o2[q][hs] = f4zero();
             }
-        for (int kb = 0; kb < KT; kb += 8) {
+        // One 128-key block.  FULL (8 key tiles) and LAST (the block holds the series' final, possibly ragged tile) are
+        // compile-time: with run-time tile guards every MFMA sits in its own basic block and the hand-made software
+        // pipeline below falls apart (measured 3x slower).
+        auto key_block = [&](int kb, auto full_c, auto last_c) {
+            constexpr bool FULL = decltype(full_c)::value, LAST = decltype(last_c)::value;
             s16x4 kf[8];
             bf16x8 vf[4];
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (kb + j < KT) kf[j] = *reinterpret_cast<const s16x4*>(kbf + ((size_t)((kb + j) * 16 + tok) * 4 + g) * 8);
+                if (FULL || kb + j < KT) kf[j] = *reinterpret_cast<const s16x4*>(kbf + ((size_t)((kb + j) * 16 + tok) * 4 + g) * 8);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
-                if ((kb >> 1) + jj < NJ)
+                if (FULL || (kb >> 1) + jj < NJ)
                     vf[jj] = *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(((kb >> 1) + jj) * 4 + g) * 16 + tok) * 16);
-            const int nk = min(8, KT - kb);
+            const int nk = FULL ? 8 : min(8, KT - kb);
             constexpr int NKT = 16 * NQ;          // score tiles per block: k = ((hs*4 + jj)*NQ + q)*2 + jl, key tile 2jj+jl
             // pass 1: row maxima of this key block (software-pipelined by hand, see fd_mega.hip)
             float bm[NQ][2];
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
                     if (k < NKT) {
                         const int jl = k & 1, q = (k >> 1) % NQ, jj = ((k >> 1) / NQ) & 3, hs = (k >> 1) / NQ >> 2;
                         const int j = 2 * jj + jl;
-                        if (j < nk) t4[k] = MFMA16(kf[j], qb[q][hs], (kb + j == KT - 1) ? cmask : f4zero());
+                        if (j < nk) t4[k] = MFMA16(kf[j], qb[q][hs], (LAST && kb + j == KT - 1) ? cmask : f4zero());
                     }
                     if (k >= LAG) {
                         const int e = k - LAG;
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
                     if (k < NKT) {
                         const int jl = k & 1, q = (k >> 1) % NQ, jj = ((k >> 1) / NQ) & 3, hs = (k >> 1) / NQ >> 2;
                         const int j = 2 * jj + jl;
-                        if (j < nk) pe[k] = MFMA16(kf[j], qb[q][hs], (kb + j == KT - 1) ? clast[q][hs] : negm[q][hs]);
+                        if (j < nk) pe[k] = MFMA16(kf[j], qb[q][hs], (LAST && kb + j == KT - 1) ? clast[q][hs] : negm[q][hs]);
                         else pe[k] = f4zero();
                     }
                     if (k >= LAG && k - LAG < NKT) {
@@ -218,6 +229,12 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        };
+        {
+            int kb = 0;
+            for (; kb + 8 < KT; kb += 8) key_block(kb, std::true_type{}, std::false_type{});
+            if (kb + 8 == KT) key_block(kb, std::true_type{}, std::true_type{});
+            else key_block(kb, std::false_type{}, std::true_type{});
         }
         // O^T rows 8*hs + [0,8) live in lane groups 2hs, 2hs+1; row 8*hs + hd is sum_j P (the ones row):
         // hd in [4,7]: register hd-4 of the odd lane group; hd < 4: register hd of the even one
@@ -258,9 +275,16 @@ int fd_attention_bf16(fd_ctx* ctx, const float* qkv, float* out, int B, int T, i
         attr = true;
     }
     const int NP = (H + 1) / 2, DUS = (KT + NQ - 1) / NQ;
-    // enough workgroups to fill the chip, but each one restages K/V: at most 4 slices, at least NW units per slice
+    // Query slices per (series, pair): every slice restages K/V (~10 % of a full slice's work); pick the count that
+    // minimises rounds x work per round (one workgroup per CU: 8 waves at the 256-VGPR budget).
     int slices = 1;
-    while (slices < 4 && (size_t)B * NP * slices < 2 * (size_t)ctx->num_cu && DUS / (slices * 2) >= NW) slices *= 2;
+    double best = 1e30;
+    for (int sl = 1; sl <= 8; sl *= 2) {
+        if (sl > 1 && DUS / sl < NW) break;                  // at least one unit per wave
+        const double rounds = (double)(((size_t)B * NP * sl + ctx->num_cu - 1) / ctx->num_cu);
+        const double cost = rounds * (1.0 / sl + 0.1);
+        if (cost < best - 1e-9) { best = cost; slices = sl; }
+    }
     const int du_per_block = (DUS + slices - 1) / slices;
     const float qscale = 1.4426950408889634f / sqrtf((float)hd);
     hipLaunchKernelGGL(k_attention_bf16, dim3(slices, NP, B), dim3(NTH), lds, s, qkv, out, T, H, hd, D, qscale, du_per_block);
