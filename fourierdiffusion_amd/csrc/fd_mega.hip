@@ -943,15 +943,27 @@ static int launch_mega_t(fd_ctx* ctx, const fd_mega_params& P, int grid, size_t 
     return FD_OK;
 }
 
-// BASELINE.json configs[1]: ecg-synth (T=100, C=12), default transformer, 2 series per workgroup, 2 head groups
+// Static-shape instantiations for the BASELINE.json workloads (default transformer: D=72, H=12, L=10, F=2048):
+// configs[1] ecg (T=100, C=12): 2 series per workgroup, 2 head groups of 3 pairs;
+// configs[2] nasdaq (T=252, C=6) and configs[3] mimiciii (T=256, C=28): 1 series (16 token tiles), 3 groups of 2 pairs.
 using ShapeEcg = ShapeStatic<100, 72, 12, 12, 2, 3, 2, 10, 2048>;
+using ShapeNasdaq = ShapeStatic<252, 72, 6, 12, 1, 2, 1, 10, 2048>;
+using ShapeMimic = ShapeStatic<256, 72, 28, 12, 1, 2, 1, 10, 2048>;
+
+template <class SH>
+static bool shape_matches(const fd_mega_params& P, int ks1, int dt, int kso, int mt) {
+    return ks1 == 3 && dt == 5 && kso == 3 && mt == 4 && P.T == SH::T && P.D == SH::D && P.C == SH::C && P.H == SH::H &&
+           P.S == SH::S && P.NPG == SH::NPG && P.rot == SH::rot && P.L == SH::L && P.F == SH::F;
+}
+
 int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int kso, int mt, int nw, int grid, size_t lds,
                    hipStream_t s) {
     if (nw != 8) return fd_fail(ctx, FD_ERR_UNSUPPORTED, "persistent kernel: only 8-wave workgroups are instantiated");
-    if (!getenv("FDIFF_MEGA_GENERIC") && ks1 == 3 && dt == 5 && kso == 3 && mt == 4 && P.T == ShapeEcg::T &&
-        P.D == ShapeEcg::D && P.C == ShapeEcg::C && P.H == ShapeEcg::H && P.S == ShapeEcg::S && P.NPG == ShapeEcg::NPG &&
-        P.rot == ShapeEcg::rot && P.L == ShapeEcg::L && P.F == ShapeEcg::F)
-        return launch_mega_t<3, 5, 3, 4, ShapeEcg>(ctx, P, grid, lds, s);
+    if (!getenv("FDIFF_MEGA_GENERIC")) {
+        if (shape_matches<ShapeEcg>(P, ks1, dt, kso, mt)) return launch_mega_t<3, 5, 3, 4, ShapeEcg>(ctx, P, grid, lds, s);
+        if (shape_matches<ShapeNasdaq>(P, ks1, dt, kso, mt)) return launch_mega_t<3, 5, 3, 4, ShapeNasdaq>(ctx, P, grid, lds, s);
+        if (shape_matches<ShapeMimic>(P, ks1, dt, kso, mt)) return launch_mega_t<3, 5, 3, 4, ShapeMimic>(ctx, P, grid, lds, s);
+    }
 #define FD_MEGA_CASE(K, T_, O, M_)                                                                 \
     if (ks1 == K && dt == T_ && kso == O && mt == M_) return launch_mega_t<K, T_, O, M_, ShapeDyn>(ctx, P, grid, lds, s);
 #define FD_MEGA_MT(K, T_, O) FD_MEGA_CASE(K, T_, O, 1) FD_MEGA_CASE(K, T_, O, 2) FD_MEGA_CASE(K, T_, O, 3) FD_MEGA_CASE(K, T_, O, 4)
