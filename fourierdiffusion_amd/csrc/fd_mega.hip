@@ -185,7 +185,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
     char* const ring = wsl;                                   // FFN weight ring + exchange alias W/K/V(/afr)
     float* const temb = reinterpret_cast<float*>(smem + P.lds_temb);   // [S][D] + emb scratch [S][D]
     float* const lpar = temb + 2 * S * D;                              // [6][D] bo, b2, g1, b1, g2, b2 of the layer
-    unsigned* const kmax = reinterpret_cast<unsigned*>(lpar + 6 * D);  // [NPG][S][2] max_j |k_j|^2 per head of the group (bits)
+    unsigned* const kmax2 = reinterpret_cast<unsigned*>(lpar + 6 * D); // [2 parities][NPG][S][2] max_j |k_j|^2 per head (bits)
+    unsigned* const ucnt = kmax2 + 4 * NPG * S;                        // next attention unit of the group (dynamic hand-out)
 
     // ---- token-tile ownership (same split as the FFN: quarters mq, F-halves fh; fh waves rotated)
     const int fh = wave / MQ;
@@ -388,16 +389,25 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
             // -------- attention, one group of head pairs at a time
             for (int pg = 0; pg < NP; pg += NPG) {
                 const int npg = min(NPG, NP - pg);
-                // W_k | W_v | W_q of this group in ONE stream (one exposed L2->LDS round trip per group)
+                // Weight stream of the attention groups.  Only the first group of a layer pays an exposed L2->LDS round
+                // trip: W_k | W_v of group g+1 are fetched into their (dead) slots while group g's units run, and
+                // become visible with the barrier that ends those units; W_q of group g+1 lands behind its K/V
+                // projection.  The max|k|^2 table is double-buffered by group parity for the same reason.
                 char* const wk = wsl;
                 char* const wv = wsl + NPG * KS1 * 1024;
                 char* const wq = wsl + 2 * NPG * KS1 * 1024;
-                dma_blocks(limg + P.off_wk + (size_t)pg * KS1 * 1024, wk, npg * KS1);
-                dma_blocks(limg + P.off_wv + (size_t)pg * KS1 * 1024, wv, npg * KS1);
-                dma_blocks(limg + P.off_wq + (size_t)pg * KS1 * 1024, wq, npg * KS1);
-                for (int i = threadIdx.x; i < NPG * S * 2; i += NTH) kmax[i] = 0u;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                const int gpar = (pg / NPG) & 1;
+                unsigned* const kmax = kmax2 + gpar * (NPG * S * 2);
+                if (pg == 0) {
+                    dma_blocks(limg + P.off_wk, wk, npg * KS1);
+                    dma_blocks(limg + P.off_wv, wv, npg * KS1);
+                    dma_blocks(limg + P.off_wq, wq, npg * KS1);
+                    for (int i = threadIdx.x; i < NPG * S * 2; i += NTH) kmax[i] = 0u;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                } else {
+                    dma_blocks(limg + P.off_wq + (size_t)pg * KS1 * 1024, wq, npg * KS1);
+                }
                 mark(2, step);
                 // ---- K projection (K^T rows pair-major, 8 rows per head) and V projection (non-transposed, so the
                 //      C tile is already the V^T A-fragment) for every token tile -> kbf / vbf
@@ -430,25 +440,30 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = pv;
                     if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
                 }
+                if (threadIdx.x == 0) *ucnt = 0u;                     // (the previous group's units ended with a barrier)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // W_q of this group
                 __syncthreads();
                 mark(3, step);
                 refresh_lane();
+                if (pg + NPG < NP) {                                  // next group's W_k | W_v and its (zeroed) max table
+                    const int npn = min(NPG, NP - pg - NPG);
+                    dma_blocks(limg + P.off_wk + (size_t)(pg + NPG) * KS1 * 1024, wk, npn * KS1);
+                    dma_blocks(limg + P.off_wv + (size_t)(pg + NPG) * KS1 * 1024, wv, npn * KS1);
+                    for (int i = threadIdx.x; i < NPG * S * 2; i += NTH) kmax2[(gpar ^ 1) * (NPG * S * 2) + i] = 0u;
+                }
                 // ---- attention units: (head pair) x (series) x (NQ consecutive query tiles).  The NQ query tiles
                 //      share every K / V fragment read and give each wave NQ independent dependency chains (one
                 //      wave has only one partner on its SIMD to hide MFMA / exp / LDS latency behind).
-                constexpr int NQ = 2;
-                const int DUS = (KT + NQ - 1) / NQ;                 // units per (pair, series)
+                //      Units are handed out dynamically (LDS counter), two-tile units first, then the single-tile
+                //      leftovers of an odd tile count: the older wave of each SIMD wins every issue arbitration and
+                //      finishes a unit ~1.5x faster than its partner, so a static split leaves the SIMD to one
+                //      (slow, alone) wave for the last third of the phase.
                 const unsigned long long tw0 = P.prof ? __builtin_readcyclecounter() : 0ull;
-                for (int u = wave; u < npg * S * DUS; u += NW) {
-                    const int pr = u / (S * DUS), ur = u - pr * (S * DUS);
-                    const int ser = ur / DUS, du = ur - ser * DUS;
+                auto do_unit = [&](auto nqc, int pr, int ser, int qt0) {
+                    constexpr int NQ = decltype(nqc)::value;
                     int qt[NQ];
-                    bool qv[NQ];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {                  // a ragged last unit recomputes its first tile
-                        qv[q] = du * NQ + q < KT;
-                        qt[q] = ser * KT + (qv[q] ? du * NQ + q : du * NQ);
-                    }
+                    for (int q = 0; q < NQ; ++q) qt[q] = ser * KT + qt0 + q;
                     mark(9, step);
                     f32x4 qa[NQ];
 #pragma unroll
@@ -648,15 +663,35 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         const int head = 2 * (pg + pr) + (g >> 1);
                         u32x2 pk = {cvt_pk_bf16(o_sel[0] * inv, o_sel[1] * inv), cvt_pk_bf16(o_sel[2] * inv, o_sel[3] * inv)};
                         if (head >= H || (P.dbg & 1)) pk = u32x2{0u, 0u};
-                        if (head < 4 * KSO && qv[q])
+                        if (head < 4 * KSO)
                             *reinterpret_cast<u32x2*>(afr + ((qt[q] * KSO + (head >> 2)) * 64 + (head & 3) * 16 + tok) * 16 +
                                                       8 * (g & 1)) = pk;
+                    }
+                };
+                {
+                    const int DF = KT >> 1;                            // two-tile units per (pair, series)
+                    const int ND = npg * S * DF, NU = ND + ((KT & 1) ? npg * S : 0);
+                    for (;;) {
+                        int u = 0;
+                        if (lane == 0) u = (int)__hip_atomic_fetch_add(ucnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        u = __builtin_amdgcn_readfirstlane(u);
+                        if (u >= NU) break;
+                        if (u < ND) {
+                            const int pr = u / (S * DF), ur = u - pr * (S * DF);
+                            const int ser = ur / DF, du = ur - ser * DF;
+                            do_unit(std::integral_constant<int, 2>{}, pr, ser, 2 * du);
+                        } else {
+                            const int v = u - ND, pr = v / S, ser = v - pr * S;
+                            do_unit(std::integral_constant<int, 1>{}, pr, ser, KT - 1);
+                        }
+                        refresh_lane();
                     }
                 }
                 if (P.prof && blockIdx.x == 0 && step == 1 && l == 1 && lane == 0) {   // per-wave unit-loop time
                     P.prof[2 * (4000 + 8 * (pg / NPG) + wave)] = 100 + wave;
                     P.prof[2 * (4000 + 8 * (pg / NPG) + wave) + 1] = __builtin_readcyclecounter() - tw0;
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // prefetched W_k | W_v of the next group
                 __syncthreads();
             }
 
