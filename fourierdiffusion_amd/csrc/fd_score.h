@@ -19,6 +19,7 @@ struct fd_score {
     std::vector<fd_layer_off> layers;
     float* params = nullptr;        // caller-owned flat fp32 masters (set by fd_score_prepare)
     bool prepared = false;
+    bool bf16_stale = true;         // bf16 weight images older than the fp32 masters (rebuilt lazily: training never reads them)
     fd_bf16_images* bf16 = nullptr; // engine-owned bf16 weight images (built by prepare)
     // ---- training state (valid between forward_train and backward)
     bool have_saved = false;
@@ -61,6 +62,7 @@ size_t fd_score_bwd_workspace(const fd_score* m, int B);   // fd_score_bwd.hip
 int fd_bf16_create(fd_score* m);
 void fd_bf16_destroy(fd_score* m);
 int fd_bf16_prepare(fd_score* m, hipStream_t s);
+int fd_bf16_refresh(fd_score* m, hipStream_t s);   // rebuilds the images if the masters changed since the last build
 int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* out, int B, hipStream_t s);
 // fd_attn_bf16.hip
 int fd_attention_bf16(fd_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int hd, hipStream_t s);

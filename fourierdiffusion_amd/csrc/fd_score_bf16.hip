@@ -643,11 +643,19 @@ void add_layernorm(const float* a, const float* r, const float* gamma, const flo
                    hipStream_t s);
 }  // namespace fdf32
 
+int fd_bf16_refresh(fd_score* m, hipStream_t s) {
+    if (!m->bf16_stale) return FD_OK;
+    if (int rc = fd_bf16_prepare(m, s)) return rc;
+    m->bf16_stale = false;
+    return FD_OK;
+}
+
 int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* out, int B, hipStream_t s) {
     fd_ctx* ctx = m->ctx;
     if (!m->bf16 || !m->bf16->supported)
         return fd_fail(ctx, FD_ERR_UNSUPPORTED,
                        "bf16 MFMA path supports d_model in {8,24,60,72} with dim_ff %% 128 == 0; use FD_MODE_F32");
+    if (int rc = fd_bf16_refresh(m, s)) return rc;
     {
         const MegaPlan pl = plan_mega(m, B);
         if (pl.ok && !getenv("FDIFF_NO_MEGA")) {
@@ -716,6 +724,7 @@ int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, c
     fd_ctx* ctx = m->ctx;
     const MegaPlan pl = plan_mega(m, B);
     if (!pl.ok || (m->d.n_channels % 4) != 0 || getenv("FDIFF_NO_MEGA")) return FD_ERR_UNSUPPORTED;
+    if (int rc = fd_bf16_refresh(m, s)) return rc;
     const size_t tab_bytes = fd_ws::padded(sizeof(fd_sde_step_coef) * (size_t)n_steps);
     if (int rc = fd_ws_reserve(ctx, tab_bytes)) return rc;
     std::vector<fd_sde_step_coef> tab(n_steps);

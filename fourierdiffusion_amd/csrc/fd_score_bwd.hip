@@ -262,7 +262,7 @@ inline unsigned ew_grid(fd_ctx* ctx, size_t n) {
 }
 
 void colsum(fd_ctx* ctx, const float* x, float* out, int M, int N, hipStream_t s) {
-    const int rows_per_block = 512;
+    const int rows_per_block = 128;
     dim3 grid((N + 63) / 64, (M + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(k_colsum, grid, dim3(256), 0, s, x, out, M, N, rows_per_block);
     (void)ctx;

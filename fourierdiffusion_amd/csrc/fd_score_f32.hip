@@ -490,7 +490,7 @@ extern "C" int fd_score_prepare(fd_score* m, const float* params, void* stream) 
     hipLaunchKernelGGL(k_renorm_rows, dim3(m->d.max_len), dim3(64), 0, (hipStream_t)stream, m->params + m->pos,
                        m->d.max_len, m->d.d_model, sqrtf((float)m->d.d_model));
     FD_LAUNCH_CHECK(ctx);
-    if (int rc = fd_bf16_prepare(m, (hipStream_t)stream)) return rc;
+    m->bf16_stale = true;     // the bf16 MFMA entry points rebuild their images on first use (fd_bf16_refresh)
     m->prepared = true;
     return FD_OK;
 }
