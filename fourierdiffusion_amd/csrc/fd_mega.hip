@@ -40,6 +40,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
 
+#ifndef FD_FFN_BARE_BARRIER
+#define FD_FFN_BARE_BARRIER 1
+#endif
 #ifndef FD_XF_REGS
 #define FD_XF_REGS 1     // FFN activation fragments: 1 = registers for the whole phase, 0 = LDS read per use
 #endif
@@ -168,6 +171,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
     };
     refresh_lane();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef FD_PRIO_YOUNG
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(FD_PRIO_YOUNG);   // experiment: static priority for the younger half
+#endif
     const int T = SHP(T), KT = SHP(KT), D = SHP(D), C = SHP(C), H = SHP(H), hd = SHP(hd), S = SHP(S);
     const int NTILE = S * KT;                    // token tiles of this workgroup (16 slots each)
     const int NTOK = NTILE * 16;
@@ -724,6 +730,23 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     __builtin_amdgcn_global_load_lds(GLB_PTR(src + b * 1024), LDS_PTR(dst + b * 1024), 16, 0, 0);
                 }
             };
+            // in the FFN loop the two F-half wave sets take turns (even / odd steps) issuing a whole buffer: a DMA
+            // instruction costs its wave 60-180 issue cycles, and with every wave issuing right after the barrier both
+            // waves of each SIMD were away from the matrix pipe at the same time
+            constexpr int NDH = (2 * NBF + MQ - 1) / MQ;
+            auto issue_ffn_half = [&](int st_seq) {
+                int st = st_seq + st_rot;
+                st -= (st >= NS) ? NS : 0;
+                const char* src = limg + P.off_ffn + (size_t)st * WB1 + lane * 16;
+                char* dst = ring + (st_seq % NBUF) * WB1;
+                const int w4 = wave % MQ;
+#pragma unroll
+                for (int i = 0; i < NDH; ++i) {
+                    int b = w4 + i * MQ;
+                    b -= (b >= 2 * NBF) ? MQ : 0;
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(src + b * 1024), LDS_PTR(dst + b * 1024), 16, 0, 0);
+                }
+            };
             issue_ffn(0);
             if (NS > 1) issue_ffn(1);
 
@@ -834,7 +857,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     do_h(0);
                     __builtin_amdgcn_sched_barrier(0);
                     for (int st = 0; st < NS; ++st) {
-                        if (st + 3 < NS && !(P.dbg & 4)) issue_ffn(st + 3);
+                        const bool my_turn = ((st & 1) == FH);
+                        if (my_turn && st + 3 < NS && !(P.dbg & 4)) issue_ffn_half(st + 3);
                         // NTT == 1: H(0) of this step issued during the previous step, before this step's successor
                         // buffer was visible -- its W1 can only be fetched now
                         if (NTT == 1 && st + 1 < NS) load_w1(st + 1);
@@ -856,9 +880,20 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             __builtin_amdgcn_sched_barrier(0);
                         }
                         // buffer st+2 must have landed before anyone reads it in step st+1 (own DMA, then barrier)
-                        if (st + 3 < NS && !(P.dbg & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                        // (this wave's share of buffer st+2 was issued one step ago if it was not its turn now; a wave
+                        // whose turn it is has nothing older than the NDH instructions it just issued, except at st = 0)
+                        if (my_turn && st + 3 < NS && !(P.dbg & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDH) : "memory");
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        // bare s_barrier: __syncthreads() carries a workgroup fence that hipcc lowers to
+                        // s_waitcnt vmcnt(0) lgkmcnt(0) -- it would drain the DMA issued this very step (3 steps of
+                        // slack thrown away, measured) and the fragment prefetch of the next step.  What must be
+                        // ordered is ordered by hand: this wave's share of buffer st+2 has landed (vmcnt above); LDS
+                        // reads of a buffer are consumed (waited on) a full step before that buffer is refilled.
+#if FD_FFN_BARE_BARRIER
+                        __builtin_amdgcn_s_barrier();
+#else
                         __syncthreads();
+#endif
                     }
                 };
                 if (ntile == MT) ffn_loop(std::integral_constant<int, MT>{});
