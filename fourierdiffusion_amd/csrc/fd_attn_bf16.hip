@@ -62,7 +62,7 @@ __device__ __forceinline__ float group_max(float v) {      // over the 4 lane gr
 
 // qkv (B*T, 3D) fp32 rows [q | k | v]; out (B*T, D) fp32.  grid (query slices, head pairs, B), 512 threads.
 __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restrict__ qkv, float* __restrict__ out, int T,
-                                                           int H, int hd, int D, float qscale, int du_per_block) {
+                                                           int H, int hd, int D, float qscale, int du_per_block, int exact_only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -70,9 +70,12 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
     const int pair = blockIdx.y, b = blockIdx.z;
     char* const kbf = smem;                       // [NTOK][4 g][8 B]: lane group g = 2*hs + (d >> 2), element d & 3
     char* const vbf = smem + (size_t)NTOK * 32;   // [NJ][4 g][16 dim slots][16 B]: (half, r) -> token (2jj+half)*16 + 4g + r
+    unsigned* const kmax = reinterpret_cast<unsigned*>(vbf + (size_t)NJ * 1024);   // [2] max_j |k_j|^2 per head (bits)
     const float* base = qkv + (size_t)b * T * 3 * D;
 
     // ---- stage K and V^T of this (series, pair) as bf16 fragments; every byte of both regions is written here
+    if (threadIdx.x < 2) kmax[threadIdx.x] = 0u;
+    __syncthreads();
     // K: one thread per (token, lane group gq): the 4 dims 4(gq&1)..+3 of head gq>>1 -> one 8-byte row
     for (int i = threadIdx.x; i < NTOK * 4; i += NTH) {
         const int t = i >> 2, gq = i & 3, head = 2 * pair + (gq >> 1);
@@ -83,6 +86,16 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
             kv[r] = (t < T && d < hd && head < H) ? base[(size_t)t * 3 * D + D + head * hd + d] : 0.f;
         }
         *reinterpret_cast<u32x2*>(kbf + (size_t)i * 8) = u32x2{cvt_pk_bf16(kv[0], kv[1]), cvt_pk_bf16(kv[2], kv[3])};
+        // |k_t|^2 of head gq>>1: the two threads (gq even / odd) holding a token's halves are lane neighbours
+        float n2 = kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2] + kv[3] * kv[3];
+        n2 += __shfl_xor(n2, 1);
+        // wave maximum per head (lanes with gq>>1 equal): xor-shuffles over the other lane bits
+        n2 = fmaxf(n2, __shfl_xor(n2, 4));
+        n2 = fmaxf(n2, __shfl_xor(n2, 8));
+        n2 = fmaxf(n2, __shfl_xor(n2, 16));
+        n2 = fmaxf(n2, __shfl_xor(n2, 32));
+        if ((threadIdx.x & 0x3d) == 0)     // lanes 0 (head 0) and 2 (head 1) of each wave
+            __hip_atomic_fetch_max(&kmax[gq >> 1], __builtin_bit_cast(unsigned, n2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // V^T: one thread per (32-key block jj, lane group gg, dim slot row): 8 keys (half, r) of that dim -> one 16-byte
     // vector.  Slot hd of each head is the ones row: the P V MFMAs then also produce sum_j P (softmax denominator).
@@ -134,13 +147,30 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
             qb[q][0] = __builtin_bit_cast(s16x4, qe);
             qb[q][1] = __builtin_bit_cast(s16x4, qo);
         }
+        // Softmax shift: the bound |q| max_j |k_j| >= max_j q.k_j (2 % headroom for the bf16 rounding) instead of a
+        // max pass; any shift cancels in P V / sum P.  A row sum below 2^-100 (bound > max + ~100) sends the unit
+        // through the exact two-pass form (see fd_mega.hip, tests/test_gpu_baseline_shapes.py).
+        float bq[NQ][2];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            // this lane's 4 dims of head g>>1, already scaled and rounded like the MFMA operand
+            const u32x2 qraw = lo_grp ? __builtin_bit_cast(u32x2, qb[q][0]) : __builtin_bit_cast(u32x2, qb[q][1]);
+            const float q0 = __builtin_bit_cast(float, qraw[0] << 16), q1 = __builtin_bit_cast(float, qraw[0] & 0xffff0000u);
+            const float q2 = __builtin_bit_cast(float, qraw[1] << 16), q3 = __builtin_bit_cast(float, qraw[1] & 0xffff0000u);
+            float ea, eb;
+            swap16(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3, ea, eb);
+            const float k2 = __builtin_bit_cast(float, kmax[g >> 1]);
+            swap32(__builtin_sqrtf((ea + eb) * k2) * 1.02f, bq[q][0], bq[q][1]);
+        }
         float m2[NQ][2];
         f32x4 o2[NQ][2];
+        auto run_unit = [&](auto exact_c) {
+        constexpr bool EXACT = decltype(exact_c)::value;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int hs = 0; hs < 2; ++hs) {
-                m2[q][hs] = kNegBig;
+                m2[q][hs] = EXACT ? kNegBig : bq[q][hs];
                 o2[q][hs] = f4zero();
             }
         // One 128-key block.  FULL (8 key tiles) and LAST (the block holds the series' final, possibly ragged tile) are
@@ -159,11 +189,11 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
                     vf[jj] = *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(((kb >> 1) + jj) * 4 + g) * 16 + tok) * 16);
             const int nk = FULL ? 8 : min(8, KT - kb);
             constexpr int NKT = 16 * NQ;          // score tiles per block: k = ((hs*4 + jj)*NQ + q)*2 + jl, key tile 2jj+jl
-            // pass 1: row maxima of this key block (software-pipelined by hand, see fd_mega.hip)
+            // pass 1 (exact path only): row maxima of this key block (software-pipelined by hand, see fd_mega.hip)
             float bm[NQ][2];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) bm[q][0] = bm[q][1] = kNegBig;
-            {
+            if (EXACT) {
                 constexpr int LAG = 3;
                 f32x4 t4[NKT];
 #pragma unroll
@@ -192,10 +222,13 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int hs = 0; hs < 2; ++hs) {
-                    const float mnew = fmaxf(m2[q][hs], group_max(bm[q][hs]));
-                    const float alpha = __builtin_amdgcn_exp2f(m2[q][hs] - mnew);
-                    o2[q][hs] = o2[q][hs] * alpha;
-                    m2[q][hs] = mnew;
+                    float mnew = m2[q][hs];
+                    if (EXACT) {
+                        mnew = fmaxf(m2[q][hs], group_max(bm[q][hs]));
+                        const float alpha = __builtin_amdgcn_exp2f(m2[q][hs] - mnew);
+                        o2[q][hs] = o2[q][hs] * alpha;
+                        m2[q][hs] = mnew;
+                    }
                     negm[q][hs] = f32x4{-mnew, -mnew, -mnew, -mnew};
                     clast[q][hs] = cmask - mnew;
                 }
@@ -236,19 +269,39 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
             if (kb + 8 == KT) key_block(kb, std::true_type{}, std::true_type{});
             else key_block(kb, std::false_type{}, std::true_type{});
         }
-        // O^T rows 8*hs + [0,8) live in lane groups 2hs, 2hs+1; row 8*hs + hd is sum_j P (the ones row):
-        // hd in [4,7]: register hd-4 of the odd lane group; hd < 4: register hd of the even one
+        };
+        // row sums of P (the ones row): hd in [4,7]: register hd-4 of the odd lane group; hd < 4: register hd of the even one
+        float lrow[NQ];
+        auto row_sums = [&]() -> bool {
+            bool bad = false;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                float cand = lo_grp ? o2[q][0][0] : o2[q][1][0];
+#pragma unroll
+                for (int r = 1; r < 4; ++r) cand = ((hd & 3) == r) ? (lo_grp ? o2[q][0][r] : o2[q][1][r]) : cand;
+                float row_even, row_odd;
+                swap16(cand, row_even, row_odd);
+                lrow[q] = (hd >= 4) ? row_odd : row_even;
+                bad |= !(lrow[q] > 7.8e-31f);
+            }
+            return bad;
+        };
+        if (exact_only) {
+            run_unit(std::true_type{});
+            (void)row_sums();
+        } else {
+            run_unit(std::false_type{});
+            if (__builtin_amdgcn_ballot_w64(row_sums()) != 0ull) {
+                run_unit(std::true_type{});
+                (void)row_sums();
+            }
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             float o_sel[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) o_sel[r] = lo_grp ? o2[q][0][r] : o2[q][1][r];
-            float cand = o_sel[0];
-#pragma unroll
-            for (int r = 1; r < 4; ++r) cand = ((hd & 3) == r) ? o_sel[r] : cand;
-            float row_even, row_odd;
-            swap16(cand, row_even, row_odd);
-            const float inv = 1.0f / ((hd >= 4) ? row_odd : row_even);
+            const float inv = 1.0f / lrow[q];
             const int t = qt[q] * 16 + tok;
             if (qv[q] && t < T && myhead < H) {
 #pragma unroll
@@ -267,7 +320,7 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
 // or K/V^T of one series exceed the LDS): the caller then runs the exact-f32 kernel.
 int fd_attention_bf16(fd_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int hd, hipStream_t s) {
     const int KT = (T + 15) / 16, NJ = (KT + 1) / 2, D = H * hd;
-    const size_t lds = (size_t)KT * 16 * 32 + (size_t)NJ * 1024;
+    const size_t lds = (size_t)KT * 16 * 32 + (size_t)NJ * 1024 + 16;
     if (hd > 7 || lds > 160 * 1024) return FD_ERR_UNSUPPORTED;
     static bool attr = false;
     if (!attr) {
@@ -287,7 +340,8 @@ int fd_attention_bf16(fd_ctx* ctx, const float* qkv, float* out, int B, int T, i
     }
     const int du_per_block = (DUS + slices - 1) / slices;
     const float qscale = 1.4426950408889634f / sqrtf((float)hd);
-    hipLaunchKernelGGL(k_attention_bf16, dim3(slices, NP, B), dim3(NTH), lds, s, qkv, out, T, H, hd, D, qscale, du_per_block);
+    hipLaunchKernelGGL(k_attention_bf16, dim3(slices, NP, B), dim3(NTH), lds, s, qkv, out, T, H, hd, D, qscale, du_per_block,
+                       getenv("FDIFF_ATTN_EXACT") ? 1 : 0);
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }

@@ -89,6 +89,39 @@ def test_mimic_full_batch_properties_bf16():
     assert (sub - a[idx]).abs().max() <= 2e-2 * a.abs().max()
 
 
+def test_softmax_shift_fallback_layer_kernel():
+    """Same property for the standalone attention kernel of the step-by-step path (FDIFF_NO_MEGA routes there;
+    FDIFF_ATTN_EXACT forces its exact two-pass form)."""
+    from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
+    from oracle.make_golden import CFG_DEFAULT
+    cfg = dict(CFG_DEFAULT, L=2)
+    saved = {k: os.environ.get(k) for k in ("FDIFF_NO_MEGA", "FDIFF_ATTN_EXACT")}
+    try:
+        os.environ["FDIFF_NO_MEGA"] = "1"
+        for scale in (1.0, 40.0):
+            m, _, sd = make_model(cfg, precision="bf16")
+            st = m.state_dict()
+            for k in list(st):
+                if k.endswith("self_attn.in_proj_weight"):
+                    st[k] = st[k] * scale
+            m.load_state_dict(st)
+            m.eval()
+            X = dev(W.randn("fb_x", (6, cfg["T"], cfg["C"]), 2))
+            t = dev(W.uniform("fb_t", (6,), 2, 1e-5, 1.0))
+            os.environ.pop("FDIFF_ATTN_EXACT", None)
+            fast = host(m(DiffusableBatch(X=X, timesteps=t)))
+            os.environ["FDIFF_ATTN_EXACT"] = "1"
+            exact = host(m(DiffusableBatch(X=X, timesteps=t)))
+            assert np.isfinite(fast).all() and np.isfinite(exact).all()
+            np.testing.assert_allclose(fast, exact, atol=2e-3 * np.abs(exact).max(), rtol=0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_softmax_shift_fallback_equals_exact_path():
     """The persistent kernel shifts the softmax by the bound |q| max|k| and redoes a unit with the exact row maximum
     when a row sum underflows.  With the attention input projection scaled up (logits of several hundred) the bound
