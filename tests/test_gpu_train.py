@@ -174,3 +174,26 @@ def test_training_changes_every_trainable_parameter_and_learns(kind):
     sampler = DiffusionSampler(score_model=m, sample_batch_size=12)
     s = sampler.sample(num_samples=48, num_diffusion_steps=10)
     assert s.shape == (48, cfg["T"], cfg["C"]) and torch.isfinite(s).all()
+
+
+def test_rccl_allreduce_single_rank():
+    """fd_comm_* / fd_allreduce_grads on a one-rank communicator: exercises the lazy RCCL binding (dlopen, symbol table,
+    unique id, communicator init, all-reduce + scale on the caller's stream) on the hardware that is available to the
+    test run; the world_size-2 averaging logic is covered on CPU (tests/test_distributed_cpu.py) and the 8-GPU run is the
+    driver's."""
+    import ctypes as C
+    from fourierdiffusion_amd import _C
+    dev = torch.device(DEV, torch.cuda.current_device()) if isinstance(DEV, str) else DEV
+    ctx = _C.ctx(torch.device("cuda", torch.cuda.current_device()))
+    lib = _C.lib()
+    uid = (C.c_ubyte * _C.FD_COMM_ID_BYTES)()
+    assert lib.fd_comm_unique_id(uid) == 0
+    _C.check(lib.fd_comm_init(ctx, 0, 1, uid), ctx)
+    try:
+        g = torch.randn(3_200_000, device="cuda")
+        ref = g.clone()
+        _C.check(lib.fd_allreduce_grads(ctx, g.data_ptr(), g.numel(), 0.5, torch.cuda.current_stream().cuda_stream), ctx)
+        torch.cuda.synchronize()
+        assert torch.allclose(g, ref * 0.5, rtol=0, atol=0)
+    finally:
+        _C.check(lib.fd_comm_destroy(ctx), ctx)
