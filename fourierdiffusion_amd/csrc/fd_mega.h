@@ -29,7 +29,6 @@ struct fd_mega_params {
     unsigned long long* prof;   // profiling aid (FDIFF_MEGA_PROF): (phase, s_memtime) pairs of WG 0 / wave 0, steps 0-3
     unsigned* dbg_out;   // debugging aid: LDS image of workgroup 0 after layer 0's attention
     int dbg_bytes;
-    float* stash;        // global scratch [grid][8 waves][2][DT][64 lanes] float4: residual tiles parked during the FFN
     // tensors
     float* x;
     float* score_out;

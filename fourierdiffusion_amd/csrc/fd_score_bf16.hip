@@ -47,8 +47,6 @@ struct fd_bf16_images {
     size_t off_emb = 0, off_unemb = 0, off_layers = 0, layer_stride = 0;
     size_t off_wk = 0, off_wv = 0, off_wq = 0, off_wo = 0, off_ffn = 0;
     fd_mega_layer_f32* layer_tab = nullptr;   // device [L]
-    float* stash = nullptr;                   // residual stash of the persistent kernel (grown on demand)
-    size_t stash_bytes = 0;
 };
 
 namespace {
@@ -491,7 +489,6 @@ void fd_bf16_destroy(fd_score* m) {
     if (m->bf16->ffn) (void)hipFree(m->bf16->ffn);
     if (m->bf16->mimg) (void)hipFree(m->bf16->mimg);
     if (m->bf16->layer_tab) (void)hipFree(m->bf16->layer_tab);
-    if (m->bf16->stash) (void)hipFree(m->bf16->stash);
     delete m->bf16;
     m->bf16 = nullptr;
 }
@@ -608,14 +605,6 @@ static MegaPlan plan_mega(const fd_score* m, int B) {
 static int fill_mega_params(const fd_score* m, const MegaPlan& pl, int B, fd_mega_params& P) {
     fd_bf16_images* im = m->bf16;
     memset(&P, 0, sizeof P);
-    const size_t need = (size_t)pl.grid * 8 * 2 * im->dt * 64 * sizeof(float) * 4;
-    if (need > im->stash_bytes) {
-        if (im->stash) { (void)hipDeviceSynchronize(); (void)hipFree(im->stash); im->stash = nullptr; im->stash_bytes = 0; }
-        if (hipMalloc((void**)&im->stash, need) != hipSuccess)
-            return fd_fail(m->ctx, FD_ERR_HIP, "persistent kernel: hipMalloc of the residual stash (%zu B) failed", need);
-        im->stash_bytes = need;
-    }
-    P.stash = im->stash;
     P.B = B; P.T = m->d.max_len; P.KT = pl.KT; P.C = m->d.n_channels; P.D = m->d.d_model; P.H = m->d.n_head;
     P.hd = P.D / P.H; P.L = m->d.num_layers; P.F = m->d.dim_ff;
     if (const char* d2 = getenv("FDIFF_MEGA_DBG")) P.dbg = atoi(d2);
