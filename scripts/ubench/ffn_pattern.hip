@@ -106,6 +106,30 @@ __global__ __launch_bounds__(512) void k_step(unsigned long long* out, const cha
     if (threadIdx.x == 0) out[1] = t1 - t0;
 }
 
+// ---- mixed pairing: does an MFMA-heavy wave (FFN items) overlap a VALU-heavy wave (attention pass-2 stages) on the
+//      same SIMD?  mode 0: all 8 waves FFN; 1: all 8 waves attention; 2: waves 0-3 FFN, waves 4-7 attention (one of each per SIMD)
+#define ATT_STAGE "v_mfma_f32_16x16x16_bf16 v[152:155], v[140:141], v[144:145], v[156:159]\n v_exp_f32 v160, v164\n v_exp_f32 v161, v165\n v_exp_f32 v162, v166\n v_exp_f32 v163, v167\n" \
+                  "v_cvt_pk_bf16_f32 v168, v160, v161\n v_cvt_pk_bf16_f32 v169, v162, v163\n" \
+                  "v_mfma_f32_16x16x16_bf16 v[164:167], v[140:141], v[144:145], v[156:159]\n v_exp_f32 v160, v152\n v_exp_f32 v161, v153\n v_exp_f32 v162, v154\n v_exp_f32 v163, v155\n" \
+                  "v_cvt_pk_bf16_f32 v170, v160, v161\n v_cvt_pk_bf16_f32 v171, v162, v163\n" MF "v[172:175], " WW ", v[168:171], v[172:175]\n"
+template <int MODE>
+__global__ __launch_bounds__(512) void k_mix(unsigned long long* out, int n_ffn, int n_att) {
+    asm volatile(".irp r,100,101,102,103,104,105,106,107,108,109,110,111,112,113,114,115,116,117,118,119,120,121,122,123,124,125,126,127,128,129,130,131,132,133,134,135,136,137,138,139,140,141,142,143,144,145,146,147,148,149,150,151,152,153,154,155,156,157,158,159,160,161,162,163,164,165,166,167,168,169,170,171,172,173,174,175\n v_mov_b32 v\\r, 0\n.endr" ::: CLOB2);
+    const int wave = threadIdx.x >> 6;
+    const bool ffn = (MODE == 0) || (MODE == 2 && wave < 4);
+    __syncthreads();
+    unsigned long long t0 = __builtin_readcyclecounter();
+    if (ffn) {
+        for (int it = 0; it < n_ffn; ++it) asm volatile(ITEM_A ITEM_B ::: CLOB);
+    } else {
+        for (int it = 0; it < n_att; ++it) asm volatile(ATT_STAGE ATT_STAGE ::: CLOB2);
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) atomicMax(&out[0], t1 - t0);
+    if (threadIdx.x == 0) out[1] = t1 - t0;
+    if (threadIdx.x == 256) out[2] = t1 - t0;
+}
+
 int main() {
     unsigned long long* d;
     hipMalloc(&d, 64);
@@ -123,6 +147,22 @@ int main() {
             hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
             const double items = 64.0 * 8 * 2;
             printf("%-34s wave0 %7.1f  slowest wave %7.1f cycles per item (11 MFMA = 176 of pipe time)\n", e.n, h[1] / items, h[0] / items);
+        }
+    }
+    {
+        printf("--- mixed pairing on each SIMD (cycles for the whole job; FFN job = 2000 items per wave, attention job = 2000 double stages per wave)\n");
+        struct { const char* n; void (*k)(unsigned long long*, int, int); int nf, na; } ms[] = {
+            {"8 waves FFN, full job each", k_mix<0>, 1000, 0}, {"8 waves attention, full job each", k_mix<1>, 0, 1000},
+            {"4 waves FFN + 4 waves attention, full job each", k_mix<2>, 1000, 1000},
+            {"8 waves FFN, half job each", k_mix<0>, 500, 0}, {"8 waves attention, half job each", k_mix<1>, 0, 500}};
+        for (auto& e : ms) {
+            hipMemset(d, 0, 64);
+            hipLaunchKernelGGL(e.k, dim3(1), dim3(512), 0, 0, d, e.nf, e.na);
+            hipMemset(d, 0, 64);
+            hipLaunchKernelGGL(e.k, dim3(1), dim3(512), 0, 0, d, e.nf, e.na);
+            unsigned long long h[3];
+            hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+            printf("%-48s wave0 %9llu  wave4 %9llu  slowest %9llu cycles\n", e.n, h[1], h[2], h[0]);
         }
     }
     {
