@@ -963,23 +963,45 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     if (valid && c0 < C) {
                         const size_t e0 = ((size_t)(b0 + ser) * T + t) * C + c0;      // element index in (B,T,C)
                         if (P.mode == FD_MEGA_SAMPLE) {
-                            // C % 4 == 0 (host-checked): one Philox counter = this lane's 4 channels
-                            const float4 xv = *reinterpret_cast<const float4*>(P.x + e0);
-                            float z[4];
-                            if (P.z_steps) {
-                                const float4 zz = *reinterpret_cast<const float4*>(P.z_steps + (size_t)step * P.n_elem + e0);
-                                z[0] = zz.x; z[1] = zz.y; z[2] = zz.z; z[3] = zz.w;
-                            } else {
-                                fd_randn4(P.offset + (uint64_t)step * P.ctr_per_step + (e0 >> 2), P.seed, z);
-                            }
+                            // The noise stream is the standalone fd_sde_step's: Philox counter q yields the normals of
+                            // elements 4q..4q+3 of the flattened (B,T,C) array.  C % 4 == 0: this lane's 4 channels are
+                            // exactly one counter and one aligned float4; otherwise they straddle two counters.
                             const float Gk = P.G[t];
                             const float gk = cf.g * Gk;
-                            float4 o;
-                            o.x = xv.x - (-cf.a_x * xv.x - (gk * gk) * sc[0]) * cf.dt + cf.sqrt_dt * (gk * z[0]);
-                            o.y = xv.y - (-cf.a_x * xv.y - (gk * gk) * sc[1]) * cf.dt + cf.sqrt_dt * (gk * z[1]);
-                            o.z = xv.z - (-cf.a_x * xv.z - (gk * gk) * sc[2]) * cf.dt + cf.sqrt_dt * (gk * z[2]);
-                            o.w = xv.w - (-cf.a_x * xv.w - (gk * gk) * sc[3]) * cf.dt + cf.sqrt_dt * (gk * z[3]);
-                            *reinterpret_cast<float4*>(P.x + e0) = o;
+                            if ((C & 3) == 0) {
+                                const float4 xv = *reinterpret_cast<const float4*>(P.x + e0);
+                                float z[4];
+                                if (P.z_steps) {
+                                    const float4 zz = *reinterpret_cast<const float4*>(P.z_steps + (size_t)step * P.n_elem + e0);
+                                    z[0] = zz.x; z[1] = zz.y; z[2] = zz.z; z[3] = zz.w;
+                                } else {
+                                    fd_randn4(P.offset + (uint64_t)step * P.ctr_per_step + (e0 >> 2), P.seed, z);
+                                }
+                                float4 o;
+                                o.x = xv.x - (-cf.a_x * xv.x - (gk * gk) * sc[0]) * cf.dt + cf.sqrt_dt * (gk * z[0]);
+                                o.y = xv.y - (-cf.a_x * xv.y - (gk * gk) * sc[1]) * cf.dt + cf.sqrt_dt * (gk * z[1]);
+                                o.z = xv.z - (-cf.a_x * xv.z - (gk * gk) * sc[2]) * cf.dt + cf.sqrt_dt * (gk * z[2]);
+                                o.w = xv.w - (-cf.a_x * xv.w - (gk * gk) * sc[3]) * cf.dt + cf.sqrt_dt * (gk * z[3]);
+                                *reinterpret_cast<float4*>(P.x + e0) = o;
+                            } else {
+                                float za[4], zb[4];
+                                const int sh = (int)(e0 & 3);
+                                if (!P.z_steps) {
+                                    const uint64_t q0 = P.offset + (uint64_t)step * P.ctr_per_step + (e0 >> 2);
+                                    fd_randn4(q0, P.seed, za);
+                                    fd_randn4(q0 + 1, P.seed, zb);
+                                }
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    if (c0 + r < C) {
+                                        float z;
+                                        if (P.z_steps) z = P.z_steps[(size_t)step * P.n_elem + e0 + r];
+                                        else z = (sh + r < 4) ? za[(sh + r) & 3] : zb[(sh + r) & 3];
+                                        const float xv = P.x[e0 + r];
+                                        P.x[e0 + r] = xv - (-cf.a_x * xv - (gk * gk) * sc[r]) * cf.dt + cf.sqrt_dt * (gk * z);
+                                    }
+                                }
+                            }
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)

@@ -30,7 +30,7 @@ extern "C" int fd_sampler_run(fd_score* m, const fd_sde_params* sde, const float
     if (!m->prepared) return fd_fail(ctx, FD_ERR_STATE, "fd_sampler_run: call fd_score_prepare first");
     hipStream_t s = (hipStream_t)stream;
     FD_REQUIRE(ctx, mode == FD_MODE_F32 || mode == FD_MODE_BF16, "fd_sampler_run: unknown mode %d", mode);
-    if (mode == FD_MODE_BF16) {
+    if (mode == FD_MODE_BF16 && !getenv("FDIFF_SAMPLER_STEPWISE")) {   // (switch: per-step launches; tests compare the two)
         const int rc = fd_sampler_run_mega(m, sde, G, timesteps, n_steps, dt, x, z_steps, seed, offset, B, s);
         if (rc != FD_ERR_UNSUPPORTED) return rc;     // ran (or failed loudly); else: step-by-step fallback below
     }

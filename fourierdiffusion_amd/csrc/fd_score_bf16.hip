@@ -712,7 +712,7 @@ int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, c
                         hipStream_t s) {
     fd_ctx* ctx = m->ctx;
     const MegaPlan pl = plan_mega(m, B);
-    if (!pl.ok || (m->d.n_channels % 4) != 0 || getenv("FDIFF_NO_MEGA")) return FD_ERR_UNSUPPORTED;
+    if (!pl.ok || getenv("FDIFF_NO_MEGA")) return FD_ERR_UNSUPPORTED;
     if (int rc = fd_bf16_refresh(m, s)) return rc;
     const size_t tab_bytes = fd_ws::padded(sizeof(fd_sde_step_coef) * (size_t)n_steps);
     if (int rc = fd_ws_reserve(ctx, tab_bytes)) return rc;

@@ -100,3 +100,33 @@ def test_stepwise_api_equals_fused_loop():
         tb = torch.full((B,), float(t), device=DEV)
         X = sampler.reverse_diffusion_step(DiffusableBatch(X=X, timesteps=tb), noise=zs[i])
     assert torch.allclose(X.cpu(), fused, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("C", [3, 6, 12])
+def test_persistent_sampler_equals_stepwise_launches_bf16(C):
+    """bf16 mode: the one-launch reverse-diffusion loop (Euler-Maruyama step + Philox noise inside the persistent kernel)
+    against one score launch + fd_sde_step per step (FDIFF_SAMPLER_STEPWISE), same seed.  C = 3 and 6 exercise lanes whose
+    4 channels straddle two Philox counters; the noise stream must be the standalone kernel's in every case."""
+    import os
+    from fourierdiffusion_amd.sampling.sampler import DiffusionSampler
+    cfg = dict(T=40, C=C, D=24, L=2, H=4)
+    outs = []
+    for stepwise in (False, True):
+        m, _, _ = make_model(cfg, precision="bf16")
+        sampler = DiffusionSampler(score_model=m, sample_batch_size=5)
+        old = os.environ.get("FDIFF_SAMPLER_STEPWISE")
+        try:
+            if stepwise:
+                os.environ["FDIFF_SAMPLER_STEPWISE"] = "1"
+            else:
+                os.environ.pop("FDIFF_SAMPLER_STEPWISE", None)
+            torch.manual_seed(77)
+            outs.append(sampler.sample(num_samples=5, num_diffusion_steps=12).numpy())
+        finally:
+            if old is None:
+                os.environ.pop("FDIFF_SAMPLER_STEPWISE", None)
+            else:
+                os.environ["FDIFF_SAMPLER_STEPWISE"] = old
+    assert np.isfinite(outs[0]).all()
+    # identical network kernel and noise; only the fusion of the SDE step differs (fp32 rounding of the update)
+    np.testing.assert_allclose(outs[0], outs[1], atol=5e-5 * max(1.0, np.abs(outs[1]).max()), rtol=0)
