@@ -155,6 +155,7 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 __device__ __forceinline__ bf16x8 relu_pack(f32x4 a, f32x4 b) {
     u32x4 r;
     r[0] = cvt_pk_bf16(relu_bits(a[0]), relu_bits(a[1]));
@@ -167,12 +168,26 @@ __device__ __forceinline__ bf16x8 relu_pack(f32x4 a, f32x4 b) {
 // Wave roles: 8 waves = 4 token quarters (mq) x 2 halves of F (fh), two waves per SIMD.  The token tiles of
 // the workgroup are dealt to the quarters as evenly as possible (e.g. 13 tiles -> 4,3,3,3) and the second
 // set of waves is rotated by one quarter, so the two waves sharing a SIMD carry (4+3, 3+3, 3+3, 3+4) tiles.
-template <int KS1, int DT, int MT>
+// Optional fused prologue (KSO > 0): x is not read but computed in the kernel as
+//   x = LayerNorm1(h0 + att . Wo^T + bo)      (attention out-projection + residual + norm1 of the encoder layer)
+// from the attention output `att` (M, D) and the layer input `h0`: one launch and two (M, D) fp32 round trips less per
+// layer on the step-by-step path.  The tile's fp32 x then never leaves the CU: it seeds the owner wave's accumulators.
+struct fd_ffn_pre {
+    const float* att;     // (M, D) concatenated head outputs
+    const float* h0;      // (M, D) layer input (residual)
+    const char* wo_img;   // [DT][KSO] 1 KiB fragment blocks of W_o (IMG_WO)
+    const float* bo;
+    const float* g1;
+    const float* b1;
+    int H, hd;
+};
+
+template <int KS1, int DT, int MT, int KSO>
 __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, float* __restrict__ out,
                                                     const char* __restrict__ wimg, const float* __restrict__ b2,
                                                     const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, int M, int D, int F,
-                                                    int tok_per_wg) {
+                                                    int tok_per_wg, fd_ffn_pre pre) {
     constexpr int NB = 2 * KS1 + DT;            // 1 KiB fragment blocks per (F-half, 32-wide chunk)
     constexpr int SUB = 2;                      // chunks per barrier step
     constexpr int WBUF = 2 * SUB * NB * 1024;   // both F-halves of one step
@@ -209,6 +224,109 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
 
     // ---- activations -> bf16 B fragments in registers (token on lane&15, 8 features per lane, "1.0" in slot D)
     bf16x8 xf[MT][KS1];
+    f32x4 acc[DT][MT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int tt = 0; tt < MT; ++tt) acc[dt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (KSO > 0) {
+        char* const xfr = smem + 2 * WBUF;                 // [4*MT tiles][KS1][64][16 B]: x fragments of this workgroup
+        bf16x8 wo[DT][KSO > 0 ? KSO : 1];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int ks = 0; ks < KSO; ++ks)
+                wo[dt][ks] = *reinterpret_cast<const bf16x8*>(pre.wo_img + ((size_t)(dt * KSO + ks) * 64 + lane) * 16);
+#pragma unroll
+        for (int tt = 0; tt < MT; ++tt) {
+            if (tt >= ntile || (tt & 1) != fh) continue;   // the two waves of a token quarter split its tiles
+            const int m = m_wg + (tile0 + tt) * 16 + tok;
+            const bool valid = m < m_end;
+            f32x4 o[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSO; ++ks) {
+                const int head = 4 * ks + g;               // k-slot group g of k-step ks = the 8 (padded) dims of one head
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    v[e] = (valid && head < pre.H && e < pre.hd) ? pre.att[(size_t)m * D + head * pre.hd + e] : 0.f;
+                u32x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
+                const bf16x8 af = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo[dt][ks], af, o[dt], 0, 0, 0);
+            }
+            float sm = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d0 = 16 * dt + 4 * g;
+                if (d0 < D) {
+                    const float4 bb = *reinterpret_cast<const float4*>(pre.bo + d0);
+                    float4 r0 = {0.f, 0.f, 0.f, 0.f};
+                    if (valid) r0 = *reinterpret_cast<const float4*>(pre.h0 + (size_t)m * D + d0);
+                    o[dt][0] += bb.x + r0.x; o[dt][1] += bb.y + r0.y; o[dt][2] += bb.z + r0.z; o[dt][3] += bb.w + r0.w;
+                    sm += (o[dt][0] + o[dt][1]) + (o[dt][2] + o[dt][3]);
+                } else {
+                    o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            const float mean = sm / (float)D;
+            float q = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                if (16 * dt + 4 * g < D) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float c = o[dt][r] - mean;
+                        q += c * c;
+                    }
+                }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            const float rstd = rsqrtf(q / (float)D + 1e-5f);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d0 = 16 * dt + 4 * g;
+                u32x2 pk = {0u, 0u};
+                if (d0 < D) {
+                    const float4 gm = *reinterpret_cast<const float4*>(pre.g1 + d0);
+                    const float4 bt = *reinterpret_cast<const float4*>(pre.b1 + d0);
+                    o[dt][0] = valid ? (o[dt][0] - mean) * rstd * gm.x + bt.x : 0.f;
+                    o[dt][1] = valid ? (o[dt][1] - mean) * rstd * gm.y + bt.y : 0.f;
+                    o[dt][2] = valid ? (o[dt][2] - mean) * rstd * gm.z + bt.z : 0.f;
+                    o[dt][3] = valid ? (o[dt][3] - mean) * rstd * gm.w + bt.w : 0.f;
+                    pk[0] = cvt_pk_bf16(o[dt][0], o[dt][1]);
+                    pk[1] = cvt_pk_bf16(o[dt][2], o[dt][3]);
+                } else if (d0 == D && valid) {
+                    pk[0] = 0x00003F80u;                   // bf16(1.0): bias row of the K padding
+                }
+                // C layout (feature 16dt + 4g + r) -> B fragment k-slot of the same feature index
+                const int ks = dt >> 1, gd = 2 * (dt & 1) + (g >> 1);
+                if (ks < KS1)
+                    *reinterpret_cast<u32x2*>(xfr + (((size_t)(tile0 + tt) * KS1 + ks) * 64 + gd * 16 + tok) * 16 + 8 * (g & 1)) = pk;
+                acc[dt][tt] = o[dt];                       // residual of the FFN block: out = x + b2 + W2 relu(..)
+            }
+            // k-slots beyond 16*DT (K padding of the last k-step) must read as zero
+            if (16 * DT < 32 * KS1) {
+#pragma unroll
+                for (int slot = 16 * DT + 4 * g; slot < 32 * KS1; slot += 16)
+                    *reinterpret_cast<u32x2*>(xfr + (((size_t)(tile0 + tt) * KS1 + (slot >> 5)) * 64 + ((slot & 31) >> 3) * 16 + tok) * 16 +
+                                              8 * ((slot >> 2) & 1)) = u32x2{0u, 0u};
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < MT; ++tt)
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks)
+                xf[tt][ks] = (tt < ntile) ? *reinterpret_cast<const bf16x8*>(xfr + (((size_t)(tile0 + tt) * KS1 + ks) * 64 + lane) * 16)
+                                          : bf16x8{};
+    } else
 #pragma unroll
     for (int tt = 0; tt < MT; ++tt) {
         const int m = m_wg + (tile0 + tt) * 16 + tok;
@@ -240,12 +358,6 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
             xf[tt][ks] = __builtin_bit_cast(bf16x8, pk);
         }
     }
-
-    f32x4 acc[DT][MT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int tt = 0; tt < MT; ++tt) acc[dt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -327,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
             float4 res = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
             if (dv) {
                 bb = *reinterpret_cast<const float4*>(b2 + d0);
-                if (valid) res = *reinterpret_cast<const float4*>(x + (size_t)m * D + d0);
+                if (valid && KSO == 0) res = *reinterpret_cast<const float4*>(x + (size_t)m * D + d0);   // (fused: already in acc)
             }
             v[dt][0] = dv ? tot[0] + bb.x + res.x : 0.f;
             v[dt][1] = dv ? tot[1] + bb.y + res.y : 0.f;
@@ -371,29 +483,30 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
     }
 }
 
-template <int KS1, int DT, int MT>
+template <int KS1, int DT, int MT, int KSO>
 int launch_ffn(fd_ctx* ctx, const float* x, float* out, const char* wimg, const float* b2, const float* gamma,
-               const float* beta, int M, int D, int F, int tok_per_wg, hipStream_t s) {
+               const float* beta, int M, int D, int F, int tok_per_wg, const fd_ffn_pre& pre, hipStream_t s) {
     constexpr int NB = 2 * KS1 + DT;
     constexpr size_t lds_main = 2 * (size_t)2 * 2 * NB * 1024;         // 2 buffers x 2 F-halves x SUB chunks
     constexpr size_t lds_xch = (size_t)4 * MT * DT * 1024;
-    const size_t lds = lds_main > lds_xch ? lds_main : lds_xch;
-    auto kern = k_ffn_ln<KS1, DT, MT>;
+    constexpr size_t lds_xfr = KSO > 0 ? (size_t)4 * MT * KS1 * 1024 : 0;   // fused prologue: x fragments behind the ring
+    const size_t lds = (lds_main > lds_xch ? lds_main : lds_xch) + lds_xfr;
+    auto kern = k_ffn_ln<KS1, DT, MT, KSO>;
     static bool attr = false;
     if (!attr) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     const int grid = (M + tok_per_wg - 1) / tok_per_wg;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, x, out, wimg, b2, gamma, beta, M, D, F, tok_per_wg);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, x, out, wimg, b2, gamma, beta, M, D, F, tok_per_wg, pre);
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }
 
 // tokens per workgroup: whole "rounds" of one workgroup per CU, each WG at most 4*MT tiles (256 tokens)
-template <int KS1, int DT>
+template <int KS1, int DT, int KSO>
 int dispatch_ffn(fd_ctx* ctx, const float* x, float* out, const char* wimg, const float* b2, const float* gamma,
-                 const float* beta, int M, int D, int F, hipStream_t s) {
+                 const float* beta, int M, int D, int F, const fd_ffn_pre& pre, hipStream_t s) {
     const long long cap = 256LL * ctx->num_cu;
     const int rounds = (int)((M + cap - 1) / cap);
     int tok = (int)((M + (long long)rounds * ctx->num_cu - 1) / ((long long)rounds * ctx->num_cu));
@@ -401,23 +514,38 @@ int dispatch_ffn(fd_ctx* ctx, const float* x, float* out, const char* wimg, cons
     if (tok < 16) tok = 16;
     const int mt = ((tok + 15) / 16 + 3) / 4;       // tiles of the fullest token quarter
     switch (mt) {
-        case 1: return launch_ffn<KS1, DT, 1>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, s);
-        case 2: return launch_ffn<KS1, DT, 2>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, s);
-        case 3: return launch_ffn<KS1, DT, 3>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, s);
-        default: return launch_ffn<KS1, DT, 4>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, s);
+        case 1: return launch_ffn<KS1, DT, 1, KSO>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, pre, s);
+        case 2: return launch_ffn<KS1, DT, 2, KSO>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, pre, s);
+        case 3: return launch_ffn<KS1, DT, 3, KSO>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, pre, s);
+        default: return launch_ffn<KS1, DT, 4, KSO>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, pre, s);
     }
 }
 
-int run_ffn(fd_score* m, const float* x, float* out, int layer, int M, hipStream_t s) {
+// x != nullptr: out = LN2(x + FFN(x)).  x == nullptr: x = LN1(h0 + att Wo^T + bo) is computed in the kernel (fused
+// prologue; needs the persistent kernel's W_o image), then the same.
+int run_ffn(fd_score* m, const float* x, float* out, int layer, int M, hipStream_t s, const float* att = nullptr,
+            const float* h0 = nullptr) {
     fd_ctx* ctx = m->ctx;
     const fd_bf16_images* im = m->bf16;
     const fd_layer_off& lo = m->layers[layer];
     const float* P = m->params;
     const char* wimg = im->ffn + (size_t)layer * im->ffn_layer_bytes;
     const int D = m->d.d_model, F = m->d.dim_ff;
+    fd_ffn_pre pre{};
+    if (!x) {
+        pre.att = att; pre.h0 = h0;
+        pre.wo_img = im->mimg + im->off_layers + (size_t)layer * im->layer_stride + im->off_wo;
+        pre.bo = P + lo.out_b; pre.g1 = P + lo.n1_w; pre.b1 = P + lo.n1_b;
+        pre.H = m->d.n_head; pre.hd = D / m->d.n_head;
+        if (im->ks1 == 3 && im->dt == 5 && im->kso == 3)
+            return dispatch_ffn<3, 5, 3>(ctx, x, out, wimg, P + lo.l2_b, P + lo.n2_w, P + lo.n2_b, M, D, F, pre, s);
+        if (im->ks1 == 2 && im->dt == 4 && im->kso == 3)
+            return dispatch_ffn<2, 4, 3>(ctx, x, out, wimg, P + lo.l2_b, P + lo.n2_w, P + lo.n2_b, M, D, F, pre, s);
+        return fd_fail(ctx, FD_ERR_UNSUPPORTED, "fused out-proj + FFN kernel not instantiated for d_model=%d", D);
+    }
 #define FD_FFN_CASE(K, T_)                                                                                     \
     if (im->ks1 == K && im->dt == T_)                                                                          \
-        return dispatch_ffn<K, T_>(ctx, x, out, wimg, P + lo.l2_b, P + lo.n2_w, P + lo.n2_b, M, D, F, s);
+        return dispatch_ffn<K, T_, 0>(ctx, x, out, wimg, P + lo.l2_b, P + lo.n2_w, P + lo.n2_b, M, D, F, pre, s);
     FD_FFN_CASE(3, 5)   // d_model 72 (hydra default)
     FD_FFN_CASE(2, 4)   // d_model 60 (class default)
     FD_FFN_CASE(1, 2)   // d_model 24
@@ -696,9 +824,18 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
         const int arc = getenv("FDIFF_ATTN_F32") ? FD_ERR_UNSUPPORTED : fd_attention_bf16(ctx, qkv, att, B, T, H, hd, s);
         if (arc == FD_ERR_UNSUPPORTED) fd_attention_f32(qkv, att, nullptr, B, T, H, hd, 0.f, 0, 0, s);
         else if (arc != FD_OK) return arc;
-        fdgemm::linear_fwd(att, P + lo.out_w, P + lo.out_b, tmp, M, D, D, false, s);
-        fdf32::add_layernorm(h0, tmp, P + lo.n1_w, P + lo.n1_b, h1, M, D, s);
-        if (int rc = run_ffn(m, h1, h0, i, M, s)) return rc;
+        const fd_bf16_images* im = m->bf16;
+        const bool fuse = im->mega && im->kso == 3 && (im->ks1 == 3 || im->ks1 == 2) && !getenv("FDIFF_FFN_UNFUSED");
+        if (fuse) {
+            // out-proj + residual + LN1 + FFN + LN2 in one kernel (it reads its own output location last: out = h1 is
+            // a different buffer from the residual input h0)
+            if (int rc = run_ffn(m, nullptr, h1, i, M, s, att, h0)) return rc;
+            std::swap(h0, h1);
+        } else {
+            fdgemm::linear_fwd(att, P + lo.out_w, P + lo.out_b, tmp, M, D, D, false, s);
+            fdf32::add_layernorm(h0, tmp, P + lo.n1_w, P + lo.n1_b, h1, M, D, s);
+            if (int rc = run_ffn(m, h1, h0, i, M, s)) return rc;
+        }
     }
     fdgemm::linear_fwd(h0, P + m->un_w, P + m->un_b, out, M, C, D, false, s);
     FD_LAUNCH_CHECK(ctx);
