@@ -60,9 +60,37 @@ __device__ __forceinline__ float group_max(float v) {      // over the 4 lane gr
     return fmaxf(a, b);
 }
 
-// qkv (B*T, 3D) fp32 rows [q | k | v]; out (B*T, D) fp32.  grid (query slices, head pairs, B), 512 threads.
-__global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restrict__ qkv, float* __restrict__ out, int T,
-                                                           int H, int hd, int D, float qscale, int du_per_block, int exact_only) {
+// row-max over the 16 lanes of a row (DPP rotations)
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_max16(float v) {
+    v = fmaxf(v, row_ror<8>(v));
+    v = fmaxf(v, row_ror<4>(v));
+    v = fmaxf(v, row_ror<2>(v));
+    v = fmaxf(v, row_ror<1>(v));
+    return v;
+}
+
+// Weight fragments of one head pair for the fused projections (KS1 1-KiB blocks each, the persistent kernel's images:
+// W_q carries log2(e)/sqrt(hd), biases ride in k-slot D against the activation's constant 1.0).
+struct fd_attn_w {
+    const char* wk;
+    const char* wv;
+    const char* wq;
+};
+
+// KS1 == 0: `in` = packed projections qkv (B*T, 3D) fp32 rows [q | k | v].
+// KS1 > 0 : `in` = the layer input h (B*T, D) fp32; Q, K, V of the pair are projected inside the kernel by MFMA (one
+//           launch and the (B*T, 3D) round trip less per layer).
+// out (B*T, D) fp32.  grid (query slices, head pairs, B), 512 threads.
+template <int KS1>
+__global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restrict__ in, float* __restrict__ out, int T,
+                                                           int H, int hd, int D, float qscale, int du_per_block, int exact_only,
+                                                           fd_attn_w wimg, size_t pair_stride) {
+    constexpr bool PROJ = KS1 > 0;
+    const float* __restrict__ qkv = in;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -71,11 +99,66 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
     char* const kbf = smem;                       // [NTOK][4 g][8 B]: lane group g = 2*hs + (d >> 2), element d & 3
     char* const vbf = smem + (size_t)NTOK * 32;   // [NJ][4 g][16 dim slots][16 B]: (half, r) -> token (2jj+half)*16 + 4g + r
     unsigned* const kmax = reinterpret_cast<unsigned*>(vbf + (size_t)NJ * 1024);   // [2] max_j |k_j|^2 per head (bits)
-    const float* base = qkv + (size_t)b * T * 3 * D;
+    const float* base = qkv + (size_t)b * T * (PROJ ? 1 : 3) * D;
+    // activation B fragment of token tile `tile` (PROJ): lane (tok, g) holds features 32ks + 8g .. +7, 1.0 in slot D
+    auto xfrag = [&](int tile, int ks) -> bf16x8 {
+        const int t = tile * 16 + tok, k0 = 32 * ks + 8 * g;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if (t < T) {
+            if (k0 + 8 <= D) {
+                const float4 a = *reinterpret_cast<const float4*>(base + (size_t)t * D + k0);
+                const float4 c = *reinterpret_cast<const float4*>(base + (size_t)t * D + k0 + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = k0 + e;
+                    if (k < D) v[e] = base[(size_t)t * D + k];
+                    else if (k == D) v[e] = 1.0f;
+                }
+            }
+        }
+        const u32x4 pk = {cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
+        return __builtin_bit_cast(bf16x8, pk);
+    };
+    auto wfrag = [&](const char* img, int ks) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(img + (size_t)pair * pair_stride + ((size_t)ks * 64 + lane) * 16);
+    };
 
     // ---- stage K and V^T of this (series, pair) as bf16 fragments; every byte of both regions is written here
     if (threadIdx.x < 2) kmax[threadIdx.x] = 0u;
     __syncthreads();
+    if (PROJ) {
+        // K^T = W_k x^T (C tile rows = the pair's 16 dim slots) and V = x W_v^T (C tile rows = tokens: already the
+        // V^T A-fragment layout; its ones row comes from the bias slot) per token tile, exactly as in fd_mega.hip
+        bf16x8 wkf[PROJ ? KS1 : 1], wvf[PROJ ? KS1 : 1];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            wkf[ks] = wfrag(wimg.wk, ks);
+            wvf[ks] = wfrag(wimg.wv, ks);
+        }
+        for (int kt = wave; kt < KT; kt += NW) {
+            f32x4 a = f4zero(), c = f4zero();
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const bf16x8 xf = xfrag(kt, ks);
+                a = MFMA(wkf[ks], xf, a);
+                c = MFMA(xf, wvf[ks], c);
+            }
+            *reinterpret_cast<u32x2*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8) = u32x2{cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
+            char* dst = vbf + ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16;
+            *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = u32x2{cvt_pk_bf16(c[0], c[1]), cvt_pk_bf16(c[2], c[3])};
+            if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
+            float n2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+            float ea, eb;
+            swap16(n2, ea, eb);
+            n2 = row_max16(ea + eb);
+            if (tok == 0 && (g & 1) == 0)
+                __hip_atomic_fetch_max(&kmax[g >> 1], __builtin_bit_cast(unsigned, n2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
     // K: one thread per (token, lane group gq): the 4 dims 4(gq&1)..+3 of head gq>>1 -> one 8-byte row
     for (int i = threadIdx.x; i < NTOK * 4; i += NTH) {
         const int t = i >> 2, gq = i & 3, head = 2 * pair + (gq >> 1);
@@ -113,7 +196,13 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
         *reinterpret_cast<u32x4*>(vbf + (size_t)i * 16) = u32x4{cvt_pk_bf16(vv[0], vv[1]), cvt_pk_bf16(vv[2], vv[3]),
                                                                cvt_pk_bf16(vv[4], vv[5]), cvt_pk_bf16(vv[6], vv[7])};
     }
+    }
     __syncthreads();
+    bf16x8 wqf[PROJ ? KS1 : 1];
+    if (PROJ) {
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) wqf[ks] = wfrag(wimg.wq, ks);
+    }
 
     const bool lo_grp = (g >> 1) == 0;
     const int myhead = 2 * pair + (g >> 1);
@@ -136,10 +225,18 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
         for (int q = 0; q < NQ; ++q) {
             const int t = qt[q] * 16 + tok;
             float qvv[4];
+            if (PROJ) {
+                f32x4 qa = f4zero();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int d = 4 * (g & 1) + r;
-                qvv[r] = (t < T && d < hd && myhead < H) ? base[(size_t)t * 3 * D + myhead * hd + d] * qscale : 0.f;
+                for (int ks = 0; ks < KS1; ++ks) qa = MFMA(wqf[ks], xfrag(qt[q], ks), qa);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qvv[r] = qa[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = 4 * (g & 1) + r;
+                    qvv[r] = (t < T && d < hd && myhead < H) ? base[(size_t)t * 3 * D + myhead * hd + d] * qscale : 0.f;
+                }
             }
             const unsigned q01 = cvt_pk_bf16(qvv[0], qvv[1]), q23 = cvt_pk_bf16(qvv[2], qvv[3]);
             const u32x2 qe = {lo_grp ? q01 : 0u, lo_grp ? q23 : 0u};
@@ -316,17 +413,20 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
 
 }  // namespace
 
-// bf16 MFMA attention over packed projections.  Returns FD_ERR_UNSUPPORTED when the shape does not fit (head_dim > 7,
-// or K/V^T of one series exceed the LDS): the caller then runs the exact-f32 kernel.
-int fd_attention_bf16(fd_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int hd, hipStream_t s) {
+// bf16 MFMA attention.  wk/wv/wq == nullptr: `in` holds the packed projections (B*T, 3D); otherwise `in` is the layer
+// input (B*T, D) and the images are the persistent kernel's per-layer W_k / W_v / W_q fragment blocks (ks1 blocks per
+// head pair).  Returns FD_ERR_UNSUPPORTED when the shape does not fit (head_dim > 7, K/V^T of one series exceed the
+// LDS, or no instantiation for ks1): the caller then runs the unfused / exact-f32 path.
+int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, int H, int hd, hipStream_t s, const char* wk,
+                      const char* wv, const char* wq, int ks1) {
     const int KT = (T + 15) / 16, NJ = (KT + 1) / 2, D = H * hd;
     const size_t lds = (size_t)KT * 16 * 32 + (size_t)NJ * 1024 + 16;
     if (hd > 7 || lds > 160 * 1024) return FD_ERR_UNSUPPORTED;
-    static bool attr = false;
-    if (!attr) {
-        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_attention_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    const bool proj = wk != nullptr;
+    if (proj && ks1 != 3 && ks1 != 2) return FD_ERR_UNSUPPORTED;
+    const void* kern = proj ? (ks1 == 3 ? (const void*)k_attention_bf16<3> : (const void*)k_attention_bf16<2>)
+                            : (const void*)k_attention_bf16<0>;
+    FD_HIP(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int NP = (H + 1) / 2, DUS = (KT + NQ - 1) / NQ;
     // Query slices per (series, pair): every slice restages K/V (~10 % of a full slice's work); pick the count that
     // minimises rounds x work per round (one workgroup per CU: 8 waves at the 256-VGPR budget).
@@ -340,8 +440,13 @@ int fd_attention_bf16(fd_ctx* ctx, const float* qkv, float* out, int B, int T, i
     }
     const int du_per_block = (DUS + slices - 1) / slices;
     const float qscale = 1.4426950408889634f / sqrtf((float)hd);
-    hipLaunchKernelGGL(k_attention_bf16, dim3(slices, NP, B), dim3(NTH), lds, s, qkv, out, T, H, hd, D, qscale, du_per_block,
-                       getenv("FDIFF_ATTN_EXACT") ? 1 : 0);
+    const int exact = getenv("FDIFF_ATTN_EXACT") ? 1 : 0;
+    const fd_attn_w w{wk, wv, wq};
+    const size_t pair_stride = (size_t)ks1 * 1024;
+    const dim3 grid(slices, NP, B), block(NTH);
+    if (!proj) hipLaunchKernelGGL(k_attention_bf16<0>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride);
+    else if (ks1 == 3) hipLaunchKernelGGL(k_attention_bf16<3>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride);
+    else hipLaunchKernelGGL(k_attention_bf16<2>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride);
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }

@@ -65,4 +65,5 @@ int fd_bf16_prepare(fd_score* m, hipStream_t s);
 int fd_bf16_refresh(fd_score* m, hipStream_t s);   // rebuilds the images if the masters changed since the last build
 int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* out, int B, hipStream_t s);
 // fd_attn_bf16.hip
-int fd_attention_bf16(fd_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int hd, hipStream_t s);
+int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, int H, int hd, hipStream_t s,
+                      const char* wk = nullptr, const char* wv = nullptr, const char* wq = nullptr, int ks1 = 0);

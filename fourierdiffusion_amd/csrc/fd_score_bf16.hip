@@ -820,10 +820,22 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
     fdf32::embed(x, P + m->emb_w, P + m->emb_b, P + m->pos, temb, h0, M, T, C, D, s);
     for (int i = 0; i < L; ++i) {
         const fd_layer_off& lo = m->layers[i];
-        fdgemm::linear_fwd(h0, P + lo.in_w, P + lo.in_b, qkv, M, 3 * D, D, false, s);
-        const int arc = getenv("FDIFF_ATTN_F32") ? FD_ERR_UNSUPPORTED : fd_attention_bf16(ctx, qkv, att, B, T, H, hd, s);
-        if (arc == FD_ERR_UNSUPPORTED) fd_attention_f32(qkv, att, nullptr, B, T, H, hd, 0.f, 0, 0, s);
-        else if (arc != FD_OK) return arc;
+        const fd_bf16_images* imq = m->bf16;
+        int arc = FD_ERR_UNSUPPORTED;
+        if (imq->mega && !getenv("FDIFF_ATTN_F32") && !getenv("FDIFF_ATTN_UNFUSED")) {
+            // Q/K/V projections inside the attention kernel (the persistent kernel's per-layer weight images)
+            const char* limg = imq->mimg + imq->off_layers + (size_t)i * imq->layer_stride;
+            arc = fd_attention_bf16(ctx, h0, att, B, T, H, hd, s, limg + imq->off_wk, limg + imq->off_wv, limg + imq->off_wq, imq->ks1);
+        }
+        if (arc == FD_ERR_UNSUPPORTED) {
+            fdgemm::linear_fwd(h0, P + lo.in_w, P + lo.in_b, qkv, M, 3 * D, D, false, s);
+            arc = getenv("FDIFF_ATTN_F32") ? FD_ERR_UNSUPPORTED : fd_attention_bf16(ctx, qkv, att, B, T, H, hd, s);
+            if (arc == FD_ERR_UNSUPPORTED) {
+                fd_attention_f32(qkv, att, nullptr, B, T, H, hd, 0.f, 0, 0, s);
+                arc = FD_OK;
+            }
+        }
+        if (arc != FD_OK) return arc;
         const fd_bf16_images* im = m->bf16;
         const bool fuse = im->mega && im->kso == 3 && (im->ks1 == 3 || im->ks1 == 2) && !getenv("FDIFF_FFN_UNFUSED");
         if (fuse) {
