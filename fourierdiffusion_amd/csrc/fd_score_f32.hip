@@ -170,15 +170,29 @@ __global__ __launch_bounds__(128) void k_time_embed(const float* __restrict__ t,
 __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ x, const float* __restrict__ We,
                                                 const float* __restrict__ be, const float* __restrict__ pe,
                                                 const float* __restrict__ temb, float* __restrict__ h, int M, int T,
-                                                int C, int D) {
+                                                int C, int D, int use_lds) {
+    // We (D, C) transposed into LDS as [c][d]: consecutive threads (consecutive d) then read consecutive words instead
+    // of a C-strided gather from L2 (the kernel was 6 % of a long-horizon diffusion step); same fma order as before
+    extern __shared__ float wsh[];
+    if (use_lds) {
+        for (int i = threadIdx.x; i < D * C; i += 256) {
+            const int d = i / C, c = i - d * C;
+            wsh[c * D + d] = We[i];
+        }
+        __syncthreads();
+    }
     const size_t id = blockIdx.x * (size_t)256 + threadIdx.x;
     if (id >= (size_t)M * D) return;
     const int m = (int)(id / D), d = (int)(id % D);
     const int b = m / T, tt = m % T;
     const float* xr = x + (size_t)m * C;
-    const float* w = We + (size_t)d * C;
     float acc = 0.f;
-    for (int c = 0; c < C; ++c) acc = fmaf(xr[c], w[c], acc);
+    if (use_lds) {
+        for (int c = 0; c < C; ++c) acc = fmaf(xr[c], wsh[c * D + d], acc);
+    } else {
+        const float* w = We + (size_t)d * C;
+        for (int c = 0; c < C; ++c) acc = fmaf(xr[c], w[c], acc);
+    }
     h[id] = ((acc + be[d]) + pe[(size_t)tt * D + d]) + temb[(size_t)b * D + d];
 }
 
@@ -345,8 +359,9 @@ void time_embed(const float* t, const float* W, const float* Wd, const float* bd
 void embed(const float* x, const float* We, const float* be, const float* pe, const float* temb, float* h, int M,
            int T, int C, int D, hipStream_t s) {
     const size_t n = (size_t)M * D;
-    hipLaunchKernelGGL(k_embed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, We, be, pe, temb, h, M, T, C,
-                       D);
+    const int use_lds = ((size_t)D * C * sizeof(float) <= 48 * 1024) ? 1 : 0;
+    hipLaunchKernelGGL(k_embed, dim3((unsigned)((n + 255) / 256)), dim3(256), use_lds ? (size_t)D * C * sizeof(float) : 0, s, x,
+                       We, be, pe, temb, h, M, T, C, D, use_lds);
 }
 void add_layernorm(const float* a, const float* r, const float* gamma, const float* beta, float* y, int M, int D,
                    hipStream_t s) {
@@ -452,8 +467,7 @@ int fd_score_forward_f32(fd_score* m, const float* x, const float* t, float* out
     float* h_in = (L > 0) ? (train ? sv.layers[0].x0 : scratch.x0) : sv.hL;
     {
         const size_t n = (size_t)M * D;
-        hipLaunchKernelGGL(k_embed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, P + m->emb_w,
-                           P + m->emb_b, P + m->pos, sv.temb, h_in, M, T, C, D);
+        fdf32::embed(x, P + m->emb_w, P + m->emb_b, P + m->pos, sv.temb, h_in, M, T, C, D, s);
     }
     for (int i = 0; i < L; ++i) {
         const fd_layer_off& lo = m->layers[i];
