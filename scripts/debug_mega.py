@@ -10,7 +10,10 @@ from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
 name = sys.argv[1] if len(sys.argv) > 1 else "default"
 cfgs = {"default": CFG_DEFAULT, "tiny": CFG_TINY, "odd": CFG_ODD,
         "nasdaq": dict(T=252, C=6, D=72, L=10, H=12), "mimic": dict(T=256, C=28, D=72, L=10, H=12),
-        "long": dict(T=1024, C=16, D=72, L=10, H=12)}
+        "long": dict(T=1024, C=16, D=72, L=10, H=12),
+        "drought": dict(T=365, C=1, D=72, L=3, H=12), "cls": dict(T=128, C=5, D=60, L=3, H=12),
+        "cls_long": dict(T=400, C=7, D=60, L=3, H=12), "wide_head": dict(T=300, C=4, D=24, L=2, H=2),
+        "t2048": dict(T=2048, C=4, D=72, L=1, H=12)}
 cfg = cfgs[name]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 nl = int(os.environ.get("FDIFF_MEGA_LAYERS", cfg["L"]))

@@ -70,6 +70,30 @@ def test_short_trajectory_f32_vs_oracle(name, kind, p):
     assert np.abs(out - ref).max() <= 1e-4 * scale, (np.abs(out - ref).max(), scale)
 
 
+ODD_SHAPES = {
+    # reference dataset-like and corner shapes: odd T beyond one workgroup, single channel, class-default model
+    # (d_model 60 -> head_dim 5), head_dim > 7 (no ones-row slot: exact-f32 attention inside the bf16 path), T = 2048
+    "drought": (dict(T=365, C=1, D=72, L=3, H=12), 3),
+    "class_default": (dict(T=128, C=5, D=60, L=3, H=12), 4),
+    "class_default_long": (dict(T=400, C=7, D=60, L=3, H=12), 3),
+    "wide_head": (dict(T=300, C=4, D=24, L=2, H=2), 3),
+    "t2048": (dict(T=2048, C=4, D=72, L=1, H=12), 1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ODD_SHAPES))
+def test_forward_bf16_odd_shapes_vs_oracle(name):
+    cfg, B = ODD_SHAPES[name]
+    m, _, sd = make_model(cfg, precision="bf16")
+    X = W.randn(f"os_x_{name}", (B, cfg["T"], cfg["C"]), 2)
+    t = W.uniform(f"os_t_{name}", (B,), 2, 1e-5, 1.0)
+    out = run(m, X, t)
+    ref = O.score_forward(sd, X, t, cfg["H"])
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    rms = np.sqrt(((out - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())
+    assert err <= 2e-2 and rms <= 1e-2, (err, rms)
+
+
 def test_mimic_full_batch_properties_bf16():
     """512 series per GPU at T=256, C=28 (configs[3] per-GPU shard): finite, deterministic, rows independent."""
     from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
