@@ -22,12 +22,17 @@ struct fd_ctx {
     void* comm = nullptr;   // ncclComm_t when fd_comm_init succeeded
     int rank = 0, nranks = 1;
     int num_cu = 256;
+    // split-K partial sums of the exact-f32 GEMMs (allocated on first use, freed with the context)
+    float* gemm_scratch = nullptr;
+    size_t gemm_scratch_floats = 0;
     // measurement hooks (fd_prof_begin / fd_prof_end)
     bool prof_on = false;
     std::string prof_name;
     double prof_flops = 0.0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
 };
+
+float* fd_gemm_scratch(fd_ctx* ctx, size_t* n_floats);   // fd_ctx.hip
 
 // Bracket one launch of the dominant kernel with events on its stream (no-op unless profiling is on).
 struct fd_prof_scope {

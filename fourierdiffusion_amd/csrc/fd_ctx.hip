@@ -23,6 +23,7 @@ extern "C" int fd_ctx_destroy(fd_ctx* ctx) {
     if (!ctx) return FD_ERR_ARG;
     fd_comm_destroy(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->gemm_scratch) (void)hipFree(ctx->gemm_scratch);
     delete ctx;
     return FD_OK;
 }
@@ -44,6 +45,20 @@ int fd_ws_reserve(fd_ctx* ctx, size_t bytes) {
     FD_HIP(ctx, hipMalloc(&ctx->ws, want));
     ctx->ws_bytes = want;
     return FD_OK;
+}
+
+// 64 MiB of split-K scratch for the exact-f32 GEMMs (skinny outputs with long reductions would otherwise run on ~100
+// workgroups); nullptr result = allocation failed, the GEMMs then simply do not split.
+float* fd_gemm_scratch(fd_ctx* ctx, size_t* n_floats) {
+    if (!ctx->gemm_scratch) {
+        const size_t n = (size_t)16 << 20;
+        if (hipSetDevice(ctx->device) == hipSuccess && hipMalloc((void**)&ctx->gemm_scratch, n * sizeof(float)) == hipSuccess)
+            ctx->gemm_scratch_floats = n;
+        else
+            ctx->gemm_scratch = nullptr;
+    }
+    *n_floats = ctx->gemm_scratch_floats;
+    return ctx->gemm_scratch;
 }
 
 extern "C" int fd_prof_begin(fd_ctx* ctx) {

@@ -246,15 +246,15 @@ inline void launch(const Args& g, hipStream_t s, float* scratch = nullptr, size_
 
 // y[M,N] = x[M,K] . W[N,K]^T + bias   (nn.Linear forward)
 inline void linear_fwd(const float* x, const float* W, const float* bias, float* y, int M, int N, int K, bool relu,
-                       hipStream_t s) {
+                       hipStream_t s, float* scratch = nullptr, size_t scratch_floats = 0) {
     Args g{x, W, y, bias, M, N, K, (long long)K, 1, 1, (long long)K, (long long)N, 1.0f, relu ? 1 : 0, 0};
-    launch(g, s);
+    launch(g, s, scratch, scratch_floats);
 }
 // dx[M,K] (+)= dy[M,N] . W[N,K]
 inline void linear_bwd_input(const float* dy, const float* W, float* dx, int M, int N, int K, bool accumulate,
-                             hipStream_t s) {
+                             hipStream_t s, float* scratch = nullptr, size_t scratch_floats = 0) {
     Args g{dy, W, dx, nullptr, M, K, N, (long long)N, 1, (long long)K, 1, (long long)K, 1.0f, 0, accumulate ? 1 : 0};
-    launch(g, s);
+    launch(g, s, scratch, scratch_floats);
 }
 // dW[N,K] (+)= dy[M,N]^T . x[M,K]
 inline void linear_bwd_weight(const float* dy, const float* x, float* dW, int M, int N, int K, bool accumulate,

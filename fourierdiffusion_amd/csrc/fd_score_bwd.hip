@@ -324,6 +324,8 @@ extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, i
     float* Dq = ws.take<float>((size_t)B * H * T);
     float* dtemb = ws.take<float>((size_t)B * D);
     float* skp = ws.take<float>(kSplitKFloats);
+    size_t gsk_n = 0;
+    float* gsk = fd_gemm_scratch(ctx, &gsk_n);
 
     if (!accumulate) FD_HIP(ctx, hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->nparams, s));
     const float inv_keep = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
@@ -349,7 +351,7 @@ extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, i
                            inv_keep);
         fdgemm::linear_bwd_weight(dact, A.x1, grads + lo.l1_w, M, F, D, true, s, skp, kSplitKFloats);
         colsum(ctx, dact, grads + lo.l1_b, M, F, s);
-        fdgemm::linear_bwd_input(dact, P + lo.l1_w, ds, M, F, D, true, s);        // ds = d x1 (residual + FFN branch)
+        fdgemm::linear_bwd_input(dact, P + lo.l1_w, ds, M, F, D, true, s, gsk, gsk_n);   // ds = d x1 (residual + FFN branch); K = F: split
         // x1 = LN1(s1): ds -> dh (= d s1)
         ln_bwd(ctx, ds, A.s1, A.mr1, P + lo.n1_w, dh, grads + lo.n1_w, grads + lo.n1_b, M, D, s);
         // s1 = x0 + drop(proj), proj = att Wo^T + bo

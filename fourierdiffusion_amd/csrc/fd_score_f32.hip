@@ -433,6 +433,8 @@ int fd_score_forward_f32(fd_score* m, const float* x, const float* t, float* out
     if (int rc = fd_ws_reserve(ctx, fd_score_f32_workspace(m, B, train) + (train ? fd_score_bwd_workspace(m, B) : 0)))
         return rc;
     fd_ws ws(ctx);
+    size_t gsk_n = 0;
+    float* gsk = fd_gemm_scratch(ctx, &gsk_n);
     fd_saved sv;
     fd_saved_layer scratch{};
     float* tmp;   // (M,D) projection scratch
@@ -483,7 +485,7 @@ int fd_score_forward_f32(fd_score* m, const float* x, const float* t, float* out
                            A.s1, A.mr1, A.x1, M, D);
         fdgemm::linear_fwd(A.x1, P + lo.l1_w, P + lo.l1_b, A.hact, M, F, D, true, s);
         if (train) fd_dropout_inplace(ctx, A.hact, (size_t)M * F, p, seed, fd_dropout_site_offset(offset, i, 2), s);
-        fdgemm::linear_fwd(A.hact, P + lo.l2_w, P + lo.l2_b, tmp, M, D, F, false, s);
+        fdgemm::linear_fwd(A.hact, P + lo.l2_w, P + lo.l2_b, tmp, M, D, F, false, s, gsk, gsk_n);   // K = F: split
         if (train) fd_dropout_inplace(ctx, tmp, (size_t)M * D, p, seed, fd_dropout_site_offset(offset, i, 3), s);
         hipLaunchKernelGGL(k_add_layernorm, dim3((M + 3) / 4), dim3(256), 0, s, A.x1, tmp, P + lo.n2_w, P + lo.n2_b,
                            A.s2, A.mr2, x_next, M, D);
