@@ -1,5 +1,8 @@
 """Time the hot path at the other BASELINE.json shapes (not bench lines: DESIGN.md section 4 quotes them).
-usage: python scripts/shape_bench.py [sample|train] NAME B [diffusion_steps]"""
+usage: python scripts/shape_bench.py [sample|train] NAME B [diffusion_steps]
+`train` also runs data-parallel under torch.distributed.run (BASELINE.json configs[2]: nasdaq, batch 64 per GPU x 8):
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts/shape_bench.py train nasdaq 64
+one process per GPU, the gradient exchange is ONE RCCL all-reduce of the flat fp32 gradient buffer per optimizer step."""
 import ctypes as C
 import os
 import sys
@@ -24,7 +27,12 @@ def main():
     from fourierdiffusion_amd.schedulers.sde import VPScheduler
     from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
     torch.manual_seed(0)
-    dev = torch.device("cuda", 0)
+    from fourierdiffusion_amd.parallel import GradExchange, init_process_group
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    denv = init_process_group(os.environ.get("FDIFF_BENCH_BACKEND"))
+    _rng.set_rank(denv.rank)
     sch = VPScheduler(beta_min=0.1, beta_max=20.0, fourier_noise_scaling=True)
     sch.set_noise_scaling(T)
     m = ScoreModule(n_channels=Cn, max_len=T, noise_scheduler=sch, fourier_noise_scaling=True, d_model=72, num_layers=10,
@@ -59,10 +67,12 @@ def main():
         m.train()
         opt = FusedAdamW(m, lr=1e-3)
         X = torch.randn(B, T, Cn, device=dev)
+        ex = GradExchange(denv, backend="rccl" if os.environ.get("FDIFF_BENCH_BACKEND", "nccl") == "nccl" else "torch")
 
         def step():
             m.zero_grad()
             loss = m.training_step(DiffusableBatch(X=X), 0)
+            ex.all_reduce_mean(m.grads)
             opt.step()
             return loss
         for _ in range(2):
@@ -73,8 +83,15 @@ def main():
             step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5
-        print(f"{name} train B={B} T={T} C={Cn}: {1e3 * dt:.2f} ms per optimizer step (fwd+bwd+AdamW), "
-              f"{3 * B * flops_fwd(T, Cn) / dt / 1e12:.2f} TFLOP/s algorithmic, {B / dt:.0f} series/s")
+        if denv.world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        if denv.rank == 0:
+            print(f"{name} train B={B}/GPU x {denv.world} T={T} C={Cn}: {1e3 * dt:.2f} ms per optimizer step "
+                  f"(fwd+bwd+all-reduce+AdamW), {3 * denv.world * B * flops_fwd(T, Cn) / dt / 1e12:.2f} TFLOP/s algorithmic, "
+                  f"{denv.world * B / dt:.0f} series/s")
 
 
 main()
