@@ -13,9 +13,12 @@
 // Operand convention (v_mfma_f32_16x16x32_bf16): token on lane&15, g = lane>>4 selects 8 k-slots; every
 // GEMM is computed transposed (out^T = W . x^T) so C tiles are [feature = 4g+r][token = lane&15] and chain
 // into the next GEMM's B operand with k-permuted weight images -- see fd_score_bf16.hip for the FFN case.
-// Attention: per (query tile, head pair) unit, S^T = K Q^T and O^T = V^T P^T with two heads sharing every
-// K / V fragment (even head in k-slots / rows of lane groups 0-1, odd head in groups 2-3), fp32 online
-// softmax in registers (exp2, scale folded into W_q), P fed back as a B operand without leaving registers.
+// Attention: units of (head pair) x (series) x (two query tiles); S^T = K Q^T by the K=16 MFMA with two heads sharing
+// every K / V fragment (even head in k-slots / rows of lane groups 0-1, odd head in groups 2-3); the softmax shift
+// (bound |q| max|k|, exact row maximum as fallback) rides in the MFMA's C operand, exp2 with the scale folded into W_q,
+// the denominator comes out of the P V MFMAs through a row of ones in V^T; P is fed back as a B operand without
+// leaving registers.  FFN: weights streamed L2 -> LDS through a 4-deep ring, hidden activations stay in registers.
+// DESIGN.md sections 3.2 / 3.3 hold the measurements behind each of these choices.
 //
 // Reference arithmetic: src/fdiff/models/score_models.py:67-94 (+ torch TransformerEncoderLayer),
 // src/fdiff/sampling/sampler.py:83-104, src/fdiff/schedulers/sde.py:129-165,215-246.
