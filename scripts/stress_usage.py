@@ -1,0 +1,65 @@
+"""Usage-pattern stress: several models alive at once, changing batch sizes (workspace regrowth), both precisions,
+sampler + forward + training interleaved, a non-default stream."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from oracle import fdiff_oracle as O, weights as W
+from tests.gpu_util import make_model, dev, host
+from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
+from fourierdiffusion_amd.sampling.sampler import DiffusionSampler
+from fourierdiffusion_amd.optim import FusedAdamW
+
+cfgA = dict(T=100, C=12, D=72, L=3, H=12)
+cfgB = dict(T=37, C=5, D=24, L=2, H=4)
+cfgC = dict(T=300, C=4, D=72, L=2, H=12)
+ms = {k: make_model(c, precision="bf16") for k, c in (("A", cfgA), ("B", cfgB), ("C", cfgC))}
+def check(k, B, prec):
+    m, _, sd = ms[k]
+    cfg = {"A": cfgA, "B": cfgB, "C": cfgC}[k]
+    m.precision = prec
+    m.eval()
+    X = W.randn(f"st_x_{k}_{B}", (B, cfg["T"], cfg["C"]), 2)
+    t = W.uniform(f"st_t_{k}_{B}", (B,), 2, 1e-5, 1.0)
+    out = host(m(DiffusableBatch(X=dev(X), timesteps=dev(t))))
+    ref = O.score_forward(sd, X, t, cfg["H"])
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    tol = 2e-2 if prec == "bf16" else 1e-5
+    assert err < tol, (k, B, prec, err)
+    return err
+for B in (1, 7, 300, 2, 513, 5):
+    for k in ("A", "B", "C"):
+        for prec in ("bf16", "fp32"):
+            if B > 100 and prec == "fp32" and k == "C":
+                continue
+            if B > 300 and k == "C":
+                continue
+            if B <= 7 or prec == "bf16":
+                e = check(k, B if B <= 7 else min(B, 40) if prec == "fp32" else B if k != "C" else 6, prec)
+print("forward grid ok")
+# interleave: train model A (fp32 path) then sample with bf16, on a side stream
+mA, schA, sdA = ms["A"]
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    mA.train()
+    opt = FusedAdamW(mA, lr=1e-3)
+    X = torch.randn(16, 100, 12, device="cuda")
+    l0 = None
+    for i in range(5):
+        mA.zero_grad()
+        loss = mA.training_step(DiffusableBatch(X=X), 0)
+        opt.step()
+        l0 = float(loss) if l0 is None else l0
+    mA.eval()
+    s = DiffusionSampler(score_model=mA, sample_batch_size=9)
+    out = s.sample(num_samples=20, num_diffusion_steps=15)
+    assert out.shape == (18, 100, 12), out.shape   # reference semantics: floor(20 / 9) full batches
+    assert torch.isfinite(out).all()
+side.synchronize()
+# the bf16 images must have been rebuilt after training: compare against the oracle with the trained weights
+sd_now = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in mA.state_dict().items()}
+Xn = W.randn("st_after", (3, 100, 12), 2); tn = W.uniform("st_after_t", (3,), 2, 1e-5, 1.0)
+mA.precision = "bf16"
+o = host(mA(DiffusableBatch(X=dev(Xn), timesteps=dev(tn))))
+r = O.score_forward(sd_now, Xn, tn, 12)
+assert np.abs(o - r).max() / np.abs(r).max() < 2e-2
+print("train -> sample -> forward with refreshed images ok; loss0", l0)
