@@ -25,6 +25,8 @@ struct fd_ctx {
     // split-K partial sums of the exact-f32 GEMMs (allocated on first use, freed with the context)
     float* gemm_scratch = nullptr;
     size_t gemm_scratch_floats = 0;
+    // FFT twiddle tables (T, device pointer), built on first use of a length
+    std::vector<std::pair<int, void*>> fft_tw;
     // measurement hooks (fd_prof_begin / fd_prof_end)
     bool prof_on = false;
     std::string prof_name;

@@ -24,6 +24,7 @@ extern "C" int fd_ctx_destroy(fd_ctx* ctx) {
     fd_comm_destroy(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->gemm_scratch) (void)hipFree(ctx->gemm_scratch);
+    for (auto& e : ctx->fft_tw) (void)hipFree(e.second);
     delete ctx;
     return FD_OK;
 }
