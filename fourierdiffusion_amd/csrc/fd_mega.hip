@@ -519,6 +519,21 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             swap32(bnd, bq[q][0], bq[q][1]);          // head 0 bound | head 1 bound, in every lane
                         }
                     }
+                    // Q with -bound in k-slot hd of its head (fast path): lane group 2hs + (hd >> 2), element hd & 3
+                    s16x4 qs[NQ][2];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int hs = 0; hs < 2; ++hs) {
+                            u32x2 w = __builtin_bit_cast(u32x2, qb[q][hs]);
+                            const unsigned nb = cvt_pk_bf16(-bq[q][hs], 0.f) & 0xffffu;
+                            const bool mine = g == 2 * hs + (hd >> 2);
+                            const int dw = (hd & 3) >> 1;
+                            const unsigned old = w[dw];
+                            const unsigned patched = (hd & 1) ? ((old & 0x0000ffffu) | (nb << 16)) : ((old & 0xffff0000u) | nb);
+                            w[dw] = mine ? patched : old;
+                            qs[q][hs] = __builtin_bit_cast(s16x4, w);
+                        }
                     float m2[NQ][2];
                     f32x4 o2[NQ][2];
                     auto run_unit = [&](auto exact_c) {
@@ -589,15 +604,20 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                                 }
                         }
                         mark(11, step);
-                        f32x4 negm[NQ][2], clast[NQ][2];
+                        // Exact path: -max rides in the C operand.  Fast path: the (per-unit constant) shift rides in
+                        // the contraction itself -- K carries a 1.0 in the free dim slot hd (bias row of the W_k image)
+                        // and Q gets -bound there -- so C is an inline 0 and no splat registers are live.
+                        f32x4 negm[EXACT ? NQ : 1][2], clast[EXACT ? NQ : 1][2];
+                        if (EXACT) {
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q)
+                            for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                            for (int hs = 0; hs < 2; ++hs) {
-                                const float mm = m2[q][hs];
-                                negm[q][hs] = f32x4{-mm, -mm, -mm, -mm};
-                                clast[q][hs] = cmask - mm;
-                            }
+                                for (int hs = 0; hs < 2; ++hs) {
+                                    const float mm = m2[q][hs];
+                                    negm[q][hs] = f32x4{-mm, -mm, -mm, -mm};
+                                    clast[q][hs] = cmask - mm;
+                                }
+                        }
                         mark(12, step);
                         // pass 2: P = exp2(S - shift) tile by tile, packed to bf16 B fragments, then P V.  The row sum of
                         // P comes out of the same MFMAs: V^T carries a row of ones (dim slot hd).
@@ -610,8 +630,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                                 if (k < NKT) {
                                     const int jl = k & 1, q = (k >> 1) % NQ, jj = ((k >> 1) / NQ) & 3, hs = (k >> 1) / NQ >> 2;
                                     const int j = 2 * jj + jl;
-                                    if (j < nk) pe[k] = MFMA16(kf[j], qb[q][hs], (kb + j == KT - 1) ? clast[q][hs] : negm[q][hs]);
-                                    else pe[k] = f4zero();
+                                    if (j < nk) {
+                                        if (EXACT) pe[k] = MFMA16(kf[j], qb[q][hs], (kb + j == KT - 1) ? clast[q][hs] : negm[q][hs]);
+                                        else pe[k] = MFMA16(kf[j], qs[q][hs], (kb + j == KT - 1) ? cmask : f4zero());
+                                    } else {
+                                        pe[k] = f4zero();
+                                    }
                                 }
                                 if (k >= LAG && k - LAG < NKT) {
                                     const int e = k - LAG;

@@ -117,9 +117,10 @@ __global__ __launch_bounds__(64) void k_build_image(int kind, const float* __res
                 const int src = (kind - IMG_Q) * D + hd * head + j;          // row of in_proj_weight (3D x D)
                 v = (k < D) ? W[(size_t)src * D + k] : (k == D ? bias[src] : 0.f);
                 v *= scale;
-            } else if (kind == IMG_V && head < H && j == hd) {
-                // "ones" feature: V[token][head, hd] = 1 (through the bias slot), so that the P.V MFMAs also
-                // deliver sum_j P[q, j] (the softmax denominator) in row hd of the head's O^T block
+            } else if ((kind == IMG_V || kind == IMG_K) && head < H && j == hd) {
+                // "ones" feature in the free dim slot hd (through the bias slot).  V: the P.V MFMAs then also deliver
+                // sum_j P[q, j] (the softmax denominator) in row hd of the head's O^T block.  K: a constant placed in
+                // Q's slot hd is added to every score of the row by the S MFMA itself (the softmax shift).
                 v = (k == D) ? 1.f : 0.f;
             }
         } else {   // IMG_WO: k-slot group (ks, g) = head 4ks+g, slot e = head dim
