@@ -182,6 +182,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
     const int NTOK = NTILE * 16;
     const int NP = (H + 1) >> 1;                 // head pairs
     const int NPG = SHP(NPG);                    // head pairs per attention group
+    // W_o through LDS for the out-proj: it fits the (dead) W_k | W_v slots of the last attention group, and the FFN ring
+    // can start one buffer later (buffers 1-2 = the first 3/4 of the ring must then lie in front of afr, which the
+    // out-proj still reads; the host plan only guarantees the first half)
+    const bool WO_LDS = (2 * NPG * KS1 >= DT * KSO) && (P.lds_afr - NTILE * KSX * 1024 >= 3 * WB1);
+    const int rb = WO_LDS ? 1 : 0;               // FFN step s lives in ring buffer (s + rb) % NBUF
     const int NJ = (KT + 1) >> 1;                // 32-key blocks per series
     const int b0 = blockIdx.x * S;               // first series of this workgroup
 
@@ -454,6 +459,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                 __syncthreads();
                 mark(3, step);
                 refresh_lane();
+                if (pg + NPG >= NP && WO_LDS) {
+                    // last group: its W_k | W_v slots are dead -> fetch W_o there for the out-proj (an L2 round trip and
+                    // DT*KSO vector loads per wave off the critical path of the next phase)
+                    dma_blocks(limg + P.off_wo, wk, DT * KSO);
+                }
                 if (pg + NPG < NP) {                                  // next group's W_k | W_v and its (zeroed) max table
                     const int npn = min(NPG, NP - pg - NPG);
                     dma_blocks(limg + P.off_wk + (size_t)(pg + NPG) * KS1 * 1024, wk, npn * KS1);
@@ -734,9 +744,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                 for (int i = threadIdx.x; i < P.dbg_bytes / 4; i += NTH) P.dbg_out[i] = reinterpret_cast<unsigned*>(smem)[i];
                 __syncthreads();
             }
-            // -------- FFN weight stream: a ring of NBUF chunk buffers filled 3 steps ahead of their use.  Buffers 0-1
-            //          overlay W/K/V only (afr is still read by the out-proj) and are filled during the out-proj;
-            //          buffers 2-3 overlay afr and are first filled after the barrier that ends the out-proj.
+            // -------- FFN weight stream: a ring of NBUF chunk buffers filled 3 steps ahead of their use; step s lives in
+            //          buffer (s + rb) % NBUF.  Steps 0 and 1 are fetched during the out-proj into dead W / K / V space:
+            //          rb = 1 -> buffers 1-2 (buffer 0 overlays the W_k | W_v slots that hold W_o during the out-proj),
+            //          rb = 0 -> buffers 0-1.  The other two buffers may overlay afr, which the out-proj still reads, and
+            //          are first filled after the barrier that ends it.
             const int NS = SHP(F) / 64;
             // Every CU streams the SAME weights; marching through them in lockstep makes all 32 CUs of an XCD hit
             // the same L2 channel at the same time (measured: the stream ran at ~25 GB/s per CU and bounded the FFN
@@ -749,7 +761,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                 // Every wave issues exactly NDMA instructions (the last ones repeat a block) so that
                 // `s_waitcnt vmcnt(NDMA)` means "everything but the newest buffer has landed" for all waves.
                 const char* src = limg + P.off_ffn + (size_t)st * WB1 + lane * 16;
-                char* dst = ring + (st_seq % NBUF) * WB1;
+                char* dst = ring + ((st_seq + rb) % NBUF) * WB1;
 #pragma unroll
                 for (int i = 0; i < NDMA; ++i) {
                     int b = wave + i * NW;
@@ -765,7 +777,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                 int st = st_seq + st_rot;
                 st -= (st >= NS) ? NS : 0;
                 const char* src = limg + P.off_ffn + (size_t)st * WB1 + lane * 16;
-                char* dst = ring + (st_seq % NBUF) * WB1;
+                char* dst = ring + ((st_seq + rb) % NBUF) * WB1;
                 const int w4 = wave % MQ;
 #pragma unroll
                 for (int i = 0; i < NDH; ++i) {
@@ -782,7 +794,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int ks = 0; ks < KSO; ++ks) wo[dt][ks] = gfrag(limg + P.off_wo, dt * KSO + ks);
+                for (int ks = 0; ks < KSO; ++ks)
+                    wo[dt][ks] = WO_LDS ? *reinterpret_cast<const bf16x8*>(wsl + ((dt * KSO + ks) * 64 + lane) * 16)
+                                        : gfrag(limg + P.off_wo, dt * KSO + ks);
 #pragma unroll
             for (int oi = 0; oi < 2; ++oi) {
                 const int tt = fh + 2 * oi;
@@ -856,7 +870,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     bf16x8 w1[2][KS1], w2[DT];
                     f32x4 h0, h1;                                     // hidden tiles of the item in flight
                     auto load_w1 = [&](int s) {
-                        const char* wb = ring + (s % NBUF) * WB1 + FH * NBF * 1024 + lane * 16;
+                        const char* wb = ring + ((s + rb) % NBUF) * WB1 + FH * NBF * 1024 + lane * 16;
 #pragma unroll
                         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -864,7 +878,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                                 w1[ft][ks] = *reinterpret_cast<const bf16x8*>(wb + (ft * KS1 + ks) * 1024);
                     };
                     auto load_w2 = [&](int s) {
-                        const char* wb = ring + (s % NBUF) * WB1 + FH * NBF * 1024 + lane * 16;
+                        const char* wb = ring + ((s + rb) % NBUF) * WB1 + FH * NBF * 1024 + lane * 16;
 #pragma unroll
                         for (int dt = 0; dt < DT; ++dt)
                             w2[dt] = *reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024);
