@@ -133,17 +133,23 @@ __device__ __forceinline__ float group_max(float v) {
 // a ShapeStatic instantiation bakes the dimensions of one workload in, which removes the index arithmetic,
 // the runtime loop guards (each guard splits a basic block and stops hipcc interleaving independent MFMA /
 // VALU chains) and ~40 live scalars -- PMC showed 6.5 VALU + 3.2 SALU instructions per MFMA in the generic build.
+// A dimension is compile-time when the policy gives it a non-zero value (every real dimension is >= 1).
 struct ShapeDyn {
-    static constexpr bool kStatic = false;
     static constexpr int T = 0, KT = 0, D = 0, C = 0, H = 0, hd = 0, S = 0, NPG = 0, KSE = 0, CT = 0, rot = 0, L = 0, F = 0;
 };
 template <int T_, int D_, int C_, int H_, int S_, int NPG_, int ROT_, int L_, int F_>
 struct ShapeStatic {
-    static constexpr bool kStatic = true;
     static constexpr int T = T_, KT = (T_ + 15) / 16, D = D_, C = C_, H = H_, hd = D_ / H_, S = S_, NPG = NPG_;
     static constexpr int KSE = (C_ + 1 + 31) / 32, CT = (C_ + 15) / 16, rot = ROT_, L = L_, F = F_;
 };
-#define SHP(name) (SH::kStatic ? SH::name : P.name)
+// Model dimensions fixed, series shape (T, C) and the workgroup plan (S, NPG, rot) read at run time: every dataset run
+// with one transformer configuration shares this instantiation (the per-feature loops of the LayerNorm / projection
+// phases are then straight-line code; only the attention's key-tile loops keep their run-time guards).
+template <int D_, int H_, int L_, int F_>
+struct ShapeModel {
+    static constexpr int T = 0, KT = 0, D = D_, C = 0, H = H_, hd = D_ / H_, S = 0, NPG = 0, KSE = 0, CT = 0, rot = 0, L = L_, F = F_;
+};
+#define SHP(name) (SH::name != 0 ? SH::name : P.name)
 
 // ---------------------------------------------------------------------------------------------------
 // NW = waves per workgroup (8: one workgroup per CU, up to 16 token tiles).  A 4-wave form (two co-resident
@@ -1096,6 +1102,17 @@ int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int ks
         if (shape_matches<ShapeEcg>(P, ks1, dt, kso, mt)) return launch_mega_t<3, 5, 3, 4, ShapeEcg>(ctx, P, grid, lds, s);
         if (shape_matches<ShapeNasdaq>(P, ks1, dt, kso, mt)) return launch_mega_t<3, 5, 3, 4, ShapeNasdaq>(ctx, P, grid, lds, s);
         if (shape_matches<ShapeMimic>(P, ks1, dt, kso, mt)) return launch_mega_t<3, 5, 3, 4, ShapeMimic>(ctx, P, grid, lds, s);
+    }
+    // the hydra default transformer (d_model 72, 12 heads, 10 layers, ff 2048) at any other series shape
+    using ShapeDefaultModel = ShapeModel<72, 12, 10, 2048>;
+    if (!getenv("FDIFF_MEGA_GENERIC") && ks1 == 3 && dt == 5 && kso == 3 && P.D == 72 && P.H == 12 && P.L == 10 && P.F == 2048) {
+        switch (mt) {
+            case 1: return launch_mega_t<3, 5, 3, 1, ShapeDefaultModel>(ctx, P, grid, lds, s);
+            case 2: return launch_mega_t<3, 5, 3, 2, ShapeDefaultModel>(ctx, P, grid, lds, s);
+            case 3: return launch_mega_t<3, 5, 3, 3, ShapeDefaultModel>(ctx, P, grid, lds, s);
+            case 4: return launch_mega_t<3, 5, 3, 4, ShapeDefaultModel>(ctx, P, grid, lds, s);
+            default: break;
+        }
     }
 #define FD_MEGA_CASE(K, T_, O, M_)                                                                 \
     if (ks1 == K && dt == T_ && kso == O && mt == M_) return launch_mega_t<K, T_, O, M_, ShapeDyn>(ctx, P, grid, lds, s);

@@ -13,7 +13,8 @@ cfgs = {"default": CFG_DEFAULT, "tiny": CFG_TINY, "odd": CFG_ODD,
         "long": dict(T=1024, C=16, D=72, L=10, H=12),
         "drought": dict(T=365, C=1, D=72, L=3, H=12), "cls": dict(T=128, C=5, D=60, L=3, H=12),
         "cls_long": dict(T=400, C=7, D=60, L=3, H=12), "wide_head": dict(T=300, C=4, D=24, L=2, H=2),
-        "t2048": dict(T=2048, C=4, D=72, L=1, H=12)}
+        "t2048": dict(T=2048, C=4, D=72, L=1, H=12), "ecg187": dict(T=187, C=1, D=72, L=10, H=12),
+        "mimic24": dict(T=24, C=40, D=72, L=10, H=12), "nasa": dict(T=134, C=10, D=72, L=10, H=12)}
 cfg = cfgs[name]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 nl = int(os.environ.get("FDIFF_MEGA_LAYERS", cfg["L"]))

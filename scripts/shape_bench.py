@@ -11,7 +11,8 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SHAPES = {"ecg": (100, 12), "nasdaq": (252, 6), "mimic": (256, 28), "long": (1024, 16)}
+SHAPES = {"ecg": (100, 12), "nasdaq": (252, 6), "mimic": (256, 28), "long": (1024, 16), "ecg187": (187, 1), "mimic24": (24, 40),
+          "nasa": (134, 10)}
 
 
 def flops_fwd(T, Cn, D=72, L=10, F=2048):
