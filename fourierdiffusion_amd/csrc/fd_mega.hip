@@ -1103,6 +1103,19 @@ int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int ks
         if (shape_matches<ShapeNasdaq>(P, ks1, dt, kso, mt)) return launch_mega_t<3, 5, 3, 4, ShapeNasdaq>(ctx, P, grid, lds, s);
         if (shape_matches<ShapeMimic>(P, ks1, dt, kso, mt)) return launch_mega_t<3, 5, 3, 4, ShapeMimic>(ctx, P, grid, lds, s);
     }
+#ifdef FD_MEGA_EXTRA_SHAPE
+    // Ahead-of-time specialisation for one more workload (scripts/specialize.sh builds a library variant with
+    //   -DFD_MEGA_EXTRA_SHAPE=T,D,C,H,S,NPG,rot,L,F -DFD_MEGA_EXTRA_TILES=KS1,DT,KSO,MT
+    // and FDIFF_LIB selects it): a static instantiation is ~1.6x faster than the run-time-shape kernel.
+    {
+        using ShapeExtra = ShapeStatic<FD_MEGA_EXTRA_SHAPE>;
+        constexpr int xt[4] = {FD_MEGA_EXTRA_TILES};
+        if (!getenv("FDIFF_MEGA_GENERIC") && ks1 == xt[0] && dt == xt[1] && kso == xt[2] && mt == xt[3] && P.T == ShapeExtra::T &&
+            P.D == ShapeExtra::D && P.C == ShapeExtra::C && P.H == ShapeExtra::H && P.S == ShapeExtra::S &&
+            P.NPG == ShapeExtra::NPG && P.rot == ShapeExtra::rot && P.L == ShapeExtra::L && P.F == ShapeExtra::F)
+            return launch_mega_t<xt[0], xt[1], xt[2], xt[3], ShapeExtra>(ctx, P, grid, lds, s);
+    }
+#endif
     // the hydra default transformer (d_model 72, 12 heads, 10 layers, ff 2048) at any other series shape
     using ShapeDefaultModel = ShapeModel<72, 12, 10, 2048>;
     if (!getenv("FDIFF_MEGA_GENERIC") && ks1 == 3 && dt == 5 && kso == 3 && P.D == 72 && P.H == 12 && P.L == 10 && P.F == 2048) {
