@@ -561,6 +561,72 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             m2[q][hs] = EXACT ? kNegBig : bq[q][hs];
                             o2[q][hs] = f4zero();
                         }
+                    if (SH::KT == 0) {
+                        // Run-time series length: the hand-unrolled pipeline below would need a guard around every MFMA
+                        // (each guard = its own basic block; measured 2.6x slower than with a static tile count).  A
+                        // rolled loop over PAIRS of key tiles (= one V^T block) keeps a static body instead: a missing
+                        // odd tile re-reads the previous one (finite data) and is masked through the C operand.
+                        const f32x4 allneg = {kNegBig, kNegBig, kNegBig, kNegBig};
+                        const char* kbase = kbf + ((size_t)(pr * NTOK + ser * KT * 16 + tok) * 4 + g) * 8;
+                        const char* vbase = vbf + ((size_t)((pr * S + ser) * NJ * 4 + g) * 16 + tok) * 16;
+                        auto kfrag = [&](int kt) { return *reinterpret_cast<const s16x4*>(kbase + (size_t)kt * 512); };
+                        auto vfrag = [&](int jb) { return *reinterpret_cast<const bf16x8*>(vbase + (size_t)jb * 1024); };
+                        if (EXACT) {
+                            // pass 1 over the whole series: exact row maxima
+                            float bm[NQ][2];
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) bm[q][0] = bm[q][1] = kNegBig;
+                            for (int kt = 0; kt < KT; ++kt) {
+                                const s16x4 kfa = kfrag(kt);
+                                const f32x4 ca = (kt == KT - 1) ? cmask : f4zero();
+#pragma unroll
+                                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                                    for (int hs = 0; hs < 2; ++hs) {
+                                        const f32x4 v = MFMA16(kfa, qb[q][hs], ca);
+                                        bm[q][hs] = fmaxf(fmaxf(fmaxf(bm[q][hs], v[0]), v[1]), fmaxf(v[2], v[3]));
+                                    }
+                            }
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                                for (int hs = 0; hs < 2; ++hs) m2[q][hs] = group_max(bm[q][hs]);
+                        }
+                        f32x4 negm[EXACT ? NQ : 1][2];
+                        if (EXACT) {
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                                for (int hs = 0; hs < 2; ++hs) negm[q][hs] = f32x4{-m2[q][hs], -m2[q][hs], -m2[q][hs], -m2[q][hs]};
+                        }
+                        for (int jb = 0; jb < NJ; ++jb) {
+                            const int ka = 2 * jb, kb2 = (2 * jb + 1 < KT) ? 2 * jb + 1 : ka;
+                            const s16x4 kfa = kfrag(ka), kfb = kfrag(kb2);
+                            const bf16x8 vfj = vfrag(jb);
+                            // tile a is the series' last only when KT is odd; tile b either is the last or does not exist
+                            const f32x4 ma = (ka == KT - 1) ? cmask : f4zero();
+                            const f32x4 mb = (2 * jb + 1 >= KT) ? allneg : ((kb2 == KT - 1) ? cmask : f4zero());
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                                for (int hs = 0; hs < 2; ++hs) {
+                                    f32x4 pa, pb;
+                                    if (EXACT) {
+                                        pa = MFMA16(kfa, qb[q][hs], ma + negm[q][hs]);
+                                        pb = MFMA16(kfb, qb[q][hs], mb + negm[q][hs]);
+                                    } else {
+                                        pa = MFMA16(kfa, qs[q][hs], ma);
+                                        pb = MFMA16(kfb, qs[q][hs], mb);
+                                    }
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        pa[r] = FD_EXP2(pa[r]);
+                                        pb[r] = FD_EXP2(pb[r]);
+                                    }
+                                    o2[q][hs] = MFMA(vfj, pack8(pa, pb), o2[q][hs]);
+                                }
+                        }
+                    } else
                     for (int kb = 0; kb < KT; kb += 8) {
                         // K and V fragments of this 128-key block: one read serves both heads and all NQ query tiles
                         s16x4 kf[8];
