@@ -43,6 +43,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
 
+#ifndef FD_ROLLED_ATTN
+#define FD_ROLLED_ATTN 0
+#endif
 #ifndef FD_FFN_BARE_BARRIER
 #define FD_FFN_BARE_BARRIER 1
 #endif
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             m2[q][hs] = EXACT ? kNegBig : bq[q][hs];
                             o2[q][hs] = f4zero();
                         }
-                    if (SH::KT == 0) {
+                    if (SH::KT == 0 || FD_ROLLED_ATTN) {
                         // Run-time series length: the hand-unrolled pipeline below would need a guard around every MFMA
                         // (each guard = its own basic block; measured 2.6x slower than with a static tile count).  A
                         // rolled loop over PAIRS of key tiles (= one V^T block) keeps a static body instead: a missing
