@@ -360,11 +360,68 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
                 }
             }
         };
+        // The series' last, partial key block (1-7 tiles): a rolled loop over key-tile PAIRS with a static body (a
+        // missing odd tile re-reads the previous one and is masked through the C operand) instead of the guarded
+        // unrolled pipeline -- same finding as in fd_mega.hip's run-time-shape path.
+        auto ragged_block = [&](int kb) {
+            const f32x4 allneg = {kNegBig, kNegBig, kNegBig, kNegBig};
+            auto kfrag = [&](int kt) { return *reinterpret_cast<const s16x4*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8); };
+            f32x4 negm[NQ][2];
+            if (EXACT) {
+                float bm[NQ][2];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) bm[q][0] = bm[q][1] = kNegBig;
+                for (int kt = kb; kt < KT; ++kt) {
+                    const s16x4 kfa = kfrag(kt);
+                    const f32x4 ca = (kt == KT - 1) ? cmask : f4zero();
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int hs = 0; hs < 2; ++hs) {
+                            const f32x4 v = MFMA16(kfa, qb[q][hs], ca);
+                            bm[q][hs] = fmaxf(fmaxf(fmaxf(bm[q][hs], v[0]), v[1]), fmaxf(v[2], v[3]));
+                        }
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int hs = 0; hs < 2; ++hs) {
+                        const float mnew = fmaxf(m2[q][hs], group_max(bm[q][hs]));
+                        const float alpha = __builtin_amdgcn_exp2f(m2[q][hs] - mnew);
+                        o2[q][hs] = o2[q][hs] * alpha;
+                        m2[q][hs] = mnew;
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int hs = 0; hs < 2; ++hs) negm[q][hs] = f32x4{-m2[q][hs], -m2[q][hs], -m2[q][hs], -m2[q][hs]};
+            for (int jb = kb >> 1; jb < NJ; ++jb) {
+                const int ka = 2 * jb, kb2 = (2 * jb + 1 < KT) ? 2 * jb + 1 : ka;
+                const s16x4 kfa = kfrag(ka), kfb = kfrag(kb2);
+                const bf16x8 vfj = *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(jb * 4 + g) * 16 + tok) * 16);
+                const f32x4 ma = (ka == KT - 1) ? cmask : f4zero();
+                const f32x4 mb = (2 * jb + 1 >= KT) ? allneg : ((kb2 == KT - 1) ? cmask : f4zero());
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int hs = 0; hs < 2; ++hs) {
+                        f32x4 pa = MFMA16(kfa, qb[q][hs], ma + negm[q][hs]);
+                        f32x4 pb = MFMA16(kfb, qb[q][hs], mb + negm[q][hs]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            pa[r] = __builtin_amdgcn_exp2f(pa[r]);
+                            pb[r] = __builtin_amdgcn_exp2f(pb[r]);
+                        }
+                        o2[q][hs] = MFMA(vfj, pack8(pa, pb), o2[q][hs]);
+                    }
+            }
+        };
         {
             int kb = 0;
             for (; kb + 8 < KT; kb += 8) key_block(kb, std::true_type{}, std::false_type{});
             if (kb + 8 == KT) key_block(kb, std::true_type{}, std::true_type{});
-            else key_block(kb, std::false_type{}, std::true_type{});
+            else ragged_block(kb);
         }
         };
         // row sums of P (the ones row): hd in [4,7]: register hd-4 of the odd lane group; hd < 4: register hd of the even one
