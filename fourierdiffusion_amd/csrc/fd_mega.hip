@@ -43,6 +43,12 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
 
+#ifndef FD_NO_PROF
+#define FD_NO_PROF 0
+#endif
+#ifndef FD_PROF_UNITS
+#define FD_PROF_UNITS 0
+#endif
 #ifndef FD_ROLLED_ATTN
 #define FD_ROLLED_ATTN 0
 #endif
@@ -226,6 +232,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
     f32x4 res[2][DT];
     int prof_cnt = 0;
     auto mark = [&](int phase, int step) {
+#if FD_NO_PROF
+        return;
+#endif
         if (P.prof && blockIdx.x == 0 && wave == 0 && (step < 4 || phase == 0) && prof_cnt < 3990) {
             const unsigned long long tm = __builtin_readcyclecounter();
             if (lane == 0) {
@@ -236,6 +245,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
         }
     };
 
+    // marks inside the attention units: only in -DFD_PROF_UNITS=1 builds (they cost registers and branches in the
+    // most register-bound code of the kernel)
+    auto umark = [&](int phase, int step) {
+#if FD_PROF_UNITS
+        mark(phase, step);
+#endif
+    };
     auto tile_token = [&](int tile, int& ser, int& t, bool& valid) {
         ser = tile / KT;
         t = (tile - ser * KT) * 16 + tok;
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     int qt[NQ];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) qt[q] = ser * KT + qt0 + q;
-                    mark(9, step);
+                    umark(9, step);
                     f32x4 qa[NQ];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) qa[q] = f4zero();
@@ -649,7 +665,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         // Tile index k = ((hs * 4 + jj) * NQ + q) * 2 + jl with key tile j = 2 jj + jl.
                         const int nk = min(8, KT - kb);                 // key tiles in this block
                         constexpr int NKT = 16 * NQ;                    // score tiles per block
-                        mark(10, step);
+                        umark(10, step);
                         if (EXACT) {
                             // pass 1 (exact path only): row maxima; the scores are recomputed in pass 2 with -max
                             // riding in the C operand, which removes one v_sub per score
@@ -688,7 +704,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                                     m2[q][hs] = mnew;
                                 }
                         }
-                        mark(11, step);
+                        umark(11, step);
                         // Exact path: -max rides in the C operand.  Fast path: the (per-unit constant) shift rides in
                         // the contraction itself -- K carries a 1.0 in the free dim slot hd (bias row of the W_k image)
                         // and Q gets -bound there -- so C is an inline 0 and no splat registers are live.
@@ -703,7 +719,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                                     clast[q][hs] = cmask - mm;
                                 }
                         }
-                        mark(12, step);
+                        umark(12, step);
                         // pass 2: P = exp2(S - shift) tile by tile, packed to bf16 B fragments, then P V.  The row sum of
                         // P comes out of the same MFMAs: V^T carries a row of ones (dim slot hd).
                         {
@@ -770,7 +786,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             (void)row_sums();
                         }
                     }
-                    mark(13, step);
+                    umark(13, step);
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         float o_sel[4];
