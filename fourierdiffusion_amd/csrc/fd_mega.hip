@@ -502,7 +502,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                 //      leftovers of an odd tile count: the older wave of each SIMD wins every issue arbitration and
                 //      finishes a unit ~1.5x faster than its partner, so a static split leaves the SIMD to one
                 //      (slow, alone) wave for the last third of the phase.
+#if FD_PROF_UNITS
                 const unsigned long long tw0 = P.prof ? __builtin_readcyclecounter() : 0ull;
+#endif
                 auto do_unit = [&](auto nqc, int pr, int ser, int qt0) {
                     constexpr int NQ = decltype(nqc)::value;
                     int qt[NQ];
@@ -796,7 +798,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         // head = 2*(pg+pr) + (g>>1); its 8 dims are one 16-B k-slot group of the out-proj B fragment
                         const int head = 2 * (pg + pr) + (g >> 1);
                         u32x2 pk = {cvt_pk_bf16(o_sel[0] * inv, o_sel[1] * inv), cvt_pk_bf16(o_sel[2] * inv, o_sel[3] * inv)};
-                        if (head >= H || (P.dbg & 1)) pk = u32x2{0u, 0u};
+                        if (head >= H) pk = u32x2{0u, 0u};
                         if (head < 4 * KSO)
                             *reinterpret_cast<u32x2*>(afr + ((qt[q] * KSO + (head >> 2)) * 64 + (head & 3) * 16 + tok) * 16 +
                                                       8 * (g & 1)) = pk;
@@ -821,10 +823,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         refresh_lane();
                     }
                 }
+#if FD_PROF_UNITS
                 if (P.prof && blockIdx.x == 0 && step == 1 && l == 1 && lane == 0) {   // per-wave unit-loop time
                     P.prof[2 * (4000 + 8 * (pg / NPG) + wave)] = 100 + wave;
                     P.prof[2 * (4000 + 8 * (pg / NPG) + wave) + 1] = __builtin_readcyclecounter() - tw0;
                 }
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // prefetched W_k | W_v of the next group
                 __syncthreads();
             }
