@@ -43,6 +43,14 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
 
+#ifndef FD_ABL_NODMA       // ablation build: FFN loop without its weight DMA (timing only, wrong results)
+#define FD_DMA_ON true
+#else
+#define FD_DMA_ON false
+#endif
+#ifndef FD_LDS_DUMP        // debugging build: FDIFF_MEGA_DUMP=file dumps workgroup 0's LDS after layer 0's attention
+#define FD_LDS_DUMP 0
+#endif
 #ifndef FD_NO_PROF
 #define FD_NO_PROF 0
 #endif
@@ -835,10 +843,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
 
             mark(4, step);
             refresh_lane();
+#if FD_LDS_DUMP
             if (P.dbg_out && blockIdx.x == 0 && l == 0 && step == 0) {      // debugging aid: dump LDS
                 for (int i = threadIdx.x; i < P.dbg_bytes / 4; i += NTH) P.dbg_out[i] = reinterpret_cast<unsigned*>(smem)[i];
                 __syncthreads();
             }
+#endif
             // -------- FFN weight stream: a ring of NBUF chunk buffers filled 3 steps ahead of their use; step s lives in
             //          buffer (s + rb) % NBUF.  Steps 0 and 1 are fetched during the out-proj into dead W / K / V space:
             //          rb = 1 -> buffers 1-2 (buffer 0 overlays the W_k | W_v slots that hold W_o during the out-proj),
@@ -994,7 +1004,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     __builtin_amdgcn_sched_barrier(0);
                     for (int st = 0; st < NS; ++st) {
                         const bool my_turn = ((st & 1) == FH);
-                        if (my_turn && st + 3 < NS && !(P.dbg & 4)) issue_ffn_half(st + 3);
+                        if (my_turn && st + 3 < NS && FD_DMA_ON) issue_ffn_half(st + 3);
                         // NTT == 1: H(0) of this step issued during the previous step, before this step's successor
                         // buffer was visible -- its W1 can only be fetched now
                         if (NTT == 1 && st + 1 < NS) load_w1(st + 1);
@@ -1018,7 +1028,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         // buffer st+2 must have landed before anyone reads it in step st+1 (own DMA, then barrier)
                         // (this wave's share of buffer st+2 was issued one step ago if it was not its turn now; a wave
                         // whose turn it is has nothing older than the NDH instructions it just issued, except at st = 0)
-                        if (my_turn && st + 3 < NS && !(P.dbg & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDH) : "memory");
+                        if (my_turn && st + 3 < NS && FD_DMA_ON) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDH) : "memory");
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         // bare s_barrier: __syncthreads() carries a workgroup fence that hipcc lowers to
                         // s_waitcnt vmcnt(0) lgkmcnt(0) -- it would drain the DMA issued this very step (3 steps of
