@@ -45,27 +45,44 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int m0 = blockIdx.x * tokens_per_block;
     const int m1 = min(M, m0 + tokens_per_block);
+    float pg[16], pb[16];                  // this lane's columns (d = lane + 64 n, D <= 1024), summed over the wave's tokens
+#pragma unroll
+    for (int n = 0; n < 16; ++n) { pg[n] = 0.f; pb[n] = 0.f; }
     for (int m = m0 + w; m < m1; m += 4) {
         const float mean = mr[(size_t)m * 2], rstd = mr[(size_t)m * 2 + 1];
         float g[16], xh[16];
         float sg = 0.f, sgx = 0.f;
-        int n = 0;
-        for (int d = lane; d < D; d += 64, ++n) {
-            const float dyv = dy[(size_t)m * D + d];
-            xh[n] = (x[(size_t)m * D + d] - mean) * rstd;
-            g[n] = dyv * gamma[d];
-            sg += g[n];
-            sgx += g[n] * xh[n];
-            atomicAdd(&sh[d], dyv * xh[n]);
-            atomicAdd(&sh[D + d], dyv);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int d = lane + 64 * n;
+            if (d < D) {
+                const float dyv = dy[(size_t)m * D + d];
+                xh[n] = (x[(size_t)m * D + d] - mean) * rstd;
+                g[n] = dyv * gamma[d];
+                sg += g[n];
+                sgx += g[n] * xh[n];
+                pg[n] = fmaf(dyv, xh[n], pg[n]);
+                pb[n] += dyv;
+            }
         }
         for (int o = 32; o > 0; o >>= 1) {
             sg += __shfl_xor(sg, o);
             sgx += __shfl_xor(sgx, o);
         }
         const float mg = sg / (float)D, mgx = sgx / (float)D;
-        n = 0;
-        for (int d = lane; d < D; d += 64, ++n) dx[(size_t)m * D + d] = rstd * (g[n] - mg - xh[n] * mgx);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int d = lane + 64 * n;
+            if (d < D) dx[(size_t)m * D + d] = rstd * (g[n] - mg - xh[n] * mgx);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        const int d = lane + 64 * n;
+        if (d < D) {
+            atomicAdd(&sh[d], pg[n]);
+            atomicAdd(&sh[D + d], pb[n]);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < D; i += 256) {
@@ -97,28 +114,39 @@ __global__ __launch_bounds__(256) void k_attn_rowdot(const float* __restrict__ d
     Dq[id] = a;
 }
 
-__device__ __forceinline__ float drop_keep(float drop_p, uint64_t seed, uint64_t offset, int bh, int T, int q, int key,
-                                           float keep_scale) {
-    if (drop_p <= 0.f) return 1.0f;
+// Attention-probability dropout mask, same stream as the forward (fd_score_f32.hip k_attention_f32): counter
+// offset + ((b*H+h)*T + q) * ceil(T/4) + key/4, component key%4.  One Philox4x32-10 costs ~900 cycles (40 quarter-rate
+// integer multiplies), so both backward kernels evaluate one per FOUR scores instead of one per score.
+__device__ __forceinline__ fd_u4 drop_bits(uint64_t seed, uint64_t offset, int bh, int T, int q, int key_group) {
     const int groups_per_row = (T + 3) / 4;
-    const uint64_t grp = (((uint64_t)bh * T + q) * groups_per_row) + key / 4;
-    const fd_u4 r = fd_philox4x32_10(offset + grp, seed);
-    const uint32_t rv = (key & 3) == 0 ? r.x : (key & 3) == 1 ? r.y : (key & 3) == 2 ? r.z : r.w;
+    return fd_philox4x32_10(offset + (((uint64_t)bh * T + q) * groups_per_row) + key_group, seed);
+}
+__device__ __forceinline__ float keep_of(uint32_t rv, float drop_p, float keep_scale) {
     return (fd_u01(rv) >= drop_p) ? keep_scale : 0.f;
 }
+// value of `v` held by lane M of this lane's quad (DPP quad_perm broadcast)
+template <int M>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, M | (M << 2) | (M << 4) | (M << 6), 0xf, 0xf, true);
+}
 
-// dq: thread per query, keys/values streamed through LDS.  dS = P * (dP - Dq), dq = scale * dS . K
-template <int HDP>
-__global__ __launch_bounds__(64) void k_attn_bwd_q(const float* __restrict__ qkv, const float* __restrict__ dO,
+// dq: lane per query, keys/values streamed through LDS.  dS = P * (dP - Dq), dq = scale * dS . K
+// As in the forward, the key tiles are dealt to the NWV waves of the block (private LDS slices, no block barrier in the
+// loop) and the partial dq are summed through LDS at the end.
+constexpr int kAttnWaves = 4;
+template <int HDP, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_attn_bwd_q(const float* __restrict__ qkv, const float* __restrict__ dO,
                                                     const float* __restrict__ lse, const float* __restrict__ Dq,
                                                     float* __restrict__ dqkv, int T, int H, int hd, float scale,
                                                     float drop_p, uint64_t seed, uint64_t offset) {
     constexpr int KT = 32;
-    __shared__ float Ks[KT][HDP];
-    __shared__ float Vs[KT][HDP];
+    __shared__ float Ks[NWV][KT][HDP];
+    __shared__ float Vs[NWV][KT][HDP];
+    __shared__ float part[NWV][HDP][64];
     const int D = H * hd;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q = blockIdx.x * 64 + threadIdx.x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 64 + lane;
     const bool active = q < T;
     const size_t row0 = (size_t)b * T;
     float qr[HDP], dor[HDP], dq[HDP];
@@ -133,10 +161,9 @@ __global__ __launch_bounds__(64) void k_attn_bwd_q(const float* __restrict__ qkv
         Dv = Dq[((size_t)b * H + h) * T + q];
     }
     const float keep_scale = (drop_p > 0.f) ? 1.0f / (1.0f - drop_p) : 1.0f;
-    for (int k0 = 0; k0 < T; k0 += KT) {
+    for (int k0 = w * KT; k0 < T; k0 += NWV * KT) {
         const int kn = min(KT, T - k0);
-        __syncthreads();
-        for (int id = threadIdx.x; id < KT * HDP; id += 64) {
+        for (int id = lane; id < KT * HDP; id += 64) {
             const int j = id / HDP, d = id % HDP;
             float kv = 0.f, vv = 0.f;
             if (j < kn && d < hd) {
@@ -144,23 +171,45 @@ __global__ __launch_bounds__(64) void k_attn_bwd_q(const float* __restrict__ qkv
                 kv = base[D];
                 vv = base[2 * D];
             }
-            Ks[j][d] = kv;
-            Vs[j][d] = vv;
+            Ks[w][j][d] = kv;
+            Vs[w][j][d] = vv;
         }
-        __syncthreads();
-        for (int j = 0; j < kn; ++j) {
-            float s = 0.f, dpd = 0.f;
-#pragma unroll
-            for (int d = 0; d < HDP; ++d) {
-                s = fmaf(qr[d], Ks[j][d], s);
-                dpd = fmaf(dor[d], Vs[j][d], dpd);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int j4 = 0; j4 < kn; j4 += 4) {                  // k0 is a multiple of 4: one Philox group per pass
+            uint32_t rv[4] = {0u, 0u, 0u, 0u};
+            if (drop_p > 0.f) {
+                const fd_u4 r = drop_bits(seed, offset, b * H + h, T, active ? q : 0, (k0 + j4) >> 2);
+                rv[0] = r.x; rv[1] = r.y; rv[2] = r.z; rv[3] = r.w;
             }
-            const float p = expf(s - L);
-            const float keep = drop_keep(drop_p, seed, offset, b * H + h, T, active ? q : 0, k0 + j, keep_scale);
-            const float ds = p * (keep * dpd - Dv);
 #pragma unroll
-            for (int d = 0; d < HDP; ++d) dq[d] = fmaf(ds, Ks[j][d], dq[d]);
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = j4 + jj;                          // rows j >= kn of Ks/Vs are zero: ds is masked below
+                float s = 0.f, dpd = 0.f;
+#pragma unroll
+                for (int d = 0; d < HDP; ++d) {
+                    s = fmaf(qr[d], Ks[w][j][d], s);
+                    dpd = fmaf(dor[d], Vs[w][j][d], dpd);
+                }
+                const float p = expf(s - L);
+                const float keep = drop_p > 0.f ? keep_of(rv[jj], drop_p, keep_scale) : 1.0f;
+                const float ds = (j < kn) ? p * (keep * dpd - Dv) : 0.f;
+#pragma unroll
+                for (int d = 0; d < HDP; ++d) dq[d] = fmaf(ds, Ks[w][j][d], dq[d]);
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                       // tile reads done before the next fill
+    }
+    if (NWV > 1) {
+#pragma unroll
+        for (int d = 0; d < HDP; ++d) part[w][d][lane] = dq[d];
+        __syncthreads();
+        if (w != 0) return;
+#pragma unroll
+        for (int v = 1; v < NWV; ++v)
+#pragma unroll
+            for (int d = 0; d < HDP; ++d) dq[d] += part[v][d][lane];
     }
     if (active) {
         float* out = dqkv + (row0 + q) * 3 * D + h * hd;
@@ -168,19 +217,25 @@ __global__ __launch_bounds__(64) void k_attn_bwd_q(const float* __restrict__ qkv
     }
 }
 
-// dk, dv: thread per key, queries streamed through LDS.
-template <int HDP>
-__global__ __launch_bounds__(64) void k_attn_bwd_kv(const float* __restrict__ qkv, const float* __restrict__ dO,
+// dk, dv: lane per key, queries streamed through LDS; query tiles dealt to the NWV waves, partial dk/dv summed at the end.
+template <int HDP, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_attn_bwd_kv(const float* __restrict__ qkv, const float* __restrict__ dO,
                                                      const float* __restrict__ lse, const float* __restrict__ Dq,
                                                      float* __restrict__ dqkv, int T, int H, int hd, float scale,
                                                      float drop_p, uint64_t seed, uint64_t offset) {
     constexpr int QT = 32;
-    __shared__ float Qs[QT][HDP];
-    __shared__ float dOs[QT][HDP];
-    __shared__ float Ls[QT], Ds[QT];
+    __shared__ float Qs_[NWV][QT][HDP];
+    __shared__ float dOs_[NWV][QT][HDP];
+    __shared__ float Ls_[NWV][QT], Ds_[NWV][QT];
+    __shared__ float part[NWV][2 * HDP][64];
     const int D = H * hd;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int key = blockIdx.x * 64 + threadIdx.x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float (*Qs)[HDP] = Qs_[w];
+    float (*dOs)[HDP] = dOs_[w];
+    float* Ls = Ls_[w];
+    float* Ds = Ds_[w];
+    const int key = blockIdx.x * 64 + lane;
     const bool active = key < T;
     const size_t row0 = (size_t)b * T;
     float kr[HDP], vr[HDP], dk[HDP], dv[HDP];
@@ -191,10 +246,9 @@ __global__ __launch_bounds__(64) void k_attn_bwd_kv(const float* __restrict__ qk
         for (int d = 0; d < hd; ++d) { kr[d] = kp[D + d]; vr[d] = kp[2 * D + d]; }
     }
     const float keep_scale = (drop_p > 0.f) ? 1.0f / (1.0f - drop_p) : 1.0f;
-    for (int q0 = 0; q0 < T; q0 += QT) {
+    for (int q0 = w * QT; q0 < T; q0 += NWV * QT) {
         const int qn = min(QT, T - q0);
-        __syncthreads();
-        for (int id = threadIdx.x; id < QT * HDP; id += 64) {
+        for (int id = lane; id < QT * HDP; id += 64) {
             const int j = id / HDP, d = id % HDP;
             float qv = 0.f, dv_ = 0.f;
             if (j < qn && d < hd) {
@@ -204,29 +258,61 @@ __global__ __launch_bounds__(64) void k_attn_bwd_kv(const float* __restrict__ qk
             Qs[j][d] = qv;
             dOs[j][d] = dv_;
         }
-        if (threadIdx.x < QT) {
-            const int j = threadIdx.x;
+        if (lane < QT) {
+            const int j = lane;
             Ls[j] = (j < qn) ? lse[((size_t)b * H + h) * T + q0 + j] : 0.f;
             Ds[j] = (j < qn) ? Dq[((size_t)b * H + h) * T + q0 + j] : 0.f;
         }
-        __syncthreads();
-        for (int j = 0; j < qn; ++j) {
-            float s = 0.f, dpd = 0.f;
-#pragma unroll
-            for (int d = 0; d < HDP; ++d) {
-                s = fmaf(Qs[j][d], kr[d], s);
-                dpd = fmaf(dOs[j][d], vr[d], dpd);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int j4 = 0; j4 < qn; j4 += 4) {
+            // The 4 lanes of a quad hold the 4 keys of one Philox group.  Lane i evaluates the group for query j4+i; the
+            // 4x4 transpose through DPP quad broadcasts gives every lane its own component for each of the 4 queries.
+            uint32_t rv[4] = {0u, 0u, 0u, 0u};
+            if (drop_p > 0.f) {
+                const int qi = lane & 3;                       // == key & 3
+                const fd_u4 r = drop_bits(seed, offset, b * H + h, T, q0 + j4 + qi, key >> 2);
+#define FD_QUAD_PICK(M)                                                                                      \
+    {                                                                                                        \
+        const uint32_t a0 = quad_bcast<M>(r.x), a1 = quad_bcast<M>(r.y), a2 = quad_bcast<M>(r.z),            \
+                       a3 = quad_bcast<M>(r.w);                                                              \
+        rv[M] = qi == 0 ? a0 : qi == 1 ? a1 : qi == 2 ? a2 : a3;                                             \
+    }
+                FD_QUAD_PICK(0) FD_QUAD_PICK(1) FD_QUAD_PICK(2) FD_QUAD_PICK(3)
+#undef FD_QUAD_PICK
             }
-            const float p = expf(s - Ls[j]);
-            const float keep = drop_keep(drop_p, seed, offset, b * H + h, T, q0 + j, active ? key : 0, keep_scale);
-            const float pd = p * keep;                        // dropped / rescaled probability
-            const float ds = p * (keep * dpd - Ds[j]);
 #pragma unroll
-            for (int d = 0; d < HDP; ++d) {
-                dv[d] = fmaf(pd, dOs[j][d], dv[d]);
-                dk[d] = fmaf(ds, Qs[j][d], dk[d]);          // Qs already carries the softmax scale
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = j4 + jj;                          // rows j >= qn of Qs/dOs are zero: masked below
+                float s = 0.f, dpd = 0.f;
+#pragma unroll
+                for (int d = 0; d < HDP; ++d) {
+                    s = fmaf(Qs[j][d], kr[d], s);
+                    dpd = fmaf(dOs[j][d], vr[d], dpd);
+                }
+                const float p = (j < qn) ? expf(s - Ls[j]) : 0.f;
+                const float keep = drop_p > 0.f ? keep_of(rv[jj], drop_p, keep_scale) : 1.0f;
+                const float pd = p * keep;                        // dropped / rescaled probability
+                const float ds = p * (keep * dpd - Ds[j]);
+#pragma unroll
+                for (int d = 0; d < HDP; ++d) {
+                    dv[d] = fmaf(pd, dOs[j][d], dv[d]);
+                    dk[d] = fmaf(ds, Qs[j][d], dk[d]);          // Qs already carries the softmax scale
+                }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                       // tile reads done before the next fill
+    }
+    if (NWV > 1) {
+#pragma unroll
+        for (int d = 0; d < HDP; ++d) { part[w][d][lane] = dk[d]; part[w][HDP + d][lane] = dv[d]; }
+        __syncthreads();
+        if (w != 0) return;
+#pragma unroll
+        for (int v = 1; v < NWV; ++v)
+#pragma unroll
+            for (int d = 0; d < HDP; ++d) { dk[d] += part[v][d][lane]; dv[d] += part[v][HDP + d][lane]; }
     }
     if (active) {
         float* out = dqkv + (row0 + key) * 3 * D + h * hd;
@@ -270,10 +356,12 @@ void colsum(fd_ctx* ctx, const float* x, float* out, int M, int N, hipStream_t s
 
 void ln_bwd(fd_ctx* ctx, const float* dy, const float* x, const float* mr, const float* gamma, float* dx, float* dgamma,
             float* dbeta, int M, int D, hipStream_t s) {
-    const int tokens_per_block = 64;
+    // enough blocks to fill the chip at the training batch (M = 6400: 64 tokens per block left 156 CUs idle), few enough
+    // that the per-block atomics on the 2*D parameter gradients stay cheap
+    int tokens_per_block = (M + ctx->num_cu * 2 - 1) / (ctx->num_cu * 2);
+    tokens_per_block = std::min(64, std::max(8, (tokens_per_block + 3) & ~3));
     hipLaunchKernelGGL(k_ln_bwd, dim3((M + tokens_per_block - 1) / tokens_per_block), dim3(256), 2 * D * sizeof(float), s,
                        dy, x, mr, gamma, dx, dgamma, dbeta, M, D, tokens_per_block);
-    (void)ctx;
 }
 
 template <int HDP>
@@ -281,8 +369,11 @@ void attn_bwd_t(const float* qkv, const float* dO, const float* lse, const float
                 int hd, float p, uint64_t seed, uint64_t offset, hipStream_t s) {
     dim3 grid((T + 63) / 64, H, B);
     const float scale = 1.0f / sqrtf((float)hd);
-    hipLaunchKernelGGL((k_attn_bwd_q<HDP>), grid, dim3(64), 0, s, qkv, dO, lse, Dq, dqkv, T, H, hd, scale, p, seed, offset);
-    hipLaunchKernelGGL((k_attn_bwd_kv<HDP>), grid, dim3(64), 0, s, qkv, dO, lse, Dq, dqkv, T, H, hd, scale, p, seed, offset);
+    constexpr int NWV = HDP <= 16 ? kAttnWaves : 1;            // (LDS: tiles + merge area per wave)
+    hipLaunchKernelGGL((k_attn_bwd_q<HDP, NWV>), grid, dim3(64 * NWV), 0, s, qkv, dO, lse, Dq, dqkv, T, H, hd, scale, p, seed,
+                       offset);
+    hipLaunchKernelGGL((k_attn_bwd_kv<HDP, NWV>), grid, dim3(64 * NWV), 0, s, qkv, dO, lse, Dq, dqkv, T, H, hd, scale, p, seed,
+                       offset);
 }
 
 }  // namespace

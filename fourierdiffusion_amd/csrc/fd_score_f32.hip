@@ -196,18 +196,23 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ x, cons
     h[id] = ((acc + be[d]) + pe[(size_t)tt * D + d]) + temb[(size_t)b * D + d];
 }
 
-// Multi-head attention core for one (b, h): thread per query, keys in LDS tiles, online softmax.
+// Multi-head attention core for one (b, h, 64-query block): lane per query, online softmax over 32-key tiles in LDS.
+// The key tiles are dealt round-robin to the NWV waves of the workgroup and the per-wave (max, sum, output) states are
+// merged through LDS at the end: at the training batch (B=64, T=100) one wave per block left each SIMD with 1-2 waves
+// walking 100 keys serially (56 us per layer); four waves per block quarter the chain and give the SIMDs 6 waves.
 // qkv: (M, 3D) rows [q | k | v]; out: (M, D) heads concatenated (torch MHA layout).
-template <int HDP>
-__global__ __launch_bounds__(64) void k_attention_f32(const float* __restrict__ qkv, float* __restrict__ out,
-                                                        float* __restrict__ lse, int T, int H, int hd, float scale,
-                                                        float drop_p, uint64_t seed, uint64_t offset) {
+template <int HDP, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_attention_f32(const float* __restrict__ qkv, float* __restrict__ out,
+                                                              float* __restrict__ lse, int T, int H, int hd, float scale,
+                                                              float drop_p, uint64_t seed, uint64_t offset) {
     constexpr int KT = 32;
-    __shared__ float Ks[KT][HDP];
-    __shared__ float Vs[KT][HDP];
+    __shared__ float Ks[NWV][KT][HDP];
+    __shared__ float Vs[NWV][KT][HDP];
+    __shared__ float part[NWV][HDP + 2][64];
     const int D = H * hd;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q = blockIdx.x * 64 + threadIdx.x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 64 + lane;
     const bool active = q < T;
     const size_t row0 = (size_t)b * T;
     float qr[HDP];
@@ -223,11 +228,13 @@ __global__ __launch_bounds__(64) void k_attention_f32(const float* __restrict__ 
     for (int d = 0; d < HDP; ++d) o[d] = 0.f;
     const float keep_scale = (drop_p > 0.f) ? 1.0f / (1.0f - drop_p) : 1.0f;
     const int groups_per_row = (T + 3) / 4;
+    // attention-probability dropout (nn.MultiheadAttention dropout=0.1): one Philox counter per 4 consecutive keys of a
+    // (b,h,q) row, evaluated ONCE per group (a Philox4x32-10 is 40 quarter-rate integer multiplies, ~900 cycles)
+    const uint64_t row_ctr = offset + ((uint64_t)(b * H + h) * T + (active ? q : 0)) * groups_per_row;
 
-    for (int k0 = 0; k0 < T; k0 += KT) {
+    for (int k0 = w * KT; k0 < T; k0 += NWV * KT) {           // this wave's tiles; its LDS slice is private: no barrier
         const int kn = min(KT, T - k0);
-        __syncthreads();
-        for (int id = threadIdx.x; id < KT * HDP; id += 64) {
+        for (int id = lane; id < KT * HDP; id += 64) {
             const int j = id / HDP, d = id % HDP;
             float kv = 0.f, vv = 0.f;
             if (j < kn && d < hd) {
@@ -235,17 +242,18 @@ __global__ __launch_bounds__(64) void k_attention_f32(const float* __restrict__ 
                 kv = base[D];
                 vv = base[2 * D];
             }
-            Ks[j][d] = kv;
-            Vs[j][d] = vv;
+            Ks[w][j][d] = kv;
+            Vs[w][j][d] = vv;
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         float s[KT];
         float mt = -INFINITY;
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
             float a = 0.f;
 #pragma unroll
-            for (int d = 0; d < HDP; ++d) a = fmaf(qr[d], Ks[j][d], a);
+            for (int d = 0; d < HDP; ++d) a = fmaf(qr[d], Ks[w][j][d], a);
             s[j] = (j < kn) ? a : -INFINITY;
             mt = fmaxf(mt, s[j]);
         }
@@ -255,23 +263,50 @@ __global__ __launch_bounds__(64) void k_attention_f32(const float* __restrict__ 
 #pragma unroll
         for (int d = 0; d < HDP; ++d) o[d] *= alpha;
 #pragma unroll
-        for (int j = 0; j < KT; ++j) {
-            const float p = expf(s[j] - mnew);
-            l += p;
-            float pk = p;
+        for (int j4 = 0; j4 < KT; j4 += 4) {
+            uint32_t rv[4] = {0u, 0u, 0u, 0u};
             if (drop_p > 0.f) {
-                // attention-probability dropout (nn.MultiheadAttention dropout=0.1): one Philox counter
-                // per 4 consecutive keys of a (b,h,q) row
-                const int key = k0 + j;
-                const uint64_t grp = (((uint64_t)(b * H + h) * T + (active ? q : 0)) * groups_per_row) + key / 4;
-                const fd_u4 r = fd_philox4x32_10(offset + grp, seed);
-                const uint32_t rv = (key & 3) == 0 ? r.x : (key & 3) == 1 ? r.y : (key & 3) == 2 ? r.z : r.w;
-                pk = (fd_u01(rv) >= drop_p) ? p * keep_scale : 0.f;
+                const fd_u4 r = fd_philox4x32_10(row_ctr + (uint64_t)((k0 + j4) >> 2), seed);
+                rv[0] = r.x; rv[1] = r.y; rv[2] = r.z; rv[3] = r.w;
             }
 #pragma unroll
-            for (int d = 0; d < HDP; ++d) o[d] = fmaf(pk, Vs[j][d], o[d]);
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = j4 + jj;
+                const float p = expf(s[j] - mnew);
+                l += p;
+                float pk = p;
+                if (drop_p > 0.f) pk = (fd_u01(rv[jj]) >= drop_p) ? p * keep_scale : 0.f;
+#pragma unroll
+                for (int d = 0; d < HDP; ++d) o[d] = fmaf(pk, Vs[w][j][d], o[d]);
+            }
         }
         mrun = mnew;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                       // tile reads done before the next fill
+    }
+    if (NWV > 1) {                                             // merge the waves' softmax states (wave 0 always has a tile)
+        part[w][0][lane] = mrun;
+        part[w][1][lane] = l;
+#pragma unroll
+        for (int d = 0; d < HDP; ++d) part[w][2 + d][lane] = o[d];
+        __syncthreads();
+        if (w != 0) return;
+        float mm = mrun;
+#pragma unroll
+        for (int v = 1; v < NWV; ++v) mm = fmaxf(mm, part[v][0][lane]);
+        const float a0 = __expf(mrun - mm);
+        l *= a0;
+#pragma unroll
+        for (int d = 0; d < HDP; ++d) o[d] *= a0;
+#pragma unroll
+        for (int v = 1; v < NWV; ++v) {
+            const float mv = part[v][0][lane];
+            const float av = (mv == -INFINITY) ? 0.f : __expf(mv - mm);
+            l = fmaf(part[v][1][lane], av, l);
+#pragma unroll
+            for (int d = 0; d < HDP; ++d) o[d] = fmaf(part[v][2 + d][lane], av, o[d]);
+        }
+        mrun = mm;
     }
     if (active) {
         const float inv = 1.0f / l;
@@ -408,8 +443,9 @@ void fd_score_carve_saved(const fd_score* m, int B, fd_ws& ws, fd_saved& sv) {
 template <int HDP>
 static void launch_attn(const float* qkv, float* out, float* lse, int B, int T, int H, int hd, float drop_p,
                         uint64_t seed, uint64_t offset, hipStream_t s) {
+    constexpr int NWV = HDP <= 16 ? 4 : 1;                     // (LDS: K | V tiles + merge area per wave)
     dim3 grid((T + 63) / 64, H, B);
-    hipLaunchKernelGGL((k_attention_f32<HDP>), grid, dim3(64), 0, s, qkv, out, lse, T, H, hd,
+    hipLaunchKernelGGL((k_attention_f32<HDP, NWV>), grid, dim3(64 * NWV), 0, s, qkv, out, lse, T, H, hd,
                        1.0f / sqrtf((float)hd), drop_p, seed, offset);
 }
 
