@@ -11,6 +11,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "fd_philox.h"
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -28,6 +30,10 @@ struct Args {
     float alpha;
     int relu;
     int accumulate;
+    // optional inverted dropout on the output (after bias / relu), fd_k_dropout's stream: element e = m * N + n uses Philox
+    // counter drop_offset + e / 4, component e % 4.  Needs N % 4 == 0 and a contiguous C (c_rs == N); MFMA path only.
+    float drop_p = 0.f;
+    uint64_t drop_seed = 0, drop_offset = 0;
 };
 
 // A_KFAST: a_cs == 1 (k contiguous) -> load with k fastest across threads; else m fastest.
@@ -169,37 +175,82 @@ __global__ __launch_bounds__(NT) void k_gemm_mfma_f32(Args g, int klen, float* _
         __syncthreads();
     }
     // C layout: register i -> row 8*(i/4) + 4*(lane>>5) + (i%4), col lane&31
+    const bool drop = !partial && g.drop_p > 0.f;
+    const float keep_scale = drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int gn = n0 + 32 * t + (lane & 31);
-        if (gn >= g.N) continue;
+        if (gn >= g.N) continue;                               // (N % 4 == 0 with dropout: uniform over a quad)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int gm = m0 + wave * 32 + 8 * (i / 4) + 4 * (lane >> 5) + (i % 4);
-            if (gm >= g.M) continue;
-            if (partial) {
-                partial[((size_t)blockIdx.z * g.M + gm) * g.N + gn] = acc[t][i];
-            } else {
-                float v = g.alpha * acc[t][i];
-                if (g.bias) v += g.bias[gn];
-                if (g.relu) v = fmaxf(v, 0.f);
-                float* c = g.C + gm * g.c_rs + gn;
-                if (g.accumulate) v += *c;
-                *c = v;
+        for (int ib = 0; ib < 4; ++ib) {
+            const int gm0 = m0 + wave * 32 + 8 * ib + 4 * (lane >> 5);
+            // dropout bits of this lane's 4 rows: the quad's lanes hold the 4 columns of one Philox group, so lane qi
+            // evaluates the group of row gm0 + qi and a 4x4 transpose over DPP quad broadcasts hands every lane its own
+            // component for each row -- one Philox per 4 outputs, like the stand-alone kernel
+            uint32_t rv[4] = {~0u, ~0u, ~0u, ~0u};
+            if (drop) {
+                const int qi = lane & 3;
+                const uint64_t e = (uint64_t)(gm0 + qi) * g.N + (gn & ~3);
+                const fd_u4 r = fd_philox4x32_10(g.drop_offset + (e >> 2), g.drop_seed);
+#define FD_QUAD_PICK(M_)                                                                                               \
+    {                                                                                                                  \
+        constexpr int c_ = M_ | (M_ << 2) | (M_ << 4) | (M_ << 6);                                                     \
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)r.x, c_, 0xf, 0xf, true);                          \
+        const uint32_t a1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)r.y, c_, 0xf, 0xf, true);                          \
+        const uint32_t a2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)r.z, c_, 0xf, 0xf, true);                          \
+        const uint32_t a3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)r.w, c_, 0xf, 0xf, true);                          \
+        rv[M_] = qi == 0 ? a0 : qi == 1 ? a1 : qi == 2 ? a2 : a3;                                                      \
+    }
+                FD_QUAD_PICK(0) FD_QUAD_PICK(1) FD_QUAD_PICK(2) FD_QUAD_PICK(3)
+#undef FD_QUAD_PICK
+            }
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = 4 * ib + ii;
+                const int gm = gm0 + ii;
+                if (gm >= g.M) continue;
+                if (partial) {
+                    partial[((size_t)blockIdx.z * g.M + gm) * g.N + gn] = acc[t][i];
+                } else {
+                    float v = g.alpha * acc[t][i];
+                    if (g.bias) v += g.bias[gn];
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    if (drop) v = (fd_u01(rv[ii]) >= g.drop_p) ? v * keep_scale : 0.f;
+                    float* c = g.C + gm * g.c_rs + gn;
+                    if (g.accumulate) v += *c;
+                    *c = v;
+                }
             }
         }
     }
 }
 
+// 64 outputs per block; the 4 waves each add every 4th partial (independent loads in flight), then wave 0 adds the four
+// strands in fixed order: deterministic, and the dependent-add chain is splits/4 long instead of splits (the 72x72 weight
+// gradients with 50 splits ran 14 us on 21 blocks)
 static __global__ __launch_bounds__(256) void k_splitk_reduce(Args g, const float* __restrict__ partial, int splits) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)g.M * g.N) return;
-    const int gm = (int)(i / g.N), gn = (int)(i - (size_t)gm * g.N);
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t mn = (size_t)g.M * g.N;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
     float v = 0.f;
-    for (int z = 0; z < splits; ++z) v += partial[(size_t)z * g.M * g.N + i];
+    if (i < mn) {
+#pragma unroll 4
+        for (int z = w; z < splits; z += 4) v += partial[(size_t)z * mn + i];
+    }
+    red[w][lane] = v;
+    __syncthreads();
+    if (w != 0 || i >= mn) return;
+    v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    const int gm = (int)(i / g.N), gn = (int)(i - (size_t)gm * g.N);
     v *= g.alpha;
     if (g.bias) v += g.bias[gn];
     if (g.relu) v = fmaxf(v, 0.f);
+    if (g.drop_p > 0.f) {                                      // (one Philox per output here: these outputs are small)
+        const fd_u4 r = fd_philox4x32_10(g.drop_offset + (i >> 2), g.drop_seed);
+        const uint32_t rv = (i & 3) == 0 ? r.x : (i & 3) == 1 ? r.y : (i & 3) == 2 ? r.z : r.w;
+        v = (fd_u01(rv) >= g.drop_p) ? v * (1.0f / (1.0f - g.drop_p)) : 0.f;
+    }
     float* c = g.C + gm * g.c_rs + gn;
     if (g.accumulate) v += *c;
     *c = v;
@@ -240,7 +291,7 @@ inline void launch(const Args& g, hipStream_t s, float* scratch = nullptr, size_
     else hipLaunchKernelGGL((k_gemm_mfma_f32<false, false>), grid, block, 0, s, g, klen, partial);
     if (splits > 1) {
         const size_t n = (size_t)g.M * g.N;
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, partial, splits);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, g, partial, splits);
     }
 }
 
@@ -248,6 +299,18 @@ inline void launch(const Args& g, hipStream_t s, float* scratch = nullptr, size_
 inline void linear_fwd(const float* x, const float* W, const float* bias, float* y, int M, int N, int K, bool relu,
                        hipStream_t s, float* scratch = nullptr, size_t scratch_floats = 0) {
     Args g{x, W, y, bias, M, N, K, (long long)K, 1, 1, (long long)K, (long long)N, 1.0f, relu ? 1 : 0, 0};
+    launch(g, s, scratch, scratch_floats);
+}
+// true when linear_fwd_dropout can apply the dropout in the GEMM's own epilogue (else: GEMM, then fd_k_dropout)
+inline bool can_fuse_dropout(int N) { return N % 4 == 0 && !use_valu_gemm(); }
+// y = dropout(x . W^T + bias [relu]) with fd_k_dropout's mask for (seed, offset)
+inline void linear_fwd_dropout(const float* x, const float* W, const float* bias, float* y, int M, int N, int K, bool relu,
+                               float p, uint64_t seed, uint64_t offset, hipStream_t s, float* scratch = nullptr,
+                               size_t scratch_floats = 0) {
+    Args g{x, W, y, bias, M, N, K, (long long)K, 1, 1, (long long)K, (long long)N, 1.0f, relu ? 1 : 0, 0};
+    g.drop_p = p;
+    g.drop_seed = seed;
+    g.drop_offset = offset;
     launch(g, s, scratch, scratch_floats);
 }
 // dx[M,K] (+)= dy[M,N] . W[N,K]

@@ -31,6 +31,39 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, flo
     if (sub == 0 && n < N) atomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// out = dropout(in) with the forward's mask (same Philox stream as fd_k_dropout: 4 elements per counter) and
+// csum[c] += sum_rows out[:, c]: the backward of `s = x + drop(linear(.))` needs the masked gradient for the weight GEMMs
+// and its column sums for the bias -- one launch instead of copy + dropout + colsum (launch-bound at the training batch).
+__global__ __launch_bounds__(256) void k_dropout_colsum(const float* __restrict__ in, float* __restrict__ out, unsigned n,
+                                                         int N, float p, uint64_t seed, uint64_t offset,
+                                                         float* __restrict__ csum) {
+    extern __shared__ float sh[];          // [N] partial column sums of this block
+    for (int i = threadIdx.x; i < N; i += 256) sh[i] = 0.f;
+    __syncthreads();
+    const unsigned ng = (n + 3) / 4;
+    const float sc = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
+    for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < ng; g += gridDim.x * 256u) {
+        uint32_t rv[4] = {~0u, ~0u, ~0u, ~0u};
+        if (p > 0.f) {
+            const fd_u4 r = fd_philox4x32_10(offset + g, seed);
+            rv[0] = r.x; rv[1] = r.y; rv[2] = r.z; rv[3] = r.w;
+        }
+        int col = (int)((g * 4u) % (unsigned)N);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned e = g * 4u + i;
+            if (e < n) {
+                const float v = (p <= 0.f || fd_u01(rv[i]) >= p) ? in[e] * sc : 0.f;
+                out[e] = v;
+                atomicAdd(&sh[col], v);
+            }
+            if (++col == N) col = 0;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += 256) atomicAdd(csum + i, sh[i]);
+}
+
 // LayerNorm backward.  y = (x - mean) * rstd * gamma + beta, x = pre-norm sum saved by the forward.
 //   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 //   dgamma += sum_tokens dy * xhat ; dbeta += sum_tokens dy
@@ -102,7 +135,8 @@ __global__ __launch_bounds__(256) void k_add_inplace(float* __restrict__ a, cons
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a[i] += b[i];
 }
 
-// Dq[b,h,q] = sum_d dO[q, h, d] * O[q, h, d]   (row term of the softmax Jacobian)
+// Dq[b,h,q] = sum_d dO[q, h, d] * O[q, h, d]   (row term of the softmax Jacobian).  Kept as its own 6 us launch: folded
+// into the two attention-backward kernels (strided 8-load chains in their prologues) it cost 11 us.
 __global__ __launch_bounds__(256) void k_attn_rowdot(const float* __restrict__ dO, const float* __restrict__ O,
                                                       float* __restrict__ Dq, int B, int T, int H, int hd) {
     const size_t id = blockIdx.x * (size_t)256 + threadIdx.x;
@@ -354,11 +388,27 @@ void colsum(fd_ctx* ctx, const float* x, float* out, int M, int N, hipStream_t s
     (void)ctx;
 }
 
+// tmp = dropout-backward(src) (site mask), bias gradient += column sums of tmp
+void dropout_bwd_colsum(fd_ctx* ctx, const float* src, float* tmp, int M, int N, float p, uint64_t seed, uint64_t offset,
+                        float* bias_grad, hipStream_t s) {
+    const size_t n = (size_t)M * N;
+    if (n >= ((size_t)1 << 31) || (size_t)N * sizeof(float) > 48 * 1024) {        // (32-bit element index / LDS row inside)
+        (void)hipMemcpyAsync(tmp, src, sizeof(float) * n, hipMemcpyDeviceToDevice, s);   // (errors surface in FD_LAUNCH_CHECK)
+        fd_dropout_inplace(ctx, tmp, n, p, seed, offset, s);
+        colsum(ctx, tmp, bias_grad, M, N, s);
+        return;
+    }
+    // few blocks: each ends with N global atomics on the same N addresses (512 blocks: 15 us, mostly that tail)
+    size_t blocks = std::min<size_t>(((n + 3) / 4 + 255) / 256, (size_t)std::max(1, ctx->num_cu / 2));
+    hipLaunchKernelGGL(k_dropout_colsum, dim3((unsigned)blocks), dim3(256), (size_t)N * sizeof(float), s, src, tmp, (unsigned)n, N,
+                       p, seed, offset, bias_grad);
+}
+
 void ln_bwd(fd_ctx* ctx, const float* dy, const float* x, const float* mr, const float* gamma, float* dx, float* dgamma,
             float* dbeta, int M, int D, hipStream_t s) {
-    // enough blocks to fill the chip at the training batch (M = 6400: 64 tokens per block left 156 CUs idle), few enough
-    // that the per-block atomics on the 2*D parameter gradients stay cheap
-    int tokens_per_block = (M + ctx->num_cu * 2 - 1) / (ctx->num_cu * 2);
+    // about one block per CU at the training batch (M = 6400: 28 tokens per block; 64 left 156 CUs idle: 29 us, 12 made the
+    // 2*D global atomics per block the tail: 21 us), never more than 64 tokens per block
+    int tokens_per_block = (M + ctx->num_cu - 1) / ctx->num_cu;
     tokens_per_block = std::min(64, std::max(8, (tokens_per_block + 3) & ~3));
     hipLaunchKernelGGL(k_ln_bwd, dim3((M + tokens_per_block - 1) / tokens_per_block), dim3(256), 2 * D * sizeof(float), s,
                        dy, x, mr, gamma, dx, dgamma, dbeta, M, D, tokens_per_block);
@@ -432,24 +482,21 @@ extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, i
         // x_next = LN2(s2): dh -> ds (= d s2)
         ln_bwd(ctx, dh, A.s2, A.mr2, P + lo.n2_w, ds, grads + lo.n2_w, grads + lo.n2_b, M, D, s);
         // s2 = x1 + drop(f2), f2 = hact W2^T + b2
-        FD_HIP(ctx, hipMemcpyAsync(tmp, ds, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, s));
-        fd_dropout_inplace(ctx, tmp, (size_t)M * D, p, m->saved_seed, fd_dropout_site_offset(m->saved_offset, i, 3), s);
+        dropout_bwd_colsum(ctx, ds, tmp, M, D, p, m->saved_seed, fd_dropout_site_offset(m->saved_offset, i, 3), grads + lo.l2_b, s);
         fdgemm::linear_bwd_weight(tmp, A.hact, grads + lo.l2_w, M, D, F, true, s, skp, kSplitKFloats);
-        colsum(ctx, tmp, grads + lo.l2_b, M, D, s);
         fdgemm::linear_bwd_input(tmp, P + lo.l2_w, dact, M, D, F, false, s);
         // hact = drop(relu(x1 W1^T + b1))
+        // (one fused pass with the bias column sums measured slower than these two: 46-79 us vs 25 + 13 us)
         hipLaunchKernelGGL(k_relu_drop_bwd, dim3(ew_grid(ctx, (size_t)M * F)), dim3(256), 0, s, dact, A.hact, (size_t)M * F,
                            inv_keep);
-        fdgemm::linear_bwd_weight(dact, A.x1, grads + lo.l1_w, M, F, D, true, s, skp, kSplitKFloats);
         colsum(ctx, dact, grads + lo.l1_b, M, F, s);
+        fdgemm::linear_bwd_weight(dact, A.x1, grads + lo.l1_w, M, F, D, true, s, skp, kSplitKFloats);
         fdgemm::linear_bwd_input(dact, P + lo.l1_w, ds, M, F, D, true, s, gsk, gsk_n);   // ds = d x1 (residual + FFN branch); K = F: split
         // x1 = LN1(s1): ds -> dh (= d s1)
         ln_bwd(ctx, ds, A.s1, A.mr1, P + lo.n1_w, dh, grads + lo.n1_w, grads + lo.n1_b, M, D, s);
         // s1 = x0 + drop(proj), proj = att Wo^T + bo
-        FD_HIP(ctx, hipMemcpyAsync(tmp, dh, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, s));
-        fd_dropout_inplace(ctx, tmp, (size_t)M * D, p, m->saved_seed, fd_dropout_site_offset(m->saved_offset, i, 1), s);
+        dropout_bwd_colsum(ctx, dh, tmp, M, D, p, m->saved_seed, fd_dropout_site_offset(m->saved_offset, i, 1), grads + lo.out_b, s);
         fdgemm::linear_bwd_weight(tmp, A.att, grads + lo.out_w, M, D, D, true, s, skp, kSplitKFloats);
-        colsum(ctx, tmp, grads + lo.out_b, M, D, s);
         fdgemm::linear_bwd_input(tmp, P + lo.out_w, ds, M, D, D, false, s);      // ds = d att
         // attention core
         {

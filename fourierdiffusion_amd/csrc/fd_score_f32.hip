@@ -503,10 +503,7 @@ int fd_score_forward_f32(fd_score* m, const float* x, const float* t, float* out
     hipLaunchKernelGGL(k_time_embed, dim3(B), dim3(128), D * sizeof(float), s, t, P + m->tW, P + m->td_w,
                        P + m->td_b, sv.emb, sv.temb, D);
     float* h_in = (L > 0) ? (train ? sv.layers[0].x0 : scratch.x0) : sv.hL;
-    {
-        const size_t n = (size_t)M * D;
-        fdf32::embed(x, P + m->emb_w, P + m->emb_b, P + m->pos, sv.temb, h_in, M, T, C, D, s);
-    }
+    fdf32::embed(x, P + m->emb_w, P + m->emb_b, P + m->pos, sv.temb, h_in, M, T, C, D, s);
     for (int i = 0; i < L; ++i) {
         const fd_layer_off& lo = m->layers[i];
         fd_saved_layer& A = train ? sv.layers[i] : scratch;
@@ -515,14 +512,32 @@ int fd_score_forward_f32(fd_score* m, const float* x, const float* t, float* out
         float* x_next = (i + 1 < L) ? (train ? sv.layers[i + 1].x0 : scratch.x0) : sv.hL;
         fdgemm::linear_fwd(x0, P + lo.in_w, P + lo.in_b, A.qkv, M, 3 * D, D, false, s);
         fd_attention_f32(A.qkv, A.att, A.lse, B, T, H, hd, p, seed, fd_dropout_site_offset(offset, i, 0), s);
-        fdgemm::linear_fwd(A.att, P + lo.out_w, P + lo.out_b, tmp, M, D, D, false, s);
-        if (train) fd_dropout_inplace(ctx, tmp, (size_t)M * D, p, seed, fd_dropout_site_offset(offset, i, 1), s);
+        // the three dropout sites of the layer ride in the epilogue of the GEMM that produces their input (three launches
+        // and a second pass over the (M, F) activations less per layer); same mask as the stand-alone kernel
+        const bool dfd = train && p > 0.f && fdgemm::can_fuse_dropout(D), dff = train && p > 0.f && fdgemm::can_fuse_dropout(F);
+        if (dfd) {
+            fdgemm::linear_fwd_dropout(A.att, P + lo.out_w, P + lo.out_b, tmp, M, D, D, false, p, seed,
+                                       fd_dropout_site_offset(offset, i, 1), s);
+        } else {
+            fdgemm::linear_fwd(A.att, P + lo.out_w, P + lo.out_b, tmp, M, D, D, false, s);
+            if (train) fd_dropout_inplace(ctx, tmp, (size_t)M * D, p, seed, fd_dropout_site_offset(offset, i, 1), s);
+        }
         hipLaunchKernelGGL(k_add_layernorm, dim3((M + 3) / 4), dim3(256), 0, s, x0, tmp, P + lo.n1_w, P + lo.n1_b,
                            A.s1, A.mr1, A.x1, M, D);
-        fdgemm::linear_fwd(A.x1, P + lo.l1_w, P + lo.l1_b, A.hact, M, F, D, true, s);
-        if (train) fd_dropout_inplace(ctx, A.hact, (size_t)M * F, p, seed, fd_dropout_site_offset(offset, i, 2), s);
-        fdgemm::linear_fwd(A.hact, P + lo.l2_w, P + lo.l2_b, tmp, M, D, F, false, s, gsk, gsk_n);   // K = F: split
-        if (train) fd_dropout_inplace(ctx, tmp, (size_t)M * D, p, seed, fd_dropout_site_offset(offset, i, 3), s);
+        if (dff) {
+            fdgemm::linear_fwd_dropout(A.x1, P + lo.l1_w, P + lo.l1_b, A.hact, M, F, D, true, p, seed,
+                                       fd_dropout_site_offset(offset, i, 2), s);
+        } else {
+            fdgemm::linear_fwd(A.x1, P + lo.l1_w, P + lo.l1_b, A.hact, M, F, D, true, s);
+            if (train) fd_dropout_inplace(ctx, A.hact, (size_t)M * F, p, seed, fd_dropout_site_offset(offset, i, 2), s);
+        }
+        if (dfd) {
+            fdgemm::linear_fwd_dropout(A.hact, P + lo.l2_w, P + lo.l2_b, tmp, M, D, F, false, p, seed,
+                                       fd_dropout_site_offset(offset, i, 3), s, gsk, gsk_n);   // K = F: split
+        } else {
+            fdgemm::linear_fwd(A.hact, P + lo.l2_w, P + lo.l2_b, tmp, M, D, F, false, s, gsk, gsk_n);   // K = F: split
+            if (train) fd_dropout_inplace(ctx, tmp, (size_t)M * D, p, seed, fd_dropout_site_offset(offset, i, 3), s);
+        }
         hipLaunchKernelGGL(k_add_layernorm, dim3((M + 3) / 4), dim3(256), 0, s, A.x1, tmp, P + lo.n2_w, P + lo.n2_b,
                            A.s2, A.mr2, x_next, M, D);
     }
