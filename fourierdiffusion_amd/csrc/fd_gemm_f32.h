@@ -108,22 +108,26 @@ __global__ __launch_bounds__(NT) void k_gemm_f32(Args g) {
 // multiplied.  grid.z splits K: long reductions with small outputs (dW = dY^T.X, K = all tokens) would otherwise
 // run on a handful of workgroups; partial sums go to `partial[z][M][N]` and are added in fixed z order by
 // k_splitk_reduce (deterministic, unlike atomics).
-constexpr int MBM = 128, MBN = 64, MBK = 16;
+// NACC = accumulator tiles per wave = 32-column panels per workgroup: 2 (128x64) in general, 3 (128x96) when that pads N
+// less -- the model width D = 72 then is ONE panel, so the big operand of the "-> D" GEMMs (the (M, F) FFN activations and
+// their gradients, 52 MB at the training batch) is streamed once instead of once per 64-column panel.
+constexpr int MBM = 128, MBK = 16;
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-template <bool A_KFAST, bool B_NFAST>
+template <bool A_KFAST, bool B_NFAST, int NACC>
 __global__ __launch_bounds__(NT) void k_gemm_mfma_f32(Args g, int klen, float* __restrict__ partial) {
+    constexpr int MBN = 32 * NACC, NB = MBK * MBN / NT;
     __shared__ float As[MBK][MBM + 4];
     __shared__ float Bs[MBK][MBN + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * MBM, n0 = blockIdx.x * MBN;
     const int kbeg = blockIdx.z * klen, kend = min(g.K, kbeg + klen);
-    f32x16_t acc[2];
+    f32x16_t acc[NACC];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    float ra[8], rb[4];
+    float ra[8], rb[NB];
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(NT) void k_gemm_mfma_f32(Args g, int klen, float* _
             ra[i] = (gm < g.M && gk < kend) ? g.A[gm * g.a_rs + gk * g.a_cs] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NB; ++i) {
             const int id = tid + i * NT;
             int n, k;
             if (B_NFAST) { n = id % MBN; k = id / MBN; } else { k = id % MBK; n = id / MBK; }
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(NT) void k_gemm_mfma_f32(Args g, int klen, float* _
             As[k][m] = ra[i];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NB; ++i) {
             const int id = tid + i * NT;
             int n, k;
             if (B_NFAST) { n = id % MBN; k = id / MBN; } else { k = id % MBK; n = id / MBK; }
@@ -168,9 +172,9 @@ __global__ __launch_bounds__(NT) void k_gemm_mfma_f32(Args g, int klen, float* _
         for (int kk = 0; kk < MBK / 2; ++kk) {
             const int k = 2 * kk + (lane >> 5);
             const float a = As[k][wave * 32 + (lane & 31)];
-            const float b0 = Bs[k][lane & 31], b1 = Bs[k][32 + (lane & 31)];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NACC; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[k][32 * t + (lane & 31)], acc[t], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(NT) void k_gemm_mfma_f32(Args g, int klen, float* _
     const bool drop = !partial && g.drop_p > 0.f;
     const float keep_scale = drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NACC; ++t) {
         const int gn = n0 + 32 * t + (lane & 31);
         if (gn >= g.N) continue;                               // (N % 4 == 0 with dropout: uniform over a quad)
 #pragma unroll
@@ -272,6 +276,14 @@ inline void launch(const Args& g, hipStream_t s, float* scratch = nullptr, size_
         else hipLaunchKernelGGL((k_gemm_f32<false, false>), grid, block, 0, s, g);
         return;
     }
+    // panel width: whichever of 64 / 96 columns pads N less (ties: the wider one, fewer passes over A) -- unless that
+    // leaves an unsplit GEMM with too few workgroups (D = 72 at the training batch: 50 tiles of 128x96 ran 1.3 % slower
+    // per optimizer step than 100 of 128x64; at T = 252, 126 tiles, the wide panel is 2.8 % faster)
+    const int pad2 = (g.N + 63) / 64 * 64, pad3 = (g.N + 95) / 96 * 96;
+    const bool may_split = scratch && g.K >= 512;
+    const int tiles3 = (pad3 / 96) * ((g.M + MBM - 1) / MBM);
+    const int nacc = (pad3 <= pad2 && (may_split || tiles3 >= 96)) ? 3 : 2;
+    const int MBN = 32 * nacc;
     const int tiles = ((g.N + MBN - 1) / MBN) * ((g.M + MBM - 1) / MBM);
     int splits = 1;
     if (scratch && tiles < 512 && g.K >= 512) {
@@ -285,10 +297,19 @@ inline void launch(const Args& g, hipStream_t s, float* scratch = nullptr, size_
     splits = (g.K + klen - 1) / klen;
     float* partial = splits > 1 ? scratch : nullptr;
     dim3 grid((g.N + MBN - 1) / MBN, (g.M + MBM - 1) / MBM, splits), block(NT);
-    if (ak && bn) hipLaunchKernelGGL((k_gemm_mfma_f32<true, true>), grid, block, 0, s, g, klen, partial);
-    else if (ak && !bn) hipLaunchKernelGGL((k_gemm_mfma_f32<true, false>), grid, block, 0, s, g, klen, partial);
-    else if (!ak && bn) hipLaunchKernelGGL((k_gemm_mfma_f32<false, true>), grid, block, 0, s, g, klen, partial);
-    else hipLaunchKernelGGL((k_gemm_mfma_f32<false, false>), grid, block, 0, s, g, klen, partial);
+#define FD_GEMM_GO(AK, BN_, NA) hipLaunchKernelGGL((k_gemm_mfma_f32<AK, BN_, NA>), grid, block, 0, s, g, klen, partial)
+    if (nacc == 3) {
+        if (ak && bn) FD_GEMM_GO(true, true, 3);
+        else if (ak && !bn) FD_GEMM_GO(true, false, 3);
+        else if (!ak && bn) FD_GEMM_GO(false, true, 3);
+        else FD_GEMM_GO(false, false, 3);
+    } else {
+        if (ak && bn) FD_GEMM_GO(true, true, 2);
+        else if (ak && !bn) FD_GEMM_GO(true, false, 2);
+        else if (!ak && bn) FD_GEMM_GO(false, true, 2);
+        else FD_GEMM_GO(false, false, 2);
+    }
+#undef FD_GEMM_GO
     if (splits > 1) {
         const size_t n = (size_t)g.M * g.N;
         hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, g, partial, splits);

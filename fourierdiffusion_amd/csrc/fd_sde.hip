@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void k_dsm_loss(const float* __restrict__ s
                                                        const float* __restrict__ target,
                                                        const float* __restrict__ stdv, int lw,
                                                        float* __restrict__ loss_out, float* __restrict__ dscore,
-                                                       int B, int T, int C) {
+                                                       int B, int T, int C, float* __restrict__ partial) {
     __shared__ float red[kBlock / 64];
     __shared__ float w_sh;
     const int b = blockIdx.x;
@@ -183,8 +183,18 @@ __global__ __launch_bounds__(kBlock) void k_dsm_loss(const float* __restrict__ s
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int i = 0; i < kBlock / 64; ++i) s += red[i];
-        atomicAdd(loss_out, s * inv_cnt);
+        if (partial) partial[b] = s * inv_cnt;                 // summed in fixed order by k_loss_sum
+        else atomicAdd(loss_out, s * inv_cnt);
     }
+}
+
+// loss = sum_b partial[b] in a fixed order (lane-strided strands, then a fixed shuffle tree): the same inputs give the
+// same loss bit for bit, which float atomics across the per-sample blocks did not
+__global__ __launch_bounds__(64) void k_loss_sum(const float* __restrict__ partial, int B, float* __restrict__ loss_out) {
+    float v = 0.f;
+    for (int b = threadIdx.x; b < B; b += 64) v += partial[b];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (threadIdx.x == 0) *loss_out = v;
 }
 
 inline int grid_for(size_t ngroups, int num_cu) {
@@ -261,9 +271,17 @@ extern "C" int fd_dsm_loss(fd_ctx* ctx, const float* score, const float* target,
     if (!ctx) return FD_ERR_ARG;
     FD_REQUIRE(ctx, score && target && std && loss_out, "fd_dsm_loss: null pointer");
     if (int rc = check_btc(ctx, B, T, C)) return rc;
-    FD_HIP(ctx, hipMemsetAsync(loss_out, 0, sizeof(float), (hipStream_t)stream));
-    hipLaunchKernelGGL(k_dsm_loss, dim3(B), dim3(kBlock), 0, (hipStream_t)stream, score, target, std,
-                       likelihood_weighting, loss_out, dscore, B, T, C);
+    size_t nscr = 0;
+    float* partial = fd_gemm_scratch(ctx, &nscr);              // ctx-owned, stream-ordered with the GEMMs that share it
+    if (partial && (size_t)B <= nscr) {
+        hipLaunchKernelGGL(k_dsm_loss, dim3(B), dim3(kBlock), 0, (hipStream_t)stream, score, target, std,
+                           likelihood_weighting, loss_out, dscore, B, T, C, partial);
+        hipLaunchKernelGGL(k_loss_sum, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, B, loss_out);
+    } else {
+        FD_HIP(ctx, hipMemsetAsync(loss_out, 0, sizeof(float), (hipStream_t)stream));
+        hipLaunchKernelGGL(k_dsm_loss, dim3(B), dim3(kBlock), 0, (hipStream_t)stream, score, target, std,
+                           likelihood_weighting, loss_out, dscore, B, T, C, (float*)nullptr);
+    }
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }
