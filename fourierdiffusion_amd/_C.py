@@ -52,6 +52,9 @@ _PROTOS = {
     "fd_irfft_unpack": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "fd_rfft_pack_standardize": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "fd_destandardize_irfft": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "fd_spectral_density": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "fd_localization_metrics": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "fd_frequency_smooth": (C.c_int, [_vp, _vp, C.c_float, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "fd_randn": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vp]),
     "fd_prior_sample": (C.c_int, [_vp, C.POINTER(SdeParams), _vp, _vp, C.c_uint64, C.c_uint64, _vp,
                                   C.c_int, C.c_int, C.c_int, _vp]),

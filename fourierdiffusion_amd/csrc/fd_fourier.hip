@@ -340,3 +340,169 @@ extern "C" int fd_destandardize_irfft(fd_ctx* ctx, const float* x, const float* 
     if (ctx && !(mean && std)) return fd_fail(ctx, FD_ERR_ARG, "fd_destandardize_irfft: null mean/std");
     return launch<true>(ctx, x, y, mean, std, B, T, C, stream, "fd_destandardize_irfft");
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Spectral utilities of the reference's fourier.py on the packed representation (dataset front-end).
+// All three work on the (B, T, C) real spectral layout rfft_pack writes: rows [0, n_real) = Re X_k, rows
+// [n_real, T) = Im X_k for k = 1..; Im X_0 (and Im X_{T/2}, T even) are zero by construction.
+namespace {
+
+__device__ __forceinline__ float packed_im(const float* __restrict__ xt_b, int k, int T, int n_real, int C, int c) {
+    const bool has_im = (k != 0) && !((T & 1) == 0 && k == T / 2);
+    return has_im ? xt_b[(size_t)(n_real + k - 1) * C + c] : 0.f;
+}
+
+// dens[b, k, c] = Re X_k^2 + Im X_k^2, k = 0..n_real-1                       (fourier.py:90-124)
+__global__ __launch_bounds__(256) void k_spectral_density(const float* __restrict__ xt, float* __restrict__ dens, int B,
+                                                           int T, int C, int n_real) {
+    const size_t per_b = (size_t)n_real * C;
+    const size_t id = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (id >= (size_t)B * per_b) return;
+    const int b = (int)(id / per_b);
+    const int r = (int)(id - (size_t)b * per_b);
+    const int k = r / C, c = r - k * C;
+    const float* xb = xt + (size_t)b * T * C;
+    const float re = xb[(size_t)k * C + c];
+    const float im = packed_im(xb, k, T, n_real, C, c);
+    dens[id] = re * re + im * im;
+}
+
+// Delocalisation of each series in time and in frequency (fourier.py:127-175): with e_t the normalised energy per time
+// step (resp. per frequency bin of the two-sided spectrum) and d(t, s) = min(|t - s|, T - |t - s|),
+//   loc = min_s sum_t e_t d(t, s)^2.          One workgroup per series; e in LDS.
+__global__ __launch_bounds__(256) void k_localization(const float* __restrict__ x, const float* __restrict__ xt,
+                                                       float* __restrict__ loc, float* __restrict__ spec_loc, int T, int C,
+                                                       int n_real) {
+    extern __shared__ float sh[];          // [T] time energy | [T] two-sided spectral energy | [8] reduction
+    float* et = sh;
+    float* es = sh + T;
+    float* red = sh + 2 * T;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* xb = x + (size_t)b * T * C;
+    const float* sb = xt + (size_t)b * T * C;
+    for (int t = tid; t < T; t += 256) {
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a = fmaf(xb[(size_t)t * C + c], xb[(size_t)t * C + c], a);
+        et[t] = a;
+        // two-sided spectrum: bins 0..n_real-1, then the mirror of bins 1..K (K = n_real-1 for odd T, n_real-2 for even T)
+        const int k = (t < n_real) ? t : T - t;
+        float d = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float re = sb[(size_t)k * C + c], im = packed_im(sb, k, T, n_real, C, c);
+            d += re * re + im * im;
+        }
+        es[t] = d;
+    }
+    __syncthreads();
+    // totals (fixed order: strided partials, wave shuffle, then the 4 wave sums)
+    float tot[2] = {0.f, 0.f};
+    for (int t = tid; t < T; t += 256) { tot[0] += et[t]; tot[1] += es[t]; }
+    for (int o = 32; o > 0; o >>= 1) { tot[0] += __shfl_down(tot[0], o); tot[1] += __shfl_down(tot[1], o); }
+    if ((tid & 63) == 0) { red[(tid >> 6) * 2] = tot[0]; red[(tid >> 6) * 2 + 1] = tot[1]; }
+    __syncthreads();
+    const float tot_t = (red[0] + red[2]) + (red[4] + red[6]);
+    const float tot_s = (red[1] + red[3]) + (red[5] + red[7]);
+    __syncthreads();
+    float best_t = INFINITY, best_s = INFINITY;
+    for (int s = tid; s < T; s += 256) {
+        float at = 0.f, as = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const int ad = abs(t - s);
+            const float d = (float)min(ad, T - ad);
+            at = fmaf(et[t], d * d, at);
+            as = fmaf(es[t], d * d, as);
+        }
+        best_t = fminf(best_t, at);
+        best_s = fminf(best_s, as);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        best_t = fminf(best_t, __shfl_down(best_t, o));
+        best_s = fminf(best_s, __shfl_down(best_s, o));
+    }
+    if ((tid & 63) == 0) { red[(tid >> 6) * 2] = best_t; red[(tid >> 6) * 2 + 1] = best_s; }
+    __syncthreads();
+    if (tid == 0) {
+        loc[b] = fminf(fminf(red[0], red[2]), fminf(red[4], red[6])) / tot_t;
+        spec_loc[b] = fminf(fminf(red[1], red[3]), fminf(red[5], red[7])) / tot_s;
+    }
+}
+
+// Gaussian mixing matrix over the packed rows (fourier.py:189-200): row i of the representation carries frequency
+// f_i = i (i < n_real) or i - n_real + 1; G[t][s] = exp(-((f_t - f_s) / sigma)^2 / 2) / sum_t' exp(...).  One block per s.
+__global__ __launch_bounds__(256) void k_gauss_matrix(float* __restrict__ G, int T, int n_real, float sigma) {
+    __shared__ float red[4];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const float fs = (float)(s < n_real ? s : s - n_real + 1);
+    float part = 0.f;
+    for (int t = tid; t < T; t += 256) {
+        const float ft = (float)(t < n_real ? t : t - n_real + 1);
+        const float u = (ft - fs) / sigma;
+        part += expf(-(u * u) / 2.0f);
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int t = tid; t < T; t += 256) {
+        const float ft = (float)(t < n_real ? t : t - n_real + 1);
+        const float u = (ft - fs) / sigma;
+        G[(size_t)t * T + s] = expf(-(u * u) / 2.0f) / tot;
+    }
+}
+
+// out[b, s, c] = sum_t xt[b, t, c] G[t, s]                                     (fourier.py:203, einsum "btc,ts->bsc")
+__global__ __launch_bounds__(256) void k_frequency_mix(const float* __restrict__ xt, const float* __restrict__ G,
+                                                        float* __restrict__ out, int T, int C) {
+    const int b = blockIdx.y;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= T * C) return;
+    const int s = id / C, c = id - s * C;
+    const float* xb = xt + (size_t)b * T * C;
+    float a = 0.f;
+    for (int t = 0; t < T; ++t) a = fmaf(xb[(size_t)t * C + c], G[(size_t)t * T + s], a);
+    out[(size_t)b * T * C + id] = a;
+}
+
+}  // namespace
+
+extern "C" int fd_spectral_density(fd_ctx* ctx, const float* xt, float* dens, int B, int T, int C, void* stream) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, xt && dens, "fd_spectral_density: null pointer");
+    FD_REQUIRE(ctx, B > 0 && T > 0 && C > 0, "fd_spectral_density: bad shape B=%d T=%d C=%d", B, T, C);
+    const int n_real = T / 2 + 1;
+    const size_t n = (size_t)B * n_real * C;
+    hipLaunchKernelGGL(k_spectral_density, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xt, dens, B, T,
+                       C, n_real);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
+extern "C" int fd_localization_metrics(fd_ctx* ctx, const float* x, const float* xt, float* loc, float* spec_loc, int B,
+                                       int T, int C, void* stream) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, x && xt && loc && spec_loc, "fd_localization_metrics: null pointer");
+    FD_REQUIRE(ctx, B > 0 && T > 0 && C > 0, "fd_localization_metrics: bad shape B=%d T=%d C=%d", B, T, C);
+    FD_REQUIRE(ctx, (size_t)T * 8 + 32 <= 64 * 1024, "fd_localization_metrics: T=%d too long", T);
+    hipLaunchKernelGGL(k_localization, dim3(B), dim3(256), (size_t)(2 * T + 8) * sizeof(float), (hipStream_t)stream, x, xt, loc,
+                       spec_loc, T, C, T / 2 + 1);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
+extern "C" int fd_frequency_smooth(fd_ctx* ctx, const float* xt, float sigma, float* gauss_scratch, float* out, int B,
+                                   int T, int C, void* stream) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, xt && gauss_scratch && out, "fd_frequency_smooth: null pointer");
+    FD_REQUIRE(ctx, xt != out, "fd_frequency_smooth: in-place mixing is not supported");
+    FD_REQUIRE(ctx, B > 0 && T > 0 && C > 0, "fd_frequency_smooth: bad shape B=%d T=%d C=%d", B, T, C);
+    FD_REQUIRE(ctx, B <= 65535, "fd_frequency_smooth: batch too large for one launch (%d > 65535)", B);
+    FD_REQUIRE(ctx, sigma > 0.f, "fd_frequency_smooth: sigma=%f", (double)sigma);
+    // the reference builds its frequency vector with T - 1 entries when T is even and then fails in the einsum
+    // (fourier.py:192-203): only odd lengths are defined
+    FD_REQUIRE(ctx, (T & 1) == 1, "fd_frequency_smooth: max_len=%d must be odd (fourier.py:192-203)", T);
+    hipLaunchKernelGGL(k_gauss_matrix, dim3(T), dim3(256), 0, (hipStream_t)stream, gauss_scratch, T, T / 2 + 1, sigma);
+    hipLaunchKernelGGL(k_frequency_mix, dim3((T * C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, xt, gauss_scratch, out,
+                       T, C);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}

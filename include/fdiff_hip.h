@@ -71,6 +71,22 @@ int fd_rfft_pack_standardize(fd_ctx* ctx, const float* x, const float* mean, con
                              float* y, int B, int T, int C, void* stream);
 int fd_destandardize_irfft(fd_ctx* ctx, const float* x, const float* mean, const float* std,
                            float* y, int B, int T, int C, void* stream);
+/* spectral utilities on the packed representation xt = dft(x) (dataset front-end); the Python surface
+ * (fdiff.utils.fourier.spectral_density / localization_metrics / smooth_frequency) composes them with fd_rfft_pack /
+ * fd_irfft_unpack exactly as the reference composes its own dft / idft:
+ *   fd_spectral_density     replaces spectral_density(x, apply_dft=False)  (src/fdiff/utils/fourier.py:90-124)
+ *                           dens (B, T/2+1, C) = Re X_k^2 + Im X_k^2
+ *   fd_localization_metrics replaces localization_metrics(X)               (src/fdiff/utils/fourier.py:127-175)
+ *                           x (B,T,C) and xt = dft(x); loc, spec_loc (B,) = min_s sum_t e_t min(|t-s|, T-|t-s|)^2 with e the
+ *                           normalised energy per time step / per bin of the two-sided spectrum
+ *   fd_frequency_smooth     replaces the Gaussian mixing of smooth_frequency(X, sigma)  (src/fdiff/utils/fourier.py:189-203)
+ *                           out[b,s,c] = sum_t xt[b,t,c] G[t,s]; gauss_scratch = T*T floats (caller-owned, receives G);
+ *                           T must be odd (the reference's frequency vector has T-1 entries for even T and its einsum fails) */
+int fd_spectral_density(fd_ctx* ctx, const float* xt, float* dens, int B, int T, int C, void* stream);
+int fd_localization_metrics(fd_ctx* ctx, const float* x, const float* xt, float* loc, float* spec_loc,
+                            int B, int T, int C, void* stream);
+int fd_frequency_smooth(fd_ctx* ctx, const float* xt, float sigma, float* gauss_scratch, float* out,
+                        int B, int T, int C, void* stream);
 
 /* ------------------------------------------------------------ a3..a8 SDE
  * kind 0 = VP  (p0 = beta_min,  p1 = beta_max)   fdiff.schedulers.sde.VPScheduler (sde.py:168-246)

@@ -66,6 +66,63 @@ def dft_by_definition(x: Array) -> Array:
 
 
 # --------------------------------------------------------------------------
+# 8(f)2  spectral utilities of the dataset front-end   src/fdiff/utils/fourier.py:90-209
+# --------------------------------------------------------------------------
+def spectral_density(x: Array, apply_dft: bool = True) -> Array:
+    """fourier.py:90-124 -- Re^2 + Im^2 per bin k = 0..T//2 of the packed representation."""
+    x = np.asarray(x, dtype=np.float64)
+    T = x.shape[1]
+    xt = dft(x) if apply_dft else x
+    n_real = math.ceil((T + 1) / 2)          # fourier.py:104
+    re = xt[:, :n_real]
+    zero = np.zeros((x.shape[0], 1, x.shape[2]))
+    im = np.concatenate([zero, xt[:, n_real:]], axis=1)      # fourier.py:109-110
+    if T % 2 == 0:
+        im = np.concatenate([im, zero], axis=1)              # fourier.py:113-114
+    assert im.shape == re.shape
+    return re**2 + im**2                                     # fourier.py:121
+
+
+def cyclic_distance_sq(T: int) -> Array:
+    """fourier.py:160-163 -- min(|t - s|, T - |t - s|)^2."""
+    t = np.arange(T, dtype=np.float64)
+    d = np.abs(t[:, None] - t[None, :])
+    return np.minimum(d, T - d) ** 2
+
+
+def localization_metrics(X: Array):
+    """fourier.py:127-175 -- (delocalisation in time, delocalisation in frequency), one value per series."""
+    X = np.asarray(X, dtype=np.float64)
+    T = X.shape[1]
+    e_t = (X**2).sum(axis=2) / (X**2).sum(axis=(1, 2))[:, None]              # fourier.py:141-144
+    spec = spectral_density(X)                                               # fourier.py:147
+    mirror = spec[:, 1:][:, ::-1] if T % 2 != 0 else spec[:, 1:-1][:, ::-1]  # fourier.py:148-152
+    spec = np.concatenate([spec, mirror], axis=1)
+    assert spec.shape[1] == T
+    e_s = spec.sum(axis=2) / spec.sum(axis=(1, 2))[:, None]                  # fourier.py:154-157
+    d2 = cyclic_distance_sq(T)
+    return (e_t @ d2).min(axis=1), (e_s @ d2).min(axis=1)                    # fourier.py:166-173
+
+
+def gaussian_frequency_kernel(T: int, sigma: float) -> Array:
+    """fourier.py:189-200 -- column-normalised Gaussian over the frequencies of the packed rows (odd T only: for even
+    T the reference's vector has T - 1 entries and its einsum raises)."""
+    if T % 2 == 0:
+        raise RuntimeError("smooth_frequency is only defined for odd max_len (fourier.py:192-203)")
+    nyq = T / 2
+    k = np.concatenate([np.arange(0, nyq), np.arange(1, nyq)]).astype(np.float64)
+    g = np.exp(-(((k[:, None] - k[None, :]) / sigma) ** 2) / 2)
+    return g / g.sum(axis=0, keepdims=True)
+
+
+def smooth_frequency(X: Array, sigma: float) -> Array:
+    """fourier.py:178-209 -- idft(einsum("btc,ts->bsc", dft(X), gaussian kernel))."""
+    X = np.asarray(X, dtype=np.float64)
+    g = gaussian_frequency_kernel(X.shape[1], sigma)
+    return idft(np.einsum("btc,ts->bsc", dft(X), g))
+
+
+# --------------------------------------------------------------------------
 # a3/a4  noise scaling and timestep grid  src/fdiff/schedulers/sde.py:42-64
 # --------------------------------------------------------------------------
 def noise_scaling(max_len: int, fourier_noise_scaling: bool) -> Array:

@@ -58,13 +58,19 @@ def import_reference():
     stub("diffusers.optimization", get_cosine_schedule_with_warmup=lambda **k: None)
     stub("torchvision")
     stub("torchvision.ops", MLP=object)
-    sys.path.insert(0, REF)
+    # the reference's `fdiff` is a namespace package (no __init__.py): the repo's own `fdiff` alias package would shadow
+    # it from ANY position on sys.path, so the repo root leaves the path while the reference is imported
+    saved_path = list(sys.path)
+    sys.path[:] = [REF] + [p for p in sys.path if os.path.abspath(p or os.getcwd()) != ROOT]
+    assert "fdiff" not in sys.modules
     import fdiff.models.score_models as sm
     import fdiff.sampling.sampler as sp
     import fdiff.schedulers.sde as sde
     import fdiff.utils.dataclasses as dc
     import fdiff.utils.fourier as fourier
     import fdiff.utils.losses as losses
+    assert fourier.__file__.startswith(REF), fourier.__file__
+    sys.path[:] = saved_path
     return types.SimpleNamespace(sm=sm, sp=sp, sde=sde, dc=dc, fourier=fourier, losses=losses)
 
 
@@ -128,6 +134,30 @@ def gen_dft(R):
         cosw = np.cos(2 * np.pi * 2 * n / T).astype(np.float32).reshape(1, T, 1)
         out[f"dft_cos2_{T}"] = R.fourier.dft(t_(cosw)).numpy()
     np.savez_compressed(os.path.join(OUT, "dft.npz"), **out)
+
+
+def gen_spectral(R):
+    """spectral_density / localization_metrics / smooth_frequency of the reference (fourier.py:90-209)."""
+    out = {}
+    for T in (16, 100, 101, 187):
+        for C in (1, 12):
+            x = W.randn(f"spec_x_{T}_{C}", (3, T, C), 0)
+            # a localised bump on top of the noise so that the two metrics differ between series
+            x[1, T // 3: T // 3 + 4] += 3.0
+            out[f"dens_{T}_{C}"] = R.fourier.spectral_density(t_(x)).numpy()
+            out[f"dens_nodft_{T}_{C}"] = R.fourier.spectral_density(t_(x), apply_dft=False).numpy()
+            loc, sloc = R.fourier.localization_metrics(t_(x))
+            out[f"loc_{T}_{C}"] = np.stack([loc.numpy(), sloc.numpy()])
+            if T % 2 == 1:
+                for sigma in (1.0, 4.5):
+                    out[f"smooth_{T}_{C}_{sigma}"] = R.fourier.smooth_frequency(t_(x), sigma).numpy()
+    # the reference fails for even lengths (kernel of T-1 frequencies): record that it does
+    try:
+        R.fourier.smooth_frequency(t_(W.randn("spec_even", (1, 16, 1), 0)), 1.0)
+        out["smooth_even_raises"] = np.array(0)
+    except RuntimeError:
+        out["smooth_even_raises"] = np.array(1)
+    np.savez_compressed(os.path.join(OUT, "spectral.npz"), **out)
 
 
 SDE_CASES = [("vp", (0.1, 20.0)), ("ve", (0.01, 2.0)), ("ve", (0.01, 50.0))]
@@ -309,13 +339,10 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = import_reference()
-    gen_dft(R)
-    gen_sde(R)
-    gen_score(R)
-    gen_loss(R)
-    gen_sampler(R)
-    gen_dataset(R)
-    gen_optim(R)
+    gens = dict(dft=gen_dft, spectral=gen_spectral, sde=gen_sde, score=gen_score, loss=gen_loss, sampler=gen_sampler,
+                dataset=gen_dataset, optim=gen_optim)
+    for name in (sys.argv[1:] or list(gens)):                  # `make_golden.py spectral` regenerates one file
+        gens[name](R)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

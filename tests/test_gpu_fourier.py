@@ -100,3 +100,61 @@ def test_argument_errors():
     h = _C.ctx(x.device)
     rc = _C.lib().fd_rfft_pack(h, x.data_ptr(), x.data_ptr(), 2, 8, 2, None)     # in place is refused
     assert rc == -1 and b"in-place" in _C.lib().fd_last_error(h)
+
+
+# ---------------------------------------------------------------- spectral utilities (fourier.py:90-209)
+@pytest.mark.parametrize("T", (16, 100, 101, 187))
+@pytest.mark.parametrize("C", (1, 12))
+def test_spectral_utilities_vs_golden(golden, T, C):
+    from fourierdiffusion_amd.utils.fourier import localization_metrics, smooth_frequency, spectral_density
+    g = golden("spectral")
+    x = W.randn(f"spec_x_{T}_{C}", (3, T, C), 0)
+    x[1, T // 3: T // 3 + 4] += 3.0
+    d = host(spectral_density(dev(x)))
+    assert d.shape == (3, T // 2 + 1, C)
+    np.testing.assert_allclose(d, g[f"dens_{T}_{C}"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(d, O.spectral_density(x), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(host(spectral_density(dev(x), apply_dft=False)), g[f"dens_nodft_{T}_{C}"], rtol=1e-5, atol=1e-6)
+    loc, sloc = localization_metrics(dev(x))
+    assert loc.shape == (3,) and sloc.shape == (3,)
+    np.testing.assert_allclose(np.stack([host(loc), host(sloc)]), g[f"loc_{T}_{C}"], rtol=1e-4)
+    if T % 2 == 1:
+        for sigma in (1.0, 4.5):
+            y = host(smooth_frequency(dev(x), sigma))
+            np.testing.assert_allclose(y, g[f"smooth_{T}_{C}_{sigma}"], atol=2e-5)
+            np.testing.assert_allclose(y, O.smooth_frequency(x, sigma), atol=2e-5)
+    else:
+        with pytest.raises(RuntimeError):                    # like the reference (its einsum raises for even lengths)
+            smooth_frequency(dev(x), 1.0)
+
+
+def test_spectral_utilities_properties_at_dataset_size():
+    """ECG-sized front-end call (20000 x 187 x 1): Parseval for the density, white noise is delocalised in both domains,
+    the sigma -> 0 limit of the smoothing; CPU inputs come back on the CPU."""
+    from fourierdiffusion_amd.utils.fourier import dft, localization_metrics, smooth_frequency, spectral_density
+    B, T, C = 20000, 187, 1
+    x = dev(W.randn("spec_big", (B, T, C), 2))
+    d = spectral_density(x)
+    two_sided = d.sum(dim=1) + d[:, 1:].sum(dim=1)
+    np.testing.assert_allclose(host(two_sided), host((x * x).sum(dim=1)), rtol=2e-4)
+    loc, sloc = localization_metrics(x)
+    assert torch.isfinite(loc).all() and torch.isfinite(sloc).all()
+    # white noise is delocalised in both domains: a little below the uniform-energy value sum_d d^2 / T (the min over
+    # the centre s picks the most favourable one), never above it
+    dd = np.minimum(np.arange(T), T - np.arange(T)).astype(np.float64)
+    uniform = float((dd**2).sum() / T)
+    for v in (loc, sloc):
+        assert 0.75 * uniform < float(v.mean()) < uniform and float(v.max()) <= uniform * (1 + 1e-4)
+    np.testing.assert_allclose(host(loc[:16]), O.localization_metrics(host(x[:16]))[0], rtol=1e-4)
+    # sigma -> 0 is NOT the identity in the reference: Re X_k and Im X_k share a frequency, so each becomes their mean
+    ys = dft(smooth_frequency(x[:64], 0.05))
+    xt = dft(x[:64])
+    n_real, K = T // 2 + 1, (T - 1) // 2
+    mean_k = 0.5 * (xt[:, 1:1 + K] + xt[:, n_real:])
+    np.testing.assert_allclose(host(ys[:, 0]), host(xt[:, 0]), atol=2e-5)
+    np.testing.assert_allclose(host(ys[:, 1:1 + K]), host(mean_k), atol=2e-5)
+    np.testing.assert_allclose(host(ys[:, n_real:]), host(mean_k), atol=2e-5)
+    np.testing.assert_allclose(host(smooth_frequency(x[:8], 2.0)), O.smooth_frequency(host(x[:8]), 2.0), atol=2e-5)
+    xc = torch.from_numpy(W.randn("spec_cpu", (2, 101, 3), 3))
+    out = spectral_density(xc)
+    assert out.device.type == "cpu" and out.shape == (2, 51, 3)

@@ -173,3 +173,40 @@ def test_cosine_warmup_formula():
     assert O.cosine_warmup_factor(10, W_, S) == 1.0
     assert abs(O.cosine_warmup_factor(55, W_, S) - 0.5) < 1e-12
     assert O.cosine_warmup_factor(100, W_, S) < 1e-12
+
+
+# ---------------------------------------------------------------- spectral utilities (fourier.py:90-209)
+SPEC_T, SPEC_C = (16, 100, 101, 187), (1, 12)
+
+
+def spectral_input(T, C):
+    x = W.randn(f"spec_x_{T}_{C}", (3, T, C), 0)
+    x[1, T // 3: T // 3 + 4] += 3.0
+    return x
+
+
+@pytest.mark.parametrize("T", SPEC_T)
+@pytest.mark.parametrize("C", SPEC_C)
+def test_spectral_utilities_vs_reference(golden, T, C):
+    g = golden("spectral")
+    x = spectral_input(T, C)
+    np.testing.assert_allclose(O.spectral_density(x), g[f"dens_{T}_{C}"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(O.spectral_density(x, apply_dft=False), g[f"dens_nodft_{T}_{C}"], rtol=1e-5, atol=1e-6)
+    loc, sloc = O.localization_metrics(x)
+    np.testing.assert_allclose(np.stack([loc, sloc]), g[f"loc_{T}_{C}"], rtol=1e-4)
+    assert loc[1] < loc[0]                                   # the series with the bump is more localised in time
+    if T % 2 == 1:
+        for sigma in (1.0, 4.5):
+            np.testing.assert_allclose(O.smooth_frequency(x, sigma), g[f"smooth_{T}_{C}_{sigma}"], atol=2e-5)
+    else:
+        assert int(g["smooth_even_raises"]) == 1             # the reference itself fails for even lengths
+        with pytest.raises(RuntimeError):
+            O.smooth_frequency(x, 1.0)
+
+
+def test_spectral_density_is_parseval():
+    """sum of the two-sided density = energy of the series (ortho norm)."""
+    x = W.randn("pars", (2, 101, 3), 4)
+    d = O.spectral_density(x)
+    two_sided = d.sum(axis=1) + d[:, 1:].sum(axis=1)
+    np.testing.assert_allclose(two_sided, (x.astype(np.float64) ** 2).sum(axis=1), rtol=1e-10)
