@@ -54,7 +54,10 @@ class SamplingRunner:
         self.score_model = model_type.load_from_checkpoint(checkpoint_path=best_checkpoint_path)
         self.score_model.to(device=torch.device("cuda", self.dist.local_rank))
         self.sampler = instantiate(cfg.sampler)(score_model=self.score_model)
-        self.metrics = instantiate(cfg.metrics) if "metrics" in cfg else None
+        # metrics against the training set, on the main rank only (reference cmd/sample.py:62-65)
+        self.metrics = None
+        if "metrics" in cfg and cfg.metrics is not None and self.dist.is_main:
+            self.metrics = instantiate(cfg.metrics)(original_samples=self.datamodule.X_train)
 
     def sample(self) -> None:
         bs = self.sampler.sample_batch_size
@@ -78,6 +81,8 @@ class SamplingRunner:
             X = torch.cat([p for p in parts if p is not None], dim=0)
         if self.dist.is_main:
             results = {"num_samples": int(X.shape[0]), "sample_mean": float(X.mean()), "sample_std": float(X.std())}
+            if self.metrics is not None:
+                results.update(self.metrics(X))                                     # reference cmd/sample.py:84-86
             logging.info(f"Saving samples ands metrics to {self.save_dir}.\n{dict_to_str(results)}")
             yaml.dump(data=results, stream=open(self.save_dir / "results.yaml", "w"))
             torch.save(X, self.save_dir / "samples.pt")

@@ -7,10 +7,11 @@ import sys
 import fourierdiffusion_amd as _pkg
 
 _SUBMODULES = [
-    "utils", "utils.dataclasses", "utils.fourier", "utils.losses", "utils.extraction", "utils.callbacks",
+    "utils", "utils.dataclasses", "utils.fourier", "utils.losses", "utils.extraction", "utils.callbacks", "utils.tensors",
+    "utils.wasserstein",
     "schedulers", "schedulers.sde",
     "models", "models.score_models", "models.transformer",
-    "sampling", "sampling.sampler",
+    "sampling", "sampling.sampler", "sampling.metrics",
     "dataloaders", "dataloaders.datamodules",
 ]
 for _name in _SUBMODULES:

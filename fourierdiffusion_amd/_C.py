@@ -83,6 +83,11 @@ _PROTOS = {
     "fd_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "fd_comm_destroy": (C.c_int, [_vp]),
     "fd_allreduce_grads": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, _vp]),
+    "fd_project_rows": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "fd_transpose_rows": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "fd_sort_rows_temp_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "fd_sort_rows": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
+    "fd_w2_sorted_rows": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

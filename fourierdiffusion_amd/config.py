@@ -27,8 +27,8 @@ TARGET_ALIASES = {
     "pytorch_lightning.callbacks.ModelCheckpoint": "fourierdiffusion_amd.trainer.ModelCheckpoint",
     "pytorch_lightning.loggers.WandbLogger": "fourierdiffusion_amd.config.NullLogger",
 }
-# evaluation metrics need POT (out of scope): configs that name them instantiate to None
-SKIPPED_TARGET_PREFIXES = ("fdiff.sampling.metrics.",)
+# `_target_` prefixes that instantiate to None (nothing is skipped any more: the Wasserstein metrics run on the engine)
+SKIPPED_TARGET_PREFIXES: tuple = ()
 
 
 class NullLogger:
@@ -209,7 +209,7 @@ def instantiate(node: Any, **extra: Any) -> Any:
     if "_target_" not in node:
         return _wrap({k: instantiate(v) for k, v in node.items()})
     target = node["_target_"]
-    if target.startswith(SKIPPED_TARGET_PREFIXES):
+    if SKIPPED_TARGET_PREFIXES and target.startswith(SKIPPED_TARGET_PREFIXES):
         return None
     kwargs = {k: instantiate(v) for k, v in node.items() if k not in ("_target_", "_partial_")}
     kwargs.update(extra)

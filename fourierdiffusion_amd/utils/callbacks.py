@@ -1,10 +1,12 @@
 """SamplingCallback -- same surface as fdiff.utils.callbacks.SamplingCallback (reference:
 src/fdiff/utils/callbacks.py:12-89): every N epochs draw samples with the model being trained, de-standardise,
-idft, score with the metrics.  The Wasserstein metrics of the reference need POT (absent, out of scope,
-SURVEY.md 2 #11): `metrics` may be any callables(X) -> dict; with none configured the callback still samples and
-records simple moment statistics, so the sampling path is exercised during training as in the reference."""
+idft, score with the metrics.  `metrics` is the reference's list of partially instantiated metrics
+(fdiff.sampling.metrics.SlicedWasserstein / MarginalWasserstein, bound to the training set in `setup_datamodule` through a
+MetricCollection without baselines, callbacks.py:33-37); plain callables(X) -> dict are accepted as well.  Simple moment
+statistics of the samples are always recorded."""
 from __future__ import annotations
 
+from functools import partial
 from typing import Any, Callable, Dict, List, Optional
 
 import torch
@@ -22,12 +24,18 @@ class SamplingCallback(Callback):
         self.num_samples = num_samples
         self.num_diffusion_steps = num_diffusion_steps
         self.metrics = [m for m in (metrics or []) if callable(m)]
+        self.metric_collection = None
         self.datamodule_initialized = False
 
     def setup_datamodule(self, datamodule) -> None:
         self.standardize = datamodule.standardize
         self.fourier_transform = datamodule.fourier_transform
         self.feature_mean, self.feature_std = datamodule.feature_mean_and_std
+        partials = [m for m in self.metrics if isinstance(m, partial)]
+        if partials:                                          # callbacks.py:33-37
+            from ..sampling.metrics import MetricCollection
+            self.metric_collection = MetricCollection(metrics=partials, original_samples=datamodule.X_train,
+                                                      include_baselines=False)
         self.datamodule_initialized = True
 
     def on_train_start(self, trainer, model) -> None:
@@ -38,8 +46,11 @@ class SamplingCallback(Callback):
             was_training = model.training
             X = self.sample()
             results: Dict[str, Any] = {"sample_mean": float(X.mean()), "sample_std": float(X.std())}
+            if self.metric_collection is not None:
+                results.update(self.metric_collection(X))
             for metric in self.metrics:
-                results.update(metric(X))
+                if not isinstance(metric, partial):
+                    results.update(metric(X))
             trainer.logged.update({f"metrics/{k}": v for k, v in results.items()})
             model.train(was_training)
 

@@ -225,6 +225,21 @@ int fd_comm_destroy(fd_ctx* ctx);
 /* buf = sum over ranks (buf) * scale, in place */
 int fd_allreduce_grads(fd_ctx* ctx, float* buf, int64_t n, float scale, void* stream);
 
+/* ------------------------------------------- (f)3 evaluation metrics on the GPU
+ * Sliced / marginal Wasserstein-2 between two sample sets (fdiff.sampling.metrics.SlicedWasserstein / MarginalWasserstein,
+ * src/fdiff/sampling/metrics.py:100-217, over fdiff.utils.wasserstein.WassersteinDistances, src/fdiff/utils/wasserstein.py:95-199).
+ * The host draws the directions exactly as the reference does (numpy Generator) and composes:
+ *   fd_project_rows    out (K, n) = dirs (K, d) . x (n, d)^T      replaces WassersteinDistances._project  (wasserstein.py:150-153)
+ *   fd_transpose_rows  out (d, n) = x (n, d)^T                    the marginal "directions" (standard basis, wasserstein.py:77-89)
+ *   fd_sort_rows       every row of (K, n) sorted ascending; temp = fd_sort_rows_temp_bytes(K, n) caller-owned device bytes
+ *   fd_w2_sorted_rows  out[k] = W2 between sorted row k of a (K, n) and of b (K, m), uniform weights, any n, m: the exact 1-D
+ *                      transport POT's emd2_1d solves, then sqrt               (wasserstein.py:112-113, 139-141)            */
+int fd_project_rows(fd_ctx* ctx, const float* x, const float* dirs, float* out, int n, int d, int K, void* stream);
+int fd_transpose_rows(fd_ctx* ctx, const float* x, float* out, int n, int d, void* stream);
+int fd_sort_rows_temp_bytes(fd_ctx* ctx, int K, int n, size_t* bytes);
+int fd_sort_rows(fd_ctx* ctx, const float* in, float* out, int K, int n, void* temp, size_t temp_bytes, void* stream);
+int fd_w2_sorted_rows(fd_ctx* ctx, const float* a, const float* b, float* out, int K, int n, int m, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

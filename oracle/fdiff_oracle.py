@@ -123,6 +123,89 @@ def smooth_frequency(X: Array, sigma: float) -> Array:
 
 
 # --------------------------------------------------------------------------
+# 8(f)3  Wasserstein evaluation metrics   src/fdiff/utils/wasserstein.py:12-199, src/fdiff/sampling/metrics.py:100-217
+#
+# The 1-D transport itself lives in POT (`ot.emd2_1d`; `pot` is unpinned in the reference's pyproject.toml and absent from
+# this image): PARITY UNPINNED against POT.  Restated from its published algorithm (sort both samples, move mass greedily
+# along the two quantile functions; uniform weights, squared Euclidean cost) and pinned instead against the transport LP
+# solved exactly by scipy on small cases and against closed forms (tests/test_oracle_golden.py).
+# --------------------------------------------------------------------------
+def emd2_1d(a: Array, b: Array) -> float:
+    """W2^2 between the empirical measures of a (n values) and b (m values), uniform weights."""
+    a = np.sort(np.asarray(a, dtype=np.float64).ravel())
+    b = np.sort(np.asarray(b, dtype=np.float64).ravel())
+    n, m = len(a), len(b)
+    i = j = 0
+    wa, wb = 1.0 / n, 1.0 / m           # mass left on a[i], b[j]
+    cost = 0.0
+    while i < n and j < m:
+        mv = min(wa, wb)
+        cost += mv * (a[i] - b[j]) ** 2
+        wa -= mv
+        wb -= mv
+        if wa <= 1e-15:
+            i += 1
+            wa = 1.0 / n
+        if wb <= 1e-15:
+            j += 1
+            wb = 1.0 / m
+    return cost
+
+
+def check_flat_array(x) -> Array:
+    """utils/tensors.py:5-23 -- (n, ...) -> (n, d)."""
+    x = np.asarray(x)
+    return x.reshape(x.shape[0], -1) if x.ndim > 2 else x
+
+
+def random_directions(seed, dim: int, num_directions: int) -> Array:
+    """wasserstein.py:38-74 -- unit vectors from ONE numpy Generator, drawn direction after direction."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((num_directions, dim))
+    for k in range(num_directions):
+        v = rng.normal(size=dim)
+        out[k] = v / np.linalg.norm(v)
+    return out
+
+
+def sliced_distances(original: Array, other: Array, seed, num_directions: int) -> Array:
+    """wasserstein.py:163-181 with directional_distance :117-143 (normalisation 'none')."""
+    original, other = check_flat_array(original), check_flat_array(other)
+    dirs = random_directions(seed, original.shape[1], num_directions)
+    return np.array([math.sqrt(emd2_1d(original @ d, other @ d)) for d in dirs])
+
+
+def marginal_distances(original: Array, other: Array) -> Array:
+    """wasserstein.py:183-199 with feature_distance :91-115."""
+    original, other = check_flat_array(original), check_flat_array(other)
+    return np.array([math.sqrt(emd2_1d(original[:, f], other[:, f])) for f in range(original.shape[1])])
+
+
+def _wasserstein_metric(kind: str, original: Array, other: Array, seed, num_directions, baselines: bool) -> dict:
+    """metrics.py:100-217 -- the dict a SlicedWasserstein / MarginalWasserstein metric contributes (with its baselines)."""
+    original, other = check_flat_array(original), check_flat_array(other)
+    dist = (lambda a, b: sliced_distances(a, b, seed, num_directions)) if kind == "sliced" else marginal_distances
+    d = dist(original, other)
+    out = {f"{kind}_wasserstein_mean": float(d.mean()), f"{kind}_wasserstein_max": float(d.max()),
+           f"{kind}_wasserstein_all": d.tolist()}
+    if baselines:
+        n = original.shape[0]
+        ds = dist(original[: n // 2], original[n // 2:])                 # metrics.py:131-137 / 189-195
+        dd = dist(original, original.mean(axis=0, keepdims=True))         # metrics.py:140-146 / 198-204
+        out.update({f"{kind}_wasserstein_mean_self": float(ds.mean()), f"{kind}_wasserstein_max_self": float(ds.max()),
+                    f"{kind}_wasserstein_mean_dummy": float(dd.mean()), f"{kind}_wasserstein_max_dummy": float(dd.max())})
+    return out
+
+
+def sliced_wasserstein_metric(original, other, seed, num_directions, baselines=True) -> dict:
+    return _wasserstein_metric("sliced", original, other, seed, num_directions, baselines)
+
+
+def marginal_wasserstein_metric(original, other, baselines=True) -> dict:
+    return _wasserstein_metric("marginal", original, other, None, None, baselines)
+
+
+# --------------------------------------------------------------------------
 # a3/a4  noise scaling and timestep grid  src/fdiff/schedulers/sde.py:42-64
 # --------------------------------------------------------------------------
 def noise_scaling(max_len: int, fourier_noise_scaling: bool) -> Array:

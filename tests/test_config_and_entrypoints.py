@@ -58,14 +58,20 @@ def test_instantiate_train_and_sample_configs(tmp_path):
     assert isinstance(tr, Trainer) and tr.max_epochs == 200 and tr.gradient_clip_val == 1.0
     kinds = [type(c) for c in tr.callbacks]
     assert kinds == [LearningRateMonitor, ModelCheckpoint, SamplingCallback]
-    assert tr.callbacks[2].metrics == []                            # POT metrics are out of scope -> dropped
+    from fourierdiffusion_amd.sampling.metrics import MarginalWasserstein, MetricCollection, SlicedWasserstein
+    cb_metrics = tr.callbacks[2].metrics                            # partially instantiated, bound to X_train later
+    assert [m.func for m in cb_metrics] == [SlicedWasserstein, MarginalWasserstein]
+    assert cb_metrics[0].keywords == {"random_seed": 42, "num_directions": 200}
     dm = instantiate(cfg.datamodule)
     assert dm.fourier_transform is True and dm.batch_size == 64 and dm.dataset_name == "synthetic"
     scfg = compose(CONF, "sample", ["model_id=abc", f"model_path={tmp_path}"])
     assert scfg.num_samples == 10000 and scfg.num_diffusion_steps == 1000 and scfg.model_id == "abc"
     sampler_partial = instantiate(scfg.sampler)
     assert isinstance(sampler_partial, partial) and sampler_partial.keywords["sample_batch_size"] == 200
-    assert instantiate(scfg.metrics) is None
+    mc = instantiate(scfg.metrics)
+    assert isinstance(mc, partial) and mc.func is MetricCollection and mc.keywords["include_spectral_density"] is True
+    assert [m.func for m in mc.keywords["metrics"]] == [SlicedWasserstein, MarginalWasserstein]
+    assert mc.keywords["metrics"][0].keywords["num_directions"] == 1000
 
 
 def test_yaml_roundtrip(tmp_path):

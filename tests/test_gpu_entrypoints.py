@@ -40,6 +40,11 @@ def test_train_then_sample(tmp_path):
     assert X.shape == (64, 24, 4) and torch.isfinite(X).all()
     res = yaml.safe_load(open(run_dir / "results.yaml"))
     assert res["num_samples"] == 64
+    # the reference's metric collection (cmd/conf/metrics/default.yaml) ran on the engine: time / freq / spectral keys
+    for k in ("time_sliced_wasserstein_mean", "freq_sliced_wasserstein_max", "time_marginal_wasserstein_mean_self",
+              "freq_marginal_wasserstein_max_dummy", "spectral_marginal_wasserstein_mean"):
+        assert k in res and res[k] >= 0.0 and res[k] == res[k], k
+    assert len(res["time_sliced_wasserstein_all"]) == 1000 and len(res["time_marginal_wasserstein_all"]) == 24 * 4
 
 
 def test_fourier_datamodule_roundtrip_and_standardisation():

@@ -210,3 +210,51 @@ def test_spectral_density_is_parseval():
     d = O.spectral_density(x)
     two_sided = d.sum(axis=1) + d[:, 1:].sum(axis=1)
     np.testing.assert_allclose(two_sided, (x.astype(np.float64) ** 2).sum(axis=1), rtol=1e-10)
+
+
+# ---------------------------------------------------------------- Wasserstein metrics (wasserstein.py, metrics.py)
+# POT is absent here and unpinned in the reference: the 1-D transport restatement is pinned against the transport LP.
+@pytest.mark.parametrize("n,m", [(3, 3), (4, 2), (5, 3), (1, 6), (6, 4), (7, 7)])
+def test_emd2_1d_is_the_optimal_transport_cost(n, m):
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(n * 10 + m)
+    a, b = rng.normal(size=n), rng.normal(size=m) + 0.3
+    cost = (a[:, None] - b[None, :]) ** 2
+    rows, rhs = [], []
+    for i in range(n):
+        r = np.zeros((n, m)); r[i] = 1; rows.append(r.ravel()); rhs.append(1 / n)
+    for j in range(m):
+        r = np.zeros((n, m)); r[:, j] = 1; rows.append(r.ravel()); rhs.append(1 / m)
+    lp = linprog(cost.ravel(), A_eq=np.array(rows), b_eq=np.array(rhs), bounds=(0, None))
+    assert lp.status == 0
+    np.testing.assert_allclose(O.emd2_1d(a, b), lp.fun, rtol=1e-9, atol=1e-12)
+
+
+def test_emd2_1d_closed_forms():
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=50)
+    assert O.emd2_1d(a, a) == 0.0
+    np.testing.assert_allclose(O.emd2_1d(a, a + 2.0), 4.0, rtol=1e-12)                 # a shift moves every quantile by 2
+    b = rng.normal(size=50)
+    np.testing.assert_allclose(O.emd2_1d(a, b), np.mean((np.sort(a) - np.sort(b)) ** 2), rtol=1e-12)   # equal sizes
+    np.testing.assert_allclose(O.emd2_1d(a, [0.7]), np.mean((a - 0.7) ** 2), rtol=1e-12)              # a point mass
+
+
+def test_wasserstein_metric_dicts():
+    X = W.randn("wm_x", (40, 6, 2), 1)
+    Y = W.randn("wm_y", (25, 6, 2), 2) * 1.5 + 0.2
+    dirs = O.random_directions(7, 12, 5)
+    np.testing.assert_allclose(np.linalg.norm(dirs, axis=1), 1.0, rtol=1e-12)
+    np.testing.assert_array_equal(dirs, O.random_directions(7, 12, 5))                   # same seed, same directions
+    s = O.sliced_wasserstein_metric(X, Y, seed=7, num_directions=5)
+    assert sorted(s) == ["sliced_wasserstein_all", "sliced_wasserstein_max", "sliced_wasserstein_max_dummy",
+                         "sliced_wasserstein_max_self", "sliced_wasserstein_mean", "sliced_wasserstein_mean_dummy",
+                         "sliced_wasserstein_mean_self"]
+    assert len(s["sliced_wasserstein_all"]) == 5 and s["sliced_wasserstein_max"] >= s["sliced_wasserstein_mean"] > 0
+    mg = O.marginal_wasserstein_metric(X, Y)
+    assert len(mg["marginal_wasserstein_all"]) == 12
+    # marginal distance of feature f = sliced distance along e_f
+    f = 3
+    e = np.zeros(12); e[f] = 1
+    Xf, Yf = O.check_flat_array(X), O.check_flat_array(Y)
+    np.testing.assert_allclose(mg["marginal_wasserstein_all"][f], math.sqrt(O.emd2_1d(Xf @ e, Yf @ e)), rtol=1e-12)
