@@ -25,3 +25,10 @@ for _name in _SUBMODULES:
         globals()[_leaf] = _mod
 
 __version__ = _pkg.__version__
+
+# Objects pickled while the alias is active name the reference's module paths (Lightning checkpoints keep the noise-scheduler
+# INSTANCE in hyper_parameters): a checkpoint written here then unpickles in the reference, and the reference's unpickle here.
+for _cls_name in ("SDE", "VPScheduler", "VEScheduler"):
+    _cls = getattr(sys.modules["fdiff.schedulers.sde"], _cls_name, None)
+    if _cls is not None:
+        _cls.__module__ = "fdiff.schedulers.sde"

@@ -292,8 +292,11 @@ class ScoreModule:
 
     # ------------------------------------------------------------------ checkpoints (Lightning layout)
     def save_checkpoint(self, path, **extra) -> None:
-        ckpt = {"state_dict": OrderedDict((k, t.cpu()) for k, t in self.state_dict().items()),
-                "hyper_parameters": dict(self.hparams), "engine": "fourierdiffusion_amd"}
+        # Lightning's layout (state_dict keys of the reference model, ctor hyper-parameters incl. the scheduler object) plus
+        # the bookkeeping keys its load_from_checkpoint expects, so the reference can load checkpoints written here
+        ckpt = {"epoch": 0, "global_step": 0, "pytorch-lightning_version": "2.1.0",
+                "state_dict": OrderedDict((k, t.cpu()) for k, t in self.state_dict().items()),
+                "hparams_name": "kwargs", "hyper_parameters": dict(self.hparams), "engine": "fourierdiffusion_amd"}
         ckpt.update(extra)
         torch.save(ckpt, path)
 

@@ -61,6 +61,12 @@ class SDE(abc.ABC):
         st["_G_dev"] = {}
         return st
 
+    def __setstate__(self, st):
+        # also the entry point for scheduler objects pickled by the REFERENCE (Lightning checkpoints keep the scheduler
+        # instance in hyper_parameters, class path fdiff.schedulers.sde.*): same attribute names, no device cache
+        self.__dict__.update(st)
+        self._G_dev = {}
+
     # ------------------------------------------------------------ sde.py:42-64
     def set_noise_scaling(self, max_len: int) -> None:
         """G_k = 1, or with Fourier scaling 1/sqrt(2) except G_0 (and G_{T/2}, T even) = 1

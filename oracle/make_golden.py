@@ -223,6 +223,20 @@ def gen_score(R):
     np.savez_compressed(os.path.join(OUT, "score_forward.npz"), **out)
 
 
+def gen_ckpt(R):
+    """A checkpoint in the reference's Lightning layout: the reference model's own state_dict and the
+    hyper-parameters Lightning's save_hyperparameters() records for ScoreModule.__init__ (score_models.py:25-43) with the
+    reference's scheduler OBJECT pickled inside (class path fdiff.schedulers.sde.VPScheduler).  Same weights / inputs as the
+    "tiny" case of score_forward.npz, so loading it on the engine must reproduce that golden output."""
+    m, sch, _ = build_ref_model(R, CFG_TINY, "vp", (0.1, 20.0), True, seed=1234)
+    hp = dict(n_channels=CFG_TINY["C"], max_len=CFG_TINY["T"], noise_scheduler=sch, fourier_noise_scaling=True,
+              d_model=CFG_TINY["D"], num_layers=CFG_TINY["L"], n_head=CFG_TINY["H"], num_training_steps=1000, lr_max=1e-3,
+              likelihood_weighting=False)
+    ckpt = {"epoch": 3, "global_step": 40, "pytorch-lightning_version": "2.1.0", "state_dict": m.state_dict(),
+            "hparams_name": "kwargs", "hyper_parameters": hp}
+    torch.save(ckpt, os.path.join(OUT, "reference_tiny.ckpt"))
+
+
 def zero_dropout(m):
     for mod in m.modules():
         if isinstance(mod, nn.Dropout):
@@ -339,7 +353,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = import_reference()
-    gens = dict(dft=gen_dft, spectral=gen_spectral, sde=gen_sde, score=gen_score, loss=gen_loss, sampler=gen_sampler,
+    gens = dict(dft=gen_dft, spectral=gen_spectral, sde=gen_sde, score=gen_score, ckpt=gen_ckpt, loss=gen_loss, sampler=gen_sampler,
                 dataset=gen_dataset, optim=gen_optim)
     for name in (sys.argv[1:] or list(gens)):                  # `make_golden.py spectral` regenerates one file
         gens[name](R)

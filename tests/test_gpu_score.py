@@ -91,3 +91,18 @@ def test_forward_bf16_vs_oracle(name, B):
     err = np.abs(out - ref).max() / scale
     rms = np.sqrt(((out - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())
     assert err <= 2e-2 and rms <= 1e-2, (err, rms)
+
+
+def test_reference_checkpoint_forward_vs_golden(golden):
+    """a checkpoint written by the reference (Lightning layout, scheduler object pickled inside) loads on the
+    engine and reproduces the reference's own forward output for the same inputs."""
+    import os
+
+    import fdiff  # noqa: F401  (alias package: the pickled fdiff.schedulers.sde.VPScheduler resolves to this engine's class)
+    from fourierdiffusion_amd.models.score_models import ScoreModule
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_tiny.ckpt")
+    m = ScoreModule.load_from_checkpoint(path).to(DEV)
+    m.precision = "fp32"
+    X = W.randn("score_x_tiny", (3, 20, 3), 2)
+    t = W.uniform("score_t_tiny", (3,), 2, 1e-5, 1.0)
+    np.testing.assert_allclose(run(m, X, t), golden("score_forward")["fast_tiny"], atol=F32_ATOL, rtol=0)
