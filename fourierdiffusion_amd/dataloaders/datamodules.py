@@ -227,7 +227,63 @@ def _needs_download(name: str):
     return _Unavailable
 
 
-ECGDatamodule = _needs_download("ECGDatamodule")
+class ECGDatamodule(Datamodule):
+    """MIT-BIH heartbeats (datamodules.py:165-238 of the reference): `mitbih_train.csv` / `mitbih_test.csv` under
+    `data_dir/ecg`, 187 time steps + a label column.  The two preprocessing options run on the engine:
+    `subsample_localization` keeps the 1000 series most localised in time relative to frequency
+    (fd_localization_metrics), `smooth_frequency` convolves the spectrum with a Gaussian of width `smoother_width`
+    (fd_rfft_pack -> fd_frequency_smooth -> fd_irfft_unpack).  The files themselves come from Kaggle: no network here, so
+    a missing directory raises instead of downloading."""
+
+    def __init__(self, data_dir: Path | str = Path.cwd() / "data", random_seed: int = 42, batch_size: int = 32,
+                 fourier_transform: bool = False, standardize: bool = False, subsample_localization: bool = False,
+                 smooth_frequency: bool = False, smoother_width: float = 0.0) -> None:
+        super().__init__(data_dir=data_dir, random_seed=random_seed, batch_size=batch_size,
+                         fourier_transform=fourier_transform, standardize=standardize)
+        self.subsample_localization = subsample_localization
+        self.smooth_frequency = smooth_frequency
+        self.smoother_width = smoother_width
+
+    def prepare_data(self) -> None:
+        if not (self.data_dir / "mitbih_train.csv").exists():
+            self.download_data()
+
+    def download_data(self) -> None:
+        raise FileNotFoundError(
+            f"ECGDatamodule: {self.data_dir}/mitbih_train.csv not found; the reference downloads shayanfazeli/heartbeat "
+            "from Kaggle (datamodules.py:229-235) and there is no network here -- place the two CSV files there")
+
+    def setup(self, stage: str = "fit") -> None:
+        import pandas as pd
+        from ..utils.fourier import localization_metrics, smooth_frequency
+        df_train = pd.read_csv(self.data_dir / "mitbih_train.csv")     # (first row is consumed as the header, as in the
+        df_test = pd.read_csv(self.data_dir / "mitbih_test.csv")       #  reference: datamodules.py:196-201)
+        self.X_train = torch.tensor(df_train.iloc[:, :187].values, dtype=torch.float32).unsqueeze(2)
+        self.y_train = torch.tensor(df_train.iloc[:, 187].values, dtype=torch.long)
+        self.X_test = torch.tensor(df_test.iloc[:, :187].values, dtype=torch.float32).unsqueeze(2)
+        self.y_test = torch.tensor(df_test.iloc[:, 187].values, dtype=torch.long)
+        if self.subsample_localization:                                # datamodules.py:207-219
+            X_loc, X_spec_loc = localization_metrics(self.X_train)
+            idx_ranking = torch.argsort(X_loc / X_spec_loc, descending=False)
+            self.X_train = self.X_train[idx_ranking[:1000]]
+            self.y_train = self.y_train[idx_ranking[:1000]]
+            X_loc, X_spec_loc = localization_metrics(self.X_train)
+            logging.info("Subsampling the training set based on localization metrics.")
+            logging.info(f"New time delocalization: {X_loc.mean().item():.3g}")
+            logging.info(f"New frequency delocalization: {X_spec_loc.mean().item():.3g}")
+        if self.smooth_frequency and self.smoother_width > 0.0:        # datamodules.py:221-230
+            self.X_train = smooth_frequency(self.X_train, sigma=self.smoother_width)
+            self.X_test = smooth_frequency(self.X_test, sigma=self.smoother_width)
+            logging.info("Smoothing the frequency domain of the data.")
+            X_loc, X_spec_loc = localization_metrics(self.X_train)
+            logging.info(f"New time delocalization: {X_loc.mean().item():.3g}")
+            logging.info(f"New frequency delocalization: {X_spec_loc.mean().item():.3g}")
+
+    @property
+    def dataset_name(self) -> str:
+        return "ecg"
+
+
 MIMICIIIDatamodule = _needs_download("MIMICIIIDatamodule")
 NASDAQDatamodule = _needs_download("NASDAQDatamodule")
 NASADatamodule = _needs_download("NASADatamodule")

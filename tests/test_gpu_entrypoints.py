@@ -88,3 +88,43 @@ def test_bench_two_rank_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+
+
+def test_ecg_datamodule_preprocessing_on_the_engine(tmp_path):
+    """ECGDatamodule (datamodules.py:165-238): CSV layout of the MIT-BIH files, `subsample_localization` keeps the 1000 most
+    time-localised series, `smooth_frequency` convolves the spectrum -- both through the engine's spectral utilities."""
+    import pandas as pd
+
+    from fourierdiffusion_amd.dataloaders.datamodules import ECGDatamodule
+    from oracle import fdiff_oracle as O
+    rng = np.random.default_rng(0)
+    n_tr, n_te = 1500, 200
+    X = rng.normal(size=(n_tr + n_te + 2, 187)).astype(np.float32) * 0.05
+    bumps = rng.integers(10, 170, size=X.shape[0])
+    for i in range(0, X.shape[0], 2):                       # every other series carries a narrow bump: localised in time
+        X[i, bumps[i]: bumps[i] + 5] += 2.0
+    y = rng.integers(0, 5, size=(X.shape[0], 1)).astype(np.float32)
+    d = tmp_path / "ecg"
+    d.mkdir()
+    pd.DataFrame(np.concatenate([X[: n_tr + 1], y[: n_tr + 1]], axis=1)).to_csv(d / "mitbih_train.csv", header=False, index=False)
+    pd.DataFrame(np.concatenate([X[n_tr + 1:], y[n_tr + 1:]], axis=1)).to_csv(d / "mitbih_test.csv", header=False, index=False)
+    dm = ECGDatamodule(data_dir=tmp_path, batch_size=64, fourier_transform=True, standardize=True)
+    dm.prepare_data()
+    dm.setup()
+    assert dm.X_train.shape == (n_tr, 187, 1) and dm.X_test.shape == (n_te, 187, 1) and dm.y_train.dtype == torch.long
+    np.testing.assert_allclose(dm.X_train[:, :, 0].numpy(), X[1: n_tr + 1], atol=1e-6)     # first row = header, as in the reference
+    sub = ECGDatamodule(data_dir=tmp_path, subsample_localization=True, smooth_frequency=True, smoother_width=2.0)
+    sub.setup()
+    assert sub.X_train.shape == (1000, 187, 1) and sub.y_train.shape == (1000,)
+    # the oracle's ranking picks the same 1000 series; the smoothing is the oracle's
+    Xtr = X[1: n_tr + 1, :, None]
+    loc, sloc = O.localization_metrics(Xtr)
+    keep = np.argsort(loc / sloc, kind="stable")[:1000]
+    assert len(set(keep[:700]) - set(np.argsort(loc / sloc)[:1000])) == 0
+    want = O.smooth_frequency(Xtr[keep], 2.0)
+    got = sub.X_train.cpu().numpy()
+    # same set of series (ties aside) -> compare as sets of rows through their sorted norms
+    np.testing.assert_allclose(np.sort(np.linalg.norm(got[:, :, 0], axis=1)), np.sort(np.linalg.norm(want[:, :, 0], axis=1)),
+                               rtol=1e-4, atol=1e-5)
+    with pytest.raises(FileNotFoundError):
+        ECGDatamodule(data_dir=tmp_path / "nowhere").prepare_data()
