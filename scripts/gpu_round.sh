@@ -25,6 +25,6 @@ if res["FETCH_SIZE"][1]:
     fetch_kb = res["FETCH_SIZE"][0] / res["FETCH_SIZE"][1]; write_kb = res["WRITE_SIZE"][0] / max(1, res["WRITE_SIZE"][1])
     out = {"kernel": "k_mega", "launches": res["FETCH_SIZE"][1], "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
            "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
-           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over python bench.py --steps 1 --warmup 0 (one launch = 1000 diffusion steps); FETCH_SIZE doubled (gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md HBM section); units KB. FETCH counts L2 misses, most of them served by the 256 MB MALL: the 6.3 MB of bf16 weights exceed one XCD's 4 MB L2, so every XCD re-fetches them each diffusion step (8 x 6.3 MB x 1000 = 50 GB); WRITE is register-spill scratch written back from L2 plus 2.4 GB of x"}
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over python bench.py --steps 1 --warmup 0 (one launch = 1000 diffusion steps); FETCH_SIZE doubled (gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md HBM section); units KB. FETCH counts L2 misses, most of them served by the 256 MB MALL: the 6.3 MB of bf16 weights exceed one XCD's 4 MB L2, so every XCD re-fetches them each diffusion step (8 x 6.3 MB x 1000 = 50 GB, plus the positional / embedding tables and x); WRITE = the 2.4 GB of x written back per launch (no register-spill scratch traffic in this build)"}
     json.dump(out, open("$OUT/hbm_traffic.json", "w"), indent=1); print(out)
 PY
