@@ -100,3 +100,30 @@ def test_metrics_at_dataset_scale():
     wd2 = WassersteinDistances(X, X + shift, seed=0)
     dirs = np.stack(wd2.get_random_directions(8))
     np.testing.assert_allclose(wd2.directional_distances(dirs), np.abs(dirs.sum(axis=1) * 0.5), rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("shift", [0.0, 0.1, 1.0])
+def test_reference_metric_tests(shift):
+    """tests/test_metrics.py of the reference (test_sliced_waserstein / test_marginal_waserstein): same data recipe, same
+    assertions; POT's sliced estimate is replaced by the oracle's (POT is absent), the marginal ground truth is the shift."""
+    from fourierdiffusion_amd.sampling.metrics import MarginalWasserstein, SlicedWasserstein
+    np.random.seed(42)
+    dataset1 = np.random.rand(1000, 2, 1)
+    dataset2 = np.random.rand(1000, 2, 1) + shift
+    sw = SlicedWasserstein(original_samples=dataset1, random_seed=42, num_directions=1000, save_all_distances=True)
+    metrics = sw(dataset2)
+    assert abs(metrics["sliced_wasserstein_mean"] - np.mean(metrics["sliced_wasserstein_all"])) <= 1e-5
+    assert metrics["sliced_wasserstein_mean"] <= metrics["sliced_wasserstein_max"]
+    want = O.sliced_distances(dataset1, dataset2, 42, 1000)
+    np.testing.assert_allclose(metrics["sliced_wasserstein_all"], want, rtol=RTOL, atol=1e-5)
+    # POT's sliced_wasserstein_distance is the root of the mean squared directional distance (its own directions): the
+    # reference only asks for agreement within 0.1
+    assert abs(metrics["sliced_wasserstein_mean"] - math.sqrt(np.mean(want ** 2))) <= 0.1
+    mw = MarginalWasserstein(original_samples=dataset1, random_seed=42, save_all_distances=True)
+    metrics = mw(dataset2)
+    assert abs(metrics["marginal_wasserstein_mean"] - np.mean(metrics["marginal_wasserstein_all"])) <= 1e-5
+    assert metrics["marginal_wasserstein_mean"] <= metrics["marginal_wasserstein_max"]
+    assert abs(metrics["marginal_wasserstein_mean"] - shift) <= 0.1
+    assert abs(metrics["marginal_wasserstein_max"] - shift) <= 0.1
+    assert sorted(mw.baseline_metrics) == ["marginal_wasserstein_max_dummy", "marginal_wasserstein_max_self",
+                                           "marginal_wasserstein_mean_dummy", "marginal_wasserstein_mean_self"]
