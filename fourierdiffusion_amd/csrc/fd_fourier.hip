@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "fd_common.h"
+#include "fd_gemm_f32.h"
 
 namespace {
 
@@ -501,8 +502,15 @@ extern "C" int fd_frequency_smooth(fd_ctx* ctx, const float* xt, float sigma, fl
     // (fourier.py:192-203): only odd lengths are defined
     FD_REQUIRE(ctx, (T & 1) == 1, "fd_frequency_smooth: max_len=%d must be odd (fourier.py:192-203)", T);
     hipLaunchKernelGGL(k_gauss_matrix, dim3(T), dim3(256), 0, (hipStream_t)stream, gauss_scratch, T, T / 2 + 1, sigma);
-    hipLaunchKernelGGL(k_frequency_mix, dim3((T * C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, xt, gauss_scratch, out,
-                       T, C);
+    if (C == 1 && (long long)B * T < 2147483647LL) {
+        // single channel (the ECG set, the one dataset the reference smooths): out (B, T) = xt (B, T) . G (T, T) is one
+        // fp32-MFMA GEMM (1.6 ms -> 0.15 ms at 87 554 x 187)
+        fdgemm::Args g{xt, gauss_scratch, out, nullptr, B, T, T, (long long)T, 1, (long long)T, 1, (long long)T, 1.0f, 0, 0};
+        fdgemm::launch(g, (hipStream_t)stream);
+    } else {
+        hipLaunchKernelGGL(k_frequency_mix, dim3((T * C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, xt, gauss_scratch,
+                           out, T, C);
+    }
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }
