@@ -127,3 +127,32 @@ def test_reference_metric_tests(shift):
     assert abs(metrics["marginal_wasserstein_max"] - shift) <= 0.1
     assert sorted(mw.baseline_metrics) == ["marginal_wasserstein_max_dummy", "marginal_wasserstein_max_self",
                                            "marginal_wasserstein_mean_dummy", "marginal_wasserstein_mean_self"]
+
+
+def test_c_abi_argument_errors():
+    """Every new entry point refuses bad arguments with FD_ERR_ARG and a message (include/fdiff_hip.h conventions)."""
+    import ctypes as C
+
+    from fourierdiffusion_amd import _C
+    x = torch.zeros(4, 9, 1, device="cuda")
+    y = torch.zeros(4, 9, 1, device="cuda")
+    h, L = _C.ctx(x.device), _C.lib()
+    p, q = x.data_ptr(), y.data_ptr()
+    cases = [
+        (L.fd_spectral_density(h, None, q, 4, 9, 1, None), b"null"),
+        (L.fd_spectral_density(h, p, q, 0, 9, 1, None), b"bad shape"),
+        (L.fd_localization_metrics(h, p, p, None, q, 4, 9, 1, None), b"null"),
+        (L.fd_frequency_smooth(h, p, 1.0, q, p, 4, 9, 1, None), b"in-place"),
+        (L.fd_frequency_smooth(h, p, 0.0, q, q, 4, 9, 1, None), b"sigma"),
+        (L.fd_frequency_smooth(h, p, 1.0, q, q, 4, 8, 1, None), b"must be odd"),
+        (L.fd_project_rows(h, p, None, q, 4, 9, 1, None), b"null"),
+        (L.fd_transpose_rows(h, p, p, 4, 9, None), b"aliased"),
+        (L.fd_sort_rows(h, p, p, 4, 9, q, 256, None), b"aliased"),
+        (L.fd_sort_rows_temp_bytes(h, 0, 9, C.byref(C.c_size_t(0))), b"bad arguments"),
+        (L.fd_w2_sorted_rows(h, p, q, q, 4, 0, 9, None), b"bad shape"),
+    ]
+    for i, (rc, needle) in enumerate(cases):
+        assert rc == -1, (i, rc)
+    # the message of the last failure is retrievable
+    assert b"bad shape" in L.fd_last_error(h)
+    assert L.fd_spectral_density(None, p, q, 4, 9, 1, None) == -1          # no context: error code only
