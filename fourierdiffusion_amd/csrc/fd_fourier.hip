@@ -122,16 +122,19 @@ __device__ __forceinline__ void stockham_butterflies(const float2* __restrict__ 
 
 // INVERSE == false : x (time)  -> y (packed spectrum), optional (y - mean)/std
 // INVERSE == true  : x (packed spectrum), optional x*std + mean  -> y (time)
-template <bool INVERSE>
+// BATCHED (single-channel data, C == 1): the workgroup transforms Cc consecutive SERIES instead of Cc channels of one series
+// -- "channel" j is series blockIdx.x * Cc + j, contiguous along time -- so that a (B, T, 1) set (the reference's ECG
+// data, 87 554 x 187 x 1) still fills complex lanes and workgroups (one series per workgroup ran at 0.6 TB/s).
+template <bool INVERSE, bool BATCHED>
 __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, float* __restrict__ y,
                                                     const float* __restrict__ mean, const float* __restrict__ stdv,
                                                     const float2* __restrict__ tw_fwd, int B, int C, int Cc, FftPlan plan) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NT = blockDim.x;
     const int T = plan.T;
-    const int b = blockIdx.x;
-    const int c0 = blockIdx.y * Cc;
-    const int cc = min(Cc, C - c0);          // channels in this chunk
+    const int b = BATCHED ? blockIdx.x * Cc : blockIdx.x;                 // first series of the group / the series
+    const int c0 = BATCHED ? 0 : blockIdx.y * Cc;
+    const int cc = BATCHED ? min(Cc, B - b) : min(Cc, C - c0);            // channels (series) in this chunk
     const int Cp = (cc + 1) >> 1;            // complex lanes (channel pairs)
     float2* tw = reinterpret_cast<float2*>(smem);
     float2* bufA = tw + T;
@@ -147,31 +150,36 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
     const int n_real = T / 2 + 1;
     const bool even = (T & 1) == 0;
     const float scale = rsqrtf((float)T);
+    // offset of (row, channel) in xb / yb, and in the (T, C) mean / std tables; BATCHED: channel = series, rows contiguous
+    const size_t cstep = BATCHED ? (size_t)T : 1, rstep = BATCHED ? 1 : (size_t)C, mstep = BATCHED ? 0 : 1;
 
-    // ---- load pass: build z[n][p]
-    const float inv_cp = 1.0f / (float)Cp;
+    // ---- load pass: build z[n][p]  (thread order: channel pairs fastest, BATCHED: rows fastest = contiguous in memory)
+    const float inv_cp = 1.0f / (float)Cp, inv_t = 1.0f / (float)T, inv_nr = 1.0f / (float)n_real;
     for (int id = threadIdx.x; id < T * Cp; id += NT) {
-        const int n = fdiv(id, inv_cp), p = id - n * Cp;
+        int n, p;
+        if (BATCHED) { p = fdiv(id, inv_t); n = id - p * T; } else { n = fdiv(id, inv_cp); p = id - n * Cp; }
         const int ca = c0 + 2 * p;
         const bool has_b = (2 * p + 1) < cc;
         float2 z;
         if (!INVERSE) {
-            z.x = xb[(size_t)n * C + ca];
-            z.y = has_b ? xb[(size_t)n * C + ca + 1] : 0.f;
+            z.x = xb[(size_t)n * rstep + ca * cstep];
+            z.y = has_b ? xb[(size_t)n * rstep + (ca + 1) * cstep] : 0.f;
         } else {
             // Hermitian extension of the packed half spectrum (fourier.py:62-77): X[T-k] = conj X[k]
             const int kk = (n <= T / 2) ? n : T - n;
             const bool has_im = (kk != 0) && !(even && kk == T / 2);
             const float sg = (n <= T / 2) ? 1.0f : -1.0f;
-            const size_t ire = (size_t)kk * C, iim = (size_t)(n_real + kk - 1) * C;
-            float are = xb[ire + ca], aim = has_im ? xb[iim + ca] : 0.f;
-            float bre = has_b ? xb[ire + ca + 1] : 0.f, bim = (has_b && has_im) ? xb[iim + ca + 1] : 0.f;
+            const size_t ire = (size_t)kk * rstep, iim = (size_t)(n_real + kk - 1) * rstep;
+            const size_t oa = ca * cstep, ob = (ca + 1) * cstep;
+            float are = xb[ire + oa], aim = has_im ? xb[iim + oa] : 0.f;
+            float bre = has_b ? xb[ire + ob] : 0.f, bim = (has_b && has_im) ? xb[iim + ob] : 0.f;
             if (mean) {   // de-standardise in the frequency domain (cmd/sample.py:76-78)
-                are = are * stdv[ire + ca] + mean[ire + ca];
-                if (has_im) aim = aim * stdv[iim + ca] + mean[iim + ca];
+                const size_t mre = (size_t)kk * C, mim = (size_t)(n_real + kk - 1) * C, ma = ca * mstep, mb = (ca + 1) * mstep;
+                are = are * stdv[mre + ma] + mean[mre + ma];
+                if (has_im) aim = aim * stdv[mim + ma] + mean[mim + ma];
                 if (has_b) {
-                    bre = bre * stdv[ire + ca + 1] + mean[ire + ca + 1];
-                    if (has_im) bim = bim * stdv[iim + ca + 1] + mean[iim + ca + 1];
+                    bre = bre * stdv[mre + mb] + mean[mre + mb];
+                    if (has_im) bim = bim * stdv[mim + mb] + mean[mim + mb];
                 }
             }
             aim *= sg;
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
             z.x = are - bim;
             z.y = aim + bre;
         }
-        bufA[id] = z;
+        bufA[n * Cp + p] = z;
     }
     __syncthreads();
 
@@ -209,7 +217,8 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
     if (!INVERSE) {
         // X_a[k] = (Z[k] + conj Z[T-k]) / 2 ,  X_b[k] = (Z[k] - conj Z[T-k]) / (2i)
         for (int id = threadIdx.x; id < n_real * Cp; id += NT) {
-            const int k = fdiv(id, inv_cp), p = id - k * Cp;
+            int k, p;
+            if (BATCHED) { p = fdiv(id, inv_nr); k = id - p * n_real; } else { k = fdiv(id, inv_cp); p = id - k * Cp; }
             const int ca = c0 + 2 * p;
             const bool has_b = (2 * p + 1) < cc;
             const float2 zk = src[k * Cp + p];
@@ -218,29 +227,32 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
             float are = (zk.x + zm.x) * h, aim = (zk.y - zm.y) * h;
             float bre = (zk.y + zm.y) * h, bim = (zm.x - zk.x) * h;
             const bool has_im = (k != 0) && !(even && k == T / 2);   // fourier.py:26-37 drop exact zeros
-            const size_t ire = (size_t)k * C, iim = (size_t)(n_real + k - 1) * C;
+            const size_t ire = (size_t)k * rstep, iim = (size_t)(n_real + k - 1) * rstep;
+            const size_t oa = ca * cstep, ob = (ca + 1) * cstep;
             if (mean) {   // standardise (datamodules.py:61-62)
-                are = (are - mean[ire + ca]) / stdv[ire + ca];
-                if (has_im) aim = (aim - mean[iim + ca]) / stdv[iim + ca];
+                const size_t mre = (size_t)k * C, mim = (size_t)(n_real + k - 1) * C, ma = ca * mstep, mb = (ca + 1) * mstep;
+                are = (are - mean[mre + ma]) / stdv[mre + ma];
+                if (has_im) aim = (aim - mean[mim + ma]) / stdv[mim + ma];
                 if (has_b) {
-                    bre = (bre - mean[ire + ca + 1]) / stdv[ire + ca + 1];
-                    if (has_im) bim = (bim - mean[iim + ca + 1]) / stdv[iim + ca + 1];
+                    bre = (bre - mean[mre + mb]) / stdv[mre + mb];
+                    if (has_im) bim = (bim - mean[mim + mb]) / stdv[mim + mb];
                 }
             }
-            yb[ire + ca] = are;
-            if (has_b) yb[ire + ca + 1] = bre;
+            yb[ire + oa] = are;
+            if (has_b) yb[ire + ob] = bre;
             if (has_im) {
-                yb[iim + ca] = aim;
-                if (has_b) yb[iim + ca + 1] = bim;
+                yb[iim + oa] = aim;
+                if (has_b) yb[iim + ob] = bim;
             }
         }
     } else {
         for (int id = threadIdx.x; id < T * Cp; id += NT) {
-            const int n = fdiv(id, inv_cp), p = id - n * Cp;
+            int n, p;
+            if (BATCHED) { p = fdiv(id, inv_t); n = id - p * T; } else { n = fdiv(id, inv_cp); p = id - n * Cp; }
             const int ca = c0 + 2 * p;
-            const float2 z = src[id];
-            yb[(size_t)n * C + ca] = z.x * scale;
-            if ((2 * p + 1) < cc) yb[(size_t)n * C + ca + 1] = z.y * scale;
+            const float2 z = src[n * Cp + p];
+            yb[(size_t)n * rstep + ca * cstep] = z.x * scale;
+            if ((2 * p + 1) < cc) yb[(size_t)n * rstep + (ca + 1) * cstep] = z.y * scale;
         }
     }
 }
@@ -289,13 +301,22 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
     if (pairs_2wg >= 4 && pairs_2wg < max_pairs) max_pairs = pairs_2wg;
     int Cc = C;
     if ((C + 1) / 2 > max_pairs) Cc = max_pairs * 2;
-    const int nchunks = (C + Cc - 1) / Cc;
+    // single-channel sets: Cc consecutive series per workgroup (BATCHED), as many as keep >= 2 workgroups per CU busy,
+    // at most 32 (16 complex lanes)
+    const bool batched = (C == 1 && B >= 4);
+    if (batched) {
+        Cc = std::min(32, std::max(2, B / (2 * ctx->num_cu)));
+        Cc = std::min(Cc & ~1, max_pairs * 2);
+        Cc = std::max(Cc, 2);
+    }
+    const int nchunks = batched ? 1 : (C + Cc - 1) / Cc;
+    const int ngroups = batched ? (B + Cc - 1) / Cc : B;
     const size_t lds = (size_t)T * 8 + 2 * (size_t)T * ((Cc + 1) / 2) * 8;
-    auto kern = k_fft<INVERSE>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[INVERSE ? 1 : 0]) {
+    auto kern = batched ? k_fft<INVERSE, true> : k_fft<INVERSE, false>;
+    static bool attr_set[2][2] = {{false, false}, {false, false}};
+    if (!attr_set[INVERSE ? 1 : 0][batched ? 1 : 0]) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[INVERSE ? 1 : 0] = true;
+        attr_set[INVERSE ? 1 : 0][batched ? 1 : 0] = true;
     }
     // twiddle table of this T (cached on the context; a handful of distinct T per process)
     const float2* tw_dev = nullptr;
@@ -317,8 +338,8 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
     const int elems = T * ((Cc + 1) / 2);
     int block = 128;
     while (block < kMaxBlock && block * 8 < elems) block *= 2;
-    hipLaunchKernelGGL(kern, dim3(B, nchunks), dim3(block), lds, (hipStream_t)stream, x, y, mean, stdv, tw_dev, B, C, Cc,
-                       plan);
+    hipLaunchKernelGGL(kern, dim3(ngroups, nchunks), dim3(block), lds, (hipStream_t)stream, x, y, mean, stdv, tw_dev, B, C,
+                       Cc, plan);
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }

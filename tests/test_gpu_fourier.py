@@ -158,3 +158,20 @@ def test_spectral_utilities_properties_at_dataset_size():
     xc = torch.from_numpy(W.randn("spec_cpu", (2, 101, 3), 3))
     out = spectral_density(xc)
     assert out.device.type == "cpu" and out.shape == (2, 51, 3)
+
+
+@pytest.mark.parametrize("B,T", [(37, 187), (4, 100), (5, 16), (130, 255), (2000, 187), (33, 1024)])
+def test_single_channel_sets_batched_path(B, T):
+    """C == 1 (the reference's ECG layout, (n, 187, 1)): several series share a workgroup; parity with the oracle for odd group
+    tails, both directions, and the fused standardise variants."""
+    from fourierdiffusion_amd.utils.fourier import destandardize_idft, dft, dft_standardize, idft
+    x = W.randn("sc_x", (B, T, 1), 21)
+    xt = W.randn("sc_xt", (B, T, 1), 22)
+    np.testing.assert_allclose(host(dft(dev(x))), O.dft(x), atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(idft(dev(xt))), O.idft(xt), atol=ATOL, rtol=0)
+    mean = W.randn("sc_m", (T, 1), 23)
+    std = np.abs(W.randn("sc_s", (T, 1), 24)) + 0.5
+    got = host(dft_standardize(dev(x), dev(mean), dev(std)))
+    np.testing.assert_allclose(got, (O.dft(x) - mean) / std, atol=3e-5, rtol=0)
+    back = host(destandardize_idft(dev(got), dev(mean), dev(std)))
+    np.testing.assert_allclose(back, x, atol=3e-5, rtol=0)
