@@ -1,6 +1,8 @@
 """GPU parity: training path -- loss, parameter gradients (fd_score_backward), fused AdamW + clip.
 Gradients are compared with the reference's autograd gradients (dropout forced to 0, injected t and z;
 tests/golden/loss.npz) at rtol 2e-4 of each tensor's max |grad| (fp32 accumulation order differs)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -73,12 +75,15 @@ def test_gradient_accumulation_and_zero_grad():
     assert float(m.grads.abs().max()) == 0.0
 
 
-def test_dropout_forward_backward_consistency():
+CFG_D10 = dict(T=12, C=2, D=10, L=1, H=2)      # d_model % 4 != 0: the dropout sites cannot ride in the GEMM epilogues
+
+
+@pytest.mark.parametrize("cfg", [CFG_TINY, CFG_D10], ids=["tiny", "d_model_10"])
+def test_dropout_forward_backward_consistency(cfg):
     """dropout p=0.1: masks are regenerated in backward from the same Philox key.  With the key pinned through
     torch.manual_seed the loss is a deterministic function of the parameters; check grad . v against a central
     difference along a random direction v (fp32: 3 % tolerance), and that masks really are applied."""
     from fourierdiffusion_amd.utils.losses import get_sde_loss_fn
-    cfg = CFG_TINY
     m, sch, _ = make_model(cfg, precision="fp32")
     assert m.dropout == pytest.approx(0.1)
     X = W.randn("dr_x", (6, cfg["T"], cfg["C"]), 3)
@@ -197,3 +202,34 @@ def test_rccl_allreduce_single_rank():
         assert torch.allclose(g, ref * 0.5, rtol=0, atol=0)
     finally:
         _C.check(lib.fd_comm_destroy(ctx), ctx)
+
+
+def test_fused_dropout_masks_equal_the_standalone_kernel(tmp_path):
+    """The training forward applies its dropout sites in the GEMM / split-K epilogues; FDIFF_GEMM=valu selects the VALU GEMM,
+    which cannot fuse, so the same sites run as stand-alone fd_k_dropout launches.  Same Philox key -> the two outputs must
+    agree to fp32 GEMM rounding (a single differing mask bit would show as an O(1) difference)."""
+    import subprocess
+    import sys
+    script = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from tests.gpu_util import make_model, dev
+from oracle import weights as W
+from oracle.make_golden import CFG_ODD
+from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
+m, sch, _ = make_model(CFG_ODD, precision="fp32")
+m.train()
+X = W.randn("fd_x", (5, CFG_ODD["T"], CFG_ODD["C"]), 3); t = W.uniform("fd_t", (5,), 3, 0.2, 1.0)
+torch.manual_seed(77)
+out = m(DiffusableBatch(X=dev(X), y=None, timesteps=dev(t)))
+np.save(sys.argv[1], out.detach().cpu().numpy())
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, env in (("fused", {}), ("valu", {"FDIFF_GEMM": "valu"})):
+        path = str(tmp_path / f"{name}.npy")
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", script, path], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    assert np.abs(outs[0]).max() > 0.1
+    np.testing.assert_allclose(outs[0], outs[1], atol=2e-5, rtol=0)
