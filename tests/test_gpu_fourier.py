@@ -175,3 +175,15 @@ def test_single_channel_sets_batched_path(B, T):
     np.testing.assert_allclose(got, (O.dft(x) - mean) / std, atol=3e-5, rtol=0)
     back = host(destandardize_idft(dev(got), dev(mean), dev(std)))
     np.testing.assert_allclose(back, x, atol=3e-5, rtol=0)
+
+
+def test_multichannel_smoothing_across_scratch_chunks():
+    """(4096, 255, 28): the mixing runs as transpose -> fp32-MFMA GEMM -> transpose over chunks of series sized by the context's
+    GEMM scratch (2 chunks here); series on both sides of the chunk boundary match the oracle."""
+    from fourierdiffusion_amd.utils.fourier import smooth_frequency
+    B, T, C = 4096, 255, 28
+    x = W.randn("mc_smooth", (B, T, C), 31)
+    y = smooth_frequency(dev(x), 3.0)
+    assert y.shape == (B, T, C)
+    pick = [0, 1, 2348, 2349, 2350, 4095]
+    np.testing.assert_allclose(host(y[pick]), O.smooth_frequency(x[pick], 3.0), atol=3e-5)
