@@ -39,8 +39,8 @@ def init_process_group(backend: Optional[str] = None) -> DistEnv:
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend is None:                     # FDIFF_DIST_BACKEND=gloo: rehearsals with several ranks on ONE GPU
+                backend = os.environ.get("FDIFF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             dist.init_process_group(backend=backend, rank=e.rank, world_size=e.world)
     return e
 

@@ -85,8 +85,9 @@ class Trainer:
         self.dist = init_process_group()
         _rng.set_rank(self.dist.rank)
         if torch.cuda.is_available():
-            torch.cuda.set_device(self.dist.local_rank)
-            model.to(torch.device("cuda", self.dist.local_rank))
+            dev_index = self.dist.local_rank % torch.cuda.device_count()      # (modulo: several ranks may share one GPU in tests)
+            torch.cuda.set_device(dev_index)
+            model.to(torch.device("cuda", dev_index))
         datamodule.set_shard(self.dist.rank, self.dist.world)
         exchange = GradExchange(self.dist, backend=self.grad_exchange_backend)
         opt_cfg = model.configure_optimizers()
