@@ -32,8 +32,10 @@ class SamplingRunner:
         logging.info(f"Welcome in the sampling script! You are using the following config:\n{dict_to_str(cfg)}")
         self.dist = init_process_group()
         _rng.set_rank(self.dist.rank)
+        self.dev_index = 0
         if torch.cuda.is_available():
-            torch.cuda.set_device(self.dist.local_rank)
+            self.dev_index = self.dist.local_rank % torch.cuda.device_count()   # (modulo: ranks may share a GPU in tests)
+            torch.cuda.set_device(self.dev_index)
         self.model_path = Path(cfg.model_path)
         self.model_id = cfg.model_id
         if self.model_id == "latest":
@@ -52,7 +54,7 @@ class SamplingRunner:
         best_checkpoint_path = get_best_checkpoint(self.save_dir / "checkpoints")
         model_type = get_model_type(train_cfg)
         self.score_model = model_type.load_from_checkpoint(checkpoint_path=best_checkpoint_path)
-        self.score_model.to(device=torch.device("cuda", self.dist.local_rank))
+        self.score_model.to(device=torch.device("cuda", self.dev_index))
         self.sampler = instantiate(cfg.sampler)(score_model=self.score_model)
         # metrics against the training set, on the main rank only (reference cmd/sample.py:62-65)
         self.metrics = None

@@ -45,6 +45,23 @@ def test_train_then_sample(tmp_path):
               "freq_marginal_wasserstein_max_dummy", "spectral_marginal_wasserstein_mean"):
         assert k in res and res[k] >= 0.0 and res[k] == res[k], k
     assert len(res["time_sliced_wasserstein_all"]) == 1000 and len(res["time_marginal_wasserstein_all"]) == 24 * 4
+    # the same sampling job as two ranks (sharing cuda:0, rendezvous over gloo): each rank samples its shard of the batches with
+    # its own Philox counter range, rank 0 gathers on the host, scores and writes
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=str(ROOT), FDIFF_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(ROOT / "cmd" / "sample.py"), "model_id=testrun",
+                        "num_samples=128", "num_diffusion_steps=10", "sampler.sample_batch_size=32"], cwd=tmp_path, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    X2 = torch.load(run_dir / "samples.pt")
+    assert X2.shape == (128, 24, 4) and torch.isfinite(X2).all()
+    assert not torch.equal(X2[:64], X2[64:])                      # the two ranks drew different noise
+    res2 = yaml.safe_load(open(run_dir / "results.yaml"))
+    assert res2["num_samples"] == 128 and res2["time_sliced_wasserstein_mean"] >= 0.0
 
 
 def test_fourier_datamodule_roundtrip_and_standardisation():
