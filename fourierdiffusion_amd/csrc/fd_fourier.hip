@@ -279,6 +279,46 @@ bool make_plan(int T, FftPlan& plan) {
     return true;
 }
 
+}  // namespace
+
+void fd_apply_row_matrix(fd_ctx* ctx, const float* in, const float* Mx, float* out, int B, int T, int C, hipStream_t stream);
+
+namespace {
+
+// The packed transform as a real (T, T) matrix, Mx[t][k] (forward: y_k = sum_t x_t Mx[t][k]) or Mx[k][t] (inverse:
+// x_t = sum_k y_k Mx[k][t]), built on the host in double and cached per (T, direction) next to the twiddle tables (key
+// -T / -T - 2^20 in ctx->fft_tw).  Row layout of the packed axis: fourier.py:30-40 / :62-77.
+const float* dense_matrix(fd_ctx* ctx, int T, bool inverse) {
+    const int key = inverse ? -T - (1 << 20) : -T;
+    for (auto& e : ctx->fft_tw)
+        if (e.first == key) return reinterpret_cast<const float*>(e.second);
+    const int n_real = T / 2 + 1;
+    const double sc = 1.0 / std::sqrt((double)T), w0 = 2.0 * 3.14159265358979323846 / (double)T;
+    std::vector<float> h((size_t)T * T);
+    for (int r = 0; r < T; ++r) {                            // packed row r: Re X_k (k = r) or Im X_k (k = r - n_real + 1)
+        const bool is_im = r >= n_real;
+        const int k = is_im ? r - n_real + 1 : r;
+        const bool edge = (k == 0) || ((T % 2 == 0) && k == T / 2);
+        for (int t = 0; t < T; ++t) {
+            const double ang = w0 * (double)((long long)k * t % T);
+            if (!inverse) {
+                h[(size_t)t * T + r] = (float)((is_im ? -std::sin(ang) : std::cos(ang)) * sc);
+            } else {                                         // Hermitian extension: every interior bin counts twice
+                const double wgt = edge ? 1.0 : 2.0;
+                h[(size_t)r * T + t] = (float)((is_im ? -std::sin(ang) : std::cos(ang)) * sc * wgt);
+            }
+        }
+    }
+    void* d = nullptr;
+    if (hipMalloc(&d, sizeof(float) * h.size()) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return nullptr;
+    }
+    ctx->fft_tw.emplace_back(key, d);
+    return reinterpret_cast<const float*>(d);
+}
+
 template <bool INVERSE>
 int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float* stdv, int B, int T, int C,
            void* stream, const char* who) {
@@ -290,6 +330,25 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
     FD_REQUIRE(ctx, B <= 2147483647 / 2, "%s: batch too large", who);
     FftPlan plan;
     FD_REQUIRE(ctx, make_plan(T, plan), "%s: T=%d has too many prime factors", who, T);
+    // A length dominated by one large prime factor p runs that factor as a direct-DFT stage, O(T p) per transform; from
+    // p ~ 0.4 T on the whole transform as ONE dense (T, T) real matrix product on the fp32 MFMA pipe is faster
+    // ((4096, 251, 12): 529 -> 170 us).  FDIFF_DFT=fft|dense overrides (parity tests run both).
+    {
+        int pmax = 1;
+        for (int i = 0; i < plan.nstages; ++i) pmax = std::max(pmax, plan.radix[i]);
+        const char* e = getenv("FDIFF_DFT");
+        bool dense = pmax > 16 && (double)pmax >= 0.4 * (double)T && T <= 2048;
+        if (e && e[0] == 'f') dense = false;
+        if (e && e[0] == 'd') dense = T <= 2048;
+        if (dense && !mean && (long long)B * T * C < 2147483647LL) {
+            const float* Mx = dense_matrix(ctx, T, INVERSE);
+            if (Mx) {
+                fd_apply_row_matrix(ctx, x, Mx, y, B, T, C, (hipStream_t)stream);
+                FD_LAUNCH_CHECK(ctx);
+                return FD_OK;
+            }
+        }
+    }
     // LDS: twiddles (8T) + two complex images of T * ceil(Cc/2) float2
     const size_t lds_cap = 128 * 1024;
     FD_REQUIRE(ctx, (size_t)T * 8 + 2 * (size_t)T * 8 <= lds_cap, "%s: T=%d too long for the LDS-resident transform",
@@ -513,6 +572,40 @@ __global__ __launch_bounds__(256) void k_transpose_batched(const float* __restri
 
 }  // namespace
 
+// out[b, s, c] = sum_t in[b, t, c] Mx[t, s]  for a (T, T) device matrix: the Gaussian mixing of smooth_frequency and the
+// dense form of the transform at lengths with a dominating prime factor.  Single channel: ONE fp32-MFMA GEMM
+// (B, T) . (T, T).  Several channels: per chunk of series, (b, t, c) -> (b, c, t) [into `out`], one GEMM (nb*C, T) . (T, T) into
+// the context's GEMM scratch, and back to (b, t, c) (3.8 ms -> 0.5 ms at (4096, 255, 28)); the per-element VALU kernel remains
+// for shapes whose single series does not fit the scratch.  `in` and `out` must not alias.
+void fd_apply_row_matrix(fd_ctx* ctx, const float* in, const float* Mx, float* out, int B, int T, int C, hipStream_t stream) {
+    if (C == 1 && (long long)B * T < 2147483647LL) {
+        fdgemm::Args g{in, Mx, out, nullptr, B, T, T, (long long)T, 1, (long long)T, 1, (long long)T, 1.0f, 0, 0};
+        fdgemm::launch(g, stream);
+        return;
+    }
+    size_t nscr = 0;
+    float* scr = fd_gemm_scratch(ctx, &nscr);
+    const size_t per_b = (size_t)T * C;
+    const int chunk = scr ? (int)std::min<size_t>(nscr / per_b, 65535) : 0;
+    if (chunk < 1 || (C + 31) / 32 > 65535) {
+        for (int b0 = 0; b0 < B; b0 += 65535) {
+            const int nb = std::min(65535, B - b0);
+            hipLaunchKernelGGL(k_frequency_mix, dim3((T * C + 255) / 256, nb), dim3(256), 0, stream, in + (size_t)b0 * per_b, Mx,
+                               out + (size_t)b0 * per_b, T, C);
+        }
+        return;
+    }
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = std::min(chunk, B - b0);
+        const float* xin = in + (size_t)b0 * per_b;
+        float* o = out + (size_t)b0 * per_b;
+        hipLaunchKernelGGL(k_transpose_batched, dim3((C + 31) / 32, (T + 31) / 32, nb), dim3(256), 0, stream, xin, o, T, C);
+        fdgemm::Args g{o, Mx, scr, nullptr, nb * C, T, T, (long long)T, 1, (long long)T, 1, (long long)T, 1.0f, 0, 0};
+        fdgemm::launch(g, stream);
+        hipLaunchKernelGGL(k_transpose_batched, dim3((T + 31) / 32, (C + 31) / 32, nb), dim3(256), 0, stream, scr, o, C, T);
+    }
+}
+
 extern "C" int fd_spectral_density(fd_ctx* ctx, const float* xt, float* dens, int B, int T, int C, void* stream) {
     if (!ctx) return FD_ERR_ARG;
     FD_REQUIRE(ctx, xt && dens, "fd_spectral_density: null pointer");
@@ -549,37 +642,7 @@ extern "C" int fd_frequency_smooth(fd_ctx* ctx, const float* xt, float sigma, fl
     // (fourier.py:192-203): only odd lengths are defined
     FD_REQUIRE(ctx, (T & 1) == 1, "fd_frequency_smooth: max_len=%d must be odd (fourier.py:192-203)", T);
     hipLaunchKernelGGL(k_gauss_matrix, dim3(T), dim3(256), 0, (hipStream_t)stream, gauss_scratch, T, T / 2 + 1, sigma);
-    if (C == 1 && (long long)B * T < 2147483647LL) {
-        // single channel (the ECG set, the one dataset the reference smooths): out (B, T) = xt (B, T) . G (T, T) is one
-        // fp32-MFMA GEMM (1.6 ms -> 0.15 ms at 87 554 x 187)
-        fdgemm::Args g{xt, gauss_scratch, out, nullptr, B, T, T, (long long)T, 1, (long long)T, 1, (long long)T, 1.0f, 0, 0};
-        fdgemm::launch(g, (hipStream_t)stream);
-    } else {
-        // several channels: per chunk of series, (b, t, c) -> (b, c, t) [into `out`], one fp32-MFMA GEMM (nb*C, T) . (T, T)
-        // into the context's GEMM scratch, and back to (b, t, c): 3.8 ms -> 0.5 ms at (4096, 255, 28).  The per-element
-        // VALU kernel remains for shapes whose single series does not fit the scratch.
-        size_t nscr = 0;
-        float* scr = fd_gemm_scratch(ctx, &nscr);
-        const size_t per_b = (size_t)T * C;
-        const int chunk = scr ? (int)std::min<size_t>(nscr / per_b, 65535) : 0;
-        if (chunk < 1 || (C + 31) / 32 > 65535) {
-            hipLaunchKernelGGL(k_frequency_mix, dim3((T * C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, xt,
-                               gauss_scratch, out, T, C);
-        } else {
-            for (int b0 = 0; b0 < B; b0 += chunk) {
-                const int nb = std::min(chunk, B - b0);
-                const float* xin = xt + (size_t)b0 * per_b;
-                float* o = out + (size_t)b0 * per_b;
-                hipLaunchKernelGGL(k_transpose_batched, dim3((C + 31) / 32, (T + 31) / 32, nb), dim3(256), 0, (hipStream_t)stream,
-                                   xin, o, T, C);
-                fdgemm::Args g{o, gauss_scratch, scr, nullptr, nb * C, T, T, (long long)T, 1, (long long)T, 1, (long long)T, 1.0f,
-                               0, 0};
-                fdgemm::launch(g, (hipStream_t)stream);
-                hipLaunchKernelGGL(k_transpose_batched, dim3((T + 31) / 32, (C + 31) / 32, nb), dim3(256), 0, (hipStream_t)stream,
-                                   scr, o, C, T);
-            }
-        }
-    }
+    fd_apply_row_matrix(ctx, xt, gauss_scratch, out, B, T, C, (hipStream_t)stream);
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }

@@ -187,3 +187,22 @@ def test_multichannel_smoothing_across_scratch_chunks():
     assert y.shape == (B, T, C)
     pick = [0, 1, 2348, 2349, 2350, 4095]
     np.testing.assert_allclose(host(y[pick]), O.smooth_frequency(x[pick], 3.0), atol=3e-5)
+
+
+@pytest.mark.parametrize("mode", ["dense", "fft"])
+def test_transform_paths_agree_with_golden(golden, mode, monkeypatch):
+    """Lengths dominated by a large prime factor run as one dense (T, T) fp32-MFMA matrix product, the others as Stockham
+    stages; FDIFF_DFT forces either path for every length, and both must match the reference's vectors."""
+    from fourierdiffusion_amd.utils.fourier import dft, idft
+    monkeypatch.setenv("FDIFF_DFT", mode)
+    g = golden("dft")
+    for T in DFT_T:
+        for C in DFT_C:
+            x = W.randn(f"dft_x_{T}_{C}", (DFT_B, T, C), 0)
+            np.testing.assert_allclose(host(dft(dev(x))), g[f"dft_{T}_{C}"], atol=ATOL, rtol=0, err_msg=f"dft {mode} {T} {C}")
+            xt = W.randn(f"idft_x_{T}_{C}", (DFT_B, T, C), 0)
+            np.testing.assert_allclose(host(idft(dev(xt))), g[f"idft_{T}_{C}"], atol=ATOL, rtol=0, err_msg=f"idft {mode} {T} {C}")
+    for shape in ((37, 187, 1), (300, 251, 12), (2500, 134, 10), (9, 67, 3)):      # chunked / single-channel / prime lengths
+        x = W.randn("paths", shape, 41)
+        np.testing.assert_allclose(host(dft(dev(x))), O.dft(x), atol=ATOL, rtol=0)
+        np.testing.assert_allclose(host(idft(dev(x))), O.idft(x), atol=ATOL, rtol=0)
