@@ -11,6 +11,13 @@ N GPUs  : one process per GPU, each samples its own batch of 512 series (the sam
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+`python bench.py --gpus N` with N > 1 and no launcher environment re-executes itself under torch.distributed.run
+(127.0.0.1 rendezvous on a free port), so both invocation styles print the same single JSON line from rank 0.
+
+Other workloads (not the headline line; same JSON contract):
+    --workload mimic --scaling strong   BASELINE.json configs[3]: 4096 series (T=256, C=28), VE-SDE, 2000 predictor
+                                        steps, the batch divided over the N ranks (strong scaling: total work fixed)
 """
 from __future__ import annotations
 
@@ -28,7 +35,17 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-T, CH, D, L, H, F = 100, 12, 72, 10, 12, 2048
+D, L, H, F = 72, 10, 12, 2048        # default transformer (cmd/conf/score_model/default.yaml)
+WORKLOADS = {
+    # name: series shape, SDE, per-GPU batch of the weak-scaling line, reverse-diffusion steps, total batch of the strong line
+    "ecg": dict(T=100, C=12, sde=("vp", 0.1, 20.0), batch=512, n_steps=1000, strong_total=4096,
+                desc="BASELINE.json configs[1]: ecg-synth (T=100, C=12), default transformer (d_model=72, L=10, H=12, "
+                     "ff=2048), VP-SDE, fourier_noise_scaling"),
+    "mimic": dict(T=256, C=28, sde=("ve", 0.01, 2.0), batch=512, n_steps=2000, strong_total=4096,
+                  desc="BASELINE.json configs[3]: mimiciii-synth (T=256, C=28), default transformer, VE-SDE(0.01, 2), "
+                       "fourier_noise_scaling, 2000 predictor steps"),
+}
+T, CH = WORKLOADS["ecg"]["T"], WORKLOADS["ecg"]["C"]
 
 
 def flops_per_series_forward(T=T, C=CH, D=D, L=L, F=F):
@@ -39,16 +56,31 @@ def flops_per_series_forward(T=T, C=CH, D=D, L=L, F=F):
 def hbm_traffic_per_launch():
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_hbm_traffic.json,
     collected with separate rocprofv3 --pmc runs of this same command; FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md).  None when no measurement is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+    MI355X_MICROARCH.md).  (None, None) when no measurement is committed; the second element names the source."""
+    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                v = json.load(f).get("hbm_bytes_per_launch")
+            if v is not None:
+                return v, f"profiles/{name}: separate rocprofv3 --pmc passes of this command, NOT measured in this run"
+        except Exception:
+            pass
+    return None, None
 
 
-def cpu_baseline(batch: int, n_timed: int = 3):
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: one rank per GPU under torch.distributed.run, same arguments."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def cpu_baseline(batch: int, T: int, CH: int, n_timed: int = 3):
     """The reference's CPU path = the same torch-op sequence it executes (nn.TransformerEncoder eval fast path +
     diag_embed/matmul scheduler step), timed on this host's cores by oracle/torch_cpu_baseline.py on a bounded
     sample (a few reverse-diffusion steps, extrapolated x1000: every step costs the same)."""
@@ -61,8 +93,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=512)
-    ap.add_argument("--diffusion-steps", type=int, default=1000)
+    ap.add_argument("--workload", default="ecg", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--batch", type=int, default=None, help="series per GPU (weak) / in total (strong)")
+    ap.add_argument("--diffusion-steps", type=int, default=None)
     ap.add_argument("--precision", default=os.environ.get("FDIFF_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -70,9 +104,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
-                         f"(WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    wl = WORKLOADS[args.workload]
+    T, CH = wl["T"], wl["C"]
     # one rank per GPU; the modulo only matters for the single-GPU rehearsal of the multi-rank path
     # (FDIFF_BENCH_BACKEND=gloo, tests/test_gpu_entrypoints.py), where two ranks share cuda:0
     dev_index = local_rank % max(1, torch.cuda.device_count())
@@ -91,18 +128,29 @@ def main():
 
     from fourierdiffusion_amd import _C, _rng
     from fourierdiffusion_amd.models.score_models import ScoreModule
-    from fourierdiffusion_amd.schedulers.sde import VPScheduler
+    from fourierdiffusion_amd.parallel import shard_range
+    from fourierdiffusion_amd.schedulers.sde import VEScheduler, VPScheduler
 
     torch.manual_seed(42)
     _rng.set_rank(rank)
-    sch = VPScheduler(beta_min=0.1, beta_max=20.0, fourier_noise_scaling=True)
+    kind, p0, p1 = wl["sde"]
+    if kind == "vp":
+        sch = VPScheduler(beta_min=p0, beta_max=p1, fourier_noise_scaling=True)
+    else:
+        sch = VEScheduler(sigma_min=p0, sigma_max=p1, fourier_noise_scaling=True)
     sch.set_noise_scaling(T)
     model = ScoreModule(n_channels=CH, max_len=T, noise_scheduler=sch, fourier_noise_scaling=True, d_model=D,
                         num_layers=L, n_head=H).to(dev)
     model.precision = args.precision
     model.eval()
-    N = args.diffusion_steps
-    B = args.batch
+    N = args.diffusion_steps or wl["n_steps"]
+    if args.scaling == "weak":
+        B = args.batch or wl["batch"]                     # per GPU, fixed as the number of GPUs grows
+        total_series = world * B
+    else:
+        total_series = args.batch or wl["strong_total"]   # fixed total, divided over the ranks
+        lo, hi = shard_range(total_series, rank, world)
+        B = hi - lo
     sch.set_timesteps(N)
     ctx, h = model._engine()
     lib = _C.lib()
@@ -145,12 +193,12 @@ def main():
         elapsed = float(tt.item())
 
     if rank == 0:
-        series = world * B * args.steps
+        series = total_series * args.steps
         value = series / elapsed
         ms_per_step = 1e3 * elapsed / args.steps
-        fwd_flops = flops_per_series_forward() * B          # per score-net forward of the batch
+        fwd_flops = flops_per_series_forward(T=T, C=CH)      # per series per score-net forward
         out = {
-            "metric": "sampled series/sec (T=100, C=12)",
+            "metric": f"sampled series/sec (T={T}, C={CH})",
             "value": value,
             "unit": "series/s",
             "n_gpus": world,
@@ -159,15 +207,15 @@ def main():
             "ms_per_step": ms_per_step,
             "score_net_step_ms": ms_per_step / N,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.precision if args.precision == "bf16" else "f32",
             "data": "synthetic (Philox prior, random-init weights seed 42)",
-            "config": {"workload": "BASELINE.json configs[1]: ecg-synth (T=100, C=12), default transformer "
-                                   "(d_model=72, L=10, H=12, ff=2048), VP-SDE, fourier_noise_scaling, "
-                                   f"batch={B}/GPU, {N} reverse-diffusion steps per bench step",
-                       "global_batch": world * B, "seq_len": T, "parallelism": f"sample-batch shard x{world}"},
-            "achieved_tflops_whole_step": fwd_flops * N * world * args.steps / elapsed / 1e12,
+            "config": {"workload": wl["desc"] + (f", batch={B}/GPU" if args.scaling == "weak" else
+                                                 f", {total_series} series divided over the ranks")
+                                   + f", {N} reverse-diffusion steps per bench step",
+                       "global_batch": total_series, "seq_len": T, "parallelism": f"sample-batch shard x{world}"},
+            "achieved_tflops_whole_step": fwd_flops * N * total_series * args.steps / elapsed / 1e12,
         }
         roof = None
         if prof:
@@ -178,14 +226,17 @@ def main():
             if lib.fd_prof_end(ctx, name, C.byref(avg_us), C.byref(cnt), C.byref(flops)) == 0 and cnt.value > 0:
                 peak = 2500.0 if args.precision == "bf16" else 157.3     # dense MFMA peak, MI355X_MICROARCH.md
                 ach = flops.value / (avg_us.value * 1e-6) / 1e12
-                roof = {"bound": "mfma", "kernel": name.value.decode(), "achieved": ach, "peak": peak,
-                        "unit": "TFLOP/s", "frac": ach / peak, "traffic": hbm_traffic_per_launch(),
+                traffic, traffic_src = hbm_traffic_per_launch() if args.workload == "ecg" and B == 512 and N == 1000 \
+                    else (None, None)
+                roof = {"bound": "mfma", "kernel": name.value.decode(), "instantiation": model.plan(B)[0],
+                        "achieved": ach, "peak": peak,
+                        "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
                         "avg_kernel_us": avg_us.value, "launches_timed": cnt.value,
                         "flops_per_launch": flops.value}
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(B)
+                out["cpu_baseline"] = cpu_baseline(B, T, CH)
             except Exception as e:   # the GPU result must still be reported
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))

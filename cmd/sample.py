@@ -20,7 +20,7 @@ import yaml  # noqa: E402
 
 from fourierdiffusion_amd import _rng  # noqa: E402
 from fourierdiffusion_amd.config import compose, instantiate, load_yaml, save_yaml  # noqa: E402
-from fourierdiffusion_amd.parallel import env, init_process_group, shard_range  # noqa: E402
+from fourierdiffusion_amd.parallel import bind_device, env, init_process_group, shard_range  # noqa: E402
 from fourierdiffusion_amd.utils.extraction import dict_to_str, get_best_checkpoint, get_model_type  # noqa: E402
 from fourierdiffusion_amd.utils.fourier import destandardize_idft, idft  # noqa: E402
 
@@ -32,10 +32,7 @@ class SamplingRunner:
         logging.info(f"Welcome in the sampling script! You are using the following config:\n{dict_to_str(cfg)}")
         self.dist = init_process_group()
         _rng.set_rank(self.dist.rank)
-        self.dev_index = 0
-        if torch.cuda.is_available():
-            self.dev_index = self.dist.local_rank % torch.cuda.device_count()   # (modulo: ranks may share a GPU in tests)
-            torch.cuda.set_device(self.dev_index)
+        self.dev_index = bind_device()
         self.model_path = Path(cfg.model_path)
         self.model_id = cfg.model_id
         if self.model_id == "latest":

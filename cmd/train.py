@@ -19,6 +19,7 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 
 from fourierdiffusion_amd.config import compose, instantiate, save_yaml  # noqa: E402
+from fourierdiffusion_amd.parallel import bind_device  # noqa: E402
 from fourierdiffusion_amd.utils.callbacks import SamplingCallback  # noqa: E402
 from fourierdiffusion_amd.utils.extraction import dict_to_str, get_training_params  # noqa: E402
 
@@ -26,6 +27,7 @@ from fourierdiffusion_amd.utils.extraction import dict_to_str, get_training_para
 class TrainingRunner:
     def __init__(self, cfg) -> None:
         torch.manual_seed(cfg.random_seed)
+        bind_device()         # this rank's GPU, before the datamodule / callbacks place anything on "cuda"
         logging.info(f"Welcome in the training script! You are using the following config:\n{dict_to_str(cfg)}")
         run_id = cfg.get("run_id") or time.strftime("run-%Y%m%d-%H%M%S")
         self.score_model = instantiate(cfg.score_model)

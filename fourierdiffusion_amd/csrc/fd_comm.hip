@@ -85,7 +85,11 @@ extern "C" int fd_comm_destroy(fd_ctx* ctx) {
 extern "C" int fd_allreduce_grads(fd_ctx* ctx, float* buf, int64_t n, float scale, void* stream) {
     if (!ctx) return FD_ERR_ARG;
     FD_REQUIRE(ctx, buf && n > 0, "fd_allreduce_grads: null buffer or n <= 0");
-    if (ctx->comm) {
+    // no communicator = no exchange happened: scaling by 1/world anyway would hand the caller a silently wrong gradient
+    if (!ctx->comm)
+        return fd_fail(ctx, FD_ERR_STATE, "fd_allreduce_grads: no communicator (call fd_comm_init first; a single-process "
+                       "job does not need this call)");
+    {
         ncclResult_t r = g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat, ncclSum, (ncclComm_t)ctx->comm,
                                           (hipStream_t)stream);
         if (r != ncclSuccess)

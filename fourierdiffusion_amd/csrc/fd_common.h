@@ -18,6 +18,9 @@ struct fd_ctx {
     // grow-only scratch arena; carved per call by fd_ws
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    // bumped whenever a call (re)carves or regrows the arena: the training forward stamps it and the backward verifies
+    // that nothing else used the arena in between (the saved activations live there)
+    uint64_t ws_gen = 0;
     // small pinned staging buffer for per-call coefficient tables
     void* comm = nullptr;   // ncclComm_t when fd_comm_init succeeded
     int rank = 0, nranks = 1;
@@ -94,7 +97,9 @@ int fd_ws_reserve(fd_ctx* ctx, size_t bytes);
 struct fd_ws {
     char* base;
     size_t off = 0, cap;
-    explicit fd_ws(fd_ctx* c) : base((char*)c->ws), cap(c->ws_bytes) {}
+    explicit fd_ws(fd_ctx* c, bool reader = false) : base((char*)c->ws), cap(c->ws_bytes) {
+        if (!reader) ++c->ws_gen;          // reader = re-derives pointers of an earlier carve without writing a new layout
+    }
     template <typename T>
     T* take(size_t n) {
         size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);

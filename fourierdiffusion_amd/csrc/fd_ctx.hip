@@ -34,6 +34,7 @@ extern "C" const char* fd_last_error(fd_ctx* ctx) { return ctx ? ctx->err.c_str(
 extern "C" size_t fd_ctx_workspace_bytes(fd_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
 
 int fd_ws_reserve(fd_ctx* ctx, size_t bytes) {
+    ++ctx->ws_gen;                      // whoever reserves is about to use the arena
     if (bytes <= ctx->ws_bytes) return FD_OK;
     FD_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->ws) {

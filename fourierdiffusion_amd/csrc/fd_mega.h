@@ -50,4 +50,4 @@ struct fd_mega_params {
 };
 
 int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int kso, int mt, int nw, int grid, size_t lds,
-                   hipStream_t s);
+                   hipStream_t s, char* describe = nullptr);

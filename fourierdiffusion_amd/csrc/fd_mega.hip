@@ -1194,13 +1194,25 @@ static bool shape_matches(const fd_mega_params& P, int ks1, int dt, int kso, int
            P.S == SH::S && P.NPG == SH::NPG && P.rot == SH::rot && P.L == SH::L && P.F == SH::F;
 }
 
+// `describe` (>= 192 bytes, nullable): when given, the instantiation that WOULD run is written there and nothing is
+// launched (fd_score_plan: the parity tests assert which kernel they exercised).
+#define FD_MEGA_GO(K, T_, O, M_, SH, NAME)                                                             \
+    do {                                                                                               \
+        if (describe) {                                                                                \
+            snprintf(describe, 192, "k_mega<%d,%d,%d,%d,%s> S=%d NPG=%d rot=%d grid=%d lds=%zu", K, T_, O, M_, NAME, P.S, \
+                     P.NPG, P.rot, grid, lds);                                                         \
+            return FD_OK;                                                                              \
+        }                                                                                              \
+        return launch_mega_t<K, T_, O, M_, SH>(ctx, P, grid, lds, s);                                  \
+    } while (0)
+
 int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int kso, int mt, int nw, int grid, size_t lds,
-                   hipStream_t s) {
+                   hipStream_t s, char* describe) {
     if (nw != 8) return fd_fail(ctx, FD_ERR_UNSUPPORTED, "persistent kernel: only 8-wave workgroups are instantiated");
     if (!getenv("FDIFF_MEGA_GENERIC")) {
-        if (shape_matches<ShapeEcg>(P, ks1, dt, kso, mt)) return launch_mega_t<3, 5, 3, 4, ShapeEcg>(ctx, P, grid, lds, s);
-        if (shape_matches<ShapeNasdaq>(P, ks1, dt, kso, mt)) return launch_mega_t<3, 5, 3, 4, ShapeNasdaq>(ctx, P, grid, lds, s);
-        if (shape_matches<ShapeMimic>(P, ks1, dt, kso, mt)) return launch_mega_t<3, 5, 3, 4, ShapeMimic>(ctx, P, grid, lds, s);
+        if (shape_matches<ShapeEcg>(P, ks1, dt, kso, mt)) FD_MEGA_GO(3, 5, 3, 4, ShapeEcg, "ShapeStatic<100,72,12,12,2,3,2,10,2048>");
+        if (shape_matches<ShapeNasdaq>(P, ks1, dt, kso, mt)) FD_MEGA_GO(3, 5, 3, 4, ShapeNasdaq, "ShapeStatic<252,72,6,12,1,2,1,10,2048>");
+        if (shape_matches<ShapeMimic>(P, ks1, dt, kso, mt)) FD_MEGA_GO(3, 5, 3, 4, ShapeMimic, "ShapeStatic<256,72,28,12,1,2,1,10,2048>");
     }
 #ifdef FD_MEGA_EXTRA_SHAPE
     // Ahead-of-time specialisation for one more workload (scripts/specialize.sh builds a library variant with
@@ -1212,22 +1224,22 @@ int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int ks
         if (!getenv("FDIFF_MEGA_GENERIC") && ks1 == xt[0] && dt == xt[1] && kso == xt[2] && mt == xt[3] && P.T == ShapeExtra::T &&
             P.D == ShapeExtra::D && P.C == ShapeExtra::C && P.H == ShapeExtra::H && P.S == ShapeExtra::S &&
             P.NPG == ShapeExtra::NPG && P.rot == ShapeExtra::rot && P.L == ShapeExtra::L && P.F == ShapeExtra::F)
-            return launch_mega_t<xt[0], xt[1], xt[2], xt[3], ShapeExtra>(ctx, P, grid, lds, s);
+            FD_MEGA_GO(xt[0], xt[1], xt[2], xt[3], ShapeExtra, "ShapeStatic<extra>");
     }
 #endif
     // the hydra default transformer (d_model 72, 12 heads, 10 layers, ff 2048) at any other series shape
     using ShapeDefaultModel = ShapeModel<72, 12, 10, 2048>;
     if (!getenv("FDIFF_MEGA_GENERIC") && ks1 == 3 && dt == 5 && kso == 3 && P.D == 72 && P.H == 12 && P.L == 10 && P.F == 2048) {
         switch (mt) {
-            case 1: return launch_mega_t<3, 5, 3, 1, ShapeDefaultModel>(ctx, P, grid, lds, s);
-            case 2: return launch_mega_t<3, 5, 3, 2, ShapeDefaultModel>(ctx, P, grid, lds, s);
-            case 3: return launch_mega_t<3, 5, 3, 3, ShapeDefaultModel>(ctx, P, grid, lds, s);
-            case 4: return launch_mega_t<3, 5, 3, 4, ShapeDefaultModel>(ctx, P, grid, lds, s);
+            case 1: FD_MEGA_GO(3, 5, 3, 1, ShapeDefaultModel, "ShapeModel<72,12,10,2048>");
+            case 2: FD_MEGA_GO(3, 5, 3, 2, ShapeDefaultModel, "ShapeModel<72,12,10,2048>");
+            case 3: FD_MEGA_GO(3, 5, 3, 3, ShapeDefaultModel, "ShapeModel<72,12,10,2048>");
+            case 4: FD_MEGA_GO(3, 5, 3, 4, ShapeDefaultModel, "ShapeModel<72,12,10,2048>");
             default: break;
         }
     }
 #define FD_MEGA_CASE(K, T_, O, M_)                                                                 \
-    if (ks1 == K && dt == T_ && kso == O && mt == M_) return launch_mega_t<K, T_, O, M_, ShapeDyn>(ctx, P, grid, lds, s);
+    if (ks1 == K && dt == T_ && kso == O && mt == M_) FD_MEGA_GO(K, T_, O, M_, ShapeDyn, "ShapeDyn");
 #define FD_MEGA_MT(K, T_, O) FD_MEGA_CASE(K, T_, O, 1) FD_MEGA_CASE(K, T_, O, 2) FD_MEGA_CASE(K, T_, O, 3) FD_MEGA_CASE(K, T_, O, 4)
     FD_MEGA_MT(3, 5, 3)   // d_model 72, 12 heads (hydra default)
     FD_MEGA_MT(2, 4, 3)   // d_model 60, 12 heads (class default)

@@ -28,6 +28,8 @@ struct fd_score {
     uint64_t saved_seed = 0, saved_offset = 0;
     const float* saved_x = nullptr;
     const float* saved_t = nullptr;
+    uint64_t saved_ws_gen = 0;      // ctx->ws_gen right after the training forward carved the arena
+    void* saved_ws = nullptr;       // arena base then (a regrow moves it)
 };
 
 // activations kept by the training forward, carved from the ctx workspace

@@ -970,3 +970,29 @@ int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, c
         return fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.nw, pl.grid, pl.lds, s);
     }
 }
+
+// Which kernel path serves a batch of B series in `mode` (no launch, no device work).  The parity tests use it to assert
+// that the instantiation they mean to exercise -- e.g. the two-series-per-workgroup static kernel the bench times -- is
+// the one that ran; environment switches (FDIFF_NO_MEGA, FDIFF_MEGA_GENERIC, FDIFF_SAMPLER_STEPWISE) are honoured exactly as
+// the product entry points honour them.
+extern "C" int fd_score_plan(fd_score* m, int B, int mode, char* out /* >= 192 bytes */, int* series_per_workgroup) {
+    if (!m) return FD_ERR_ARG;
+    fd_ctx* ctx = m->ctx;
+    FD_REQUIRE(ctx, out && B > 0, "fd_score_plan: null output or B=%d", B);
+    if (series_per_workgroup) *series_per_workgroup = 0;
+    if (mode == FD_MODE_F32) {
+        snprintf(out, 192, "fp32 parity path (per-op kernels, fd_score_f32.hip)");
+        return FD_OK;
+    }
+    FD_REQUIRE(ctx, mode == FD_MODE_BF16, "fd_score_plan: unknown mode %d", mode);
+    if (!m->bf16 || !m->bf16->supported) return fd_fail(ctx, FD_ERR_UNSUPPORTED, "fd_score_plan: bf16 path unsupported for this model");
+    const MegaPlan pl = plan_mega(m, B);
+    if (pl.ok && !getenv("FDIFF_NO_MEGA")) {
+        fd_mega_params MP;
+        if (int rc = fill_mega_params(m, pl, B, MP)) return rc;
+        if (series_per_workgroup) *series_per_workgroup = pl.S;
+        return fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.nw, pl.grid, pl.lds, nullptr, out);
+    }
+    snprintf(out, 192, "per-layer bf16 kernels (k_attention_bf16 + k_ffn_ln)");
+    return FD_OK;
+}

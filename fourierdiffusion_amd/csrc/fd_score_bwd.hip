@@ -453,7 +453,13 @@ extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, i
     const size_t fwd_bytes = fd_score_f32_workspace(m, B, true);
     if (ctx->ws_bytes < fwd_bytes + fd_score_bwd_workspace(m, B))
         return fd_fail(ctx, FD_ERR_STATE, "fd_score_backward: workspace was resized since the training forward");
-    fd_ws ws(ctx);
+    if (ctx->ws_gen != m->saved_ws_gen || ctx->ws != m->saved_ws)
+        return fd_fail(ctx, FD_ERR_STATE, "fd_score_backward: another engine call used the context workspace after "
+                       "fd_score_forward_train (the saved activations live there); run forward_train -> loss -> backward "
+                       "without other workspace-using calls on this context in between");
+    m->have_saved = false;            // one backward per training forward (its scratch overlays nothing, but the dropout
+                                      // masks / inputs belong to that forward only)
+    fd_ws ws(ctx, /*reader=*/true);
     fd_saved sv;
     fd_score_carve_saved(m, B, ws, sv);
     ws.off = fwd_bytes;

@@ -591,6 +591,8 @@ extern "C" int fd_score_forward_train(fd_score* m, const float* x, const float* 
         m->saved_offset = offset;
         m->saved_x = x;
         m->saved_t = t;
+        m->saved_ws_gen = ctx->ws_gen;
+        m->saved_ws = ctx->ws;
     }
     return rc;
 }

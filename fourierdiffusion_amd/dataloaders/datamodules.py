@@ -66,7 +66,11 @@ class DiffusionDataset:
 
 class BatchLoader:
     """Iterates DiffusableBatch slices of a device-resident dataset (the DataLoader + collate_batch of the
-    reference, datamodules.py:109-114).  `rank/world` shard every batch for data-parallel training."""
+    reference, datamodules.py:109-114).  `rank/world` shard every GLOBAL batch for data-parallel training: rank r takes
+    the strided slice idx[r::world].  Every rank yields exactly one item per global batch -- also when its slice is empty
+    (a last batch smaller than `world`): the Trainer still joins the gradient all-reduce with a zero contribution, so
+    the collective counts of the ranks can never diverge.  Each item carries `global_size` (samples of the global batch)
+    so that the exchange can weight a rank by n_local / n_global (unequal slices would otherwise bias the mean)."""
 
     def __init__(self, dataset: DiffusionDataset, batch_size: int, shuffle: bool, rank: int = 0, world: int = 1) -> None:
         self.dataset, self.batch_size, self.shuffle, self.rank, self.world = dataset, batch_size, shuffle, rank, world
@@ -80,13 +84,13 @@ class BatchLoader:
         order = torch.randperm(n) if self.shuffle else torch.arange(n)      # torch's generator: same on every rank
         for i in range(0, n, self.batch_size):
             idx = order[i:i + self.batch_size]
+            n_global = int(idx.numel())
             if self.world > 1:
                 idx = idx[self.rank::self.world]
-                if idx.numel() == 0:
-                    continue
-            idx = idx.to(Xs.device)
-            y = None if self.dataset.y is None else self.dataset.y[idx.cpu()]
-            yield DiffusableBatch(X=Xs.index_select(0, idx).contiguous(), y=y, timesteps=None)
+            y = None if self.dataset.y is None else self.dataset.y[idx]
+            batch = DiffusableBatch(X=Xs.index_select(0, idx.to(Xs.device)).contiguous(), y=y, timesteps=None)
+            batch.global_size = n_global            # plain attribute: the reference's dataclass has no such field
+            yield batch
 
 
 class Datamodule:
@@ -105,6 +109,7 @@ class Datamodule:
         self.y_test: Optional[torch.Tensor] = None
         self.rank, self.world = 0, 1
         self._train_set: Optional[DiffusionDataset] = None
+        self._train_src: Optional[torch.Tensor] = None      # the X_train object the cache was built from
 
     # -- hooks kept from LightningDataModule
     def prepare_data(self) -> None:
@@ -121,9 +126,16 @@ class Datamodule:
 
     def set_shard(self, rank: int, world: int) -> None:
         self.rank, self.world = rank, world
+        self._train_set = None              # rebuilt on the (possibly new) current device
+
+    def invalidate(self) -> None:
+        """Call after replacing X_train / y_train: the cached device-resident training set is rebuilt."""
+        self._train_set = None
 
     def _train_dataset(self) -> DiffusionDataset:
-        if self._train_set is None or self._train_set.X.shape[0] != self.X_train.shape[0]:
+        if (self._train_set is None or self._train_set.X.shape[0] != self.X_train.shape[0]
+                or self._train_src is not self.X_train):
+            self._train_src = self.X_train
             self._train_set = DiffusionDataset(X=self.X_train, y=self.y_train, fourier_transform=self.fourier_transform,
                                                standardize=self.standardize)
         return self._train_set

@@ -221,6 +221,15 @@ class ScoreModule:
             self._dirty = False
         return ctx, self._handle
 
+    def plan(self, batch_size: int, precision: Optional[str] = None) -> Tuple[str, int]:
+        """(description of the kernel path a batch of this size takes, series per workgroup) -- fd_score_plan."""
+        ctx, h = self._engine()
+        buf = C.create_string_buffer(192)
+        spw = C.c_int(0)
+        rc = _C.lib().fd_score_plan(h, int(batch_size), _PRECISIONS[precision or self.precision], buf, C.byref(spw))
+        _C.check(rc, ctx)
+        return buf.value.decode(), spw.value
+
     # ------------------------------------------------------------------ forward / backward
     def forward(self, batch: DiffusableBatch) -> torch.Tensor:
         X = batch.X
@@ -269,8 +278,9 @@ class ScoreModule:
                            for name, off, numel, shape, _ in self._layout)
 
     # ------------------------------------------------------------------ Lightning-style hooks
-    def training_step(self, batch: DiffusableBatch, batch_idx: int = 0, dataloader_idx: int = 0) -> torch.Tensor:
-        return self.training_loss_fn(self, batch)
+    def training_step(self, batch: DiffusableBatch, batch_idx: int = 0, dataloader_idx: int = 0,
+                      grad_weight: float = 1.0) -> torch.Tensor:
+        return self.training_loss_fn(self, batch, grad_weight=grad_weight)
 
     def validation_step(self, batch: DiffusableBatch, batch_idx: int = 0, dataloader_idx: int = 0) -> torch.Tensor:
         return self.validation_loss_fn(self, batch)

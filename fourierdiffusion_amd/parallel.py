@@ -31,6 +31,17 @@ def env() -> DistEnv:
                    int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def bind_device() -> int:
+    """Make this rank's GPU (LOCAL_RANK modulo the device count) the current device.  Entry points call it BEFORE anything
+    places tensors on "cuda" (the datamodule's resident training set, callbacks' statistics, the engine context), so
+    that a multi-process run never parks every rank's data and HIP context on GPU 0.  Returns the device index."""
+    if not torch.cuda.is_available():
+        return 0
+    idx = env().local_rank % torch.cuda.device_count()      # (modulo: several ranks may share one GPU in rehearsals)
+    torch.cuda.set_device(idx)
+    return idx
+
+
 def init_process_group(backend: Optional[str] = None) -> DistEnv:
     """torch.distributed rendezvous from the launcher's env (RANK / WORLD_SIZE / MASTER_*); idempotent."""
     e = env()

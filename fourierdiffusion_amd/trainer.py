@@ -14,7 +14,7 @@ import torch
 
 from . import _rng
 from .optim import FusedAdamW
-from .parallel import DistEnv, GradExchange, init_process_group
+from .parallel import DistEnv, GradExchange, bind_device, init_process_group
 
 
 class Callback:
@@ -85,9 +85,7 @@ class Trainer:
         self.dist = init_process_group()
         _rng.set_rank(self.dist.rank)
         if torch.cuda.is_available():
-            dev_index = self.dist.local_rank % torch.cuda.device_count()      # (modulo: several ranks may share one GPU in tests)
-            torch.cuda.set_device(dev_index)
-            model.to(torch.device("cuda", dev_index))
+            model.to(torch.device("cuda", bind_device()))
         datamodule.set_shard(self.dist.rank, self.dist.world)
         exchange = GradExchange(self.dist, backend=self.grad_exchange_backend)
         opt_cfg = model.configure_optimizers()
@@ -102,19 +100,39 @@ class Trainer:
             # ---- train
             losses = []
             model.zero_grad()
-            for bi, batch in enumerate(datamodule.train_dataloader()):
-                if self.limit_train_batches is not None and bi >= self.limit_train_batches:
-                    break
-                loss = model.training_step(batch, bi)             # forward + backward inside the engine
-                losses.append(loss)
-                if (bi + 1) % self.accumulate_grad_batches:
-                    continue
+            pending = 0                                            # micro-batches accumulated since the last optimizer step
+
+            def optimizer_step() -> None:
+                nonlocal sched_step, pending
                 exchange.all_reduce_mean(model.grads)
                 self.optimizer.lr = self.optimizer.base_lr * lr_lambda(sched_step)
                 self.optimizer.step(grad_scale=1.0 / self.accumulate_grad_batches)
                 sched_step += 1                                    # LambdaLR stepped per optimizer step (interval: step)
                 self.global_step += 1
                 model.zero_grad()
+                pending = 0
+
+            for bi, batch in enumerate(datamodule.train_dataloader()):
+                if self.limit_train_batches is not None and bi >= self.limit_train_batches:
+                    break
+                # Every rank sees every global batch (possibly an EMPTY slice of a small last batch) and joins every
+                # all-reduce; a rank's contribution is weighted by its share n_local * world / n_global, so the exchange
+                # (sum / world) yields the mean over the global batch whatever the slice sizes.
+                n_local = len(batch)
+                n_global = int(getattr(batch, "global_size", n_local * self.dist.world))
+                weight = n_local * self.dist.world / max(1, n_global)
+                if n_local > 0:
+                    loss = model.training_step(batch, bi, grad_weight=weight)   # forward + backward inside the engine
+                    losses.append(loss * weight)
+                else:
+                    if model.grads is None:
+                        model.grads = torch.zeros_like(model.flat_parameters)
+                    losses.append(torch.zeros((), device=model.device))
+                pending += 1
+                if pending == self.accumulate_grad_batches:
+                    optimizer_step()
+            if pending:                                            # Lightning steps on the last batch of an epoch even when
+                optimizer_step()                                   # the accumulation window is not full
             train_loss = float(torch.stack(losses).mean().item()) if losses else float("nan")
             self.logged["train/loss"] = exchange.all_reduce_scalar_mean(train_loss)
             for cb in self.callbacks:

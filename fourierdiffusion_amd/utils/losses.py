@@ -29,8 +29,10 @@ def get_sde_loss_fn(
         raise NotImplementedError("reduce_mean=False (0.5 * sum) is never used by the reference's callers")
 
     def loss_fn(model, batch: DiffusableBatch, noise: Optional[torch.Tensor] = None,
-                backward: Optional[bool] = None) -> torch.Tensor:
-        """Scalar loss tensor (device).  noise= injects z (parity tests); backward=None means "iff train"."""
+                backward: Optional[bool] = None, grad_weight: float = 1.0) -> torch.Tensor:
+        """Scalar loss tensor (device).  noise= injects z (parity tests); backward=None means "iff train";
+        grad_weight scales this batch's gradient contribution (data-parallel ranks holding unequal slices of a global
+        batch weight theirs by n_local * world / n_global; 1.0 in every evenly divided batch)."""
         if train:
             model.train()
         else:
@@ -44,7 +46,19 @@ def get_sde_loss_fn(
             timesteps = torch.rand(X.shape[0]) * (scheduler.T - scheduler.eps) + scheduler.eps
         timesteps = _C.dev_f32(timesteps.to(dev), "timesteps")
         x_noisy, target, std = scheduler.perturb(X, timesteps, noise=noise)
-        score = model(DiffusableBatch(X=x_noisy, y=batch.y, timesteps=timesteps))
+        if train:
+            score = model(DiffusableBatch(X=x_noisy, y=batch.y, timesteps=timesteps))
+        else:
+            # The validation loss drives ModelCheckpoint's best-model choice and the two-decimal checkpoint name: it is
+            # evaluated with the exact-f32 kernels whatever `model.precision` says (bf16 MFMA is for sampling).
+            saved = getattr(model, "precision", None)
+            if saved is not None:
+                model.precision = getattr(model, "eval_loss_precision", "fp32")
+            try:
+                score = model(DiffusableBatch(X=x_noisy, y=batch.y, timesteps=timesteps))
+            finally:
+                if saved is not None:
+                    model.precision = saved
         B, T, Cn = X.shape
         loss = torch.empty(1, device=dev, dtype=torch.float32)
         dscore = torch.empty_like(score) if do_bwd else None
@@ -54,6 +68,8 @@ def get_sde_loss_fn(
                                   _C.stream_of(score))
         _C.check(rc, h)
         if do_bwd:
+            if grad_weight != 1.0:
+                dscore.mul_(float(grad_weight))      # only on unevenly divided (last) batches: off the steady-state path
             model.backward(dscore, accumulate=True)
         return loss[0]
 

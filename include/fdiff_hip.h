@@ -184,6 +184,12 @@ int fd_score_prepare(fd_score* m, const float* params, void* stream);
 int fd_score_forward(fd_score* m, const float* x, const float* t, float* out, int B, int mode,
                      void* stream);
 
+/* Introspection (no launch): writes a description of the kernel path that fd_score_forward / fd_sampler_run take for a
+ * batch of B series in `mode` -- for the persistent kernel the template instantiation, series per workgroup S, grid and
+ * LDS bytes.  The parity tests assert through it that the instantiation they target really runs (the ecg bench workload
+ * is `ShapeStatic<100,72,12,12,2,...>` with S = 2 on a 256-CU device).  No reference counterpart. */
+int fd_score_plan(fd_score* m, int B, int mode, char* out /* >= 192 bytes */, int* series_per_workgroup /* nullable */);
+
 /* Training forward: keeps activations in the ctx workspace for fd_score_backward.
  * dropout_p > 0 applies the four dropout sites of nn.TransformerEncoderLayer with masks
  * from Philox(seed, offset) (regenerated in backward). */

@@ -35,3 +35,22 @@ def make_model(cfg, kind="vp", p=(0.1, 20.0), scaling=True, seed=1234, precision
 
 def oracle_sde(kind, p, scaling, T):
     return O.SDEParams(kind, p[0], p[1], O.noise_scaling(T, scaling))
+
+
+def report_err(tag, got, ref):
+    """(max error / scale of ref, relative rms); printed and appended to gpurun_out/parity_errors.log so that the margins
+    of the bf16 tolerances are on record (profiles/r02_parity_errors.txt is a copy of one such run)."""
+    import os
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    err = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+    rms = float(np.sqrt(((got - ref) ** 2).mean()) / max(np.sqrt((ref ** 2).mean()), 1e-30))
+    line = f"[parity] {tag}: max err / scale = {err:.3e}, relative rms = {rms:.3e}"
+    print(line)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity_errors.log"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    return err, rms

@@ -82,3 +82,126 @@ def test_rank_offsets_are_disjoint():
     k3, o3 = _rng.stream()
     _rng.set_rank(0)
     assert k0 == k3 and o0 == 0 and o3 == 3 << 56
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Trainer.fit under world_size 2 with a LAST BATCH SMALLER THAN THE WORLD (n % batch_size == 1, the reference's ECG case:
+# 87 553 rows, batch 64): every rank must join every all-reduce (an empty slice contributes zero), slices of unequal size
+# are weighted by n_local / n_global, and a partial accumulation window is flushed at the end of the epoch.
+class _QuadModel:
+    """Stand-in for ScoreModule on the CPU: loss = mean_i |w - x_i|^2 / 2 over the batch; the gradient of a batch is
+    w - mean(x).  Implements exactly the surface Trainer.fit touches."""
+
+    def __init__(self, dim):
+        self.flat_parameters = torch.zeros(dim, dtype=torch.float64)
+        self.grads = None
+        self.device = torch.device("cpu")
+        self.steps = []
+
+    def to(self, dev):
+        return self
+
+    def eval(self):
+        return self
+
+    def zero_grad(self):
+        if self.grads is not None:
+            self.grads.zero_()
+
+    def training_step(self, batch, bi, grad_weight=1.0):
+        x = batch.X.reshape(len(batch), -1).double()
+        if self.grads is None:
+            self.grads = torch.zeros_like(self.flat_parameters)
+        self.grads += grad_weight * (self.flat_parameters - x.mean(0))
+        return 0.5 * ((self.flat_parameters - x) ** 2).sum(1).mean()
+
+    def validation_step(self, batch, bi):
+        return torch.zeros(())
+
+    def configure_optimizers(self):
+        model = self
+
+        class _SGD:
+            lr = base_lr = 0.5
+            max_grad_norm = None
+
+            def step(self, grad_scale=1.0):
+                model.steps.append(model.grads.clone() * grad_scale)
+                model.flat_parameters -= self.lr * grad_scale * model.grads
+
+            def state_dict(self):
+                return {}
+        return {"optimizer": _SGD(), "lr_scheduler": {"scheduler": lambda step: 1.0, "interval": "step"}}
+
+
+def _fit_worker(rank, world, port, out_dir, n, bs, accum):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), FDIFF_DIST_BACKEND="gloo", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    import torch.distributed as dist
+    from fourierdiffusion_amd.dataloaders.datamodules import TensorDatamodule
+    from fourierdiffusion_amd.trainer import Trainer
+    torch.manual_seed(5)
+    X = torch.randn(n, 3, 2)
+    dm = TensorDatamodule(X_train=X, X_test=X[:4], batch_size=bs)
+    model = _QuadModel(6)
+    tr = Trainer(max_epochs=2, grad_exchange="torch", accumulate_grad_batches=accum, enable_progress_bar=False)
+    torch.manual_seed(77)                    # the shuffle permutation: same on every rank
+    tr.fit(model, dm)
+    torch.save({"w": model.flat_parameters, "steps": tr.global_step, "loss": tr.logged["train/loss"]},
+               os.path.join(out_dir, f"fit_{rank}.pt"))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,bs,accum", [(17, 8, 1), (9, 4, 2), (21, 5, 1)])
+def test_world2_fit_small_last_batch_matches_single_process(tmp_path, n, bs, accum):
+    """(17, 8): last global batch has ONE sample -> rank 1's slice is empty.  (9, 4, accum 2): 3 batches, the last
+    accumulation window is partial.  (21, 5): uneven 3 + 2 slices in every batch.  Both ranks must finish (no hang), end
+    with identical parameters, and match the single-process run on the full batches to fp64 rounding."""
+    world = 2
+    mp.spawn(_fit_worker, args=(world, _free_port(), str(tmp_path), n, bs, accum), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"fit_{r}.pt") for r in range(world)]
+    single = tmp_path / "single"
+    single.mkdir()
+    _fit_single(str(single), n, bs, accum)
+    ref = torch.load(single / "fit_0.pt")
+    assert res[0]["steps"] == res[1]["steps"] == ref["steps"]
+    assert torch.equal(res[0]["w"], res[1]["w"])
+    assert torch.allclose(res[0]["w"], ref["w"], rtol=0, atol=1e-12)
+    assert res[0]["loss"] == pytest.approx(ref["loss"], rel=1e-9)
+
+
+def _fit_single(out_dir, n, bs, accum):
+    saved = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    for k in saved:
+        os.environ.pop(k, None)
+    try:
+        from fourierdiffusion_amd.dataloaders.datamodules import TensorDatamodule
+        from fourierdiffusion_amd.trainer import Trainer
+        torch.manual_seed(5)
+        X = torch.randn(n, 3, 2)
+        dm = TensorDatamodule(X_train=X, X_test=X[:4], batch_size=bs)
+        model = _QuadModel(6)
+        tr = Trainer(max_epochs=2, grad_exchange="torch", accumulate_grad_batches=accum, enable_progress_bar=False)
+        torch.manual_seed(77)
+        tr.fit(model, dm)
+        torch.save({"w": model.flat_parameters, "steps": tr.global_step, "loss": tr.logged["train/loss"]},
+                   os.path.join(out_dir, "fit_0.pt"))
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                os.environ[k] = v
+
+
+def test_batchloader_every_rank_yields_every_global_batch():
+    from fourierdiffusion_amd.dataloaders.datamodules import BatchLoader, DiffusionDataset
+    ds = DiffusionDataset(torch.arange(65 * 2, dtype=torch.float32).reshape(65, 2, 1))
+    counts = []
+    for rank in range(4):
+        torch.manual_seed(0)
+        items = list(BatchLoader(ds, 64, shuffle=True, rank=rank, world=4))
+        counts.append([len(b) for b in items])
+        assert [b.global_size for b in items] == [64, 1]
+    assert counts == [[16, 1], [16, 0], [16, 0], [16, 0]]

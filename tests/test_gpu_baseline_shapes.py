@@ -13,7 +13,7 @@ import torch
 from oracle import fdiff_oracle as O
 from oracle import weights as W
 
-from .gpu_util import DEV, dev, host, make_model, oracle_sde
+from .gpu_util import DEV, dev, host, make_model, oracle_sde, report_err
 
 pytestmark = pytest.mark.gpu
 
@@ -49,8 +49,7 @@ def test_forward_bf16_vs_oracle(name, B):
     t = W.uniform(f"bs_t_{name}", (B,), 2, 1e-5, 1.0)
     out = run(m, X, t)
     ref = O.score_forward(sd, X, t, cfg["H"])
-    err = np.abs(out - ref).max() / np.abs(ref).max()
-    rms = np.sqrt(((out - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())
+    err, rms = report_err(f"forward bf16 {name} B={B} ({m.plan(B)[0].split(' S=')[0]})", out, ref)
     assert err <= 2e-2 and rms <= 1e-2, (err, rms)
 
 
@@ -89,8 +88,7 @@ def test_forward_bf16_odd_shapes_vs_oracle(name):
     t = W.uniform(f"os_t_{name}", (B,), 2, 1e-5, 1.0)
     out = run(m, X, t)
     ref = O.score_forward(sd, X, t, cfg["H"])
-    err = np.abs(out - ref).max() / np.abs(ref).max()
-    rms = np.sqrt(((out - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())
+    err, rms = report_err(f"forward bf16 {name} B={B} ({m.plan(B)[0].split(' S=')[0]})", out, ref)
     assert err <= 2e-2 and rms <= 1e-2, (err, rms)
 
 

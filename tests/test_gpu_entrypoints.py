@@ -82,29 +82,48 @@ def test_fourier_datamodule_roundtrip_and_standardisation():
     assert tr.shape == (60, 20, 3) and abs(float(tr.mean())) < 0.05 and abs(float(tr.std()) - 1.0) < 0.05
 
 
-def test_bench_two_rank_rehearsal():
-    """bench.py's multi-rank path (one process per rank under torch.distributed.run, barrier-bracketed timing, MAX over
-    ranks, rank 0 prints ONE JSON line with the whole-job value).  The box has one GPU, so both ranks share cuda:0 and
-    rendezvous over gloo (FDIFF_BENCH_BACKEND); on the 8-GPU node the same code runs with backend "nccl" (= RCCL)."""
+def _run_bench(extra, launcher):
     import json
     import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, FDIFF_BENCH_BACKEND="gloo", PYTHONPATH=root)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--batch", "64", "--diffusion-steps", "20"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--diffusion-steps", "20"] + extra
+    if launcher:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + args
+    else:
+        cmd = [sys.executable] + args                     # plain `python bench.py --gpus 2`: bench.py launches its own ranks
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("launcher", [False, True])
+def test_bench_two_rank_rehearsal(launcher):
+    """bench.py's multi-rank path (one process per rank, barrier-bracketed timing, MAX over ranks, rank 0 prints ONE JSON
+    line with the whole-job value), driven both ways: plain `python bench.py --gpus 2` (self-launching) and under
+    torch.distributed.run.  The box has one GPU, so both ranks share cuda:0 and rendezvous over gloo
+    (FDIFF_BENCH_BACKEND); on the 8-GPU node the same code runs with backend "nccl" (= RCCL)."""
+    d = _run_bench(["--batch", "64"], launcher)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+    assert d["metric"] == "sampled series/sec (T=100, C=12)"
+
+
+def test_bench_strong_scaling_rehearsal():
+    """--workload mimic --scaling strong (BASELINE.json configs[3]): a fixed total divided over the ranks."""
+    d = _run_bench(["--workload", "mimic", "--scaling", "strong", "--batch", "33"], launcher=False)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 33 and d["scaling"] == "strong"
+    assert d["metric"] == "sampled series/sec (T=256, C=28)" and d["value"] > 0
 
 
 def test_ecg_datamodule_preprocessing_on_the_engine(tmp_path):

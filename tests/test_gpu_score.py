@@ -9,7 +9,7 @@ from oracle import fdiff_oracle as O
 from oracle import weights as W
 from oracle.make_golden import CFG_DEFAULT, CFG_ODD, CFG_TINY
 
-from .gpu_util import DEV, dev, host, make_model
+from .gpu_util import DEV, dev, host, make_model, report_err
 
 pytestmark = pytest.mark.gpu
 CFGS = {"default": CFG_DEFAULT, "tiny": CFG_TINY, "odd": CFG_ODD}
@@ -87,10 +87,11 @@ def test_forward_bf16_vs_oracle(name, B):
     t = W.uniform(f"score_t_{name}", (B,), 2, 1e-5, 1.0)
     out = run(m, X, t)
     ref = O.score_forward(sd, X, t, cfg["H"])
-    scale = np.abs(ref).max()
-    err = np.abs(out - ref).max() / scale
-    rms = np.sqrt(((out - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())
-    assert err <= 2e-2 and rms <= 1e-2, (err, rms)
+    err, rms = report_err(f"forward bf16 {name} B={B} ({m.plan(B)[0].split(' S=')[0]})", out, ref)
+    # default / odd models: SURVEY A.7's 1e-2; the d_model=8 toy has 8-term dot products, where a single bf16 rounding
+    # (2^-9) is a larger share of the output: 2e-2
+    tol = 2e-2 if name == "tiny" else 1e-2
+    assert err <= tol and rms <= 1e-2, (err, rms)
 
 
 def test_reference_checkpoint_forward_vs_golden(golden):
