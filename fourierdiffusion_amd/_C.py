@@ -72,6 +72,7 @@ _PROTOS = {
     "fd_score_prepare": (C.c_int, [_vp, _vp, _vp]),
     "fd_score_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "fd_score_plan": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int)]),
+    "fd_score_set_train_mode": (C.c_int, [_vp, C.c_int]),
     "fd_score_forward_train": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_float, C.c_uint64, C.c_uint64, _vp]),
     "fd_score_backward": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "fd_sampler_run": (C.c_int, [_vp, C.POINTER(SdeParams), _vp, _vp, C.c_int, C.c_float, _vp, _vp,

@@ -28,6 +28,10 @@ struct fd_ctx {
     // split-K partial sums of the exact-f32 GEMMs (allocated on first use, freed with the context)
     float* gemm_scratch = nullptr;
     size_t gemm_scratch_floats = 0;
+    // per-block partial sums of the two-stage (fixed-order, atomic-free) reductions: column sums, LayerNorm parameter
+    // gradients, gradient norm
+    float* red_scratch = nullptr;
+    size_t red_scratch_floats = 0;
     // FFT twiddle tables (T, device pointer), built on first use of a length
     std::vector<std::pair<int, void*>> fft_tw;
     // measurement hooks (fd_prof_begin / fd_prof_end)
@@ -38,6 +42,11 @@ struct fd_ctx {
 };
 
 float* fd_gemm_scratch(fd_ctx* ctx, size_t* n_floats);   // fd_ctx.hip
+float* fd_red_scratch(fd_ctx* ctx, size_t n_floats);      // fd_ctx.hip; nullptr when the allocation fails
+// out[n] (+)= sum_r part[r][n], r in ascending order (fd_score_bwd.hip)
+void fd_sum_rows(const float* part, int R, int N, float* out, bool accumulate, hipStream_t s);
+// out[n] += sum_m x[m][n] without atomics: per-block partials, then fd_sum_rows (fd_score_bwd.hip)
+int fd_colsum_det(fd_ctx* ctx, const float* x, float* out, int M, int N, hipStream_t s);
 
 // Bracket one launch of the dominant kernel with events on its stream (no-op unless profiling is on).
 struct fd_prof_scope {

@@ -1,4 +1,6 @@
 // fd_ctx.hip -- context, error string, workspace arena.
+#include <algorithm>
+
 #include "fd_common.h"
 
 extern "C" int fd_version(void) { return 100; }
@@ -24,6 +26,7 @@ extern "C" int fd_ctx_destroy(fd_ctx* ctx) {
     fd_comm_destroy(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->gemm_scratch) (void)hipFree(ctx->gemm_scratch);
+    if (ctx->red_scratch) (void)hipFree(ctx->red_scratch);
     for (auto& e : ctx->fft_tw) (void)hipFree(e.second);
     delete ctx;
     return FD_OK;
@@ -47,6 +50,24 @@ int fd_ws_reserve(fd_ctx* ctx, size_t bytes) {
     FD_HIP(ctx, hipMalloc(&ctx->ws, want));
     ctx->ws_bytes = want;
     return FD_OK;
+}
+
+float* fd_red_scratch(fd_ctx* ctx, size_t n_floats) {
+    if (ctx->red_scratch_floats < n_floats) {
+        if (ctx->red_scratch) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(ctx->red_scratch);
+            ctx->red_scratch = nullptr;
+            ctx->red_scratch_floats = 0;
+        }
+        const size_t want = std::max(n_floats, (size_t)1 << 20);
+        if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&ctx->red_scratch, want * sizeof(float)) != hipSuccess) {
+            ctx->red_scratch = nullptr;
+            return nullptr;
+        }
+        ctx->red_scratch_floats = want;
+    }
+    return ctx->red_scratch;
 }
 
 // 64 MiB of split-K scratch for the exact-f32 GEMMs (skinny outputs with long reductions would otherwise run on ~100

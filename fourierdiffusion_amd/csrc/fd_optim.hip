@@ -7,7 +7,10 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void k_sqnorm(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+// stage 1 of the squared gradient norm: one double partial per block (fixed strand order inside the block); stage 2
+// (k_sqnorm_final) adds the blocks in ascending order -- the clipping coefficient, hence the parameter update, is then
+// bit-reproducible from run to run (a float atomic per block was not)
+__global__ __launch_bounds__(256) void k_sqnorm(const float* __restrict__ g, int64_t n, double* __restrict__ part) {
     __shared__ double red[4];
     double acc = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -17,7 +20,13 @@ __global__ __launch_bounds__(256) void k_sqnorm(const float* __restrict__ g, int
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, (float)(red[0] + red[1] + red[2] + red[3]));
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void k_sqnorm_final(const double* __restrict__ part, int nblk, float* __restrict__ out) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) v += part[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (threadIdx.x == 0) *out = (float)v;
 }
 
 __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g,
@@ -57,8 +66,11 @@ inline unsigned grid_for(fd_ctx* ctx, int64_t n) {
 extern "C" int fd_grad_sqnorm(fd_ctx* ctx, const float* grads, int64_t n, float* sqnorm_out, void* stream) {
     if (!ctx) return FD_ERR_ARG;
     FD_REQUIRE(ctx, grads && sqnorm_out && n > 0, "fd_grad_sqnorm: bad arguments");
-    FD_HIP(ctx, hipMemsetAsync(sqnorm_out, 0, sizeof(float), (hipStream_t)stream));
-    hipLaunchKernelGGL(k_sqnorm, dim3(grid_for(ctx, n)), dim3(256), 0, (hipStream_t)stream, grads, n, sqnorm_out);
+    const unsigned nblk = grid_for(ctx, n);
+    double* part = reinterpret_cast<double*>(fd_red_scratch(ctx, 2 * (size_t)nblk));
+    if (!part) return fd_fail(ctx, FD_ERR_HIP, "fd_grad_sqnorm: reduction scratch allocation failed");
+    hipLaunchKernelGGL(k_sqnorm, dim3(nblk), dim3(256), 0, (hipStream_t)stream, grads, n, part);
+    hipLaunchKernelGGL(k_sqnorm_final, dim3(1), dim3(64), 0, (hipStream_t)stream, part, (int)nblk, sqnorm_out);
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }

@@ -28,6 +28,8 @@ struct fd_score {
     uint64_t saved_seed = 0, saved_offset = 0;
     const float* saved_x = nullptr;
     const float* saved_t = nullptr;
+    bool saved_bf16 = false;        // the training forward ran the bf16 MFMA kernels (fd_train_bf16.hip)
+    int train_mode = 0;             // FD_MODE_F32 (exact-f32 kernels) or FD_MODE_BF16 for fd_score_forward_train
     uint64_t saved_ws_gen = 0;      // ctx->ws_gen right after the training forward carved the arena
     void* saved_ws = nullptr;       // arena base then (a regrow moves it)
 };
@@ -66,6 +68,13 @@ void fd_bf16_destroy(fd_score* m);
 int fd_bf16_prepare(fd_score* m, hipStream_t s);
 int fd_bf16_refresh(fd_score* m, hipStream_t s);   // rebuilds the images if the masters changed since the last build
 int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* out, int B, hipStream_t s);
+// fd_train_bf16.hip: bf16 MFMA training path (forward with dropout, backward)
+bool fd_train_bf16_supported(const fd_score* m);
+int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, float* out, int B, float p, uint64_t seed,
+                                uint64_t offset, hipStream_t s);
+int fd_score_backward_bf16(fd_score* m, const float* dout, float* grads, int accumulate, hipStream_t s);
+int fd_embed_backward(fd_score* m, const float* dh, const float* emb, float* dtemb, float* grads, int B, float* skp,
+                      size_t skp_floats, hipStream_t s);   // fd_score_bwd.hip
 // fd_attn_bf16.hip
 int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, int H, int hd, hipStream_t s,
                       const char* wk = nullptr, const char* wv = nullptr, const char* wq = nullptr, int ks1 = 0);

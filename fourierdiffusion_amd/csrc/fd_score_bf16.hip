@@ -20,6 +20,7 @@
 #include <map>
 
 #include "fd_gemm_f32.h"
+#include "fd_bf16_images.h"
 #include "fd_mega.h"
 #include "fd_score.h"
 #include "fd_sde.h"
@@ -35,19 +36,6 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 void fd_attention_f32(const float* qkv, float* out, float* lse, int B, int T, int H, int hd, float drop_p,
                       uint64_t seed, uint64_t offset, hipStream_t s);
 
-struct fd_bf16_images {
-    bool supported = false;     // fused FFN kernel available (hybrid path)
-    bool mega = false;          // persistent series-resident kernel available
-    int ks1 = 0, dt = 0;        // k-steps of GEMM1 (incl. bias slot), 16-row tiles of d_model
-    int kso = 0, kse = 0, ct = 0, np = 0;
-    size_t ffn_layer_bytes = 0;
-    char* ffn = nullptr;        // [L][fh 2][chunk F/64][NB blocks][64 lanes][8 bf16]
-    // persistent-kernel images: emb | unemb | per layer {wk, wv, wq, wo} (FFN image shared with `ffn`)
-    char* mimg = nullptr;
-    size_t off_emb = 0, off_unemb = 0, off_layers = 0, layer_stride = 0;
-    size_t off_wk = 0, off_wv = 0, off_wq = 0, off_wo = 0, off_ffn = 0;
-    fd_mega_layer_f32* layer_tab = nullptr;   // device [L]
-};
 
 namespace {
 
@@ -57,16 +45,14 @@ namespace {
 //   W2 block (dt)    : lane (row=l&15, g): slot j<4 -> f = fbase+4g+j ; j>=4 -> f = fbase+16+4g+(j-4)
 //                                          value W2[d = 16dt+row][f] (0 when d >= D)
 // The W2 k-permutation is exactly the (token, 4g+r) register layout of the two 16x16 hidden tiles.
-__global__ __launch_bounds__(64) void k_build_ffn_image(const float* __restrict__ W1, const float* __restrict__ b1,
-                                                         const float* __restrict__ W2, __bf16* __restrict__ img,
-                                                         int D, int F, int KS1, int DT, int chunk_major) {
+__device__ void build_ffn_block(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+                                __bf16* __restrict__ img, int D, int F, int KS1, int DT, int chunk_major, int blk, int lane) {
     const int NB = 2 * KS1 + DT;
     const int NC = F / 64;                      // 32-wide chunks per F-half
-    const int blk = blockIdx.x;                 // ((fh*NC + c)*NB + j)
-    const int j = blk % NB;
+    const int j = blk % NB;                     // blk = ((fh*NC + c)*NB + j)
     const int c = (blk / NB) % NC;
     const int fh = blk / (NB * NC);
-    const int lane = threadIdx.x, row = lane & 15, g = lane >> 4;
+    const int row = lane & 15, g = lane >> 4;
     const int fbase = fh * (F / 2) + c * 32;
     // chunk_major: [chunk][F-half][block] (the persistent kernel streams whole chunk pairs linearly);
     // otherwise [F-half][chunk][block] (k_ffn_ln: each workgroup half walks its own F-half)
@@ -96,12 +82,11 @@ __global__ __launch_bounds__(64) void k_build_ffn_image(const float* __restrict_
 // One 64-lane block = one 1 KiB MFMA fragment: lane (row = l&15, g = l>>4) holds 8 bf16 = k-slots 8g..8g+7 of
 // k-step ks for matrix row `row` of row tile rt.  kind selects how (rt, row, k) maps onto the fp32 weights.
 enum { IMG_EMB = 0, IMG_UNEMB = 1, IMG_Q = 2, IMG_K = 3, IMG_V = 4, IMG_WO = 5 };
-__global__ __launch_bounds__(64) void k_build_image(int kind, const float* __restrict__ W, const float* __restrict__ bias,
-                                                     __bf16* __restrict__ img, int KS, int rows, int K, int H, int hd,
-                                                     int D, float scale) {
-    const int blk = blockIdx.x;
+__device__ void build_image_block(int kind, const float* __restrict__ W, const float* __restrict__ bias,
+                                  __bf16* __restrict__ img, int KS, int rows, int K, int H, int hd, int D, float scale,
+                                  int blk, int lane) {
     const int rt = blk / KS, ks = blk - rt * KS;
-    const int lane = threadIdx.x, row = lane & 15, g = lane >> 4;
+    const int row = lane & 15, g = lane >> 4;
     __bf16* dst = img + ((size_t)blk * 64 + lane) * 8;
     for (int e = 0; e < 8; ++e) {
         const int k = 32 * ks + 8 * g + e;
@@ -129,6 +114,108 @@ __global__ __launch_bounds__(64) void k_build_image(int kind, const float* __res
         }
         dst[e] = (__bf16)v;
     }
+}
+
+__global__ __launch_bounds__(64) void k_build_image(int kind, const float* __restrict__ W, const float* __restrict__ bias,
+                                                     __bf16* __restrict__ img, int KS, int rows, int K, int H, int hd,
+                                                     int D, float scale) {
+    build_image_block(kind, W, bias, img, KS, rows, K, H, hd, D, scale, blockIdx.x, threadIdx.x);
+}
+
+// ---- transposed-weight blocks of the bf16 backward pass (fd_train_bf16.hip)
+// FFN backward image, chunk-major like the persistent kernel's forward image: block (c*2 + fh)*NB + j of chunk c, F-half fh
+// (hidden units fbase = fh*F/2 + 32c .. +31):
+//   j <  2*KS1 (ft, ks): A rows = hidden unit fbase+16ft+row, k = d:            W2[d = 32ks+8g+e][f]     (d hidden^T = W2^T d out^T)
+//   j >= 2*KS1 (dt)    : A rows = d = 16dt+row, k-slots in the C-tile order of the two hidden tiles (e<4: f = fbase+4g+e,
+//                        e>=4: f = fbase+16+4g+e-4):                              W1[f][d]                 (d x^T += W1^T d hidden^T)
+__device__ void build_ffn_bwd_block(const float* __restrict__ W1, const float* __restrict__ W2, __bf16* __restrict__ img, int D,
+                                    int F, int KS1, int DT, int blk, int lane) {
+    const int NB = 2 * KS1 + DT;
+    const int j = blk % NB, fh = (blk / NB) & 1, c = blk / (2 * NB);
+    const int row = lane & 15, g = lane >> 4;
+    const int fbase = fh * (F / 2) + c * 32;
+    __bf16* dst = img + ((size_t)blk * 64 + lane) * 8;
+    if (j < 2 * KS1) {
+        const int ft = j / KS1, ks = j % KS1;
+        const int f = fbase + 16 * ft + row;
+        for (int e = 0; e < 8; ++e) {
+            const int k = 32 * ks + 8 * g + e;
+            dst[e] = (__bf16)((k < D) ? W2[(size_t)k * F + f] : 0.f);
+        }
+    } else {
+        const int dt = j - 2 * KS1, d = 16 * dt + row;
+        for (int e = 0; e < 8; ++e) {
+            const int f = fbase + ((e < 4) ? (4 * g + e) : (16 + 4 * g + (e - 4)));
+            dst[e] = (__bf16)((d < D) ? W1[(size_t)f * D + d] : 0.f);
+        }
+    }
+}
+// W_o^T block (dt, ks): A rows = attention feature i = 16dt+row (natural order head*hd + e), k = d = 32ks+8g+e: W_o[d][i]
+__device__ void build_wot_block(const float* __restrict__ Wo, __bf16* __restrict__ img, int D, int KS1, int blk, int lane) {
+    const int dt = blk / KS1, ks = blk - dt * KS1;
+    const int row = lane & 15, g = lane >> 4, i = 16 * dt + row;
+    __bf16* dst = img + ((size_t)blk * 64 + lane) * 8;
+    for (int e = 0; e < 8; ++e) {
+        const int d = 32 * ks + 8 * g + e;
+        dst[e] = (__bf16)((i < D && d < D) ? Wo[(size_t)d * D + i] : 0.f);
+    }
+}
+// in_proj^T half-blocks (512 B = 64 lanes x 4 bf16, K=16 MFMA) of head pair `pair`, which in {q,k,v}, row tile dt:
+// A rows = d = 16dt+row, k-slot 4g+e = dim 4(g&1)+e of head 2pair+(g>>1): in_proj_weight[which*D + head*hd + j][d]
+__device__ void build_win_block(const float* __restrict__ Win, __bf16* __restrict__ img, int D, int H, int hd, int DT, int blk,
+                                int lane) {
+    const int dt = blk % DT, which = (blk / DT) % 3, pair = blk / (3 * DT);
+    const int row = lane & 15, g = lane >> 4, d = 16 * dt + row, head = 2 * pair + (g >> 1);
+    __bf16* dst = img + ((size_t)blk * 64 + lane) * 4;
+    for (int e = 0; e < 4; ++e) {
+        const int j = 4 * (g & 1) + e;
+        dst[e] = (__bf16)((d < D && head < H && j < hd) ? Win[(size_t)(which * D + head * hd + j) * D + d] : 0.f);
+    }
+}
+
+// Every per-layer image of every layer in ONE launch (an optimizer step invalidates them all; 7 launches per layer made
+// the rebuild the largest launch count of a training step).  grid (blocks per layer, L), one 64-lane block per image block.
+struct fd_img_build {
+    const float* P;
+    const long long* lofs;     // [L][12] fd_layer_off
+    char* mimg; size_t off_layers, layer_stride, off_wk, off_wv, off_wq, off_wo, off_ffn;
+    char* ffn; size_t ffn_layer_bytes;
+    char* bimg; size_t b_layer_stride, boff_ffn, boff_wot, boff_win;
+    int D, F, H, hd, KS1, DT, KSO, NP;
+    int n_qkv, n_wo, n_ffn, n_wot, n_win;   // block counts per layer (n_qkv = NP*KS1 per matrix)
+    int mega, train;
+    float qscale;
+};
+__global__ __launch_bounds__(64) void k_build_layer_images(const fd_img_build B) {
+    const int l = blockIdx.y, lane = threadIdx.x;
+    int blk = blockIdx.x;
+    const long long* lo = B.lofs + (size_t)l * 12;      // in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, ...
+    const float* P = B.P;
+    // (1) inference FFN image [F-half][chunk][block]
+    if (blk < B.n_ffn) {
+        build_ffn_block(P + lo[4], P + lo[5], P + lo[6], (__bf16*)(B.ffn + (size_t)l * B.ffn_layer_bytes), B.D, B.F, B.KS1, B.DT, 0, blk, lane);
+        return;
+    }
+    blk -= B.n_ffn;
+    if (!B.mega) return;
+    char* limg = B.mimg + B.off_layers + (size_t)l * B.layer_stride;
+    if (blk < B.n_qkv) { build_image_block(IMG_K, P + lo[0], P + lo[1], (__bf16*)(limg + B.off_wk), B.KS1, 0, B.D, B.H, B.hd, B.D, 1.f, blk, lane); return; }
+    blk -= B.n_qkv;
+    if (blk < B.n_qkv) { build_image_block(IMG_V, P + lo[0], P + lo[1], (__bf16*)(limg + B.off_wv), B.KS1, 0, B.D, B.H, B.hd, B.D, 1.f, blk, lane); return; }
+    blk -= B.n_qkv;
+    if (blk < B.n_qkv) { build_image_block(IMG_Q, P + lo[0], P + lo[1], (__bf16*)(limg + B.off_wq), B.KS1, 0, B.D, B.H, B.hd, B.D, B.qscale, blk, lane); return; }
+    blk -= B.n_qkv;
+    if (blk < B.n_wo) { build_image_block(IMG_WO, P + lo[2], nullptr, (__bf16*)(limg + B.off_wo), B.KSO, 0, B.D, B.H, B.hd, B.D, 1.f, blk, lane); return; }
+    blk -= B.n_wo;
+    if (blk < B.n_ffn) { build_ffn_block(P + lo[4], P + lo[5], P + lo[6], (__bf16*)(limg + B.off_ffn), B.D, B.F, B.KS1, B.DT, 1, blk, lane); return; }
+    blk -= B.n_ffn;
+    if (!B.train) return;
+    char* bl = B.bimg + (size_t)l * B.b_layer_stride;
+    if (blk < B.n_ffn) { build_ffn_bwd_block(P + lo[4], P + lo[6], (__bf16*)(bl + B.boff_ffn), B.D, B.F, B.KS1, B.DT, blk, lane); return; }
+    blk -= B.n_ffn;
+    if (blk < B.n_wot) { build_wot_block(P + lo[2], (__bf16*)(bl + B.boff_wot), B.D, B.KS1, blk, lane); return; }
+    blk -= B.n_wot;
+    if (blk < B.n_win) build_win_block(P + lo[0], (__bf16*)(bl + B.boff_win), B.D, B.H, B.hd, B.DT, blk, lane);
 }
 
 // ------------------------------------------------------------------ fused FFN + residual + LayerNorm
@@ -610,6 +697,32 @@ int fd_bf16_create(fd_score* m) {
             return fd_fail(m->ctx, FD_ERR_HIP, "fd_bf16_create: upload of the layer table failed");
         }
     }
+    {   // parameter offsets of every layer for the single-launch image build
+        std::vector<long long> lofs((size_t)L * 12);
+        for (int i = 0; i < L; ++i) {
+            const fd_layer_off& lo = m->layers[i];
+            const long long v[12] = {lo.in_w, lo.in_b, lo.out_w, lo.out_b, lo.l1_w, lo.l1_b, lo.l2_w, lo.l2_b, lo.n1_w, lo.n1_b, lo.n2_w, lo.n2_b};
+            for (int k = 0; k < 12; ++k) lofs[(size_t)i * 12 + k] = v[k];
+        }
+        if (hipMalloc((void**)&im->layer_off_tab, sizeof(long long) * lofs.size()) != hipSuccess ||
+            hipMemcpy(im->layer_off_tab, lofs.data(), sizeof(long long) * lofs.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            fd_bf16_destroy(m);
+            return fd_fail(m->ctx, FD_ERR_HIP, "fd_bf16_create: upload of the layer offset table failed");
+        }
+    }
+    // bf16 training kernels (fd_train_bf16.hip) exist for the persistent kernel's model family; their transposed-weight
+    // images: FFN backward (same block count as the forward image) | W_o^T (dt x ks1) | in_proj^T half-blocks (np x 3 x dt)
+    im->train = im->mega;
+    if (im->train) {
+        im->boff_ffn = 0;
+        im->boff_wot = im->ffn_layer_bytes;
+        im->boff_win = im->boff_wot + (size_t)im->dt * im->ks1 * 1024;
+        im->b_layer_stride = im->boff_win + (size_t)im->np * 3 * im->dt * 512;
+        if (hipMalloc((void**)&im->bimg, im->b_layer_stride * L) != hipSuccess) {
+            fd_bf16_destroy(m);
+            return fd_fail(m->ctx, FD_ERR_HIP, "fd_bf16_create: hipMalloc of the backward weight images failed");
+        }
+    }
     return FD_OK;
 }
 
@@ -618,6 +731,8 @@ void fd_bf16_destroy(fd_score* m) {
     if (m->bf16->ffn) (void)hipFree(m->bf16->ffn);
     if (m->bf16->mimg) (void)hipFree(m->bf16->mimg);
     if (m->bf16->layer_tab) (void)hipFree(m->bf16->layer_tab);
+    if (m->bf16->layer_off_tab) (void)hipFree(m->bf16->layer_off_tab);
+    if (m->bf16->bimg) (void)hipFree(m->bf16->bimg);
     delete m->bf16;
     m->bf16 = nullptr;
 }
@@ -625,35 +740,29 @@ void fd_bf16_destroy(fd_score* m) {
 int fd_bf16_prepare(fd_score* m, hipStream_t s) {
     fd_bf16_images* im = m->bf16;
     if (!im || !im->supported) return FD_OK;
-    const int D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, C = m->d.n_channels, hd = D / H;
+    const int D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, C = m->d.n_channels, hd = D / H, L = m->d.num_layers;
     const int NB = 2 * im->ks1 + im->dt;
-    const int nblk = 2 * (F / 64) * NB;
     const float* P = m->params;
-    for (int i = 0; i < m->d.num_layers; ++i) {
-        const fd_layer_off& lo = m->layers[i];
-        hipLaunchKernelGGL(k_build_ffn_image, dim3(nblk), dim3(64), 0, s, P + lo.l1_w, P + lo.l1_b, P + lo.l2_w,
-                           (__bf16*)(im->ffn + (size_t)i * im->ffn_layer_bytes), D, F, im->ks1, im->dt, 0);
-    }
+    fd_img_build B{};
+    B.P = P; B.lofs = im->layer_off_tab;
+    B.mimg = im->mimg; B.off_layers = im->off_layers; B.layer_stride = im->layer_stride;
+    B.off_wk = im->off_wk; B.off_wv = im->off_wv; B.off_wq = im->off_wq; B.off_wo = im->off_wo; B.off_ffn = im->off_ffn;
+    B.ffn = im->ffn; B.ffn_layer_bytes = im->ffn_layer_bytes;
+    B.bimg = im->bimg; B.b_layer_stride = im->b_layer_stride; B.boff_ffn = im->boff_ffn; B.boff_wot = im->boff_wot; B.boff_win = im->boff_win;
+    B.D = D; B.F = F; B.H = H; B.hd = hd; B.KS1 = im->ks1; B.DT = im->dt; B.KSO = im->kso; B.NP = im->np;
+    B.n_qkv = im->np * im->ks1; B.n_wo = im->dt * im->kso; B.n_ffn = 2 * (F / 64) * NB; B.n_wot = im->dt * im->ks1; B.n_win = im->np * 3 * im->dt;
+    B.mega = im->mega ? 1 : 0; B.train = (im->train && im->bimg) ? 1 : 0;
+    // softmax scale and log2(e) folded into W_q / b_q: the kernels' softmax is exp2(s - max)
+    B.qscale = (float)(1.4426950408889634 / std::sqrt((double)hd));
+    int per_layer = B.n_ffn;
+    if (B.mega) per_layer += 3 * B.n_qkv + B.n_wo + B.n_ffn;
+    if (B.mega && B.train) per_layer += B.n_ffn + B.n_wot + B.n_win;
+    if (L > 0) hipLaunchKernelGGL(k_build_layer_images, dim3(per_layer, L), dim3(64), 0, s, B);
     if (im->mega) {
-        auto build = [&](int kind, const float* W, const float* b, size_t off, int ntiles, int KS, int rows, int K,
-                         float scale) {
-            hipLaunchKernelGGL(k_build_image, dim3(ntiles * KS), dim3(64), 0, s, kind, W, b, (__bf16*)(im->mimg + off), KS,
-                               rows, K, H, hd, D, scale);
-        };
-        build(IMG_EMB, P + m->emb_w, P + m->emb_b, im->off_emb, im->dt, im->kse, D, C, 1.f);
-        build(IMG_UNEMB, P + m->un_w, P + m->un_b, im->off_unemb, im->ct, im->ks1, C, D, 1.f);
-        // softmax scale and log2(e) folded into W_q / b_q: the kernel's softmax is exp2(s - max)
-        const float qscale = (float)(1.4426950408889634 / std::sqrt((double)hd));
-        for (int i = 0; i < m->d.num_layers; ++i) {
-            const fd_layer_off& lo = m->layers[i];
-            const size_t base = im->off_layers + (size_t)i * im->layer_stride;
-            build(IMG_K, P + lo.in_w, P + lo.in_b, base + im->off_wk, im->np, im->ks1, 0, D, 1.f);
-            build(IMG_V, P + lo.in_w, P + lo.in_b, base + im->off_wv, im->np, im->ks1, 0, D, 1.f);
-            build(IMG_Q, P + lo.in_w, P + lo.in_b, base + im->off_wq, im->np, im->ks1, 0, D, qscale);
-            build(IMG_WO, P + lo.out_w, nullptr, base + im->off_wo, im->dt, im->kso, 0, D, 1.f);
-            hipLaunchKernelGGL(k_build_ffn_image, dim3(nblk), dim3(64), 0, s, P + lo.l1_w, P + lo.l1_b, P + lo.l2_w,
-                               (__bf16*)(im->mimg + base + im->off_ffn), D, F, im->ks1, im->dt, 1);
-        }
+        hipLaunchKernelGGL(k_build_image, dim3(im->dt * im->kse), dim3(64), 0, s, IMG_EMB, P + m->emb_w, P + m->emb_b,
+                           (__bf16*)(im->mimg + im->off_emb), im->kse, D, C, H, hd, D, 1.f);
+        hipLaunchKernelGGL(k_build_image, dim3(im->ct * im->ks1), dim3(64), 0, s, IMG_UNEMB, P + m->un_w, P + m->un_b,
+                           (__bf16*)(im->mimg + im->off_unemb), im->ks1, C, D, H, hd, D, 1.f);
     }
     FD_LAUNCH_CHECK(m->ctx);
     return FD_OK;

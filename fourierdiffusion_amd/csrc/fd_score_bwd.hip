@@ -15,9 +15,11 @@ uint64_t fd_dropout_site_offset(uint64_t base, int layer, int site);
 
 namespace {
 
-// out[n] += sum_m x[m, n]      (bias gradients)
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, float* __restrict__ out, int M, int N,
-                                                 int rows_per_block) {
+// Column sums without atomics (two runs must give bit-identical gradients): stage 1 writes one partial row per block
+// (rows m0 .. m0+rows_per_block-1, 4 row strands added in a fixed order), stage 2 (k_sum_rows) adds the blocks' rows in
+// ascending order.
+__global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ x, float* __restrict__ part, int M, int N,
+                                                      int rows_per_block) {
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int sub = threadIdx.x >> 6;                 // 4 row-strands per block
     const int m0 = blockIdx.y * rows_per_block;
@@ -28,40 +30,44 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, flo
     __shared__ float red[4][64];
     red[sub][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (sub == 0 && n < N) atomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (sub == 0 && n < N)
+        part[(size_t)blockIdx.y * N + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void k_sum_rows(const float* __restrict__ part, int R, int N, float* __restrict__ out, int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float v = 0.f;
+    for (int r = 0; r < R; ++r) v += part[(size_t)r * N + n];
+    out[n] = accumulate ? out[n] + v : v;
 }
 
-// out = dropout(in) with the forward's mask (same Philox stream as fd_k_dropout: 4 elements per counter) and
-// csum[c] += sum_rows out[:, c]: the backward of `s = x + drop(linear(.))` needs the masked gradient for the weight GEMMs
-// and its column sums for the bias -- one launch instead of copy + dropout + colsum (launch-bound at the training batch).
-__global__ __launch_bounds__(256) void k_dropout_colsum(const float* __restrict__ in, float* __restrict__ out, unsigned n,
-                                                         int N, float p, uint64_t seed, uint64_t offset,
-                                                         float* __restrict__ csum) {
-    extern __shared__ float sh[];          // [N] partial column sums of this block
-    for (int i = threadIdx.x; i < N; i += 256) sh[i] = 0.f;
-    __syncthreads();
-    const unsigned ng = (n + 3) / 4;
+// out[n] += sum_r part[r * stride + col0 + n], n < N
+__global__ __launch_bounds__(256) void k_sum_rows_strided(const float* __restrict__ part, int R, int stride, int col0, int N,
+                                                           float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float v = 0.f;
+    for (int r = 0; r < R; ++r) v += part[(size_t)r * stride + col0 + n];
+    out[n] += v;
+}
+
+// out = dropout(in) with the forward's mask (same Philox stream as fd_k_dropout: 4 elements per counter)
+__global__ __launch_bounds__(256) void k_dropout_copy(const float* __restrict__ in, float* __restrict__ out, size_t n, float p,
+                                                       uint64_t seed, uint64_t offset) {
+    const size_t ng = (n + 3) / 4;
     const float sc = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
-    for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < ng; g += gridDim.x * 256u) {
+    for (size_t g = blockIdx.x * (size_t)256 + threadIdx.x; g < ng; g += (size_t)gridDim.x * 256) {
         uint32_t rv[4] = {~0u, ~0u, ~0u, ~0u};
         if (p > 0.f) {
             const fd_u4 r = fd_philox4x32_10(offset + g, seed);
             rv[0] = r.x; rv[1] = r.y; rv[2] = r.z; rv[3] = r.w;
         }
-        int col = (int)((g * 4u) % (unsigned)N);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const unsigned e = g * 4u + i;
-            if (e < n) {
-                const float v = (p <= 0.f || fd_u01(rv[i]) >= p) ? in[e] * sc : 0.f;
-                out[e] = v;
-                atomicAdd(&sh[col], v);
-            }
-            if (++col == N) col = 0;
+            const size_t e = g * 4 + i;
+            if (e < n) out[e] = (p <= 0.f || fd_u01(rv[i]) >= p) ? in[e] * sc : 0.f;
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < N; i += 256) atomicAdd(csum + i, sh[i]);
 }
 
 // LayerNorm backward.  y = (x - mean) * rstd * gamma + beta, x = pre-norm sum saved by the forward.
@@ -70,11 +76,9 @@ __global__ __launch_bounds__(256) void k_dropout_colsum(const float* __restrict_
 // One wave per token, 4 tokens per block pass; per-block partial parameter gradients go through LDS.
 __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ x,
                                                  const float* __restrict__ mr, const float* __restrict__ gamma,
-                                                 float* __restrict__ dx, float* __restrict__ dgamma,
-                                                 float* __restrict__ dbeta, int M, int D, int tokens_per_block) {
-    extern __shared__ float sh[];          // [2][D] partial dgamma, dbeta
-    for (int i = threadIdx.x; i < 2 * D; i += 256) sh[i] = 0.f;
-    __syncthreads();
+                                                 float* __restrict__ dx, float* __restrict__ part, int M, int D,
+                                                 int tokens_per_block) {
+    extern __shared__ float sh[];          // [4 waves][2][D] partial dgamma, dbeta of the waves
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int m0 = blockIdx.x * tokens_per_block;
     const int m1 = min(M, m0 + tokens_per_block);
@@ -113,14 +117,16 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
     for (int n = 0; n < 16; ++n) {
         const int d = lane + 64 * n;
         if (d < D) {
-            atomicAdd(&sh[d], pg[n]);
-            atomicAdd(&sh[D + d], pb[n]);
+            sh[(w * 2 + 0) * D + d] = pg[n];
+            sh[(w * 2 + 1) * D + d] = pb[n];
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < D; i += 256) {
-        atomicAdd(dgamma + i, sh[i]);
-        atomicAdd(dbeta + i, sh[D + i]);
+    // block partial row [dgamma | dbeta], waves added in a fixed order; the blocks' rows are added by k_sum_rows
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        const int which = i / D, d = i - which * D;
+        part[(size_t)blockIdx.x * 2 * D + i] = (sh[(0 * 2 + which) * D + d] + sh[(1 * 2 + which) * D + d]) +
+                                               (sh[(2 * 2 + which) * D + d] + sh[(3 * 2 + which) * D + d]);
     }
 }
 
@@ -381,37 +387,28 @@ inline unsigned ew_grid(fd_ctx* ctx, size_t n) {
     return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
-void colsum(fd_ctx* ctx, const float* x, float* out, int M, int N, hipStream_t s) {
-    const int rows_per_block = 128;
-    dim3 grid((N + 63) / 64, (M + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL(k_colsum, grid, dim3(256), 0, s, x, out, M, N, rows_per_block);
-    (void)ctx;
-}
+void colsum(fd_ctx* ctx, const float* x, float* out, int M, int N, hipStream_t s) { (void)fd_colsum_det(ctx, x, out, M, N, s); }
 
-// tmp = dropout-backward(src) (site mask), bias gradient += column sums of tmp
+// tmp = dropout-backward(src) (site mask), bias gradient += column sums of tmp (fixed-order reduction)
 void dropout_bwd_colsum(fd_ctx* ctx, const float* src, float* tmp, int M, int N, float p, uint64_t seed, uint64_t offset,
                         float* bias_grad, hipStream_t s) {
     const size_t n = (size_t)M * N;
-    if (n >= ((size_t)1 << 31) || (size_t)N * sizeof(float) > 48 * 1024) {        // (32-bit element index / LDS row inside)
-        (void)hipMemcpyAsync(tmp, src, sizeof(float) * n, hipMemcpyDeviceToDevice, s);   // (errors surface in FD_LAUNCH_CHECK)
-        fd_dropout_inplace(ctx, tmp, n, p, seed, offset, s);
-        colsum(ctx, tmp, bias_grad, M, N, s);
-        return;
-    }
-    // few blocks: each ends with N global atomics on the same N addresses (512 blocks: 15 us, mostly that tail)
-    size_t blocks = std::min<size_t>(((n + 3) / 4 + 255) / 256, (size_t)std::max(1, ctx->num_cu / 2));
-    hipLaunchKernelGGL(k_dropout_colsum, dim3((unsigned)blocks), dim3(256), (size_t)N * sizeof(float), s, src, tmp, (unsigned)n, N,
-                       p, seed, offset, bias_grad);
+    hipLaunchKernelGGL(k_dropout_copy, dim3(ew_grid(ctx, (n + 3) / 4)), dim3(256), 0, s, src, tmp, n, p, seed, offset);
+    colsum(ctx, tmp, bias_grad, M, N, s);
 }
 
 void ln_bwd(fd_ctx* ctx, const float* dy, const float* x, const float* mr, const float* gamma, float* dx, float* dgamma,
             float* dbeta, int M, int D, hipStream_t s) {
-    // about one block per CU at the training batch (M = 6400: 28 tokens per block; 64 left 156 CUs idle: 29 us, 12 made the
-    // 2*D global atomics per block the tail: 21 us), never more than 64 tokens per block
+    // about one block per CU at the training batch, never more than 64 tokens per block
     int tokens_per_block = (M + ctx->num_cu - 1) / ctx->num_cu;
     tokens_per_block = std::min(64, std::max(8, (tokens_per_block + 3) & ~3));
-    hipLaunchKernelGGL(k_ln_bwd, dim3((M + tokens_per_block - 1) / tokens_per_block), dim3(256), 2 * D * sizeof(float), s,
-                       dy, x, mr, gamma, dx, dgamma, dbeta, M, D, tokens_per_block);
+    const int nblk = (M + tokens_per_block - 1) / tokens_per_block;
+    float* part = fd_red_scratch(ctx, (size_t)nblk * 2 * D);
+    if (!part) return;                       // (allocation failure surfaces as a HIP error at the launch check)
+    hipLaunchKernelGGL(k_ln_bwd, dim3(nblk), dim3(256), 8 * D * sizeof(float), s, dy, x, mr, gamma, dx, part, M, D, tokens_per_block);
+    // rows are [dgamma | dbeta]: two strided sums
+    hipLaunchKernelGGL(k_sum_rows_strided, dim3((D + 255) / 256), dim3(256), 0, s, part, nblk, 2 * D, 0, D, dgamma);
+    hipLaunchKernelGGL(k_sum_rows_strided, dim3((D + 255) / 256), dim3(256), 0, s, part, nblk, 2 * D, D, D, dbeta);
 }
 
 template <int HDP>
@@ -428,6 +425,21 @@ void attn_bwd_t(const float* qkv, const float* dO, const float* lse, const float
 
 }  // namespace
 
+void fd_sum_rows(const float* part, int R, int N, float* out, bool accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_rows, dim3((N + 255) / 256), dim3(256), 0, s, part, R, N, out, accumulate ? 1 : 0);
+}
+
+int fd_colsum_det(fd_ctx* ctx, const float* x, float* out, int M, int N, hipStream_t s) {
+    const int rows_per_block = 128;
+    const int nblk = (M + rows_per_block - 1) / rows_per_block;
+    float* part = fd_red_scratch(ctx, (size_t)nblk * N);
+    if (!part) return fd_fail(ctx, FD_ERR_HIP, "fd_colsum_det: reduction scratch allocation failed");
+    dim3 grid((N + 63) / 64, nblk);
+    hipLaunchKernelGGL(k_colsum_part, grid, dim3(256), 0, s, x, part, M, N, rows_per_block);
+    fd_sum_rows(part, nblk, N, out, true, s);
+    return FD_OK;
+}
+
 // split-K partial sums of the weight-gradient GEMMs (dW = dY^T X reduces over all B*T tokens): 16 x the largest dW
 constexpr size_t kSplitKFloats = (size_t)4 << 20;
 
@@ -437,12 +449,39 @@ size_t fd_score_bwd_workspace(const fd_score* m, int B) {
     return 3 * fl(M * D) + fl(M * F) + fl(M * 3 * D) + fl((size_t)B * H * T) + fl((size_t)B * D) + fl(kSplitKFloats) + 4096;
 }
 
+// Gradients of the input side of the network from dh = d loss / d h0 (B*T, D): embedder, positional table, time embedding
+// (h0 = X We^T + be + pe[t] + temb[b]; temb = emb Wd^T + bd; time_encoder.W is frozen: transformer.py:72-74).
+// Shared by the exact-f32 and the bf16 backward; accumulates into `grads`.
+int fd_embed_backward(fd_score* m, const float* dh, const float* emb, float* dtemb, float* grads, int B, float* skp,
+                      size_t skp_floats, hipStream_t s) {
+    fd_ctx* ctx = m->ctx;
+    const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model;
+    const int M = B * T;
+    fdgemm::linear_bwd_weight(dh, m->saved_x, grads + m->emb_w, M, D, C, true, s, skp, skp_floats);
+    colsum(ctx, dh, grads + m->emb_b, M, D, s);
+    {
+        const size_t n = std::max((size_t)T * D, (size_t)B * D);
+        hipLaunchKernelGGL(k_embed_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dh, grads + m->pos, dtemb, B, T, D);
+    }
+    fdgemm::linear_bwd_weight(dtemb, emb, grads + m->td_w, B, D, D, true, s, skp, skp_floats);
+    colsum(ctx, dtemb, grads + m->td_b, B, D, s);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
 extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, int accumulate, void* stream) {
     if (!m) return FD_ERR_ARG;
     fd_ctx* ctx = m->ctx;
     FD_REQUIRE(ctx, dout && grads, "fd_score_backward: null pointer");
     if (!m->have_saved) return fd_fail(ctx, FD_ERR_STATE, "fd_score_backward: no training forward to differentiate");
     hipStream_t s = (hipStream_t)stream;
+    if (m->saved_bf16) {
+        if (ctx->ws_gen != m->saved_ws_gen || ctx->ws != m->saved_ws)
+            return fd_fail(ctx, FD_ERR_STATE, "fd_score_backward: another engine call used the context workspace after "
+                           "fd_score_forward_train (the saved activations live there)");
+        m->have_saved = false;
+        return fd_score_backward_bf16(m, dout, grads, accumulate, s);
+    }
     const int B = m->saved_B;
     const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model, H = m->d.n_head, F = m->d.dim_ff;
     const int L = m->d.num_layers, hd = D / H;
@@ -520,17 +559,7 @@ extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, i
         fdgemm::linear_bwd_input(dqkv, P + lo.in_w, dh, M, 3 * D, D, true, s);   // dh = d x0 (residual + attention branch)
     }
 
-    // ---- embed: h0 = X We^T + be + pe[t] + temb[b]
-    fdgemm::linear_bwd_weight(dh, m->saved_x, grads + m->emb_w, M, D, C, true, s, skp, kSplitKFloats);
-    colsum(ctx, dh, grads + m->emb_b, M, D, s);
-    {
-        const size_t n = std::max((size_t)T * D, (size_t)B * D);
-        hipLaunchKernelGGL(k_embed_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dh, grads + m->pos, dtemb, B, T,
-                           D);
-    }
-    // temb = emb Wd^T + bd   (time_encoder.W is frozen: transformer.py:72-74)
-    fdgemm::linear_bwd_weight(dtemb, sv.emb, grads + m->td_w, B, D, D, true, s, skp, kSplitKFloats);
-    colsum(ctx, dtemb, grads + m->td_b, B, D, s);
+    if (int rc = fd_embed_backward(m, dh, sv.emb, dtemb, grads, B, skp, kSplitKFloats, s)) return rc;
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }

@@ -582,8 +582,14 @@ extern "C" int fd_score_forward_train(fd_score* m, const float* x, const float* 
     FD_REQUIRE(ctx, B > 0, "fd_score_forward_train: B=%d", B);
     FD_REQUIRE(ctx, dropout_p >= 0.f && dropout_p < 1.f, "fd_score_forward_train: dropout_p=%f", dropout_p);
     if (!m->prepared) return fd_fail(ctx, FD_ERR_STATE, "fd_score_forward_train: call fd_score_prepare first");
-    int rc = fd_score_forward_f32(m, x, t, out, B, (hipStream_t)stream, true, dropout_p, seed, offset);
+    const bool bf16 = m->train_mode == FD_MODE_BF16;
+    if (bf16 && !fd_train_bf16_supported(m))
+        return fd_fail(ctx, FD_ERR_UNSUPPORTED, "fd_score_forward_train: bf16 training kernels are not instantiated for this "
+                       "model (d_model in {8,24,60,72}, head_dim <= 7, dim_ff %% 128 == 0); select FD_MODE_F32");
+    int rc = bf16 ? fd_score_forward_train_bf16(m, x, t, out, B, dropout_p, seed, offset, (hipStream_t)stream)
+                  : fd_score_forward_f32(m, x, t, out, B, (hipStream_t)stream, true, dropout_p, seed, offset);
     if (rc == FD_OK) {
+        m->saved_bf16 = bf16;
         m->have_saved = true;
         m->saved_B = B;
         m->saved_p = dropout_p;
@@ -595,6 +601,25 @@ extern "C" int fd_score_forward_train(fd_score* m, const float* x, const float* 
         m->saved_ws = ctx->ws;
     }
     return rc;
+}
+
+// Arithmetic of fd_score_forward_train / fd_score_backward: FD_MODE_F32 = exact-f32 kernels (parity anchor, any model),
+// FD_MODE_BF16 = bf16 MFMA operands with fp32 accumulation (fd_train_bf16.hip).  Returns FD_ERR_UNSUPPORTED (and keeps the
+// previous mode) when the bf16 kernels are not instantiated for the model.
+extern "C" int fd_score_set_train_mode(fd_score* m, int mode) {
+    if (!m) return FD_ERR_ARG;
+    fd_ctx* ctx = m->ctx;
+    FD_REQUIRE(ctx, mode == FD_MODE_F32 || mode == FD_MODE_BF16, "fd_score_set_train_mode: unknown mode %d", mode);
+    if (mode == FD_MODE_BF16 && !fd_train_bf16_supported(m))
+        return fd_fail(ctx, FD_ERR_UNSUPPORTED, "fd_score_set_train_mode: bf16 training kernels not instantiated for this model");
+    m->train_mode = mode;
+    return FD_OK;
+}
+
+int fd_time_embed_train(const float* t, const float* W, const float* Wd, const float* bd, float* emb, float* temb, int B, int D,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(k_time_embed, dim3(B), dim3(128), D * sizeof(float), s, t, W, Wd, bd, emb, temb, D);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // ------------------------------------------------------------------ stand-alone encoders (transformer.py)

@@ -1,0 +1,1504 @@
+// fd_train_bf16.hip -- bf16 MFMA training path of the score network: forward with dropout + backward, fp32 accumulate.
+//
+// Reference: ScoreModule.training_step (src/fdiff/models/score_models.py:96-108) through torch autograd over
+// nn.TransformerEncoderLayer (post-LN, relu, dropout 0.1 at the attention probabilities, after the out-projection, after
+// relu and after linear2; score_models.py:57-62), loss of src/fdiff/utils/losses.py:39-125.
+//
+// Five kernels per encoder layer instead of ~40 launches of the exact-f32 path (fd_score_f32.hip / fd_score_bwd.hip):
+//   forward   k_tr_attn_fwd   (series, head pair): Q/K/V projections, softmax, dropout, P V            -> att
+//             k_tr_ffn_fwd    128 tokens: out-proj + dropout + residual + LN1 + FFN (hidden in registers, dropout)
+//                             + dropout + residual + LN2                                               -> next layer input
+//   backward  k_tr_ffn_bwd    128 tokens: LN2 bwd, FFN input gradient (d hidden never leaves registers), LN1 bwd,
+//                             out-proj input gradient                                                  -> d att, d residual
+//             k_tr_attn_bwd   (series, head pair): recomputes Q/K/V and P, d Q/K/V, input gradient of in_proj
+//   once      k_tr_wgrad      every weight gradient of every layer: each output element is owned by ONE wave that walks the
+//                             tokens of its split in a fixed order (the FFN hidden / d hidden are recomputed per 32-token
+//                             block, never materialised); k_tr_reduce adds the token splits in a fixed order.
+// No float atomics anywhere: two runs give bit-identical gradients.
+//
+// Conventions (v_mfma_f32_16x16x32_bf16 / _16x16x16): token on lane&15, g = lane>>4; C tile [row 4g+r][col lane&15];
+// weights are the A operand in 1 KiB fragment blocks (fd_bf16_images.h).  Activations that a later kernel needs with the
+// TOKEN axis as the contraction (weight gradients) are also kept as bf16 "T-blocks" [32-token block][feature row][32 tokens];
+// activations needed as MFMA operands with the FEATURE axis as the contraction are kept as bf16 rows [token][32*KS1 k-slots]
+// with the constant 1.0 in k-slot D (the bias row of the weight images).  Dropout decisions are stored as bits by the forward
+// (hidden: kept AND h > 0; attention: kept) -- the two orientations in which the backward needs them (token on lane /
+// feature on lane) cannot both be regenerated from one counter layout without 4x the Philox evaluations.
+#include <algorithm>
+#include <cmath>
+
+#include "fd_bf16_images.h"
+#include "fd_gemm_f32.h"
+#include "fd_philox.h"
+#include "fd_score.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+uint64_t fd_dropout_site_offset(uint64_t base, int layer, int site);   // fd_score_f32.hip
+namespace fdf32 {
+void time_embed(const float* t, const float* W, const float* Wd, const float* bd, float* temb, int B, int D, hipStream_t s);
+void embed(const float* x, const float* We, const float* be, const float* pe, const float* temb, float* h, int M, int T, int C,
+           int D, hipStream_t s);
+}  // namespace fdf32
+int fd_time_embed_train(const float* t, const float* W, const float* Wd, const float* bd, float* emb, float* temb, int B, int D,
+                        hipStream_t s);                                  // fd_score_f32.hip
+int fd_embed_backward(fd_score* m, const float* dh, const float* emb, float* dtemb, float* grads, int B, float* skp,
+                      size_t skp_floats, hipStream_t s);                 // fd_score_bwd.hip
+
+namespace {
+
+constexpr float kNegBig = -1.0e30f;
+constexpr int TW = 8;            // waves per token-parallel workgroup (one 16-token tile each)
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
+    u32x4 r = {cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3]), cvt_pk_bf16(b[0], b[1]), cvt_pk_bf16(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ s16x4 pack4(f32x4 a) {
+    u32x2 r = {cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
+    return __builtin_bit_cast(s16x4, r);
+}
+__device__ __forceinline__ f32x4 f4zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ bf16x8 frag_zero() {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    return __builtin_bit_cast(bf16x8, z);
+}
+__device__ __forceinline__ void swap32(float v, float& a, float& b) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned r0 = r.x, r1 = r.y;
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void swap16(float v, float& a, float& b) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned r0 = r.x, r1 = r.y;
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ float group_sum(float v) {      // over the 4 lane groups (same lane&15)
+    float a, b;
+    swap32(v, a, b);
+    swap16(a + b, a, b);
+    return a + b;
+}
+__device__ __forceinline__ float group_max(float v) {
+    float a, b;
+    swap32(v, a, b);
+    swap16(fmaxf(a, b), a, b);
+    return fmaxf(a, b);
+}
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_sum16(float v) {      // over the 16 lanes of a row (fixed order: deterministic)
+    v += row_ror<8>(v);
+    v += row_ror<4>(v);
+    v += row_ror<2>(v);
+    v += row_ror<1>(v);
+    return v;
+}
+
+// 8 dropout decisions from one Philox4x32-10 evaluation: bit e = (16-bit field e >= thr16), i.e. kept with probability
+// 1 - thr16 / 65536 (thr16 = round(p * 65536): p = 0.1 -> 0.100006; the rescale uses the exact keep probability).
+__device__ __forceinline__ unsigned drop8(uint64_t ctr, uint64_t seed, unsigned thr16) {
+    const fd_u4 r = fd_philox4x32_10(ctr, seed);
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+    unsigned m = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        m |= ((w[i] & 0xffffu) >= thr16 ? 1u : 0u) << (2 * i);
+        m |= ((w[i] >> 16) >= thr16 ? 1u : 0u) << (2 * i + 1);
+    }
+    return m;
+}
+
+struct TrDims {
+    int B, T, M, D, F, H, hd, NP, KT, NJ, NFT, RBW;   // NFT = 16*DT feature rows of a T-block, RBW = 32*KS1 slots of a row
+    float p, keep_scale;
+    unsigned thr16;
+    unsigned long long seed;
+};
+
+// ------------------------------------------------------------------------------------------------ shared device pieces
+// C-layout tile (features 16dt+4g+r of token `m`) <- fp32 rows
+template <int DT>
+__device__ __forceinline__ void load_ctile(const float* __restrict__ base, int m, bool valid, int D, int g, f32x4 (&v)[DT]) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int d0 = 16 * dt + 4 * g;
+        v[dt] = f4zero();
+        if (valid && d0 < D) {
+            const float4 a = *reinterpret_cast<const float4*>(base + (size_t)m * D + d0);
+            v[dt] = f32x4{a.x, a.y, a.z, a.w};
+        }
+    }
+}
+template <int DT>
+__device__ __forceinline__ void store_ctile(float* __restrict__ base, int m, bool valid, int D, int g, const f32x4 (&v)[DT]) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int d0 = 16 * dt + 4 * g;
+        if (valid && d0 < D) *reinterpret_cast<float4*>(base + (size_t)m * D + d0) = float4{v[dt][0], v[dt][1], v[dt][2], v[dt][3]};
+    }
+}
+// T-block store: feature rows 16dt+4g+r, column m&31; `ones` puts 1.0 into row D (bias column of the weight gradients).
+// Every row of the 16*DT block rows is written for this token (pads as 0), invalid tokens write zeros.
+template <int DT>
+__device__ __forceinline__ void store_T(__bf16* __restrict__ tb, int m, bool valid, int D, int g, const f32x4 (&v)[DT], bool ones) {
+    const int NFT = 16 * DT;
+    __bf16* col = tb + ((size_t)(m >> 5) * NFT) * 32 + (m & 31);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 16 * dt + 4 * g + r;
+            float x = 0.f;
+            if (valid) x = (f < D) ? v[dt][r] : ((f == D && ones) ? 1.0f : 0.f);
+            col[(size_t)f * 32] = (__bf16)x;
+        }
+}
+// Row store (k-slot layout of the weight images): slots d < D, slot D = 1.0 when `ones`, zero padding up to 32*KS1.
+template <int DT, int KS1>
+__device__ __forceinline__ void store_rows(__bf16* __restrict__ rb, int m, bool valid, int D, int g, const f32x4 (&v)[DT], bool ones) {
+    __bf16* row = rb + (size_t)m * (32 * KS1);
+#pragma unroll
+    for (int dt = 0; dt < 2 * KS1; ++dt) {
+        const int d0 = 16 * dt + 4 * g;
+        u32x2 pk = {0u, 0u};
+        if (valid) {
+            if (dt < DT && d0 < D) {
+                pk[0] = cvt_pk_bf16(v[dt < DT ? dt : 0][0], v[dt < DT ? dt : 0][1]);
+                pk[1] = cvt_pk_bf16(v[dt < DT ? dt : 0][2], v[dt < DT ? dt : 0][3]);
+            } else if (d0 == D && ones) {
+                pk[0] = 0x00003F80u;
+            }
+        }
+        *reinterpret_cast<u32x2*>(row + d0) = pk;
+    }
+}
+__device__ __forceinline__ bf16x8 row_frag(const __bf16* __restrict__ rb, int m, bool valid, int RBW, int ks, int g) {
+    if (!valid) return frag_zero();
+    return *reinterpret_cast<const bf16x8*>(rb + (size_t)m * RBW + 32 * ks + 8 * g);
+}
+// C layout -> B fragments through a wave-private LDS scratch of KS1 KiB (same lanes write and read; LDS is in order per wave)
+template <int DT, int KS1>
+__device__ __forceinline__ void ctile_to_frags(char* scratch, int lane, int D, const f32x4 (&v)[DT], bool ones, bf16x8 (&xf)[KS1]) {
+    const int tok = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int dt = 0; dt < 2 * KS1; ++dt) {
+        const int d0 = 16 * dt + 4 * g;
+        u32x2 pk = {0u, 0u};
+        if (dt < DT && d0 < D) {
+            pk[0] = cvt_pk_bf16(v[dt < DT ? dt : 0][0], v[dt < DT ? dt : 0][1]);
+            pk[1] = cvt_pk_bf16(v[dt < DT ? dt : 0][2], v[dt < DT ? dt : 0][3]);
+        } else if (d0 == D && ones) {
+            pk[0] = 0x00003F80u;
+        }
+        const int ks = dt >> 1, gd = 2 * (dt & 1) + (g >> 1);
+        *reinterpret_cast<u32x2*>(scratch + ((ks * 64 + gd * 16 + tok) * 16 + 8 * (g & 1))) = pk;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(scratch + (ks * 64 + lane) * 16);
+    __builtin_amdgcn_wave_barrier();
+}
+// LayerNorm statistics of a C-layout tile over the D features of token lane&15
+template <int DT>
+__device__ __forceinline__ void ln_stats(const f32x4 (&v)[DT], int D, int g, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+        if (16 * dt + 4 * g < D) s += (v[dt][0] + v[dt][1]) + (v[dt][2] + v[dt][3]);
+    mean = group_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+        if (16 * dt + 4 * g < D) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float c = v[dt][r] - mean;
+                q += c * c;
+            }
+        }
+    rstd = rsqrtf(group_sum(q) / (float)D + 1e-5f);
+}
+// dropout bits of a (token, D features) row in C layout: three Philox evaluations cover tiles (0,1), (2,3), (4,5)
+template <int DT>
+__device__ __forceinline__ void row_drop_bits(const TrDims& d, unsigned long long site_off, int m, int g, unsigned (&bits)[DT]) {
+#pragma unroll
+    for (int j = 0; j < (DT + 1) / 2; ++j) {
+        unsigned b8 = 0xffu;
+        if (d.p > 0.f) b8 = drop8(site_off + ((unsigned long long)m * ((DT + 1) / 2) + j) * 4ull + (unsigned)g, d.seed, d.thr16);
+        bits[2 * j] = b8 & 15u;
+        if (2 * j + 1 < DT) bits[2 * j + 1] = b8 >> 4;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ layer-input preparation
+// fp32 (M, D) -> bf16 rows (ones in slot D) + T-block (ones row), for the first layer's input (the embedding kernel is the
+// exact-f32 one).  One wave per 16-token tile.
+template <int KS1, int DT>
+__global__ __launch_bounds__(256) void k_tr_prep(const float* __restrict__ x, __bf16* __restrict__ rb, __bf16* __restrict__ tb,
+                                                  int M, int Mpad, int D) {
+    const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m = tile * 16 + tok;
+    if (tile * 16 >= Mpad) return;
+    const bool valid = m < M;
+    f32x4 v[DT];
+    load_ctile<DT>(x, m, valid, D, g, v);
+    store_rows<DT, KS1>(rb, m, valid, D, g, v, true);
+    store_T<DT>(tb, m, valid, D, g, v, true);
+}
+
+// ------------------------------------------------------------------------------------------------ attention forward
+// grid (NP, B), 256 threads.  K (both heads of the pair, 8-byte rows) and V^T (16-byte rows of 8 keys) of the series in LDS.
+struct AttnFwdArgs {
+    const __bf16* x0rb;       // (Mpad, RBW) layer input rows
+    float* att;               // (M, D)
+    __bf16* attT;             // T-block, ones row
+    float* lse2;              // (B, H, T): row maximum + log2(row sum) of the scaled scores (base-2 logits)
+    unsigned char* pmask;     // (B, H, T, NJ, 4) keep bits of the attention dropout
+    const char* wk; const char* wv; const char* wq;   // pair images (KS1 blocks per pair)
+    unsigned long long site_off;
+};
+
+template <int KS1>
+__global__ __launch_bounds__(256) void k_tr_attn_fwd(const TrDims d, const AttnFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = blockIdx.x, b = blockIdx.y;
+    const int T = d.T, KT = d.KT, NJ = d.NJ, NTOK = KT * 16, hd = d.hd, H = d.H, D = d.D;
+    char* const kbf = smem;                          // [NTOK][4][8 B]
+    char* const vbf = smem + (size_t)NTOK * 32;      // [NJ][4][16][16 B]
+    const size_t pstride = (size_t)KS1 * 1024;
+    auto wfrag = [&](const char* img, int ks) { return *reinterpret_cast<const bf16x8*>(img + pair * pstride + ((size_t)ks * 64 + lane) * 16); };
+    auto xfrag = [&](int tile, int ks) { const int t = tile * 16 + tok; return row_frag(a.x0rb, b * T + t, t < T, d.RBW, ks, g); };
+    {
+        bf16x8 wkf[KS1], wvf[KS1];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) { wkf[ks] = wfrag(a.wk, ks); wvf[ks] = wfrag(a.wv, ks); }
+        for (int kt = wave; kt < KT; kt += 4) {
+            f32x4 ka = f4zero(), vc = f4zero();
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const bf16x8 xf = xfrag(kt, ks);
+                ka = MFMA(wkf[ks], xf, ka);
+                vc = MFMA(xf, wvf[ks], vc);
+            }
+            *reinterpret_cast<u32x2*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8) = u32x2{cvt_pk_bf16(ka[0], ka[1]), cvt_pk_bf16(ka[2], ka[3])};
+            char* dst = vbf + ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16;
+            *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = u32x2{cvt_pk_bf16(vc[0], vc[1]), cvt_pk_bf16(vc[2], vc[3])};
+            if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
+        }
+    }
+    __syncthreads();
+    bf16x8 wqf[KS1];
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) wqf[ks] = wfrag(a.wq, ks);
+    const bool lo_grp = (g >> 1) == 0;
+    const int myhead = 2 * pair + (g >> 1);
+    f32x4 cmask;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cmask[r] = ((KT - 1) * 16 + 4 * g + r >= T) ? kNegBig : 0.f;
+    const f32x4 allneg = {kNegBig, kNegBig, kNegBig, kNegBig};
+    auto kfrag = [&](int kt) { return *reinterpret_cast<const s16x4*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8); };
+    for (int qt = wave; qt < KT; qt += 4) {
+        const int t = qt * 16 + tok;
+        f32x4 qa = f4zero();
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) qa = MFMA(wqf[ks], xfrag(qt, ks), qa);
+        const unsigned q01 = cvt_pk_bf16(qa[0], qa[1]), q23 = cvt_pk_bf16(qa[2], qa[3]);
+        s16x4 qb[2];
+        qb[0] = __builtin_bit_cast(s16x4, u32x2{lo_grp ? q01 : 0u, lo_grp ? q23 : 0u});
+        qb[1] = __builtin_bit_cast(s16x4, u32x2{lo_grp ? 0u : q01, lo_grp ? 0u : q23});
+        // pass 1: exact row maxima (base-2 logits: log2(e)/sqrt(hd) is folded into W_q)
+        float mx[2] = {kNegBig, kNegBig};
+        for (int kt = 0; kt < KT; ++kt) {
+            const s16x4 kf = kfrag(kt);
+            const f32x4 c0 = (kt == KT - 1) ? cmask : f4zero();
+#pragma unroll
+            for (int hs = 0; hs < 2; ++hs) {
+                const f32x4 v = MFMA16(kf, qb[hs], c0);
+                mx[hs] = fmaxf(fmaxf(fmaxf(mx[hs], v[0]), v[1]), fmaxf(v[2], v[3]));
+            }
+        }
+        f32x4 negm[2];
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+            mx[hs] = group_max(mx[hs]);
+            negm[hs] = f32x4{-mx[hs], -mx[hs], -mx[hs], -mx[hs]};
+        }
+        // pass 2: P = exp2(S - max); row sums of the UNDROPPED P; dropped P (unscaled) times V
+        float ls[2] = {0.f, 0.f};
+        f32x4 o2[2] = {f4zero(), f4zero()};
+        for (int jb = 0; jb < NJ; ++jb) {
+            const int ka = 2 * jb, kb = (2 * jb + 1 < KT) ? 2 * jb + 1 : ka;
+            const s16x4 kfa = kfrag(ka), kfb = kfrag(kb);
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(jb * 4 + g) * 16 + tok) * 16);
+            const f32x4 ma = (ka == KT - 1) ? cmask : f4zero();
+            const f32x4 mb = (2 * jb + 1 >= KT) ? allneg : ((kb == KT - 1) ? cmask : f4zero());
+#pragma unroll
+            for (int hs = 0; hs < 2; ++hs) {
+                f32x4 pa = MFMA16(kfa, qb[hs], ma + negm[hs]);
+                f32x4 pb = MFMA16(kfb, qb[hs], mb + negm[hs]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pa[r] = __builtin_amdgcn_exp2f(pa[r]);
+                    pb[r] = __builtin_amdgcn_exp2f(pb[r]);
+                }
+                ls[hs] += (pa[0] + pa[1]) + (pa[2] + pa[3]) + (pb[0] + pb[1]) + (pb[2] + pb[3]);
+                const int head = 2 * pair + hs;
+                const size_t bidx = ((((size_t)b * H + head) * T + (t < T ? t : 0)) * NJ + jb) * 4 + g;
+                unsigned bits = 0xffu;
+                if (d.p > 0.f) bits = drop8(a.site_off + bidx, d.seed, d.thr16);
+                if (t < T && head < H) a.pmask[bidx] = (unsigned char)bits;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pa[r] = (bits >> r) & 1u ? pa[r] : 0.f;
+                    pb[r] = (bits >> (4 + r)) & 1u ? pb[r] : 0.f;
+                }
+                o2[hs] = MFMA(vf, pack8(pa, pb), o2[hs]);
+            }
+        }
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) ls[hs] = group_sum(ls[hs]);
+        const float lmine = lo_grp ? ls[0] : ls[1], mmine = lo_grp ? mx[0] : mx[1];
+        const float inv = d.keep_scale / lmine;
+        const int m = b * T + t;
+        if (t < T && myhead < H) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int dd = 4 * (g & 1) + r;
+                if (dd < hd) {
+                    const float o = (lo_grp ? o2[0][r] : o2[1][r]) * inv;
+                    a.att[(size_t)m * D + myhead * hd + dd] = o;
+                    a.attT[((size_t)(m >> 5) * d.NFT + myhead * hd + dd) * 32 + (m & 31)] = (__bf16)o;
+                }
+            }
+            if ((g & 1) == 0) a.lse2[((size_t)b * H + myhead) * T + t] = mmine + __builtin_amdgcn_logf(lmine);
+        }
+        if (pair == 0 && t < T) {          // ones row (bias column of d W_o) and the zero rows of the T-block padding
+            for (int f = D + g; f < d.NFT; f += 4)
+                a.attT[((size_t)(m >> 5) * d.NFT + f) * 32 + (m & 31)] = (__bf16)((f == D) ? 1.0f : 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ FFN-side forward
+struct FfnFwdArgs {
+    const float* x0;          // (M, D) layer input (residual)
+    const float* att;         // (M, D)
+    float* s1; float* s2;     // (M, D) pre-LayerNorm sums (saved)
+    float* out;               // (M, D) layer output
+    __bf16* x1rb; __bf16* x1T;
+    __bf16* outrb; __bf16* outT;   // next layer's input in operand form (null for the last layer)
+    unsigned char* active;    // (Mpad, F/32, 4): bit e of byte (m, chunk, g): hidden unit kept by dropout AND > 0
+    const char* wo_img;       // [DT][KSO]
+    const char* ffn_img;      // chunk-major forward image of the layer
+    const float* bo; const float* g1; const float* be1; const float* b2; const float* g2; const float* be2;
+    unsigned long long off1, off2, off3;   // Philox counter bases of the three dropout sites
+};
+
+template <int KS1, int DT, int KSO>
+__global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const FfnFwdArgs a) {
+    constexpr int NB = 2 * KS1 + DT, WB = 2 * NB * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* const ring = smem;                                   // 2 x [F-half][NB] KiB
+    char* const scratch = smem + 2 * WB + wave * KS1 * 1024;   // wave-private fragment scratch
+    const int D = d.D, M = d.M, NS = d.F / 64;
+    const int m = (blockIdx.x * TW + wave) * 16 + tok;
+    const bool valid = m < M;
+    auto issue = [&](int c, int buf) {
+        const char* src = a.ffn_img + (size_t)c * WB + lane * 16;
+        char* dst = ring + buf * WB;
+        for (int bb = wave; bb < 2 * NB; bb += TW)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src + bb * 1024), LDS_PTR(dst + bb * 1024), 16, 0, 0);
+    };
+    issue(0, 0);
+    // ---- out-projection + bias + dropout + residual -> s1
+    f32x4 v[DT];
+    {
+        f32x4 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = f4zero();
+#pragma unroll
+        for (int ks = 0; ks < KSO; ++ks) {
+            const int head = 4 * ks + g;
+            float e8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) e8[e] = (valid && head < d.H && e < d.hd) ? a.att[(size_t)m * D + head * d.hd + e] : 0.f;
+            const u32x4 pk = {cvt_pk_bf16(e8[0], e8[1]), cvt_pk_bf16(e8[2], e8[3]), cvt_pk_bf16(e8[4], e8[5]), cvt_pk_bf16(e8[6], e8[7])};
+            const bf16x8 af = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                o[dt] = MFMA(*reinterpret_cast<const bf16x8*>(a.wo_img + ((size_t)(dt * KSO + ks) * 64 + lane) * 16), af, o[dt]);
+        }
+        unsigned bits[DT];
+        row_drop_bits<DT>(d, a.off1, m, g, bits);
+        load_ctile<DT>(a.x0, m, valid, D, g, v);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            if (d0 < D) {
+                const float4 bb = *reinterpret_cast<const float4*>(a.bo + d0);
+                const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[dt][r] += ((bits[dt] >> r) & 1u) ? (o[dt][r] + bv[r]) * d.keep_scale : 0.f;
+            }
+        }
+    }
+    store_ctile<DT>(a.s1, m, valid, D, g, v);
+    // ---- LayerNorm1 -> x1 (registers = residual of the FFN block; operand copies for the backward)
+    {
+        float mean, rstd;
+        ln_stats<DT>(v, D, g, mean, rstd);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            if (d0 < D) {
+                const float4 gm = *reinterpret_cast<const float4*>(a.g1 + d0), bt = *reinterpret_cast<const float4*>(a.be1 + d0);
+                v[dt][0] = (v[dt][0] - mean) * rstd * gm.x + bt.x;
+                v[dt][1] = (v[dt][1] - mean) * rstd * gm.y + bt.y;
+                v[dt][2] = (v[dt][2] - mean) * rstd * gm.z + bt.z;
+                v[dt][3] = (v[dt][3] - mean) * rstd * gm.w + bt.w;
+            } else {
+                v[dt] = f4zero();
+            }
+        }
+    }
+    store_rows<DT, KS1>(a.x1rb, m, valid, D, g, v, true);
+    store_T<DT>(a.x1T, m, valid, D, g, v, true);
+    bf16x8 xf[KS1];
+    ctile_to_frags<DT, KS1>(scratch, lane, D, v, true, xf);
+    f32x4 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f4zero();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- FFN: weights streamed L2 -> LDS (double buffer, one 32-wide chunk per F-half per step), hidden in registers
+    for (int c = 0; c < NS; ++c) {
+        if (c + 1 < NS) issue(c + 1, (c + 1) & 1);
+#pragma unroll
+        for (int fh = 0; fh < 2; ++fh) {
+            const char* wb = ring + (c & 1) * WB + fh * NB * 1024 + lane * 16;
+            f32x4 h0 = f4zero(), h1 = f4zero();
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                h0 = MFMA(*reinterpret_cast<const bf16x8*>(wb + ks * 1024), xf[ks], h0);
+                h1 = MFMA(*reinterpret_cast<const bf16x8*>(wb + (KS1 + ks) * 1024), xf[ks], h1);
+            }
+            const int chunk = fh * NS + c;
+            const size_t bidx = ((size_t)m * (2 * NS) + chunk) * 4 + g;
+            unsigned bits = 0xffu;
+            if (d.p > 0.f) bits = drop8(a.off2 + bidx, d.seed, d.thr16);
+            unsigned act = 0u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool k0 = ((bits >> r) & 1u) && h0[r] > 0.f, k1 = ((bits >> (4 + r)) & 1u) && h1[r] > 0.f;
+                act |= (k0 ? 1u : 0u) << r;
+                act |= (k1 ? 1u : 0u) << (4 + r);
+                h0[r] = k0 ? h0[r] * d.keep_scale : 0.f;
+                h1[r] = k1 ? h1[r] * d.keep_scale : 0.f;
+            }
+            if (valid) a.active[bidx] = (unsigned char)act;
+            const bf16x8 hb = pack8(h0, h1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(*reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024), hb, acc[dt]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // ---- + b2, dropout, residual -> s2, LayerNorm2 -> layer output
+    {
+        unsigned bits[DT];
+        row_drop_bits<DT>(d, a.off3, m, g, bits);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            if (d0 < D) {
+                const float4 bb = *reinterpret_cast<const float4*>(a.b2 + d0);
+                const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[dt][r] += ((bits[dt] >> r) & 1u) ? (acc[dt][r] + bv[r]) * d.keep_scale : 0.f;
+            }
+        }
+    }
+    store_ctile<DT>(a.s2, m, valid, D, g, v);
+    {
+        float mean, rstd;
+        ln_stats<DT>(v, D, g, mean, rstd);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            if (d0 < D) {
+                const float4 gm = *reinterpret_cast<const float4*>(a.g2 + d0), bt = *reinterpret_cast<const float4*>(a.be2 + d0);
+                v[dt][0] = (v[dt][0] - mean) * rstd * gm.x + bt.x;
+                v[dt][1] = (v[dt][1] - mean) * rstd * gm.y + bt.y;
+                v[dt][2] = (v[dt][2] - mean) * rstd * gm.z + bt.z;
+                v[dt][3] = (v[dt][3] - mean) * rstd * gm.w + bt.w;
+            } else {
+                v[dt] = f4zero();
+            }
+        }
+    }
+    store_ctile<DT>(a.out, m, valid, D, g, v);
+    if (a.outrb) {
+        store_rows<DT, KS1>(a.outrb, m, valid, D, g, v, true);
+        store_T<DT>(a.outT, m, valid, D, g, v, true);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ FFN-side backward
+struct FfnBwdArgs {
+    const float* dy0;         // (M, D) gradient of the layer output: residual-path part ...
+    const float* dyp;         // ... plus `npart` partial tensors (the next layer's attention backward, one per head pair)
+    int npart; size_t part_stride;
+    const float* s1; const float* s2;
+    const unsigned char* active;
+    float* datt;              // (M, D) gradient of the attention output
+    float* dres;              // (M, D) gradient of the layer input through the residual path (= d s1)
+    __bf16* dffnT; __bf16* dffnrb; __bf16* doT;
+    float* vecpart;           // [grid][5][D]: column sums of this workgroup: d b2, d beta2, d gamma2, d beta1, d gamma1
+    const char* bffn;         // backward FFN image (chunk-major)
+    const char* wot;          // [DT][KS1]
+    const float* g1; const float* be1; const float* g2;
+    unsigned long long off1, off3;
+};
+
+// LayerNorm backward on a C-layout tile: dy -> ds (in place), xhat given; returns nothing (column sums done by the caller)
+template <int DT>
+__device__ __forceinline__ void ln_bwd_tile(f32x4 (&dy)[DT], const f32x4 (&xhat)[DT], const float* __restrict__ gamma, float rstd,
+                                            int D, int g) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int d0 = 16 * dt + 4 * g;
+        if (d0 < D) {
+            const float4 gm = *reinterpret_cast<const float4*>(gamma + d0);
+            const float gv[4] = {gm.x, gm.y, gm.z, gm.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dy[dt][r] *= gv[r];
+                s1 += dy[dt][r];
+                s2 += dy[dt][r] * xhat[dt][r];
+            }
+        } else {
+            dy[dt] = f4zero();
+        }
+    }
+    const float m1 = group_sum(s1) / (float)D, m2 = group_sum(s2) / (float)D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+        if (16 * dt + 4 * g < D) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dy[dt][r] = rstd * (dy[dt][r] - m1 - xhat[dt][r] * m2);
+        }
+}
+
+template <int KS1, int DT>
+__global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const FfnBwdArgs a) {
+    constexpr int NB = 2 * KS1 + DT, WB = 2 * NB * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* const ring = smem;
+    char* const scratch = smem + 2 * WB + wave * KS1 * 1024;
+    float* const colred = reinterpret_cast<float*>(smem + 2 * WB + TW * KS1 * 1024);   // [TW][5][16*DT]
+    const int D = d.D, M = d.M, NS = d.F / 64;
+    const int m = (blockIdx.x * TW + wave) * 16 + tok;
+    const bool valid = m < M;
+    auto issue = [&](int c, int buf) {
+        const char* src = a.bffn + (size_t)c * WB + lane * 16;
+        char* dst = ring + buf * WB;
+        for (int bb = wave; bb < 2 * NB; bb += TW)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src + bb * 1024), LDS_PTR(dst + bb * 1024), 16, 0, 0);
+    };
+    issue(0, 0);
+    // column sums over this wave's 16 tokens -> colred[wave][slot][feature]
+    auto colsum = [&](int slot, const f32x4 (&t)[DT]) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sres = row_sum16(t[dt][r]);
+                if (tok == 0) colred[(wave * 5 + slot) * (16 * DT) + 16 * dt + 4 * g + r] = sres;
+            }
+    };
+    // ---- gradient of the layer output
+    f32x4 dy[DT];
+    load_ctile<DT>(a.dy0, m, valid, D, g, dy);
+    for (int pi = 0; pi < a.npart; ++pi) {
+        f32x4 t[DT];
+        load_ctile<DT>(a.dyp + (size_t)pi * a.part_stride, m, valid, D, g, t);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dy[dt] += t[dt];
+    }
+    // ---- LayerNorm2 backward
+    f32x4 xh[DT];
+    float rstd2;
+    {
+        float mean;
+        load_ctile<DT>(a.s2, m, valid, D, g, xh);
+        ln_stats<DT>(xh, D, g, mean, rstd2);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xh[dt][r] = (16 * dt + 4 * g < D && valid) ? (xh[dt][r] - mean) * rstd2 : 0.f;
+    }
+    colsum(1, dy);                                   // d beta2
+    {
+        f32x4 t[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) t[dt] = dy[dt] * xh[dt];
+        colsum(2, t);                                // d gamma2
+    }
+    ln_bwd_tile<DT>(dy, xh, a.g2, rstd2, D, g);      // dy = d s2
+    // ---- d f (FFN output after its dropout)
+    f32x4 df[DT];
+    {
+        unsigned bits[DT];
+        row_drop_bits<DT>(d, a.off3, m, g, bits);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) df[dt][r] = ((bits[dt] >> r) & 1u) ? dy[dt][r] * d.keep_scale : 0.f;
+    }
+    colsum(0, df);                                   // d b2
+    store_T<DT>(a.dffnT, m, valid, D, g, df, false);
+    store_rows<DT, KS1>(a.dffnrb, m, valid, D, g, df, false);
+    bf16x8 dfr[KS1];
+    ctile_to_frags<DT, KS1>(scratch, lane, D, df, false, dfr);
+    f32x4 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f4zero();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- d x1 += W1^T (active . W2^T d f): d hidden lives in registers only
+    for (int c = 0; c < NS; ++c) {
+        if (c + 1 < NS) issue(c + 1, (c + 1) & 1);
+#pragma unroll
+        for (int fh = 0; fh < 2; ++fh) {
+            const char* wb = ring + (c & 1) * WB + fh * NB * 1024 + lane * 16;
+            f32x4 h0 = f4zero(), h1 = f4zero();
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                h0 = MFMA(*reinterpret_cast<const bf16x8*>(wb + ks * 1024), dfr[ks], h0);
+                h1 = MFMA(*reinterpret_cast<const bf16x8*>(wb + (KS1 + ks) * 1024), dfr[ks], h1);
+            }
+            const int chunk = fh * NS + c;
+            const unsigned act = valid ? a.active[((size_t)m * (2 * NS) + chunk) * 4 + g] : 0u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                h0[r] = ((act >> r) & 1u) ? h0[r] * d.keep_scale : 0.f;
+                h1[r] = ((act >> (4 + r)) & 1u) ? h1[r] * d.keep_scale : 0.f;
+            }
+            const bf16x8 hb = pack8(h0, h1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(*reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024), hb, acc[dt]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dy[dt] += acc[dt];          // d x1 = residual path + FFN branch
+    // ---- LayerNorm1 backward
+    float rstd1;
+    {
+        float mean;
+        load_ctile<DT>(a.s1, m, valid, D, g, xh);
+        ln_stats<DT>(xh, D, g, mean, rstd1);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xh[dt][r] = (16 * dt + 4 * g < D && valid) ? (xh[dt][r] - mean) * rstd1 : 0.f;
+    }
+    colsum(3, dy);                                   // d beta1
+    {
+        f32x4 t[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) t[dt] = dy[dt] * xh[dt];
+        colsum(4, t);                                // d gamma1
+    }
+    ln_bwd_tile<DT>(dy, xh, a.g1, rstd1, D, g);      // dy = d s1
+    store_ctile<DT>(a.dres, m, valid, D, g, dy);
+    // ---- d o (out-projection output after its dropout) -> d att = d o W_o
+    {
+        unsigned bits[DT];
+        row_drop_bits<DT>(d, a.off1, m, g, bits);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) df[dt][r] = ((bits[dt] >> r) & 1u) ? dy[dt][r] * d.keep_scale : 0.f;
+    }
+    store_T<DT>(a.doT, m, valid, D, g, df, false);
+    ctile_to_frags<DT, KS1>(scratch, lane, D, df, false, dfr);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        f32x4 o = f4zero();
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+            o = MFMA(*reinterpret_cast<const bf16x8*>(a.wot + ((size_t)(dt * KS1 + ks) * 64 + lane) * 16), dfr[ks], o);
+        acc[dt] = o;
+    }
+    store_ctile<DT>(a.datt, m, valid, D, g, acc);
+    // ---- column sums of the workgroup, waves added in a fixed order
+    __syncthreads();
+    for (int i = threadIdx.x; i < 5 * 16 * DT; i += TW * 64) {
+        const int slot = i / (16 * DT), f = i - slot * (16 * DT);
+        float sres = 0.f;
+        for (int w = 0; w < TW; ++w) sres += colred[(w * 5 + slot) * (16 * DT) + f];
+        if (f < D) a.vecpart[((size_t)blockIdx.x * 5 + slot) * D + f] = sres;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ attention backward
+struct AttnBwdArgs {
+    const __bf16* x0rb;
+    const float* att;         // (M, D) forward output O (after dropout scaling)
+    const float* datt;        // (M, D)
+    const float* lse2;
+    const unsigned char* pmask;
+    float* dxp;               // [NP][M, D]: this pair's contribution to the layer-input gradient
+    __bf16* dqkvT;            // T-block with 3*NP*16 rows: row which*(NP*16) + pair*16 + (8 hs + dim)
+    const char* wk; const char* wv; const char* wq;
+    const char* winT;         // [pair][which][DT] half blocks
+    size_t part_stride;
+};
+
+template <int KS1, int DT>
+__global__ __launch_bounds__(256) void k_tr_attn_bwd(const TrDims d, const AttnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = blockIdx.x, b = blockIdx.y;
+    const int T = d.T, KT = d.KT, NJ = d.NJ, NTOK = KT * 16, hd = d.hd, H = d.H, D = d.D;
+    // "row" form [token][4 g][8 B] (16x16x16 operand with the pair's 16 dim slots as k) and "column" form
+    // [32-token block][4 g][16 dim rows][16 B] (16x16x32 A operand with 32 tokens as k) of q, k, v, dO
+    const size_t RSZ = (size_t)NTOK * 32, CSZ = (size_t)NJ * 1024;
+    char* const qR = smem;            char* const kR = qR + RSZ;  char* const vR = kR + RSZ;  char* const oR = vR + RSZ;
+    char* const qC = oR + RSZ;        char* const kC = qC + CSZ;  char* const oC = kC + CSZ;
+    float* const drow = reinterpret_cast<float*>(oC + CSZ);      // [2][NTOK]  rowsum(dO . O) per (head of the pair, query)
+    float* const lse = drow + 2 * NTOK;                          // [2][NTOK]
+    const size_t pstride = (size_t)KS1 * 1024;
+    auto wfrag = [&](const char* img, int ks) { return *reinterpret_cast<const bf16x8*>(img + pair * pstride + ((size_t)ks * 64 + lane) * 16); };
+    auto xfrag = [&](int tile, int ks) { const int t = tile * 16 + tok; return row_frag(a.x0rb, b * T + t, t < T, d.RBW, ks, g); };
+    const bool lo_grp = (g >> 1) == 0;
+    const int myhead = 2 * pair + (g >> 1);
+    // ---- stage q, k, v (recomputed), dO, rowsum(dO.O), lse
+    {
+        bf16x8 wqf[KS1], wkf[KS1], wvf[KS1];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) { wqf[ks] = wfrag(a.wq, ks); wkf[ks] = wfrag(a.wk, ks); wvf[ks] = wfrag(a.wv, ks); }
+        for (int kt = wave; kt < KT; kt += 4) {
+            f32x4 qr = f4zero(), kr = f4zero(), vr = f4zero(), qc = f4zero(), kc = f4zero();
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const bf16x8 xf = xfrag(kt, ks);
+                qr = MFMA(wqf[ks], xf, qr);       // [dim rows][token col] -> row form
+                kr = MFMA(wkf[ks], xf, kr);
+                vr = MFMA(wvf[ks], xf, vr);
+                qc = MFMA(xf, wqf[ks], qc);       // [token rows][dim col] -> column form
+                kc = MFMA(xf, wkf[ks], kc);
+            }
+            const size_t ro = ((size_t)(kt * 16 + tok) * 4 + g) * 8;
+            *reinterpret_cast<s16x4*>(qR + ro) = pack4(qr);
+            *reinterpret_cast<s16x4*>(kR + ro) = pack4(kr);
+            *reinterpret_cast<s16x4*>(vR + ro) = pack4(vr);
+            const size_t co = ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16 + 8 * (kt & 1);
+            *reinterpret_cast<s16x4*>(qC + co) = pack4(qc);
+            *reinterpret_cast<s16x4*>(kC + co) = pack4(kc);
+            if ((KT & 1) && kt == KT - 1) {
+                *reinterpret_cast<u32x2*>(qC + co + 8) = u32x2{0u, 0u};
+                *reinterpret_cast<u32x2*>(kC + co + 8) = u32x2{0u, 0u};
+            }
+            // dO rows and rowsum(dO . O) of this lane's head (4 of its dims per lane, the lane pair g, g^1 holds all 8)
+            const int t = kt * 16 + tok, mm = b * T + t;
+            f32x4 dor = f4zero();
+            float part = 0.f;
+            if (t < T && myhead < H) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int dd = 4 * (g & 1) + r;
+                    if (dd < hd) {
+                        dor[r] = a.datt[(size_t)mm * D + myhead * hd + dd];
+                        part += dor[r] * a.att[(size_t)mm * D + myhead * hd + dd];
+                    }
+                }
+            }
+            *reinterpret_cast<s16x4*>(oR + ro) = pack4(dor);
+            float ea, eb;
+            swap16(part, ea, eb);
+            if ((g & 1) == 0) {
+                drow[(g >> 1) * NTOK + kt * 16 + tok] = ea + eb;
+                lse[(g >> 1) * NTOK + kt * 16 + tok] = (t < T && myhead < H) ? a.lse2[((size_t)b * H + myhead) * T + t] : 0.f;
+            }
+            // dO column form: lane (dim row = tok, g) holds tokens 4g+r of this tile
+            {
+                const int hs = tok >> 3, dd = tok & 7, head = 2 * pair + hs;
+                f32x4 doc = f4zero();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int tt = kt * 16 + 4 * g + r;
+                    if (tt < T && head < H && dd < hd) doc[r] = a.datt[((size_t)b * T + tt) * D + head * hd + dd];
+                }
+                *reinterpret_cast<s16x4*>(oC + co) = pack4(doc);
+                if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(oC + co + 8) = u32x2{0u, 0u};
+            }
+        }
+    }
+    __syncthreads();
+    auto rfrag = [&](const char* base, int tile) { return *reinterpret_cast<const s16x4*>(base + ((size_t)(tile * 16 + tok) * 4 + g) * 8); };
+    auto cfrag = [&](const char* base, int jb) { return *reinterpret_cast<const bf16x8*>(base + ((size_t)(jb * 4 + g) * 16 + tok) * 16); };
+    auto headmask = [&](s16x4 v, int hs) {        // keep only the k-slots of head hs of the pair
+        const u32x2 u = __builtin_bit_cast(u32x2, v);
+        const bool mine = (g >> 1) == hs;
+        return __builtin_bit_cast(s16x4, u32x2{mine ? u[0] : 0u, mine ? u[1] : 0u});
+    };
+    const float ln2 = 0.6931471805599453f;
+    const float inv_sqrt_hd = 1.0f / sqrtf((float)hd);
+    // each wave owns token tiles tt = wave, wave+4, ...: as QUERY tile (d q), then as KEY tile (d k, d v), then the
+    // input gradient of in_proj for those 16 tokens
+    for (int tt = wave; tt < KT; tt += 4) {
+        f32x4 dq[2] = {f4zero(), f4zero()}, dk[2] = {f4zero(), f4zero()}, dv[2] = {f4zero(), f4zero()};
+        // ---------------- as query tile: S^T tiles [key rows 4g+r][query col]
+        {
+            const int t = tt * 16 + tok;
+            s16x4 qb[2], ob[2];
+            float lq[2], dr[2];
+            {
+                const s16x4 qf = rfrag(qR, tt), of = rfrag(oR, tt);
+#pragma unroll
+                for (int hs = 0; hs < 2; ++hs) {
+                    qb[hs] = headmask(qf, hs);
+                    ob[hs] = headmask(of, hs);
+                    lq[hs] = lse[hs * NTOK + tt * 16 + tok];
+                    dr[hs] = drow[hs * NTOK + tt * 16 + tok];
+                }
+            }
+            for (int jb = 0; jb < NJ; ++jb) {
+                const int ka = 2 * jb, kb = (2 * jb + 1 < KT) ? 2 * jb + 1 : ka;
+                const bool has_b = 2 * jb + 1 < KT;
+                const s16x4 kfa = rfrag(kR, ka), kfb = rfrag(kR, kb), vfa = rfrag(vR, ka), vfb = rfrag(vR, kb);
+                const bf16x8 kcf = cfrag(kC, jb);
+#pragma unroll
+                for (int hs = 0; hs < 2; ++hs) {
+                    f32x4 sa = MFMA16(kfa, qb[hs], f4zero()), sb = MFMA16(kfb, qb[hs], f4zero());
+                    f32x4 pa = MFMA16(vfa, ob[hs], f4zero()), pb = MFMA16(vfb, ob[hs], f4zero());    // dP (dropped P's gradient)
+                    const int head = 2 * pair + hs;
+                    unsigned bits = 0xffu;
+                    if (d.p > 0.f && t < T && head < H) bits = a.pmask[((((size_t)b * H + head) * T + t) * NJ + jb) * 4 + g];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool va = ka * 16 + 4 * g + r < T, vb = has_b && (kb * 16 + 4 * g + r < T);
+                        const float Pa = va ? __builtin_amdgcn_exp2f(sa[r] - lq[hs]) : 0.f;
+                        const float Pb = vb ? __builtin_amdgcn_exp2f(sb[r] - lq[hs]) : 0.f;
+                        const float ga = ((bits >> r) & 1u) ? pa[r] * d.keep_scale : 0.f;
+                        const float gb = ((bits >> (4 + r)) & 1u) ? pb[r] * d.keep_scale : 0.f;
+                        sa[r] = Pa * (ga - dr[hs]);
+                        sb[r] = Pb * (gb - dr[hs]);
+                    }
+                    dq[hs] = MFMA(kcf, pack8(sa, sb), dq[hs]);       // [dim rows][query col] += K^T dS^T
+                }
+            }
+        }
+        // ---------------- as key tile: S tiles [query rows 4g+r][key col]
+        {
+            const int kt = tt;
+            const s16x4 kf = rfrag(kR, kt), vf = rfrag(vR, kt);
+            const int key = kt * 16 + tok;
+            for (int jq = 0; jq < NJ; ++jq) {
+                const int qa_t = 2 * jq, qb_t = (2 * jq + 1 < KT) ? 2 * jq + 1 : qa_t;
+                const bool has_b = 2 * jq + 1 < KT;
+                const s16x4 qfa = rfrag(qR, qa_t), qfb = rfrag(qR, qb_t), ofa = rfrag(oR, qa_t), ofb = rfrag(oR, qb_t);
+                const bf16x8 qcf = cfrag(qC, jq), ocf = cfrag(oC, jq);
+#pragma unroll
+                for (int hs = 0; hs < 2; ++hs) {
+                    f32x4 sa = MFMA16(headmask(qfa, hs), kf, f4zero()), sb = MFMA16(headmask(qfb, hs), kf, f4zero());
+                    f32x4 pa = MFMA16(headmask(ofa, hs), vf, f4zero()), pb = MFMA16(headmask(ofb, hs), vf, f4zero());
+                    const int head = 2 * pair + hs;
+                    const f32x4 la = *reinterpret_cast<const f32x4*>(lse + hs * NTOK + qa_t * 16 + 4 * g);
+                    const f32x4 lb = *reinterpret_cast<const f32x4*>(lse + hs * NTOK + qb_t * 16 + 4 * g);
+                    const f32x4 da = *reinterpret_cast<const f32x4*>(drow + hs * NTOK + qa_t * 16 + 4 * g);
+                    const f32x4 db = *reinterpret_cast<const f32x4*>(drow + hs * NTOK + qb_t * 16 + 4 * g);
+                    f32x4 pda, pdb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qa_i = qa_t * 16 + 4 * g + r, qb_i = qb_t * 16 + 4 * g + r;
+                        const bool va = qa_i < T && key < T && head < H, vb = has_b && qb_i < T && key < T && head < H;
+                        bool ba = true, bb = true;
+                        if (d.p > 0.f) {
+                            const size_t base = (((size_t)b * H + (head < H ? head : 0)) * T);
+                            if (va) ba = (a.pmask[((base + qa_i) * NJ + (kt >> 1)) * 4 + (tok >> 2)] >> ((kt & 1) * 4 + (tok & 3))) & 1u;
+                            if (vb) bb = (a.pmask[((base + qb_i) * NJ + (kt >> 1)) * 4 + (tok >> 2)] >> ((kt & 1) * 4 + (tok & 3))) & 1u;
+                        }
+                        const float Pa = va ? __builtin_amdgcn_exp2f(sa[r] - la[r]) : 0.f;
+                        const float Pb = vb ? __builtin_amdgcn_exp2f(sb[r] - lb[r]) : 0.f;
+                        pda[r] = ba ? Pa * d.keep_scale : 0.f;
+                        pdb[r] = bb ? Pb * d.keep_scale : 0.f;
+                        sa[r] = Pa * ((ba ? pa[r] * d.keep_scale : 0.f) - da[r]);
+                        sb[r] = Pb * ((bb ? pb[r] * d.keep_scale : 0.f) - db[r]);
+                    }
+                    dv[hs] = MFMA(ocf, pack8(pda, pdb), dv[hs]);     // [dim rows][key col] += dO^T P_drop
+                    dk[hs] = MFMA(qcf, pack8(sa, sb), dk[hs]);       // += Q^T dS
+                }
+            }
+        }
+        // ---------------- combine the heads' rows, scale, write d(qkv) and the in_proj input gradient
+        {
+            const int t = tt * 16 + tok, mm = b * T + t;
+            const bool tv = t < T;
+            f32x4 gq, gk, gv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool dv_ok = (4 * (g & 1) + r < hd) && myhead < H && tv;
+                // s_nat = q_raw . k / sqrt(hd);  q_img = q_raw log2(e)/sqrt(hd)
+                gq[r] = dv_ok ? (lo_grp ? dq[0][r] : dq[1][r]) * inv_sqrt_hd : 0.f;      // d q_raw
+                gk[r] = dv_ok ? (lo_grp ? dk[0][r] : dk[1][r]) * ln2 : 0.f;              // d k = sum dS q_img ln2
+                gv[r] = dv_ok ? (lo_grp ? dv[0][r] : dv[1][r]) : 0.f;
+            }
+            const s16x4 bq = pack4(gq), bk = pack4(gk), bv = pack4(gv);
+            const int rows = d.NP * 16;
+            __bf16* tcol = a.dqkvT + ((size_t)(mm >> 5) * (3 * rows)) * 32 + (mm & 31);
+            if (t < ((T + 15) & ~15)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = pair * 16 + 4 * g + r;
+                    if (tv) {
+                        tcol[(size_t)(0 * rows + j) * 32] = (__bf16)gq[r];
+                        tcol[(size_t)(1 * rows + j) * 32] = (__bf16)gk[r];
+                        tcol[(size_t)(2 * rows + j) * 32] = (__bf16)gv[r];
+                    }
+                }
+            }
+            const char* wbase = a.winT + (size_t)pair * 3 * DT * 512;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                f32x4 o = f4zero();
+                o = MFMA16(*reinterpret_cast<const s16x4*>(wbase + ((size_t)(0 * DT + dt) * 64 + lane) * 8), bq, o);
+                o = MFMA16(*reinterpret_cast<const s16x4*>(wbase + ((size_t)(1 * DT + dt) * 64 + lane) * 8), bk, o);
+                o = MFMA16(*reinterpret_cast<const s16x4*>(wbase + ((size_t)(2 * DT + dt) * 64 + lane) * 8), bv, o);
+                const int d0 = 16 * dt + 4 * g;
+                if (tv && d0 < D)
+                    *reinterpret_cast<float4*>(a.dxp + (size_t)pair * a.part_stride + (size_t)mm * D + d0) = float4{o[0], o[1], o[2], o[3]};
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradients
+struct WgLayer {
+    const __bf16* x0T; const __bf16* x1T; const __bf16* attT; const __bf16* dffnT; const __bf16* doT; const __bf16* dqkvT;
+    const __bf16* x1rb; const __bf16* dffnrb;
+    const unsigned char* active;
+    const char* ffn_img; const char* bffn;
+    long long in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w;
+};
+struct WgArgs {
+    const WgLayer* layers;    // device [L]
+    float* part;              // [TS][nparams]
+    long long nparams;
+    int TS, nblk;             // token splits; 32-token blocks in total
+};
+
+// T-block fragment: rows 16*rt + (lane&15), 8 of the block's 32 tokens per lane group.  perm: the token order of a packed
+// pair of C tiles (slots 0-3 = tokens 4g.., slots 4-7 = tokens 16+4g..), else natural (tokens 8g..8g+7).
+__device__ __forceinline__ bf16x8 t_frag(const __bf16* __restrict__ tb, int blk, int NF, int rt, int lane, bool perm, int nvalid) {
+    const int row = lane & 15, g = lane >> 4;
+    const __bf16* p = tb + ((size_t)blk * NF + 16 * rt + row) * 32;
+    u32x4 v;
+    if (perm) {
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(p + 4 * g), hi = *reinterpret_cast<const u32x2*>(p + 16 + 4 * g);
+        v = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        if (nvalid < 32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int tk = (e < 4) ? 4 * g + e : 16 + 4 * g + (e - 4);
+                if (tk >= nvalid) v[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+            }
+        }
+    } else {
+        v = *reinterpret_cast<const u32x4*>(p + 8 * g);
+        if (nvalid < 32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (8 * g + e >= nvalid) v[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+        }
+    }
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// grid (F/128 + 1, TS, L), 512 threads.  blockIdx.x < F/128: FFN role (wave = one 16-wide hidden tile);
+// blockIdx.x == F/128: in_proj and out_proj weights (waves split the output row tiles).
+template <int KS1, int DT>
+__global__ __launch_bounds__(512, 2) void k_tr_wgrad(const TrDims d, const WgArgs a) {
+    const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const WgLayer L = a.layers[blockIdx.z];
+    const int ts = blockIdx.y;
+    const int D = d.D, F = d.F, M = d.M, NFT = d.NFT;
+    const int blk0 = (int)(((long long)a.nblk * ts) / a.TS), blk1 = (int)(((long long)a.nblk * (ts + 1)) / a.TS);
+    float* const part = a.part + (size_t)ts * a.nparams;
+    constexpr int NB = 2 * KS1 + DT;
+    if ((int)blockIdx.x < F / 128) {
+        // ------------------------------------------------ linear1 / linear2 (+ linear1.bias through the ones row of x1T)
+        const int ftile = blockIdx.x * 8 + wave;            // 16 hidden units f0 .. f0+15
+        const int f0 = ftile * 16, chunk = ftile >> 1, ft = ftile & 1;
+        const int NS = F / 64, fh = chunk / NS, c = chunk - fh * NS;
+        bf16x8 w1[KS1], w2[KS1];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            w1[ks] = *reinterpret_cast<const bf16x8*>(L.ffn_img + ((size_t)((c * 2 + fh) * NB + ft * KS1 + ks) * 64 + lane) * 16);
+            w2[ks] = *reinterpret_cast<const bf16x8*>(L.bffn + ((size_t)((c * 2 + fh) * NB + ft * KS1 + ks) * 64 + lane) * 16);
+        }
+        f32x4 a1[DT], a2[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { a1[dt] = f4zero(); a2[dt] = f4zero(); }
+        for (int blk = blk0; blk < blk1; ++blk) {
+            const int nvalid = min(32, M - blk * 32);
+            f32x4 hh[2], dh[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int mrow = blk * 32 + half * 16 + tok;          // A operand row (token) of this lane
+                const bool rv = mrow < M;
+                f32x4 h = f4zero(), e = f4zero();
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {
+                    h = MFMA(row_frag(L.x1rb, mrow, rv, d.RBW, ks, g), w1[ks], h);     // [token rows 4g+r][f col]
+                    e = MFMA(row_frag(L.dffnrb, mrow, rv, d.RBW, ks, g), w2[ks], e);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mt = blk * 32 + half * 16 + 4 * g + r;
+                    bool on = false;
+                    if (mt < M) on = (L.active[((size_t)mt * (2 * NS) + chunk) * 4 + (tok >> 2)] >> (ft * 4 + (tok & 3))) & 1u;
+                    h[r] = on ? h[r] * d.keep_scale : 0.f;
+                    e[r] = on ? e[r] * d.keep_scale : 0.f;
+                }
+                hh[half] = h;
+                dh[half] = e;
+            }
+            const bf16x8 hB = pack8(hh[0], hh[1]), dB = pack8(dh[0], dh[1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                a2[dt] = MFMA(t_frag(L.dffnT, blk, NFT, dt, lane, true, nvalid), hB, a2[dt]);   // d W2[d][f]
+                a1[dt] = MFMA(t_frag(L.x1T, blk, NFT, dt, lane, true, nvalid), dB, a1[dt]);     // d W1[f][d], row D = d b1[f]
+            }
+        }
+        const int f = f0 + tok;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int dd = 16 * dt + 4 * g + r;
+                if (dd < D) {
+                    part[L.l2_w + (size_t)dd * F + f] = a2[dt][r];
+                    part[L.l1_w + (size_t)f * D + dd] = a1[dt][r];
+                } else if (dd == D) {
+                    part[L.l1_b + f] = a1[dt][r];
+                }
+            }
+    } else {
+        // ------------------------------------------------ in_proj (+ bias through the ones row of x0T) and out_proj (+ bias)
+        const int NRI = 3 * d.NP;                          // 16-row tiles of d(qkv)^T
+        constexpr int MAXR = 4;
+        f32x4 acc[MAXR][DT];
+        int rts[MAXR];
+        int nr = 0;
+        for (int rt = wave; rt < NRI && nr < MAXR - 1; rt += 8) rts[nr++] = rt;
+        const int nri = nr;
+        const bool has_o = wave < DT;
+        if (has_o) rts[nr++] = 1000 + wave;
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[i][dt] = f4zero();
+        for (int blk = blk0; blk < blk1; ++blk) {
+            const int nvalid = min(32, M - blk * 32);
+            bf16x8 xb[DT], ab[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                xb[dt] = t_frag(L.x0T, blk, NFT, dt, lane, false, nvalid);
+                ab[dt] = t_frag(L.attT, blk, NFT, dt, lane, false, nvalid);
+            }
+#pragma unroll
+            for (int i = 0; i < MAXR; ++i) {
+                if (i < nri) {
+                    const bf16x8 af = t_frag(L.dqkvT, blk, 3 * d.NP * 16, rts[i], lane, false, nvalid);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) acc[i][dt] = MFMA(af, xb[dt], acc[i][dt]);    // [qkv row][d col]
+                } else if (i == nri && has_o) {
+                    const bf16x8 af = t_frag(L.doT, blk, NFT, wave, lane, false, nvalid);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) acc[i][dt] = MFMA(af, ab[dt], acc[i][dt]);    // [d row][att feature col]
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            if (i < nri) {
+                const int rt = rts[i];
+                const int which = rt / d.NP, pr = rt - which * d.NP;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 4 * g + r, hs = j >> 3, dd = j & 7, head = 2 * pr + hs;
+                    if (head < d.H && dd < d.hd) {
+                        const long long row = (long long)which * D + head * d.hd + dd;
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) {
+                            const int col = 16 * dt + tok;
+                            if (col < D) part[L.in_w + row * D + col] = acc[i][dt][r];
+                            else if (col == D) part[L.in_b + row] = acc[i][dt][r];
+                        }
+                    }
+                }
+            } else if (i == nri && has_o) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int dd = 16 * wave + 4 * g + r;
+                    if (dd < D) {
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) {
+                            const int col = 16 * dt + tok;
+                            if (col < D) part[L.out_w + (size_t)dd * D + col] = acc[i][dt][r];
+                            else if (col == D) part[L.out_b + dd] = acc[i][dt][r];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// grads[i] (+)= sum over the token splits (fixed order) for the matrices / biases the weight-gradient kernel owns, the
+// per-workgroup column sums (fixed order) for the five vector parameters of the FFN-side backward, and 0 for everything
+// else in the layer range (alignment gaps of the flat layout: the fused AdamW and the gradient norm run over them).
+struct RedArgs {
+    const float* part; long long nparams; int TS;
+    const float* vecpart;      // [L][nwg][5][D]
+    int nwg, D, L;
+    long long begin;           // first layer parameter
+    long long layer_stride;    // parameters per layer
+    long long rel[5];          // offsets of l2_b, n2_b, n2_w, n1_b, n1_w relative to the layer's first parameter
+    long long wrel[7], wnum[7];   // in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w: offsets / element counts
+    float* grads; int accumulate;
+};
+__global__ __launch_bounds__(256) void k_tr_reduce(const RedArgs a) {
+    const long long i = a.begin + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.nparams) return;
+    const long long li = (i - a.begin) / a.layer_stride, rel = (i - a.begin) - li * a.layer_stride;
+    float v = 0.f;
+    bool owned = false;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) owned |= (rel >= a.wrel[k] && rel < a.wrel[k] + a.wnum[k]);
+    if (owned)
+        for (int t = 0; t < a.TS; ++t) v += a.part[(size_t)t * a.nparams + i];
+#pragma unroll
+    for (int sidx = 0; sidx < 5; ++sidx) {
+        const long long o = rel - a.rel[sidx];
+        if (o >= 0 && o < a.D) {
+            owned = true;
+            const float* vp = a.vecpart + ((size_t)li * a.nwg * 5 + sidx) * a.D + o;
+            for (int w = 0; w < a.nwg; ++w) v += vp[(size_t)w * 5 * a.D];
+        }
+    }
+    a.grads[i] = (a.accumulate && owned) ? a.grads[i] + v : (owned ? v : (a.accumulate ? a.grads[i] : 0.f));
+}
+
+// out = a + sum of `np` partial tensors (fixed order)
+__global__ __launch_bounds__(256) void k_tr_sum_parts(const float* __restrict__ a0, const float* __restrict__ parts, int np,
+                                                       size_t stride, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = a0[i];
+    for (int p = 0; p < np; ++p) v += parts[(size_t)p * stride + i];
+    out[i] = v;
+}
+
+}  // namespace
+
+// ================================================================================================ host side
+namespace {
+
+struct TrLayerBufs {
+    float *x0, *att, *s1, *s2, *lse2;
+    __bf16 *x0rb, *x0T, *x1rb, *x1T, *attT, *dffnT, *dffnrb, *doT, *dqkvT;
+    unsigned char *pmask, *active;
+};
+struct TrBufs {
+    std::vector<TrLayerBufs> layers;
+    float *emb, *temb, *hL;
+    // backward transients
+    float *dh, *datt, *dres[2], *dxp[2], *dtemb, *skp, *vecpart, *part;
+    WgLayer* wg_tab;
+    int Mpad, nwg, TS;
+    size_t part_stride;
+};
+
+constexpr size_t kSkpFloats = (size_t)1 << 20;
+
+int tr_TS(const fd_score* m) { return 4; }
+
+size_t al(size_t b) { return fd_ws::padded(b); }
+
+// one carve routine for size computation (base == nullptr) and pointer assignment
+size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
+    const fd_bf16_images* im = m->bf16;
+    const size_t T = m->d.max_len, D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, L = m->d.num_layers;
+    const size_t M = (size_t)B * T, Mpad = (M + 127) & ~size_t(127);
+    const size_t NFT = 16 * (size_t)im->dt, RBW = 32 * (size_t)im->ks1, NP = im->np, NJ = ((T + 15) / 16 + 1) / 2;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al(bytes); return p; };
+    TrBufs tb;
+    tb.Mpad = (int)Mpad;
+    tb.nwg = (int)(Mpad / 128);
+    tb.TS = tr_TS(m);
+    tb.part_stride = M * D;
+    tb.emb = (float*)take(sizeof(float) * B * D);
+    tb.temb = (float*)take(sizeof(float) * B * D);
+    tb.hL = (float*)take(sizeof(float) * M * D);
+    tb.layers.resize(L);
+    for (size_t l = 0; l < L; ++l) {
+        TrLayerBufs& b = tb.layers[l];
+        b.x0 = (float*)take(sizeof(float) * M * D);
+        b.att = (float*)take(sizeof(float) * M * D);
+        b.s1 = (float*)take(sizeof(float) * M * D);
+        b.s2 = (float*)take(sizeof(float) * M * D);
+        b.lse2 = (float*)take(sizeof(float) * B * H * T);
+        b.x0rb = (__bf16*)take(2 * Mpad * RBW);
+        b.x1rb = (__bf16*)take(2 * Mpad * RBW);
+        b.dffnrb = (__bf16*)take(2 * Mpad * RBW);
+        b.x0T = (__bf16*)take(2 * Mpad * NFT);
+        b.x1T = (__bf16*)take(2 * Mpad * NFT);
+        b.attT = (__bf16*)take(2 * Mpad * NFT);
+        b.dffnT = (__bf16*)take(2 * Mpad * NFT);
+        b.doT = (__bf16*)take(2 * Mpad * NFT);
+        b.dqkvT = (__bf16*)take(2 * Mpad * 3 * NP * 16);
+        b.pmask = (unsigned char*)take((size_t)B * H * T * NJ * 4);
+        b.active = (unsigned char*)take(Mpad * (F / 32) * 4);
+    }
+    tb.dh = (float*)take(sizeof(float) * M * D);
+    tb.datt = (float*)take(sizeof(float) * M * D);
+    for (int i = 0; i < 2; ++i) {
+        tb.dres[i] = (float*)take(sizeof(float) * M * D);
+        tb.dxp[i] = (float*)take(sizeof(float) * NP * M * D);
+    }
+    tb.dtemb = (float*)take(sizeof(float) * B * D);
+    tb.skp = (float*)take(sizeof(float) * kSkpFloats);
+    tb.vecpart = (float*)take(sizeof(float) * L * tb.nwg * 5 * D);
+    tb.wg_tab = (WgLayer*)take(sizeof(WgLayer) * L);
+    tb.part = (float*)take(sizeof(float) * (size_t)tb.TS * (size_t)m->nparams);
+    if (out) *out = tb;
+    return off + 4096;
+}
+
+TrDims make_dims(const fd_score* m, int B, float p, uint64_t seed) {
+    const fd_bf16_images* im = m->bf16;
+    TrDims d{};
+    d.B = B; d.T = m->d.max_len; d.M = B * d.T; d.D = m->d.d_model; d.F = m->d.dim_ff; d.H = m->d.n_head; d.hd = d.D / d.H;
+    d.NP = im->np; d.KT = (d.T + 15) / 16; d.NJ = (d.KT + 1) / 2; d.NFT = 16 * im->dt; d.RBW = 32 * im->ks1;
+    d.p = p;
+    d.thr16 = (unsigned)std::lround((double)p * 65536.0);
+    if (p > 0.f && d.thr16 == 0) d.thr16 = 1;
+    d.keep_scale = (p > 0.f) ? (float)(65536.0 / (65536.0 - (double)d.thr16)) : 1.0f;
+    d.seed = seed;
+    return d;
+}
+
+template <int KS1, int DT, int KSO>
+int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B, float p, uint64_t seed, uint64_t offset,
+                 hipStream_t s, TrBufs& tb) {
+    fd_ctx* ctx = m->ctx;
+    const fd_bf16_images* im = m->bf16;
+    const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model, L = m->d.num_layers;
+    const int M = B * T;
+    const float* P = m->params;
+    const TrDims d = make_dims(m, B, p, seed);
+    if (fd_time_embed_train(t, P + m->tW, P + m->td_w, P + m->td_b, tb.emb, tb.temb, B, D, s)) return FD_ERR_HIP;
+    float* h0 = L > 0 ? tb.layers[0].x0 : tb.hL;
+    fdf32::embed(x, P + m->emb_w, P + m->emb_b, P + m->pos, tb.temb, h0, M, T, C, D, s);
+    if (L > 0)
+        hipLaunchKernelGGL((k_tr_prep<KS1, DT>), dim3((tb.Mpad / 16 + 3) / 4), dim3(256), 0, s, h0, tb.layers[0].x0rb, tb.layers[0].x0T,
+                           M, tb.Mpad, D);
+    const size_t lds_attn = (size_t)d.KT * 16 * 32 + (size_t)d.NJ * 1024;
+    const size_t lds_ffn = (size_t)2 * 2 * (2 * KS1 + DT) * 1024 + (size_t)TW * KS1 * 1024;
+    static bool attr = false;
+    if (!attr) {
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_fwd<KS1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_ffn_fwd<KS1, DT, KSO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    for (int l = 0; l < L; ++l) {
+        const fd_layer_off& lo = m->layers[l];
+        TrLayerBufs& b = tb.layers[l];
+        const char* limg = im->mimg + im->off_layers + (size_t)l * im->layer_stride;
+        AttnFwdArgs aa{};
+        aa.x0rb = b.x0rb; aa.att = b.att; aa.attT = b.attT; aa.lse2 = b.lse2; aa.pmask = b.pmask;
+        aa.wk = limg + im->off_wk; aa.wv = limg + im->off_wv; aa.wq = limg + im->off_wq;
+        aa.site_off = fd_dropout_site_offset(offset, l, 0);
+        hipLaunchKernelGGL((k_tr_attn_fwd<KS1>), dim3(d.NP, B), dim3(256), lds_attn, s, d, aa);
+        FfnFwdArgs fa{};
+        fa.x0 = b.x0; fa.att = b.att; fa.s1 = b.s1; fa.s2 = b.s2;
+        fa.out = (l + 1 < L) ? tb.layers[l + 1].x0 : tb.hL;
+        fa.x1rb = b.x1rb; fa.x1T = b.x1T;
+        fa.outrb = (l + 1 < L) ? tb.layers[l + 1].x0rb : nullptr;
+        fa.outT = (l + 1 < L) ? tb.layers[l + 1].x0T : nullptr;
+        fa.active = b.active;
+        fa.wo_img = limg + im->off_wo; fa.ffn_img = limg + im->off_ffn;
+        fa.bo = P + lo.out_b; fa.g1 = P + lo.n1_w; fa.be1 = P + lo.n1_b; fa.b2 = P + lo.l2_b; fa.g2 = P + lo.n2_w; fa.be2 = P + lo.n2_b;
+        fa.off1 = fd_dropout_site_offset(offset, l, 1); fa.off2 = fd_dropout_site_offset(offset, l, 2); fa.off3 = fd_dropout_site_offset(offset, l, 3);
+        hipLaunchKernelGGL((k_tr_ffn_fwd<KS1, DT, KSO>), dim3(tb.nwg), dim3(TW * 64), lds_ffn, s, d, fa);
+    }
+    fdgemm::linear_fwd(tb.hL, P + m->un_w, P + m->un_b, out, M, C, D, false, s);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
+template <int KS1, int DT, int KSO>
+int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, hipStream_t s, TrBufs& tb) {
+    fd_ctx* ctx = m->ctx;
+    const fd_bf16_images* im = m->bf16;
+    const int B = m->saved_B;
+    const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model, L = m->d.num_layers, F = m->d.dim_ff;
+    const int M = B * T;
+    const float* P = m->params;
+    const TrDims d = make_dims(m, B, m->saved_p, m->saved_seed);
+    const uint64_t offset = m->saved_offset;
+    if (!accumulate) FD_HIP(ctx, hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(L > 0 ? m->layers[0].in_w : m->nparams), s));
+    // ---- unembedder
+    fdgemm::linear_bwd_weight(dout, tb.hL, grads + m->un_w, M, C, D, true, s, tb.skp, kSkpFloats);
+    fd_colsum_det(ctx, dout, grads + m->un_b, M, C, s);
+    fdgemm::linear_bwd_input(dout, P + m->un_w, tb.dh, M, C, D, false, s);
+    const size_t lds_bwd = (size_t)2 * 2 * (2 * KS1 + DT) * 1024 + (size_t)TW * KS1 * 1024 + (size_t)TW * 5 * 16 * DT * sizeof(float);
+    const size_t lds_ab = (size_t)4 * d.KT * 16 * 32 + (size_t)3 * d.NJ * 1024 + (size_t)4 * d.KT * 16 * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_ffn_bwd<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_bwd<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    std::vector<WgLayer> tab(L);
+    for (int l = L - 1; l >= 0; --l) {
+        const fd_layer_off& lo = m->layers[l];
+        TrLayerBufs& b = tb.layers[l];
+        const char* limg = im->mimg + im->off_layers + (size_t)l * im->layer_stride;
+        const char* bl = im->bimg + (size_t)l * im->b_layer_stride;
+        const int par = l & 1;
+        FfnBwdArgs fa{};
+        if (l == L - 1) { fa.dy0 = tb.dh; fa.dyp = nullptr; fa.npart = 0; }
+        else { fa.dy0 = tb.dres[par ^ 1]; fa.dyp = tb.dxp[par ^ 1]; fa.npart = d.NP; }
+        fa.part_stride = tb.part_stride;
+        fa.s1 = b.s1; fa.s2 = b.s2; fa.active = b.active;
+        fa.datt = tb.datt; fa.dres = tb.dres[par];
+        fa.dffnT = b.dffnT; fa.dffnrb = b.dffnrb; fa.doT = b.doT;
+        fa.vecpart = tb.vecpart + (size_t)l * tb.nwg * 5 * D;
+        fa.bffn = bl + im->boff_ffn; fa.wot = bl + im->boff_wot;
+        fa.g1 = P + lo.n1_w; fa.be1 = P + lo.n1_b; fa.g2 = P + lo.n2_w;
+        fa.off1 = fd_dropout_site_offset(offset, l, 1); fa.off3 = fd_dropout_site_offset(offset, l, 3);
+        hipLaunchKernelGGL((k_tr_ffn_bwd<KS1, DT>), dim3(tb.nwg), dim3(TW * 64), lds_bwd, s, d, fa);
+        AttnBwdArgs ab{};
+        ab.x0rb = b.x0rb; ab.att = b.att; ab.datt = tb.datt; ab.lse2 = b.lse2; ab.pmask = b.pmask;
+        ab.dxp = tb.dxp[par]; ab.dqkvT = b.dqkvT;
+        ab.wk = limg + im->off_wk; ab.wv = limg + im->off_wv; ab.wq = limg + im->off_wq;
+        ab.winT = bl + im->boff_win; ab.part_stride = tb.part_stride;
+        hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT>), dim3(d.NP, B), dim3(256), lds_ab, s, d, ab);
+        WgLayer& w = tab[l];
+        w.x0T = b.x0T; w.x1T = b.x1T; w.attT = b.attT; w.dffnT = b.dffnT; w.doT = b.doT; w.dqkvT = b.dqkvT;
+        w.x1rb = b.x1rb; w.dffnrb = b.dffnrb; w.active = b.active;
+        w.ffn_img = limg + im->off_ffn; w.bffn = bl + im->boff_ffn;
+        w.in_w = lo.in_w; w.in_b = lo.in_b; w.out_w = lo.out_w; w.out_b = lo.out_b; w.l1_w = lo.l1_w; w.l1_b = lo.l1_b; w.l2_w = lo.l2_w;
+    }
+    if (L > 0) {
+        // pageable source: staged by the runtime before the call returns
+        FD_HIP(ctx, hipMemcpyAsync(tb.wg_tab, tab.data(), sizeof(WgLayer) * L, hipMemcpyHostToDevice, s));
+        WgArgs wa{};
+        wa.layers = tb.wg_tab; wa.part = tb.part; wa.nparams = m->nparams; wa.TS = tb.TS; wa.nblk = (M + 31) / 32;
+        hipLaunchKernelGGL((k_tr_wgrad<KS1, DT>), dim3(F / 128 + 1, tb.TS, L), dim3(512), 0, s, d, wa);
+        RedArgs ra{};
+        ra.part = tb.part; ra.nparams = m->nparams; ra.TS = tb.TS; ra.vecpart = tb.vecpart; ra.nwg = tb.nwg; ra.D = D; ra.L = L;
+        ra.begin = m->layers[0].in_w;
+        ra.layer_stride = (L > 1) ? (m->layers[1].in_w - m->layers[0].in_w) : (m->nparams - m->layers[0].in_w);
+        const fd_layer_off& l0 = m->layers[0];
+        ra.rel[0] = l0.l2_b - l0.in_w; ra.rel[1] = l0.n2_b - l0.in_w; ra.rel[2] = l0.n2_w - l0.in_w;
+        ra.rel[3] = l0.n1_b - l0.in_w; ra.rel[4] = l0.n1_w - l0.in_w;
+        const long long wr[7] = {0, l0.in_b - l0.in_w, l0.out_w - l0.in_w, l0.out_b - l0.in_w, l0.l1_w - l0.in_w, l0.l1_b - l0.in_w, l0.l2_w - l0.in_w};
+        const long long wn[7] = {3LL * D * D, 3LL * D, (long long)D * D, D, (long long)F * D, F, (long long)D * F};
+        for (int k = 0; k < 7; ++k) { ra.wrel[k] = wr[k]; ra.wnum[k] = wn[k]; }
+        ra.grads = grads; ra.accumulate = accumulate;
+        const long long n = m->nparams - ra.begin;
+        hipLaunchKernelGGL(k_tr_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ra);
+        // gradient of the first layer's input = residual path + the pairs' in_proj contributions
+        const size_t nn = (size_t)M * D;
+        hipLaunchKernelGGL(k_tr_sum_parts, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, tb.dres[0], tb.dxp[0], d.NP,
+                           tb.part_stride, tb.dh, nn);
+    }
+    if (int rc = fd_embed_backward(m, tb.dh, tb.emb, tb.dtemb, grads, B, tb.skp, kSkpFloats, s)) return rc;
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
+}  // namespace
+
+bool fd_train_bf16_supported(const fd_score* m) {
+    const fd_bf16_images* im = m->bf16;
+    return im && im->train && im->bimg && m->d.dim_ff % 128 == 0 && m->d.num_layers > 0 && m->d.max_len <= 1024;
+}
+
+size_t fd_train_bf16_workspace(const fd_score* m, int B) { return tr_carve(m, B, nullptr, nullptr); }
+
+#define FD_TR_DISPATCH(CALL)                                                                         \
+    do {                                                                                             \
+        const fd_bf16_images* im_ = m->bf16;                                                         \
+        if (im_->ks1 == 3 && im_->dt == 5 && im_->kso == 3) return CALL(3, 5, 3);                    \
+        if (im_->ks1 == 2 && im_->dt == 4 && im_->kso == 3) return CALL(2, 4, 3);                    \
+        if (im_->ks1 == 1 && im_->dt == 2 && im_->kso == 1) return CALL(1, 2, 1);                    \
+        if (im_->ks1 == 1 && im_->dt == 1 && im_->kso == 1) return CALL(1, 1, 1);                    \
+        return fd_fail(m->ctx, FD_ERR_UNSUPPORTED, "bf16 training kernels not instantiated for this model"); \
+    } while (0)
+
+int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, float* out, int B, float p, uint64_t seed,
+                                uint64_t offset, hipStream_t s) {
+    fd_ctx* ctx = m->ctx;
+    if (!fd_train_bf16_supported(m)) return fd_fail(ctx, FD_ERR_UNSUPPORTED, "bf16 training path unsupported for this model");
+    if (int rc = fd_bf16_refresh(m, s)) return rc;
+    const size_t need = fd_train_bf16_workspace(m, B);
+    if (int rc = fd_ws_reserve(ctx, need)) return rc;
+    fd_ws ws(ctx);
+    TrBufs tb;
+    tr_carve(m, B, (char*)ctx->ws, &tb);
+#define CALL_F(K, T_, O) tr_forward_t<K, T_, O>(m, x, t, out, B, p, seed, offset, s, tb)
+    FD_TR_DISPATCH(CALL_F);
+#undef CALL_F
+}
+
+int fd_score_backward_bf16(fd_score* m, const float* dout, float* grads, int accumulate, hipStream_t s) {
+    fd_ctx* ctx = m->ctx;
+    const size_t need = fd_train_bf16_workspace(m, m->saved_B);
+    if (ctx->ws_bytes < need) return fd_fail(ctx, FD_ERR_STATE, "fd_score_backward: workspace was resized since the training forward");
+    TrBufs tb;
+    tr_carve(m, m->saved_B, (char*)ctx->ws, &tb);
+#define CALL_B(K, T_, O) tr_backward_t<K, T_, O>(m, dout, grads, accumulate, s, tb)
+    FD_TR_DISPATCH(CALL_B);
+#undef CALL_B
+}

@@ -63,6 +63,10 @@ class ScoreModule:
         self.likelihood_weighting = likelihood_weighting
         self.training = True
         self.precision = _default_precision()      # eval/sampling arithmetic: "bf16" (MFMA) or "fp32" (parity)
+        # training arithmetic (forward with dropout + backward): "bf16" = fused MFMA kernels with fp32 accumulation where they
+        # are instantiated for the model's dims (else the exact-f32 kernels), "fp32" = exact-f32 kernels (parity anchor)
+        self.train_precision = os.environ.get("FDIFF_TRAIN_PRECISION", "bf16")
+        self._train_mode_set: Optional[str] = None
         self.hparams: Dict[str, Any] = dict(
             n_channels=n_channels, max_len=max_len, noise_scheduler=noise_scheduler,
             fourier_noise_scaling=fourier_noise_scaling, d_model=d_model, num_layers=num_layers, n_head=n_head,
@@ -215,10 +219,20 @@ class ScoreModule:
             _C.check(rc, ctx)
             self._handle = h
             self._dirty = True
+            self._train_mode_set = None
         if self._dirty:
             rc = _C.lib().fd_score_prepare(self._handle, self._flat.data_ptr(), _C.stream_of(self._flat))
             _C.check(rc, ctx)
             self._dirty = False
+        if self._train_mode_set != self.train_precision:
+            rc = _C.lib().fd_score_set_train_mode(self._handle, _PRECISIONS[self.train_precision])
+            if rc == -5 and self.train_precision == "bf16":       # FD_ERR_UNSUPPORTED: dims without bf16 training kernels
+                rc = _C.lib().fd_score_set_train_mode(self._handle, _C.FD_MODE_F32)
+                self.train_mode_effective = "fp32"
+            else:
+                self.train_mode_effective = self.train_precision
+            _C.check(rc, ctx)
+            self._train_mode_set = self.train_precision
         return ctx, self._handle
 
     def plan(self, batch_size: int, precision: Optional[str] = None) -> Tuple[str, int]:

@@ -190,6 +190,12 @@ int fd_score_forward(fd_score* m, const float* x, const float* t, float* out, in
  * is `ShapeStatic<100,72,12,12,2,...>` with S = 2 on a 256-CU device).  No reference counterpart. */
 int fd_score_plan(fd_score* m, int B, int mode, char* out /* >= 192 bytes */, int* series_per_workgroup /* nullable */);
 
+/* Arithmetic of the training pair below: FD_MODE_F32 (default; exact-f32 kernels, the parity anchor, any model) or
+ * FD_MODE_BF16 (bf16 MFMA operands, fp32 accumulate/LayerNorm/softmax; five fused kernels per encoder layer, weight
+ * gradients reduced in a fixed order: bit-reproducible).  FD_ERR_UNSUPPORTED when the bf16 kernels are not instantiated
+ * for the model's dims (the mode then stays unchanged).  Replaces nothing in the reference (torch autograd is fp32). */
+int fd_score_set_train_mode(fd_score* m, int mode);
+
 /* Training forward: keeps activations in the ctx workspace for fd_score_backward.
  * dropout_p > 0 applies the four dropout sites of nn.TransformerEncoderLayer with masks
  * from Philox(seed, offset) (regenerated in backward). */

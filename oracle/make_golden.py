@@ -277,6 +277,36 @@ def gen_loss(R):
     np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
 
 
+GRAD_STRIDE = 97      # the default-model gradient fixture keeps every 97th element of each tensor + its norms
+
+
+def gen_grad_default(R):
+    """Reference autograd gradients of the ONLY model the hydra configs name (d_model 72, 10 layers, ff 2048) at the ecg
+    shape and at the BASELINE training shape (nasdaq T=252, C=6): per tensor the l2 norm, max |g| and a strided subset
+    (every GRAD_STRIDE-th element), so that 3.2 M gradients cost 0.3 MB of fixture.  Dropout forced to 0, injected t, z."""
+    out = {}
+    for name, cfg, B in (("default", CFG_DEFAULT, 4), ("nasdaq", dict(T=252, C=6, D=72, L=10, H=12), 2)):
+        X = W.randn(f"gd_x_{name}", (B, cfg["T"], cfg["C"]), 3)
+        z = W.randn(f"gd_z_{name}", (B, cfg["T"], cfg["C"]), 3)
+        t = W.uniform(f"gd_t_{name}", (B,), 3, 0.05, 1.0)
+        m, sch, _ = build_ref_model(R, cfg, "vp", (0.1, 20.0), True, seed=1234)
+        zero_dropout(m)
+        batch = R.dc.DiffusableBatch(X=t_(X), y=None, timesteps=t_(t))
+        fn_tr = R.losses.get_sde_loss_fn(sch, train=True, likelihood_weighting=False)
+        m.zero_grad()
+        with replay_noise(randn_like_seq=[t_(z)]):
+            lt = fn_tr(m, batch)
+        lt.backward()
+        out[f"loss_{name}"] = np.array(lt.item(), np.float64)
+        for k, prm in m.named_parameters():
+            if prm.grad is None:
+                continue
+            g = prm.grad.numpy().astype(np.float64).ravel()
+            out[f"norm_{name}/{k}"] = np.array([np.linalg.norm(g), np.abs(g).max()], np.float64)
+            out[f"sub_{name}/{k}"] = g[::GRAD_STRIDE].astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "grad_default.npz"), **out)
+
+
 def gen_sampler(R):
     out = {}
     N = 20
@@ -354,7 +384,7 @@ def main():
     torch.set_num_threads(8)
     R = import_reference()
     gens = dict(dft=gen_dft, spectral=gen_spectral, sde=gen_sde, score=gen_score, ckpt=gen_ckpt, loss=gen_loss, sampler=gen_sampler,
-                dataset=gen_dataset, optim=gen_optim)
+                dataset=gen_dataset, optim=gen_optim, grad_default=gen_grad_default)
     for name in (sys.argv[1:] or list(gens)):                  # `make_golden.py spectral` regenerates one file
         gens[name](R)
     for f in sorted(os.listdir(OUT)):

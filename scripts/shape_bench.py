@@ -39,6 +39,7 @@ def main():
     m = ScoreModule(n_channels=Cn, max_len=T, noise_scheduler=sch, fourier_noise_scaling=True, d_model=72, num_layers=10,
                     n_head=12).to(dev)
     m.precision = os.environ.get("FDIFF_PRECISION", "bf16")
+    m.train_precision = os.environ.get("FDIFF_TRAIN_PRECISION", "bf16")
     if what == "sample":
         m.eval()
         sch.set_timesteps(N)
@@ -76,21 +77,22 @@ def main():
             ex.all_reduce_mean(m.grads)
             opt.step()
             return loss
-        for _ in range(2):
+        for _ in range(3):
             step()
         torch.cuda.synchronize()
+        nrep = 20
         t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(nrep):
             step()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 5
+        dt = (time.perf_counter() - t0) / nrep
         if denv.world > 1:
             import torch.distributed as dist
             tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         if denv.rank == 0:
-            print(f"{name} train B={B}/GPU x {denv.world} T={T} C={Cn}: {1e3 * dt:.2f} ms per optimizer step "
+            print(f"{name} train ({m.train_mode_effective}) B={B}/GPU x {denv.world} T={T} C={Cn}: {1e3 * dt:.2f} ms per optimizer step "
                   f"(fwd+bwd+all-reduce+AdamW), {3 * denv.world * B * flops_fwd(T, Cn) / dt / 1e12:.2f} TFLOP/s algorithmic, "
                   f"{denv.world * B / dt:.0f} series/s")
 

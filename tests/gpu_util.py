@@ -30,6 +30,7 @@ def make_model(cfg, kind="vp", p=(0.1, 20.0), scaling=True, seed=1234, precision
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     m.to(DEV)
     m.precision = precision
+    m.train_precision = precision        # fp32 models train with the exact-f32 kernels (parity anchor)
     return m, sch, sd
 
 
