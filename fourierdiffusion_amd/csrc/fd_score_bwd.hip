@@ -364,20 +364,35 @@ __global__ __launch_bounds__(64 * NWV) void k_attn_bwd_kv(const float* __restric
 }
 
 // dpos[t, :] += sum_b dh[b, t, :] ; dtemb[b, :] = sum_t dh[b, t, :]
+// Four independent strands per output (loads in flight instead of one dependent chain), combined in a fixed order.
 __global__ __launch_bounds__(256) void k_embed_reduce(const float* __restrict__ dh, float* __restrict__ dpos,
                                                        float* __restrict__ dtemb, int B, int T, int D) {
     const size_t id = blockIdx.x * (size_t)256 + threadIdx.x;
     if (id < (size_t)T * D) {
         const int t = (int)(id / D), d = (int)(id % D);
-        float a = 0.f;
-        for (int b = 0; b < B; ++b) a += dh[((size_t)b * T + t) * D + d];
-        dpos[id] += a;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int b = 0;
+        for (; b + 3 < B; b += 4) {
+            a0 += dh[((size_t)(b + 0) * T + t) * D + d];
+            a1 += dh[((size_t)(b + 1) * T + t) * D + d];
+            a2 += dh[((size_t)(b + 2) * T + t) * D + d];
+            a3 += dh[((size_t)(b + 3) * T + t) * D + d];
+        }
+        for (; b < B; ++b) a0 += dh[((size_t)b * T + t) * D + d];
+        dpos[id] += (a0 + a1) + (a2 + a3);
     }
     if (id < (size_t)B * D) {
         const int b = (int)(id / D), d = (int)(id % D);
-        float a = 0.f;
-        for (int t = 0; t < T; ++t) a += dh[((size_t)b * T + t) * D + d];
-        dtemb[id] = a;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int t = 0;
+        for (; t + 3 < T; t += 4) {
+            a0 += dh[((size_t)b * T + t + 0) * D + d];
+            a1 += dh[((size_t)b * T + t + 1) * D + d];
+            a2 += dh[((size_t)b * T + t + 2) * D + d];
+            a3 += dh[((size_t)b * T + t + 3) * D + d];
+        }
+        for (; t < T; ++t) a0 += dh[((size_t)b * T + t) * D + d];
+        dtemb[id] = (a0 + a1) + (a2 + a3);
     }
 }
 

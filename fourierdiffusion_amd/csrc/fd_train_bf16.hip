@@ -412,32 +412,54 @@ struct FfnFwdArgs {
     float* out;               // (M, D) layer output
     __bf16* x1rb; __bf16* x1T;
     __bf16* outrb; __bf16* outT;   // next layer's input in operand form (null for the last layer)
-    unsigned char* active;    // (Mpad, F/32, 4): bit e of byte (m, chunk, g): hidden unit kept by dropout AND > 0
+    unsigned char* active;    // (Mpad, 4, F/32): bit e of byte (m, g, chunk): hidden unit kept by dropout AND > 0
+    unsigned short* activeT;  // (Mpad/32, 2, F): bit j of word (block, half, f): the same for token 32 block + 16 half + j
     const char* wo_img;       // [DT][KSO]
     const char* ffn_img;      // chunk-major forward image of the layer
     const float* bo; const float* g1; const float* be1; const float* b2; const float* g2; const float* be2;
     unsigned long long off1, off2, off3;   // Philox counter bases of the three dropout sites
 };
 
+// 8 waves = 4 token tiles (64 tokens) x 2 halves of F.  The weight stream (one 32-wide chunk per F-half per step, 2*NB KiB)
+// runs through a ring of 4 LDS buffers filled 3 steps ahead by global_load_lds; nothing else touches vector memory inside
+// the loop (mask bits go through LDS), so `s_waitcnt vmcnt(2*NDMA)` means "all but the two newest buffers have landed".
 template <int KS1, int DT, int KSO>
 __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const FfnFwdArgs a) {
-    constexpr int NB = 2 * KS1 + DT, WB = 2 * NB * 1024;
+    constexpr int NB = 2 * KS1 + DT, WB = 2 * NB * 1024, NBUF = 4, NDMA = (2 * NB + TW - 1) / TW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char* const ring = smem;                                   // 2 x [F-half][NB] KiB
-    char* const scratch = smem + 2 * WB + wave * KS1 * 1024;   // wave-private fragment scratch
-    const int D = d.D, M = d.M, NS = d.F / 64;
-    const int m = (blockIdx.x * TW + wave) * 16 + tok;
+    const int tile = wave & 3, fhw = wave >> 2;
+    const int D = d.D, M = d.M, NS = d.F / 64, F = d.F;
+    char* const ring = smem;
+    char* const scratch = smem + NBUF * WB + wave * KS1 * 1024;            // wave-private fragment scratch (prologue)
+    f32x4* const xch = reinterpret_cast<f32x4*>(smem + NBUF * WB);          // [4 tiles][DT][64] (after the loop: aliases scratch)
+    constexpr int SCR = (TW * KS1 * 1024 > 4 * DT * 1024) ? TW * KS1 * 1024 : 4 * DT * 1024;
+    unsigned char* const actB = reinterpret_cast<unsigned char*>(smem + NBUF * WB + SCR) + wave * (64 * NS);   // [64 lanes][NS]
+    unsigned short* const actT = reinterpret_cast<unsigned short*>(smem + NBUF * WB + SCR + TW * 64 * NS) + wave * (NS * 32);   // [NS][32]
+    const int m = (blockIdx.x * 4 + tile) * 16 + tok;
     const bool valid = m < M;
-    auto issue = [&](int c, int buf) {
-        const char* src = a.ffn_img + (size_t)c * WB + lane * 16;
-        char* dst = ring + buf * WB;
-        for (int bb = wave; bb < 2 * NB; bb += TW)
+    const bool owner = fhw == 0;
+    // Every workgroup streams the SAME weights: marching through them in lockstep makes all CUs hit the same L2 channel at the
+    // same time (measured in the persistent kernel: ~25 GB/s per CU).  The chunks are summed, so each workgroup walks them in
+    // its own rotated order.
+    const int rot = (int)((blockIdx.x * 5u) % (unsigned)NS);
+    auto issue = [&](int st) {
+        int ce = st + rot;
+        ce -= (ce >= NS) ? NS : 0;
+        const char* src = a.ffn_img + (size_t)ce * WB + lane * 16;
+        char* dst = ring + (st % NBUF) * WB;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            int bb = wave + i * TW;
+            bb %= 2 * NB;                 // padding copies repeat a block (uniform vmcnt bookkeeping)
             __builtin_amdgcn_global_load_lds(GLB_PTR(src + bb * 1024), LDS_PTR(dst + bb * 1024), 16, 0, 0);
+        }
     };
-    issue(0, 0);
-    // ---- out-projection + bias + dropout + residual -> s1
+    issue(0);
+    if (NS > 1) issue(1);
+    if (NS > 2) issue(2);
+    // ---- out-projection + bias + dropout + residual -> s1  (both waves of a tile compute it; the owner stores)
     f32x4 v[DT];
     {
         f32x4 o[DT];
@@ -469,8 +491,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
             }
         }
     }
-    store_ctile<DT>(a.s1, m, valid, D, g, v);
-    // ---- LayerNorm1 -> x1 (registers = residual of the FFN block; operand copies for the backward)
+    if (owner) store_ctile<DT>(a.s1, m, valid, D, g, v);
     {
         float mean, rstd;
         ln_stats<DT>(v, D, g, mean, rstd);
@@ -488,8 +509,10 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
             }
         }
     }
-    store_rows<DT, KS1>(a.x1rb, m, valid, D, g, v, true);
-    store_T<DT>(a.x1T, m, valid, D, g, v, true);
+    if (owner) {
+        store_rows<DT, KS1>(a.x1rb, m, valid, D, g, v, true);
+        store_T<DT>(a.x1T, m, valid, D, g, v, true);
+    }
     bf16x8 xf[KS1];
     ctile_to_frags<DT, KS1>(scratch, lane, D, v, true, xf);
     f32x4 acc[DT];
@@ -497,40 +520,69 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f4zero();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // ---- FFN: weights streamed L2 -> LDS (double buffer, one 32-wide chunk per F-half per step), hidden in registers
+    // ---- FFN: this wave's F-half, hidden in registers
     for (int c = 0; c < NS; ++c) {
-        if (c + 1 < NS) issue(c + 1, (c + 1) & 1);
+        if (c + 3 < NS) issue(c + 3);
+        const char* wb = ring + (c % NBUF) * WB + fhw * NB * 1024 + lane * 16;
+        f32x4 h0 = f4zero(), h1 = f4zero();
 #pragma unroll
-        for (int fh = 0; fh < 2; ++fh) {
-            const char* wb = ring + (c & 1) * WB + fh * NB * 1024 + lane * 16;
-            f32x4 h0 = f4zero(), h1 = f4zero();
-#pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                h0 = MFMA(*reinterpret_cast<const bf16x8*>(wb + ks * 1024), xf[ks], h0);
-                h1 = MFMA(*reinterpret_cast<const bf16x8*>(wb + (KS1 + ks) * 1024), xf[ks], h1);
-            }
-            const int chunk = fh * NS + c;
-            const size_t bidx = ((size_t)m * (2 * NS) + chunk) * 4 + g;
-            unsigned bits = 0xffu;
-            if (d.p > 0.f) bits = drop8(a.off2 + bidx, d.seed, d.thr16);
-            unsigned act = 0u;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool k0 = ((bits >> r) & 1u) && h0[r] > 0.f, k1 = ((bits >> (4 + r)) & 1u) && h1[r] > 0.f;
-                act |= (k0 ? 1u : 0u) << r;
-                act |= (k1 ? 1u : 0u) << (4 + r);
-                h0[r] = k0 ? h0[r] * d.keep_scale : 0.f;
-                h1[r] = k1 ? h1[r] * d.keep_scale : 0.f;
-            }
-            if (valid) a.active[bidx] = (unsigned char)act;
-            const bf16x8 hb = pack8(h0, h1);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(*reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024), hb, acc[dt]);
+        for (int ks = 0; ks < KS1; ++ks) {
+            h0 = MFMA(*reinterpret_cast<const bf16x8*>(wb + ks * 1024), xf[ks], h0);
+            h1 = MFMA(*reinterpret_cast<const bf16x8*>(wb + (KS1 + ks) * 1024), xf[ks], h1);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        int ce = c + rot;
+        ce -= (ce >= NS) ? NS : 0;
+        const int chunk = fhw * NS + ce;
+        unsigned bits = 0xffu;
+        if (d.p > 0.f) bits = drop8(a.off2 + ((unsigned long long)m * (2 * NS) + chunk) * 4ull + (unsigned)g, d.seed, d.thr16);
+        unsigned act = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool k0 = valid && ((bits >> r) & 1u) && h0[r] > 0.f, k1 = valid && ((bits >> (4 + r)) & 1u) && h1[r] > 0.f;
+            act |= (k0 ? 1u : 0u) << r;
+            act |= (k1 ? 1u : 0u) << (4 + r);
+            h0[r] = k0 ? h0[r] * d.keep_scale : 0.f;
+            h1[r] = k1 ? h1[r] * d.keep_scale : 0.f;
+            // the same decisions with the 16 tokens of the tile as bits of one word per hidden unit (weight-gradient kernel)
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(k0), b1 = __builtin_amdgcn_ballot_w64(k1);
+            if (lane < 4) {
+                actT[ce * 32 + 4 * lane + r] = (unsigned short)(b0 >> (16 * lane));
+                actT[ce * 32 + 16 + 4 * lane + r] = (unsigned short)(b1 >> (16 * lane));
+            }
+        }
+        actB[lane * NS + ce] = (unsigned char)act;
+        const bf16x8 hb = pack8(h0, h1);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(*reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024), hb, acc[dt]);
+        if (c + 3 < NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this step's LDS reads are done before the buffer may be refilled
+        __builtin_amdgcn_s_barrier();
     }
-    // ---- + b2, dropout, residual -> s2, LayerNorm2 -> layer output
+    // ---- mask bits out: bytes [token][g][chunk] (token-on-lane backward), words [32-token block][half][hidden unit]
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+        unsigned char* dstb = a.active + ((size_t)m * 4 + g) * (2 * NS) + fhw * NS;
+        for (int c = 0; c < NS; c += 16)
+            *reinterpret_cast<u32x4*>(dstb + c) = *reinterpret_cast<const u32x4*>(actB + lane * NS + c);
+    }
+    {
+        const int m0 = (blockIdx.x * 4 + tile) * 16;
+        unsigned short* dstw = a.activeT + ((size_t)(m0 >> 5) * 2 + ((m0 >> 4) & 1)) * F + fhw * (F / 2);
+        for (int i = lane * 8; i < NS * 32; i += 64 * 8)
+            *reinterpret_cast<u32x4*>(dstw + i) = *reinterpret_cast<const u32x4*>(actT + i);
+    }
+    // ---- combine the F-halves; the owner finishes the tile
+    __syncthreads();
+    if (!owner) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) xch[(tile * DT + dt) * 64 + lane] = acc[dt];
+    }
+    __syncthreads();
+    if (!owner) return;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] += xch[(tile * DT + dt) * 64 + lane];
     {
         unsigned bits[DT];
         row_drop_bits<DT>(d, a.off3, m, g, bits);
@@ -619,33 +671,55 @@ __device__ __forceinline__ void ln_bwd_tile(f32x4 (&dy)[DT], const f32x4 (&xhat)
 
 template <int KS1, int DT>
 __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const FfnBwdArgs a) {
-    constexpr int NB = 2 * KS1 + DT, WB = 2 * NB * 1024;
+    constexpr int NB = 2 * KS1 + DT, WB = 2 * NB * 1024, NBUF = 4, NDMA = (2 * NB + TW - 1) / TW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = wave & 3, fhw = wave >> 2;
+    const bool owner = fhw == 0;
     char* const ring = smem;
-    char* const scratch = smem + 2 * WB + wave * KS1 * 1024;
-    float* const colred = reinterpret_cast<float*>(smem + 2 * WB + TW * KS1 * 1024);   // [TW][5][16*DT]
+    char* const scratch = smem + NBUF * WB + wave * KS1 * 1024;
+    f32x4* const xch = reinterpret_cast<f32x4*>(smem + NBUF * WB);
+    constexpr int SCR = (TW * KS1 * 1024 > 4 * DT * 1024) ? TW * KS1 * 1024 : 4 * DT * 1024;
     const int D = d.D, M = d.M, NS = d.F / 64;
-    const int m = (blockIdx.x * TW + wave) * 16 + tok;
+    unsigned char* const actB = reinterpret_cast<unsigned char*>(smem + NBUF * WB + SCR) + wave * (64 * NS);
+    float* const colred = reinterpret_cast<float*>(smem + NBUF * WB + SCR + TW * 64 * NS);   // [4 tiles][5][16*DT]
+    char* const scratch2 = smem + NBUF * WB + SCR + TW * 64 * NS + 4 * 5 * 16 * DT * sizeof(float) + wave * KS1 * 1024;
+    const int m = (blockIdx.x * 4 + tile) * 16 + tok;
     const bool valid = m < M;
-    auto issue = [&](int c, int buf) {
-        const char* src = a.bffn + (size_t)c * WB + lane * 16;
-        char* dst = ring + buf * WB;
-        for (int bb = wave; bb < 2 * NB; bb += TW)
+    const int rot = (int)((blockIdx.x * 5u) % (unsigned)NS);      // rotated chunk order per workgroup (see k_tr_ffn_fwd)
+    auto issue = [&](int st) {
+        int ce = st + rot;
+        ce -= (ce >= NS) ? NS : 0;
+        const char* src = a.bffn + (size_t)ce * WB + lane * 16;
+        char* dst = ring + (st % NBUF) * WB;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            int bb = wave + i * TW;
+            bb %= 2 * NB;                 // padding copies repeat a block (uniform vmcnt bookkeeping)
             __builtin_amdgcn_global_load_lds(GLB_PTR(src + bb * 1024), LDS_PTR(dst + bb * 1024), 16, 0, 0);
+        }
     };
-    issue(0, 0);
-    // column sums over this wave's 16 tokens -> colred[wave][slot][feature]
+    issue(0);
+    if (NS > 1) issue(1);
+    if (NS > 2) issue(2);
+    // column sums over this tile's 16 tokens -> colred[tile][slot][feature] (owner waves only)
     auto colsum = [&](int slot, const f32x4 (&t)[DT]) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float sres = row_sum16(t[dt][r]);
-                if (tok == 0) colred[(wave * 5 + slot) * (16 * DT) + 16 * dt + 4 * g + r] = sres;
+                if (owner && tok == 0) colred[(tile * 5 + slot) * (16 * DT) + 16 * dt + 4 * g + r] = sres;
             }
     };
+    // this wave's keep bytes of the whole F-half -> LDS (no vector-memory traffic inside the loop)
+    if (valid) {
+        const unsigned char* srcb = a.active + ((size_t)m * 4 + g) * (2 * NS) + fhw * NS;
+        for (int c = 0; c < NS; c += 16) *reinterpret_cast<u32x4*>(actB + lane * NS + c) = *reinterpret_cast<const u32x4*>(srcb + c);
+    } else {
+        for (int c = 0; c < NS; c += 16) *reinterpret_cast<u32x4*>(actB + lane * NS + c) = u32x4{0u, 0u, 0u, 0u};
+    }
     // ---- gradient of the layer output
     f32x4 dy[DT];
     load_ctile<DT>(a.dy0, m, valid, D, g, dy);
@@ -686,8 +760,10 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
             for (int r = 0; r < 4; ++r) df[dt][r] = ((bits[dt] >> r) & 1u) ? dy[dt][r] * d.keep_scale : 0.f;
     }
     colsum(0, df);                                   // d b2
-    store_T<DT>(a.dffnT, m, valid, D, g, df, false);
-    store_rows<DT, KS1>(a.dffnrb, m, valid, D, g, df, false);
+    if (owner) {
+        store_T<DT>(a.dffnT, m, valid, D, g, df, false);
+        store_rows<DT, KS1>(a.dffnrb, m, valid, D, g, df, false);
+    }
     bf16x8 dfr[KS1];
     ctile_to_frags<DT, KS1>(scratch, lane, D, df, false, dfr);
     f32x4 acc[DT];
@@ -695,80 +771,89 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f4zero();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // ---- d x1 += W1^T (active . W2^T d f): d hidden lives in registers only
+    // ---- d x1 += W1^T (active . W2^T d f) over this wave's F-half: d hidden lives in registers only
     for (int c = 0; c < NS; ++c) {
-        if (c + 1 < NS) issue(c + 1, (c + 1) & 1);
+        if (c + 3 < NS) issue(c + 3);
+        const char* wb = ring + (c % NBUF) * WB + fhw * NB * 1024 + lane * 16;
+        f32x4 h0 = f4zero(), h1 = f4zero();
 #pragma unroll
-        for (int fh = 0; fh < 2; ++fh) {
-            const char* wb = ring + (c & 1) * WB + fh * NB * 1024 + lane * 16;
-            f32x4 h0 = f4zero(), h1 = f4zero();
-#pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                h0 = MFMA(*reinterpret_cast<const bf16x8*>(wb + ks * 1024), dfr[ks], h0);
-                h1 = MFMA(*reinterpret_cast<const bf16x8*>(wb + (KS1 + ks) * 1024), dfr[ks], h1);
-            }
-            const int chunk = fh * NS + c;
-            const unsigned act = valid ? a.active[((size_t)m * (2 * NS) + chunk) * 4 + g] : 0u;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                h0[r] = ((act >> r) & 1u) ? h0[r] * d.keep_scale : 0.f;
-                h1[r] = ((act >> (4 + r)) & 1u) ? h1[r] * d.keep_scale : 0.f;
-            }
-            const bf16x8 hb = pack8(h0, h1);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(*reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024), hb, acc[dt]);
+        for (int ks = 0; ks < KS1; ++ks) {
+            h0 = MFMA(*reinterpret_cast<const bf16x8*>(wb + ks * 1024), dfr[ks], h0);
+            h1 = MFMA(*reinterpret_cast<const bf16x8*>(wb + (KS1 + ks) * 1024), dfr[ks], h1);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        int ce = c + rot;
+        ce -= (ce >= NS) ? NS : 0;
+        const unsigned act = actB[lane * NS + ce];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            h0[r] = ((act >> r) & 1u) ? h0[r] * d.keep_scale : 0.f;
+            h1[r] = ((act >> (4 + r)) & 1u) ? h1[r] * d.keep_scale : 0.f;
+        }
+        const bf16x8 hb = pack8(h0, h1);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(*reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024), hb, acc[dt]);
+        if (c + 3 < NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
     }
+    __syncthreads();
+    if (!owner) {
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) dy[dt] += acc[dt];          // d x1 = residual path + FFN branch
-    // ---- LayerNorm1 backward
-    float rstd1;
-    {
-        float mean;
-        load_ctile<DT>(a.s1, m, valid, D, g, xh);
-        ln_stats<DT>(xh, D, g, mean, rstd1);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xh[dt][r] = (16 * dt + 4 * g < D && valid) ? (xh[dt][r] - mean) * rstd1 : 0.f;
+        for (int dt = 0; dt < DT; ++dt) xch[(tile * DT + dt) * 64 + lane] = acc[dt];
     }
-    colsum(3, dy);                                   // d beta1
-    {
-        f32x4 t[DT];
+    __syncthreads();
+    if (owner) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) t[dt] = dy[dt] * xh[dt];
-        colsum(4, t);                                // d gamma1
+        for (int dt = 0; dt < DT; ++dt) dy[dt] += acc[dt] + xch[(tile * DT + dt) * 64 + lane];     // d x1 = residual path + FFN branch
+        // ---- LayerNorm1 backward
+        float rstd1;
+        {
+            float mean;
+            load_ctile<DT>(a.s1, m, valid, D, g, xh);
+            ln_stats<DT>(xh, D, g, mean, rstd1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xh[dt][r] = (16 * dt + 4 * g < D && valid) ? (xh[dt][r] - mean) * rstd1 : 0.f;
+        }
+        colsum(3, dy);                                   // d beta1
+        {
+            f32x4 t[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) t[dt] = dy[dt] * xh[dt];
+            colsum(4, t);                                // d gamma1
+        }
+        ln_bwd_tile<DT>(dy, xh, a.g1, rstd1, D, g);      // dy = d s1
+        store_ctile<DT>(a.dres, m, valid, D, g, dy);
+        // ---- d o (out-projection output after its dropout) -> d att = d o W_o
+        {
+            unsigned bits[DT];
+            row_drop_bits<DT>(d, a.off1, m, g, bits);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) df[dt][r] = ((bits[dt] >> r) & 1u) ? dy[dt][r] * d.keep_scale : 0.f;
+        }
+        store_T<DT>(a.doT, m, valid, D, g, df, false);
+        // (a second scratch: the first one is aliased by the exchange area, which other owners may still be reading)
+        ctile_to_frags<DT, KS1>(scratch2, lane, D, df, false, dfr);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x4 o = f4zero();
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks)
+                o = MFMA(*reinterpret_cast<const bf16x8*>(a.wot + ((size_t)(dt * KS1 + ks) * 64 + lane) * 16), dfr[ks], o);
+            acc[dt] = o;
+        }
+        store_ctile<DT>(a.datt, m, valid, D, g, acc);
     }
-    ln_bwd_tile<DT>(dy, xh, a.g1, rstd1, D, g);      // dy = d s1
-    store_ctile<DT>(a.dres, m, valid, D, g, dy);
-    // ---- d o (out-projection output after its dropout) -> d att = d o W_o
-    {
-        unsigned bits[DT];
-        row_drop_bits<DT>(d, a.off1, m, g, bits);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) df[dt][r] = ((bits[dt] >> r) & 1u) ? dy[dt][r] * d.keep_scale : 0.f;
-    }
-    store_T<DT>(a.doT, m, valid, D, g, df, false);
-    ctile_to_frags<DT, KS1>(scratch, lane, D, df, false, dfr);
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        f32x4 o = f4zero();
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks)
-            o = MFMA(*reinterpret_cast<const bf16x8*>(a.wot + ((size_t)(dt * KS1 + ks) * 64 + lane) * 16), dfr[ks], o);
-        acc[dt] = o;
-    }
-    store_ctile<DT>(a.datt, m, valid, D, g, acc);
-    // ---- column sums of the workgroup, waves added in a fixed order
+    // ---- column sums of the workgroup, tiles added in a fixed order
     __syncthreads();
     for (int i = threadIdx.x; i < 5 * 16 * DT; i += TW * 64) {
         const int slot = i / (16 * DT), f = i - slot * (16 * DT);
         float sres = 0.f;
-        for (int w = 0; w < TW; ++w) sres += colred[(w * 5 + slot) * (16 * DT) + f];
+        for (int w = 0; w < 4; ++w) sres += colred[(w * 5 + slot) * (16 * DT) + f];
         if (f < D) a.vecpart[((size_t)blockIdx.x * 5 + slot) * D + f] = sres;
     }
 }
@@ -1011,7 +1096,7 @@ __global__ __launch_bounds__(256) void k_tr_attn_bwd(const TrDims d, const AttnB
 struct WgLayer {
     const __bf16* x0T; const __bf16* x1T; const __bf16* attT; const __bf16* dffnT; const __bf16* doT; const __bf16* dqkvT;
     const __bf16* x1rb; const __bf16* dffnrb;
-    const unsigned char* active;
+    const unsigned short* activeT;
     const char* ffn_img; const char* bffn;
     long long in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w;
 };
@@ -1022,37 +1107,27 @@ struct WgArgs {
     int TS, nblk;             // token splits; 32-token blocks in total
 };
 
-// T-block fragment: rows 16*rt + (lane&15), 8 of the block's 32 tokens per lane group.  perm: the token order of a packed
-// pair of C tiles (slots 0-3 = tokens 4g.., slots 4-7 = tokens 16+4g..), else natural (tokens 8g..8g+7).
-__device__ __forceinline__ bf16x8 t_frag(const __bf16* __restrict__ tb, int blk, int NF, int rt, int lane, bool perm, int nvalid) {
+// T-block fragment straight from global memory: rows 16*rt + (lane&15), tokens 8g..8g+7 of the block (natural order)
+__device__ __forceinline__ bf16x8 t_frag(const __bf16* __restrict__ tb, int blk, int NF, int rt, int lane, int nvalid) {
     const int row = lane & 15, g = lane >> 4;
-    const __bf16* p = tb + ((size_t)blk * NF + 16 * rt + row) * 32;
-    u32x4 v;
-    if (perm) {
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(p + 4 * g), hi = *reinterpret_cast<const u32x2*>(p + 16 + 4 * g);
-        v = u32x4{lo[0], lo[1], hi[0], hi[1]};
-        if (nvalid < 32) {
+    u32x4 v = *reinterpret_cast<const u32x4*>(tb + ((size_t)blk * NF + 16 * rt + row) * 32 + 8 * g);
+    if (nvalid < 32) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int tk = (e < 4) ? 4 * g + e : 16 + 4 * g + (e - 4);
-                if (tk >= nvalid) v[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
-            }
-        }
-    } else {
-        v = *reinterpret_cast<const u32x4*>(p + 8 * g);
-        if (nvalid < 32) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (8 * g + e >= nvalid) v[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
-        }
+        for (int e = 0; e < 8; ++e)
+            if (8 * g + e >= nvalid) v[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
     }
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// grid (F/128 + 1, TS, L), 512 threads.  blockIdx.x < F/128: FFN role (wave = one 16-wide hidden tile);
-// blockIdx.x == F/128: in_proj and out_proj weights (waves split the output row tiles).
+// grid (F/128 + 4, TS, L), 256 threads.
+//   blockIdx.x < F/128 : linear1 / linear2.  A wave owns one 32-wide chunk of hidden units (two 16-wide tiles) and walks the
+//                        32-token blocks of its split; the operands every wave needs (x1 / d f rows and T-blocks of the
+//                        block: 4 KS1 + 2 DT KiB) are staged once per workgroup in a 3-deep LDS ring by global_load_lds.
+//   the other four     : in_proj rows of q | k | v, and out_proj (operands straight from the T-blocks, next block's
+//                        fragments prefetched into registers).
 template <int KS1, int DT>
-__global__ __launch_bounds__(512, 2) void k_tr_wgrad(const TrDims d, const WgArgs a) {
+__global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const WgLayer L = a.layers[blockIdx.z];
@@ -1062,109 +1137,201 @@ __global__ __launch_bounds__(512, 2) void k_tr_wgrad(const TrDims d, const WgArg
     float* const part = a.part + (size_t)ts * a.nparams;
     constexpr int NB = 2 * KS1 + DT;
     if ((int)blockIdx.x < F / 128) {
-        // ------------------------------------------------ linear1 / linear2 (+ linear1.bias through the ones row of x1T)
-        const int ftile = blockIdx.x * 8 + wave;            // 16 hidden units f0 .. f0+15
-        const int f0 = ftile * 16, chunk = ftile >> 1, ft = ftile & 1;
-        const int NS = F / 64, fh = chunk / NS, c = chunk - fh * NS;
-        bf16x8 w1[KS1], w2[KS1];
+        constexpr int SB = (4 * KS1 + 2 * DT) * 1024;        // staged bytes per block: x1 rows | d f rows | x1 T | d f T
+        constexpr int NBUF = 3, NDMA = (4 * KS1 + 2 * DT + 3) / 4;
+        const int NS = F / 64;
+        const int chunk = blockIdx.x * 4 + wave;              // hidden units 32 chunk .. +31
+        const int fh = chunk / NS, c = chunk - fh * NS;
+        bf16x8 w1[2][KS1], w2[2][KS1];
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) {
-            w1[ks] = *reinterpret_cast<const bf16x8*>(L.ffn_img + ((size_t)((c * 2 + fh) * NB + ft * KS1 + ks) * 64 + lane) * 16);
-            w2[ks] = *reinterpret_cast<const bf16x8*>(L.bffn + ((size_t)((c * 2 + fh) * NB + ft * KS1 + ks) * 64 + lane) * 16);
-        }
-        f32x4 a1[DT], a2[DT];
+        for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) { a1[dt] = f4zero(); a2[dt] = f4zero(); }
-        for (int blk = blk0; blk < blk1; ++blk) {
+            for (int ks = 0; ks < KS1; ++ks) {
+                w1[ft][ks] = *reinterpret_cast<const bf16x8*>(L.ffn_img + ((size_t)((c * 2 + fh) * NB + ft * KS1 + ks) * 64 + lane) * 16);
+                w2[ft][ks] = *reinterpret_cast<const bf16x8*>(L.bffn + ((size_t)((c * 2 + fh) * NB + ft * KS1 + ks) * 64 + lane) * 16);
+            }
+        f32x4 a1[2][DT], a2[2][DT];
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) { a1[ft][dt] = f4zero(); a2[ft][dt] = f4zero(); }
+        // staging: every wave issues exactly NDMA 1-KiB copies + 4 mask loads per block (uniform vmcnt bookkeeping)
+        unsigned short mk[NBUF][4];
+        auto issue = [&](int blk, int slot) {
+            char* dst = smem + slot * SB;
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) {
+                int bb = wave + 4 * i;
+                bb %= 4 * KS1 + 2 * DT;
+                const char* src;
+                if (bb < 2 * KS1) src = reinterpret_cast<const char*>(L.x1rb) + (size_t)blk * (2 * KS1 * 1024) + bb * 1024;
+                else if (bb < 4 * KS1) src = reinterpret_cast<const char*>(L.dffnrb) + (size_t)blk * (2 * KS1 * 1024) + (bb - 2 * KS1) * 1024;
+                else if (bb < 4 * KS1 + DT) src = reinterpret_cast<const char*>(L.x1T) + (size_t)blk * (DT * 1024) + (bb - 4 * KS1) * 1024;
+                else src = reinterpret_cast<const char*>(L.dffnT) + (size_t)blk * (DT * 1024) + (bb - 4 * KS1 - DT) * 1024;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src + lane * 16), LDS_PTR(dst + bb * 1024), 16, 0, 0);
+            }
+        };
+        auto load_masks = [&](int blk, unsigned short (&o)[4]) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft)
+                    o[half * 2 + ft] = L.activeT[((size_t)blk * 2 + half) * F + chunk * 32 + ft * 16 + tok];
+        };
+        const int nb = blk1 - blk0;
+        // the 16 workgroups of a (split, layer) read the same token blocks: each starts at its own block (fixed per workgroup,
+        // so the summation order -- and the result -- is still reproducible)
+        const int brot = nb > 0 ? (int)((blockIdx.x * 3u) % (unsigned)nb) : 0;
+        auto blk_of = [&](int ib) { int bq = ib + brot; bq -= (bq >= nb) ? nb : 0; return blk0 + bq; };
+        if (nb > 0) { issue(blk_of(0), 0); load_masks(blk_of(0), mk[0]); }
+        if (nb > 1) { issue(blk_of(1), 1); load_masks(blk_of(1), mk[1]); }
+        for (int ib = 0; ib < nb; ++ib) {
+            const int blk = blk_of(ib), slot = ib % NBUF;
+            // block ib must have landed (this wave's share), then everybody's
+            if (ib + 1 < nb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 4) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (ib + 2 < nb) {
+                const int bn2 = blk_of(ib + 2);
+                issue(bn2, (ib + 2) % NBUF);
+                if ((ib + 2) % NBUF == 0) load_masks(bn2, mk[0]);
+                else if ((ib + 2) % NBUF == 1) load_masks(bn2, mk[1]);
+                else load_masks(bn2, mk[2]);
+            }
+            const char* sx = smem + slot * SB;
+            const char* sd = sx + 2 * KS1 * 1024;
+            const char* tx = sx + 4 * KS1 * 1024;
+            const char* td = tx + DT * 1024;
             const int nvalid = min(32, M - blk * 32);
-            f32x4 hh[2], dh[2];
+            unsigned short mks[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mks[i] = (slot == 0) ? mk[0][i] : (slot == 1 ? mk[1][i] : mk[2][i]);
+            f32x4 hh[2][2], dh[2][2];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                const int mrow = blk * 32 + half * 16 + tok;          // A operand row (token) of this lane
-                const bool rv = mrow < M;
-                f32x4 h = f4zero(), e = f4zero();
+                f32x4 h[2] = {f4zero(), f4zero()}, e[2] = {f4zero(), f4zero()};
 #pragma unroll
                 for (int ks = 0; ks < KS1; ++ks) {
-                    h = MFMA(row_frag(L.x1rb, mrow, rv, d.RBW, ks, g), w1[ks], h);     // [token rows 4g+r][f col]
-                    e = MFMA(row_frag(L.dffnrb, mrow, rv, d.RBW, ks, g), w2[ks], e);
+                    // A operands: rows = the 16 tokens of this half (row stride 64 KS1 bytes), 8 k-slots per lane group
+                    const bf16x8 ax = *reinterpret_cast<const bf16x8*>(sx + (size_t)(half * 16 + tok) * (64 * KS1) + (32 * ks + 8 * g) * 2);
+                    const bf16x8 ad = *reinterpret_cast<const bf16x8*>(sd + (size_t)(half * 16 + tok) * (64 * KS1) + (32 * ks + 8 * g) * 2);
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft) {
+                        h[ft] = MFMA(ax, w1[ft][ks], h[ft]);      // [token rows 4g+r][hidden col]
+                        e[ft] = MFMA(ad, w2[ft][ks], e[ft]);
+                    }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int mt = blk * 32 + half * 16 + 4 * g + r;
-                    bool on = false;
-                    if (mt < M) on = (L.active[((size_t)mt * (2 * NS) + chunk) * 4 + (tok >> 2)] >> (ft * 4 + (tok & 3))) & 1u;
-                    h[r] = on ? h[r] * d.keep_scale : 0.f;
-                    e[r] = on ? e[r] * d.keep_scale : 0.f;
+                for (int ft = 0; ft < 2; ++ft) {
+                    const unsigned mw = mks[half * 2 + ft];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool on = (mw >> (4 * g + r)) & 1u;
+                        h[ft][r] = on ? h[ft][r] * d.keep_scale : 0.f;
+                        e[ft][r] = on ? e[ft][r] * d.keep_scale : 0.f;
+                    }
+                    hh[ft][half] = h[ft];
+                    dh[ft][half] = e[ft];
                 }
-                hh[half] = h;
-                dh[half] = e;
             }
-            const bf16x8 hB = pack8(hh[0], hh[1]), dB = pack8(dh[0], dh[1]);
+            bf16x8 hB[2], dB[2];
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) { hB[ft] = pack8(hh[ft][0], hh[ft][1]); dB[ft] = pack8(dh[ft][0], dh[ft][1]); }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                a2[dt] = MFMA(t_frag(L.dffnT, blk, NFT, dt, lane, true, nvalid), hB, a2[dt]);   // d W2[d][f]
-                a1[dt] = MFMA(t_frag(L.x1T, blk, NFT, dt, lane, true, nvalid), dB, a1[dt]);     // d W1[f][d], row D = d b1[f]
-            }
-        }
-        const int f = f0 + tok;
+                // T-block A operands in the token order of the packed C tiles: slots 0-3 = tokens 4g.., slots 4-7 = tokens 16+4g..
+                const char* px = tx + (size_t)(16 * dt + tok) * 64, *pd = td + (size_t)(16 * dt + tok) * 64;
+                u32x2 xl = *reinterpret_cast<const u32x2*>(px + 8 * g), xh = *reinterpret_cast<const u32x2*>(px + 32 + 8 * g);
+                u32x2 dl = *reinterpret_cast<const u32x2*>(pd + 8 * g), dhh = *reinterpret_cast<const u32x2*>(pd + 32 + 8 * g);
+                u32x4 xv = {xl[0], xl[1], xh[0], xh[1]}, dv = {dl[0], dl[1], dhh[0], dhh[1]};
+                if (nvalid < 32) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+                    for (int e = 0; e < 8; ++e) {
+                        const int tk = (e < 4) ? 4 * g + e : 16 + 4 * g + (e - 4);
+                        if (tk >= nvalid) {
+                            xv[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+                            dv[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+                        }
+                    }
+                }
+                const bf16x8 ax = __builtin_bit_cast(bf16x8, xv), ad = __builtin_bit_cast(bf16x8, dv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int dd = 16 * dt + 4 * g + r;
-                if (dd < D) {
-                    part[L.l2_w + (size_t)dd * F + f] = a2[dt][r];
-                    part[L.l1_w + (size_t)f * D + dd] = a1[dt][r];
-                } else if (dd == D) {
-                    part[L.l1_b + f] = a1[dt][r];
+                for (int ft = 0; ft < 2; ++ft) {
+                    a2[ft][dt] = MFMA(ad, hB[ft], a2[ft][dt]);        // d W2[d][f]
+                    a1[ft][dt] = MFMA(ax, dB[ft], a1[ft][dt]);        // d W1[f][d], row D = d b1[f]
                 }
             }
+        }
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+            const int f = chunk * 32 + ft * 16 + tok;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int dd = 16 * dt + 4 * g + r;
+                    if (dd < D) {
+                        part[L.l2_w + (size_t)dd * F + f] = a2[ft][dt][r];
+                        part[L.l1_w + (size_t)f * D + dd] = a1[ft][dt][r];
+                    } else if (dd == D) {
+                        part[L.l1_b + f] = a1[ft][dt][r];
+                    }
+                }
+        }
     } else {
         // ------------------------------------------------ in_proj (+ bias through the ones row of x0T) and out_proj (+ bias)
-        const int NRI = 3 * d.NP;                          // 16-row tiles of d(qkv)^T
-        constexpr int MAXR = 4;
+        const int role = blockIdx.x - F / 128;              // 0..2: q | k | v rows of in_proj, 3: out_proj
+        const int NRT = (role < 3) ? d.NP : DT;             // 16-row tiles of this role
+        const __bf16* At = (role < 3) ? L.dqkvT : L.doT;
+        const int ANF = (role < 3) ? 3 * d.NP * 16 : NFT;
+        const int rt_base = (role < 3) ? role * d.NP : 0;
+        const __bf16* Bt = (role < 3) ? L.x0T : L.attT;
+        constexpr int MAXR = 2;
+        const int nr = (wave < NRT ? 1 : 0) + (wave + 4 < NRT ? 1 : 0);
         f32x4 acc[MAXR][DT];
-        int rts[MAXR];
-        int nr = 0;
-        for (int rt = wave; rt < NRI && nr < MAXR - 1; rt += 8) rts[nr++] = rt;
-        const int nri = nr;
-        const bool has_o = wave < DT;
-        if (has_o) rts[nr++] = 1000 + wave;
 #pragma unroll
         for (int i = 0; i < MAXR; ++i)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) acc[i][dt] = f4zero();
-        for (int blk = blk0; blk < blk1; ++blk) {
-            const int nvalid = min(32, M - blk * 32);
-            bf16x8 xb[DT], ab[DT];
+        if (nr == 0 || blk1 <= blk0) {
+            // (nothing owned: still nothing to write -- every output element has exactly one owner wave)
+        } else {
+            bf16x8 bn[DT], an[MAXR];
+            auto fetch = [&](int blk) {
+                const int nvalid = min(32, M - blk * 32);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                xb[dt] = t_frag(L.x0T, blk, NFT, dt, lane, false, nvalid);
-                ab[dt] = t_frag(L.attT, blk, NFT, dt, lane, false, nvalid);
-            }
+                for (int dt = 0; dt < DT; ++dt) bn[dt] = t_frag(Bt, blk, NFT, dt, lane, nvalid);
 #pragma unroll
-            for (int i = 0; i < MAXR; ++i) {
-                if (i < nri) {
-                    const bf16x8 af = t_frag(L.dqkvT, blk, 3 * d.NP * 16, rts[i], lane, false, nvalid);
+                for (int i = 0; i < MAXR; ++i)
+                    if (i < nr) an[i] = t_frag(At, blk, ANF, rt_base + wave + 4 * i, lane, nvalid);
+            };
+            fetch(blk0);
+            for (int blk = blk0; blk < blk1; ++blk) {
+                bf16x8 bc[DT], ac[MAXR];
 #pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) acc[i][dt] = MFMA(af, xb[dt], acc[i][dt]);    // [qkv row][d col]
-                } else if (i == nri && has_o) {
-                    const bf16x8 af = t_frag(L.doT, blk, NFT, wave, lane, false, nvalid);
+                for (int dt = 0; dt < DT; ++dt) bc[dt] = bn[dt];
 #pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) acc[i][dt] = MFMA(af, ab[dt], acc[i][dt]);    // [d row][att feature col]
-                }
+                for (int i = 0; i < MAXR; ++i) ac[i] = an[i];
+                if (blk + 1 < blk1) fetch(blk + 1);
+#pragma unroll
+                for (int i = 0; i < MAXR; ++i)
+                    if (i < nr) {
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) acc[i][dt] = MFMA(ac[i], bc[dt], acc[i][dt]);
+                    }
             }
         }
 #pragma unroll
         for (int i = 0; i < MAXR; ++i) {
-            if (i < nri) {
-                const int rt = rts[i];
-                const int which = rt / d.NP, pr = rt - which * d.NP;
+            if (i >= nr) continue;
+            const int rt = wave + 4 * i;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = 4 * g + r, hs = j >> 3, dd = j & 7, head = 2 * pr + hs;
+            for (int r = 0; r < 4; ++r) {
+                const int j = 4 * g + r;
+                if (role < 3) {
+                    const int hs = j >> 3, dd = j & 7, head = 2 * rt + hs;
                     if (head < d.H && dd < d.hd) {
-                        const long long row = (long long)which * D + head * d.hd + dd;
+                        const long long row = (long long)role * D + head * d.hd + dd;
 #pragma unroll
                         for (int dt = 0; dt < DT; ++dt) {
                             const int col = 16 * dt + tok;
@@ -1172,11 +1339,8 @@ __global__ __launch_bounds__(512, 2) void k_tr_wgrad(const TrDims d, const WgArg
                             else if (col == D) part[L.in_b + row] = acc[i][dt][r];
                         }
                     }
-                }
-            } else if (i == nri && has_o) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int dd = 16 * wave + 4 * g + r;
+                } else {
+                    const int dd = 16 * rt + j;
                     if (dd < D) {
 #pragma unroll
                         for (int dt = 0; dt < DT; ++dt) {
@@ -1205,25 +1369,38 @@ struct RedArgs {
     float* grads; int accumulate;
 };
 __global__ __launch_bounds__(256) void k_tr_reduce(const RedArgs a) {
-    const long long i = a.begin + (long long)blockIdx.x * 256 + threadIdx.x;
+    // 4 consecutive parameters per thread: every tensor of the flat layout starts on a 16-byte boundary and every owned range
+    // has a multiple of 4 elements (d_model % 4 == 0), so a group is owned / vector / gap as a whole
+    const long long i = a.begin + ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= a.nparams) return;
     const long long li = (i - a.begin) / a.layer_stride, rel = (i - a.begin) - li * a.layer_stride;
-    float v = 0.f;
+    float4 v = {0.f, 0.f, 0.f, 0.f};
     bool owned = false;
 #pragma unroll
     for (int k = 0; k < 7; ++k) owned |= (rel >= a.wrel[k] && rel < a.wrel[k] + a.wnum[k]);
     if (owned)
-        for (int t = 0; t < a.TS; ++t) v += a.part[(size_t)t * a.nparams + i];
+        for (int t = 0; t < a.TS; ++t) {
+            const float4 p4 = *reinterpret_cast<const float4*>(a.part + (size_t)t * a.nparams + i);
+            v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+        }
 #pragma unroll
     for (int sidx = 0; sidx < 5; ++sidx) {
         const long long o = rel - a.rel[sidx];
         if (o >= 0 && o < a.D) {
             owned = true;
             const float* vp = a.vecpart + ((size_t)li * a.nwg * 5 + sidx) * a.D + o;
-            for (int w = 0; w < a.nwg; ++w) v += vp[(size_t)w * 5 * a.D];
+            for (int w = 0; w < a.nwg; ++w) {
+                const float4 p4 = *reinterpret_cast<const float4*>(vp + (size_t)w * 5 * a.D);
+                v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+            }
         }
     }
-    a.grads[i] = (a.accumulate && owned) ? a.grads[i] + v : (owned ? v : (a.accumulate ? a.grads[i] : 0.f));
+    float4* gp = reinterpret_cast<float4*>(a.grads + i);
+    if (a.accumulate) {
+        if (owned) { const float4 g4 = *gp; *gp = float4{g4.x + v.x, g4.y + v.y, g4.z + v.z, g4.w + v.w}; }
+    } else {
+        *gp = v;
+    }
 }
 
 // out = a + sum of `np` partial tensors (fixed order)
@@ -1245,6 +1422,7 @@ struct TrLayerBufs {
     float *x0, *att, *s1, *s2, *lse2;
     __bf16 *x0rb, *x0T, *x1rb, *x1T, *attT, *dffnT, *dffnrb, *doT, *dqkvT;
     unsigned char *pmask, *active;
+    unsigned short* activeT;
 };
 struct TrBufs {
     std::vector<TrLayerBufs> layers;
@@ -1266,13 +1444,13 @@ size_t al(size_t b) { return fd_ws::padded(b); }
 size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
     const fd_bf16_images* im = m->bf16;
     const size_t T = m->d.max_len, D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, L = m->d.num_layers;
-    const size_t M = (size_t)B * T, Mpad = (M + 127) & ~size_t(127);
+    const size_t M = (size_t)B * T, Mpad = (M + 63) & ~size_t(63);
     const size_t NFT = 16 * (size_t)im->dt, RBW = 32 * (size_t)im->ks1, NP = im->np, NJ = ((T + 15) / 16 + 1) / 2;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al(bytes); return p; };
     TrBufs tb;
     tb.Mpad = (int)Mpad;
-    tb.nwg = (int)(Mpad / 128);
+    tb.nwg = (int)(Mpad / 64);
     tb.TS = tr_TS(m);
     tb.part_stride = M * D;
     tb.emb = (float*)take(sizeof(float) * B * D);
@@ -1297,6 +1475,7 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
         b.dqkvT = (__bf16*)take(2 * Mpad * 3 * NP * 16);
         b.pmask = (unsigned char*)take((size_t)B * H * T * NJ * 4);
         b.active = (unsigned char*)take(Mpad * (F / 32) * 4);
+        b.activeT = (unsigned short*)take((Mpad / 32) * 2 * F * sizeof(unsigned short));
     }
     tb.dh = (float*)take(sizeof(float) * M * D);
     tb.datt = (float*)take(sizeof(float) * M * D);
@@ -1342,7 +1521,9 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         hipLaunchKernelGGL((k_tr_prep<KS1, DT>), dim3((tb.Mpad / 16 + 3) / 4), dim3(256), 0, s, h0, tb.layers[0].x0rb, tb.layers[0].x0T,
                            M, tb.Mpad, D);
     const size_t lds_attn = (size_t)d.KT * 16 * 32 + (size_t)d.NJ * 1024;
-    const size_t lds_ffn = (size_t)2 * 2 * (2 * KS1 + DT) * 1024 + (size_t)TW * KS1 * 1024;
+    const size_t scr = std::max((size_t)TW * KS1 * 1024, (size_t)4 * DT * 1024);
+    const size_t NSh = (size_t)m->d.dim_ff / 64;
+    const size_t lds_ffn = (size_t)4 * 2 * (2 * KS1 + DT) * 1024 + scr + (size_t)TW * 64 * NSh + (size_t)TW * NSh * 32 * sizeof(unsigned short);
     static bool attr = false;
     if (!attr) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_fwd<KS1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1364,7 +1545,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         fa.x1rb = b.x1rb; fa.x1T = b.x1T;
         fa.outrb = (l + 1 < L) ? tb.layers[l + 1].x0rb : nullptr;
         fa.outT = (l + 1 < L) ? tb.layers[l + 1].x0T : nullptr;
-        fa.active = b.active;
+        fa.active = b.active; fa.activeT = b.activeT;
         fa.wo_img = limg + im->off_wo; fa.ffn_img = limg + im->off_ffn;
         fa.bo = P + lo.out_b; fa.g1 = P + lo.n1_w; fa.be1 = P + lo.n1_b; fa.b2 = P + lo.l2_b; fa.g2 = P + lo.n2_w; fa.be2 = P + lo.n2_b;
         fa.off1 = fd_dropout_site_offset(offset, l, 1); fa.off2 = fd_dropout_site_offset(offset, l, 2); fa.off3 = fd_dropout_site_offset(offset, l, 3);
@@ -1390,12 +1571,16 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     fdgemm::linear_bwd_weight(dout, tb.hL, grads + m->un_w, M, C, D, true, s, tb.skp, kSkpFloats);
     fd_colsum_det(ctx, dout, grads + m->un_b, M, C, s);
     fdgemm::linear_bwd_input(dout, P + m->un_w, tb.dh, M, C, D, false, s);
-    const size_t lds_bwd = (size_t)2 * 2 * (2 * KS1 + DT) * 1024 + (size_t)TW * KS1 * 1024 + (size_t)TW * 5 * 16 * DT * sizeof(float);
+    const size_t scr = std::max((size_t)TW * KS1 * 1024, (size_t)4 * DT * 1024);
+    const size_t NSh = (size_t)m->d.dim_ff / 64;
+    const size_t lds_bwd = (size_t)4 * 2 * (2 * KS1 + DT) * 1024 + scr + (size_t)TW * 64 * NSh + (size_t)4 * 5 * 16 * DT * sizeof(float) +
+                           (size_t)TW * KS1 * 1024;
     const size_t lds_ab = (size_t)4 * d.KT * 16 * 32 + (size_t)3 * d.NJ * 1024 + (size_t)4 * d.KT * 16 * sizeof(float);
     static bool attr = false;
     if (!attr) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_ffn_bwd<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_bwd<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_wgrad<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     std::vector<WgLayer> tab(L);
@@ -1425,7 +1610,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT>), dim3(d.NP, B), dim3(256), lds_ab, s, d, ab);
         WgLayer& w = tab[l];
         w.x0T = b.x0T; w.x1T = b.x1T; w.attT = b.attT; w.dffnT = b.dffnT; w.doT = b.doT; w.dqkvT = b.dqkvT;
-        w.x1rb = b.x1rb; w.dffnrb = b.dffnrb; w.active = b.active;
+        w.x1rb = b.x1rb; w.dffnrb = b.dffnrb; w.activeT = b.activeT;
         w.ffn_img = limg + im->off_ffn; w.bffn = bl + im->boff_ffn;
         w.in_w = lo.in_w; w.in_b = lo.in_b; w.out_w = lo.out_w; w.out_b = lo.out_b; w.l1_w = lo.l1_w; w.l1_b = lo.l1_b; w.l2_w = lo.l2_w;
     }
@@ -1434,7 +1619,8 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         FD_HIP(ctx, hipMemcpyAsync(tb.wg_tab, tab.data(), sizeof(WgLayer) * L, hipMemcpyHostToDevice, s));
         WgArgs wa{};
         wa.layers = tb.wg_tab; wa.part = tb.part; wa.nparams = m->nparams; wa.TS = tb.TS; wa.nblk = (M + 31) / 32;
-        hipLaunchKernelGGL((k_tr_wgrad<KS1, DT>), dim3(F / 128 + 1, tb.TS, L), dim3(512), 0, s, d, wa);
+        const size_t lds_wg = (size_t)3 * (4 * KS1 + 2 * DT) * 1024;
+        hipLaunchKernelGGL((k_tr_wgrad<KS1, DT>), dim3(F / 128 + 4, tb.TS, L), dim3(256), lds_wg, s, d, wa);
         RedArgs ra{};
         ra.part = tb.part; ra.nparams = m->nparams; ra.TS = tb.TS; ra.vecpart = tb.vecpart; ra.nwg = tb.nwg; ra.D = D; ra.L = L;
         ra.begin = m->layers[0].in_w;
@@ -1447,7 +1633,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         for (int k = 0; k < 7; ++k) { ra.wrel[k] = wr[k]; ra.wnum[k] = wn[k]; }
         ra.grads = grads; ra.accumulate = accumulate;
         const long long n = m->nparams - ra.begin;
-        hipLaunchKernelGGL(k_tr_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ra);
+        hipLaunchKernelGGL(k_tr_reduce, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, ra);
         // gradient of the first layer's input = residual path + the pairs' in_proj contributions
         const size_t nn = (size_t)M * D;
         hipLaunchKernelGGL(k_tr_sum_parts, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, tb.dres[0], tb.dxp[0], d.NP,
@@ -1462,7 +1648,9 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
 
 bool fd_train_bf16_supported(const fd_score* m) {
     const fd_bf16_images* im = m->bf16;
-    return im && im->train && im->bimg && m->d.dim_ff % 128 == 0 && m->d.num_layers > 0 && m->d.max_len <= 1024;
+    // dim_ff: the FFN kernels keep one keep-byte per 32-wide chunk per lane in 16-byte groups (F % 1024 == 0) and their LDS
+    // budget covers F <= 2048 (torch's default 2048 is the only value the reference uses)
+    return im && im->train && im->bimg && m->d.dim_ff % 1024 == 0 && m->d.dim_ff <= 2048 && m->d.num_layers > 0 && m->d.max_len <= 1024;
 }
 
 size_t fd_train_bf16_workspace(const fd_score* m, int B) { return tr_carve(m, B, nullptr, nullptr); }
