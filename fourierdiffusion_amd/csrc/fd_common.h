@@ -32,6 +32,10 @@ struct fd_ctx {
     // gradients, gradient norm
     float* red_scratch = nullptr;
     size_t red_scratch_floats = 0;
+    // side stream + events: the training backward runs each layer's weight-gradient kernel beside the (latency-bound)
+    // input-gradient chain of the earlier layers
+    hipStream_t side_stream = nullptr;
+    std::vector<hipEvent_t> side_events;
     // FFT twiddle tables (T, device pointer), built on first use of a length
     std::vector<std::pair<int, void*>> fft_tw;
     // measurement hooks (fd_prof_begin / fd_prof_end)

@@ -27,6 +27,8 @@ extern "C" int fd_ctx_destroy(fd_ctx* ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->gemm_scratch) (void)hipFree(ctx->gemm_scratch);
     if (ctx->red_scratch) (void)hipFree(ctx->red_scratch);
+    for (hipEvent_t e : ctx->side_events) (void)hipEventDestroy(e);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     for (auto& e : ctx->fft_tw) (void)hipFree(e.second);
     delete ctx;
     return FD_OK;

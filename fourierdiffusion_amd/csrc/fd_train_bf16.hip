@@ -193,6 +193,52 @@ __device__ __forceinline__ void store_rows(__bf16* __restrict__ rb, int m, bool 
         *reinterpret_cast<u32x2*>(row + d0) = pk;
     }
 }
+// "Stage" layout of the operands the weight-gradient kernel streams through LDS: per 32-token block ONE contiguous record
+//   [x1 rows 32 x RBS][d f rows 32 x RBS][x1 T-block NFT x TBS][d f T-block NFT x TBS]   (bf16, record padded to 1 KiB)
+// with row strides padded off the LDS bank period (RBS = 32 KS1 + 8 -> 16-lane b128 reads hit every bank twice, the
+// minimum; TBS = 40 -> b64 reads two-way) -- the natural strides (192 B / 64 B) made every fragment read an 8-way conflict,
+// 2.7 us per 32-token block.  global_load_lds copies a record verbatim.
+template <int KS1, int DT>
+struct StageL {
+    static constexpr int RBS = 32 * KS1 + 8, TBS = 40, NFT = 16 * DT;
+    static constexpr int off_xr = 0, off_dr = 32 * RBS * 2, off_xT = 2 * 32 * RBS * 2, off_dT = off_xT + NFT * TBS * 2;
+    static constexpr int bytes = (off_dT + NFT * TBS * 2 + 1023) & ~1023;
+};
+template <int DT, int KS1>
+__device__ __forceinline__ void stage_rows(char* __restrict__ stage, int region_off, int m, bool valid, int D, int g,
+                                           const f32x4 (&v)[DT], bool ones) {
+    using SL = StageL<KS1, DT>;
+    __bf16* row = reinterpret_cast<__bf16*>(stage + (size_t)(m >> 5) * SL::bytes + region_off) + (size_t)(m & 31) * SL::RBS;
+#pragma unroll
+    for (int dt = 0; dt < 2 * KS1; ++dt) {
+        const int d0 = 16 * dt + 4 * g;
+        u32x2 pk = {0u, 0u};
+        if (valid) {
+            if (dt < DT && d0 < D) {
+                pk[0] = cvt_pk_bf16(v[dt < DT ? dt : 0][0], v[dt < DT ? dt : 0][1]);
+                pk[1] = cvt_pk_bf16(v[dt < DT ? dt : 0][2], v[dt < DT ? dt : 0][3]);
+            } else if (d0 == D && ones) {
+                pk[0] = 0x00003F80u;
+            }
+        }
+        *reinterpret_cast<u32x2*>(row + d0) = pk;
+    }
+}
+template <int DT, int KS1>
+__device__ __forceinline__ void stage_T(char* __restrict__ stage, int region_off, int m, bool valid, int D, int g,
+                                        const f32x4 (&v)[DT], bool ones) {
+    using SL = StageL<KS1, DT>;
+    __bf16* col = reinterpret_cast<__bf16*>(stage + (size_t)(m >> 5) * SL::bytes + region_off) + (m & 31);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 16 * dt + 4 * g + r;
+            float x = 0.f;
+            if (valid) x = (f < D) ? v[dt][r] : ((f == D && ones) ? 1.0f : 0.f);
+            col[(size_t)f * SL::TBS] = (__bf16)x;
+        }
+}
 __device__ __forceinline__ bf16x8 row_frag(const __bf16* __restrict__ rb, int m, bool valid, int RBW, int ks, int g) {
     if (!valid) return frag_zero();
     return *reinterpret_cast<const bf16x8*>(rb + (size_t)m * RBW + 32 * ks + 8 * g);
@@ -410,10 +456,11 @@ struct FfnFwdArgs {
     const float* att;         // (M, D)
     float* s1; float* s2;     // (M, D) pre-LayerNorm sums (saved)
     float* out;               // (M, D) layer output
-    __bf16* x1rb; __bf16* x1T;
+    char* stage;              // StageL records of the layer (x1 rows / T here, d f rows / T by the backward)
     __bf16* outrb; __bf16* outT;   // next layer's input in operand form (null for the last layer)
     unsigned char* active;    // (Mpad, 4, F/32): bit e of byte (m, g, chunk): hidden unit kept by dropout AND > 0
-    unsigned short* activeT;  // (Mpad/32, 2, F): bit j of word (block, half, f): the same for token 32 block + 16 half + j
+    unsigned short* activeT;  // (Mpad/32, 2, F/32, 8, 4): bit j of word (block, half, chunk, w, gq): the same for token
+                              // 32 block + 16 half + j and hidden unit 32 chunk + 16 (w >> 2) + 4 gq + (w & 3)
     const char* wo_img;       // [DT][KSO]
     const char* ffn_img;      // chunk-major forward image of the layer
     const float* bo; const float* g1; const float* be1; const float* b2; const float* g2; const float* be2;
@@ -510,8 +557,8 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         }
     }
     if (owner) {
-        store_rows<DT, KS1>(a.x1rb, m, valid, D, g, v, true);
-        store_T<DT>(a.x1T, m, valid, D, g, v, true);
+        stage_rows<DT, KS1>(a.stage, StageL<KS1, DT>::off_xr, m, valid, D, g, v, true);
+        stage_T<DT, KS1>(a.stage, StageL<KS1, DT>::off_xT, m, valid, D, g, v, true);
     }
     bf16x8 xf[KS1];
     ctile_to_frags<DT, KS1>(scratch, lane, D, v, true, xf);
@@ -533,9 +580,10 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         int ce = c + rot;
         ce -= (ce >= NS) ? NS : 0;
         const int chunk = fhw * NS + ce;
-        unsigned bits = 0xffu;
-        if (d.p > 0.f) bits = drop8(a.off2 + ((unsigned long long)m * (2 * NS) + chunk) * 4ull + (unsigned)g, d.seed, d.thr16);
+        // (thr16 = 0 keeps everything: no branch on p inside the loop -- branches split the MFMA chains into basic blocks)
+        const unsigned bits = drop8(a.off2 + ((unsigned long long)m * (2 * NS) + chunk) * 4ull + (unsigned)g, d.seed, d.thr16);
         unsigned act = 0u;
+        unsigned long long bal[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool k0 = valid && ((bits >> r) & 1u) && h0[r] > 0.f, k1 = valid && ((bits >> (4 + r)) & 1u) && h1[r] > 0.f;
@@ -543,12 +591,14 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
             act |= (k1 ? 1u : 0u) << (4 + r);
             h0[r] = k0 ? h0[r] * d.keep_scale : 0.f;
             h1[r] = k1 ? h1[r] * d.keep_scale : 0.f;
-            // the same decisions with the 16 tokens of the tile as bits of one word per hidden unit (weight-gradient kernel)
-            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(k0), b1 = __builtin_amdgcn_ballot_w64(k1);
-            if (lane < 4) {
-                actT[ce * 32 + 4 * lane + r] = (unsigned short)(b0 >> (16 * lane));
-                actT[ce * 32 + 16 + 4 * lane + r] = (unsigned short)(b1 >> (16 * lane));
-            }
+            // the same decisions with the 16 tokens of the tile as the bits of one word per hidden unit (weight-gradient
+            // kernel): ballot bit 16 g + tok of register r <-> hidden unit 4 g + r (+16 for the second tile)
+            bal[r] = __builtin_amdgcn_ballot_w64(k0);
+            bal[4 + r] = __builtin_amdgcn_ballot_w64(k1);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) reinterpret_cast<unsigned long long*>(actT)[ce * 8 + w8] = bal[w8];
         }
         actB[lane * NS + ce] = (unsigned char)act;
         const bf16x8 hb = pack8(h0, h1);
@@ -631,7 +681,7 @@ struct FfnBwdArgs {
     const unsigned char* active;
     float* datt;              // (M, D) gradient of the attention output
     float* dres;              // (M, D) gradient of the layer input through the residual path (= d s1)
-    __bf16* dffnT; __bf16* dffnrb; __bf16* doT;
+    char* stage; __bf16* doT;
     float* vecpart;           // [grid][5][D]: column sums of this workgroup: d b2, d beta2, d gamma2, d beta1, d gamma1
     const char* bffn;         // backward FFN image (chunk-major)
     const char* wot;          // [DT][KS1]
@@ -761,8 +811,8 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     }
     colsum(0, df);                                   // d b2
     if (owner) {
-        store_T<DT>(a.dffnT, m, valid, D, g, df, false);
-        store_rows<DT, KS1>(a.dffnrb, m, valid, D, g, df, false);
+        stage_T<DT, KS1>(a.stage, StageL<KS1, DT>::off_dT, m, valid, D, g, df, false);
+        stage_rows<DT, KS1>(a.stage, StageL<KS1, DT>::off_dr, m, valid, D, g, df, false);
     }
     bf16x8 dfr[KS1];
     ctile_to_frags<DT, KS1>(scratch, lane, D, df, false, dfr);
@@ -773,7 +823,9 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     __syncthreads();
     // ---- d x1 += W1^T (active . W2^T d f) over this wave's F-half: d hidden lives in registers only
     for (int c = 0; c < NS; ++c) {
+#ifndef FD_TR_ABL_NODMA
         if (c + 3 < NS) issue(c + 3);
+#endif
         const char* wb = ring + (c % NBUF) * WB + fhw * NB * 1024 + lane * 16;
         f32x4 h0 = f4zero(), h1 = f4zero();
 #pragma unroll
@@ -795,7 +847,9 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
         if (c + 3 < NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xc07f);
+#ifndef FD_TR_ABL_NOBAR
         __builtin_amdgcn_s_barrier();
+#endif
     }
     __syncthreads();
     if (!owner) {
@@ -1094,14 +1148,13 @@ __global__ __launch_bounds__(256) void k_tr_attn_bwd(const TrDims d, const AttnB
 
 // ------------------------------------------------------------------------------------------------ weight gradients
 struct WgLayer {
-    const __bf16* x0T; const __bf16* x1T; const __bf16* attT; const __bf16* dffnT; const __bf16* doT; const __bf16* dqkvT;
-    const __bf16* x1rb; const __bf16* dffnrb;
+    const __bf16* x0T; const __bf16* attT; const __bf16* doT; const __bf16* dqkvT;
+    const char* stage;
     const unsigned short* activeT;
     const char* ffn_img; const char* bffn;
     long long in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w;
 };
 struct WgArgs {
-    const WgLayer* layers;    // device [L]
     float* part;              // [TS][nparams]
     long long nparams;
     int TS, nblk;             // token splits; 32-token blocks in total
@@ -1119,26 +1172,26 @@ __device__ __forceinline__ bf16x8 t_frag(const __bf16* __restrict__ tb, int blk,
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// grid (F/128 + 4, TS, L), 256 threads.
+// One launch per layer: grid (F/128 + 4, TS), 256 threads.
 //   blockIdx.x < F/128 : linear1 / linear2.  A wave owns one 32-wide chunk of hidden units (two 16-wide tiles) and walks the
 //                        32-token blocks of its split; the operands every wave needs (x1 / d f rows and T-blocks of the
 //                        block: 4 KS1 + 2 DT KiB) are staged once per workgroup in a 3-deep LDS ring by global_load_lds.
 //   the other four     : in_proj rows of q | k | v, and out_proj (operands straight from the T-blocks, next block's
 //                        fragments prefetched into registers).
 template <int KS1, int DT>
-__global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgArgs a) {
+__global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLayer L, const WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const WgLayer L = a.layers[blockIdx.z];
     const int ts = blockIdx.y;
     const int D = d.D, F = d.F, M = d.M, NFT = d.NFT;
     const int blk0 = (int)(((long long)a.nblk * ts) / a.TS), blk1 = (int)(((long long)a.nblk * (ts + 1)) / a.TS);
     float* const part = a.part + (size_t)ts * a.nparams;
     constexpr int NB = 2 * KS1 + DT;
     if ((int)blockIdx.x < F / 128) {
-        constexpr int SB = (4 * KS1 + 2 * DT) * 1024;        // staged bytes per block: x1 rows | d f rows | x1 T | d f T
-        constexpr int NBUF = 3, NDMA = (4 * KS1 + 2 * DT + 3) / 4;
+        using SL = StageL<KS1, DT>;
+        constexpr int SB = SL::bytes;                         // staged bytes per 32-token block (one StageL record)
+        constexpr int NBUF = 3, NDMA = (SB / 1024 + 3) / 4;
         const int NS = F / 64;
         const int chunk = blockIdx.x * 4 + wave;              // hidden units 32 chunk .. +31
         const int fh = chunk / NS, c = chunk - fh * NS;
@@ -1159,16 +1212,12 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgArg
         unsigned short mk[NBUF][4];
         auto issue = [&](int blk, int slot) {
             char* dst = smem + slot * SB;
+            const char* src = L.stage + (size_t)blk * SB + lane * 16;
 #pragma unroll
             for (int i = 0; i < NDMA; ++i) {
                 int bb = wave + 4 * i;
-                bb %= 4 * KS1 + 2 * DT;
-                const char* src;
-                if (bb < 2 * KS1) src = reinterpret_cast<const char*>(L.x1rb) + (size_t)blk * (2 * KS1 * 1024) + bb * 1024;
-                else if (bb < 4 * KS1) src = reinterpret_cast<const char*>(L.dffnrb) + (size_t)blk * (2 * KS1 * 1024) + (bb - 2 * KS1) * 1024;
-                else if (bb < 4 * KS1 + DT) src = reinterpret_cast<const char*>(L.x1T) + (size_t)blk * (DT * 1024) + (bb - 4 * KS1) * 1024;
-                else src = reinterpret_cast<const char*>(L.dffnT) + (size_t)blk * (DT * 1024) + (bb - 4 * KS1 - DT) * 1024;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(src + lane * 16), LDS_PTR(dst + bb * 1024), 16, 0, 0);
+                bb %= SB / 1024;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src + bb * 1024), LDS_PTR(dst + bb * 1024), 16, 0, 0);
             }
         };
         auto load_masks = [&](int blk, unsigned short (&o)[4]) {
@@ -1176,7 +1225,7 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgArg
             for (int half = 0; half < 2; ++half)
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft)
-                    o[half * 2 + ft] = L.activeT[((size_t)blk * 2 + half) * F + chunk * 32 + ft * 16 + tok];
+                    o[half * 2 + ft] = L.activeT[((size_t)blk * 2 + half) * F + chunk * 32 + ft * 16 + (tok & 3) * 4 + (tok >> 2)];
         };
         const int nb = blk1 - blk0;
         // the 16 workgroups of a (split, layer) read the same token blocks: each starts at its own block (fixed per workgroup,
@@ -1198,10 +1247,10 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgArg
                 else if ((ib + 2) % NBUF == 1) load_masks(bn2, mk[1]);
                 else load_masks(bn2, mk[2]);
             }
-            const char* sx = smem + slot * SB;
-            const char* sd = sx + 2 * KS1 * 1024;
-            const char* tx = sx + 4 * KS1 * 1024;
-            const char* td = tx + DT * 1024;
+            const char* sx = smem + slot * SB + SL::off_xr;
+            const char* sd = smem + slot * SB + SL::off_dr;
+            const char* tx = smem + slot * SB + SL::off_xT;
+            const char* td = smem + slot * SB + SL::off_dT;
             const int nvalid = min(32, M - blk * 32);
             unsigned short mks[4];
 #pragma unroll
@@ -1213,8 +1262,8 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgArg
 #pragma unroll
                 for (int ks = 0; ks < KS1; ++ks) {
                     // A operands: rows = the 16 tokens of this half (row stride 64 KS1 bytes), 8 k-slots per lane group
-                    const bf16x8 ax = *reinterpret_cast<const bf16x8*>(sx + (size_t)(half * 16 + tok) * (64 * KS1) + (32 * ks + 8 * g) * 2);
-                    const bf16x8 ad = *reinterpret_cast<const bf16x8*>(sd + (size_t)(half * 16 + tok) * (64 * KS1) + (32 * ks + 8 * g) * 2);
+                    const bf16x8 ax = *reinterpret_cast<const bf16x8*>(sx + (size_t)(half * 16 + tok) * (SL::RBS * 2) + (32 * ks + 8 * g) * 2);
+                    const bf16x8 ad = *reinterpret_cast<const bf16x8*>(sd + (size_t)(half * 16 + tok) * (SL::RBS * 2) + (32 * ks + 8 * g) * 2);
 #pragma unroll
                     for (int ft = 0; ft < 2; ++ft) {
                         h[ft] = MFMA(ax, w1[ft][ks], h[ft]);      // [token rows 4g+r][hidden col]
@@ -1240,7 +1289,7 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgArg
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 // T-block A operands in the token order of the packed C tiles: slots 0-3 = tokens 4g.., slots 4-7 = tokens 16+4g..
-                const char* px = tx + (size_t)(16 * dt + tok) * 64, *pd = td + (size_t)(16 * dt + tok) * 64;
+                const char* px = tx + (size_t)(16 * dt + tok) * (SL::TBS * 2), *pd = td + (size_t)(16 * dt + tok) * (SL::TBS * 2);
                 u32x2 xl = *reinterpret_cast<const u32x2*>(px + 8 * g), xh = *reinterpret_cast<const u32x2*>(px + 32 + 8 * g);
                 u32x2 dl = *reinterpret_cast<const u32x2*>(pd + 8 * g), dhh = *reinterpret_cast<const u32x2*>(pd + 32 + 8 * g);
                 u32x4 xv = {xl[0], xl[1], xh[0], xh[1]}, dv = {dl[0], dl[1], dhh[0], dhh[1]};
@@ -1358,6 +1407,7 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgArg
 // grads[i] (+)= sum over the token splits (fixed order) for the matrices / biases the weight-gradient kernel owns, the
 // per-workgroup column sums (fixed order) for the five vector parameters of the FFN-side backward, and 0 for everything
 // else in the layer range (alignment gaps of the flat layout: the fused AdamW and the gradient norm run over them).
+constexpr int kMaxTS = 4;
 struct RedArgs {
     const float* part; long long nparams; int TS;
     const float* vecpart;      // [L][nwg][5][D]
@@ -1378,22 +1428,39 @@ __global__ __launch_bounds__(256) void k_tr_reduce(const RedArgs a) {
     bool owned = false;
 #pragma unroll
     for (int k = 0; k < 7; ++k) owned |= (rel >= a.wrel[k] && rel < a.wrel[k] + a.wnum[k]);
-    if (owned)
-        for (int t = 0; t < a.TS; ++t) {
-            const float4 p4 = *reinterpret_cast<const float4*>(a.part + (size_t)t * a.nparams + i);
-            v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
-        }
+    if (owned) {
+        // all splits' loads in flight together (a rolled loop waits for each load before issuing the next), added in order
+        float4 p4[kMaxTS];
+#pragma unroll
+        for (int t = 0; t < kMaxTS; ++t)
+            p4[t] = (t < a.TS) ? *reinterpret_cast<const float4*>(a.part + (size_t)t * a.nparams + i) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < kMaxTS; ++t) { v.x += p4[t].x; v.y += p4[t].y; v.z += p4[t].z; v.w += p4[t].w; }
+    }
+    int vs = -1;
+    long long vo = 0;
 #pragma unroll
     for (int sidx = 0; sidx < 5; ++sidx) {
         const long long o = rel - a.rel[sidx];
-        if (o >= 0 && o < a.D) {
-            owned = true;
-            const float* vp = a.vecpart + ((size_t)li * a.nwg * 5 + sidx) * a.D + o;
-            for (int w = 0; w < a.nwg; ++w) {
-                const float4 p4 = *reinterpret_cast<const float4*>(vp + (size_t)w * 5 * a.D);
-                v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
-            }
+        if (o >= 0 && o < a.D) { vs = sidx; vo = o; }
+    }
+    if (vs >= 0) {
+        owned = true;
+        const float* vp = a.vecpart + ((size_t)li * a.nwg * 5 + vs) * a.D + vo;
+        // 8 strands (workgroup index mod 8), each in ascending order, combined in a fixed order: 8 loads in flight
+        float4 st[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st[k] = float4{0.f, 0.f, 0.f, 0.f};
+        for (int w0 = 0; w0 < a.nwg; w0 += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (w0 + k < a.nwg) {
+                    const float4 q4 = *reinterpret_cast<const float4*>(vp + (size_t)(w0 + k) * 5 * a.D);
+                    st[k].x += q4.x; st[k].y += q4.y; st[k].z += q4.z; st[k].w += q4.w;
+                }
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v.x += st[k].x; v.y += st[k].y; v.z += st[k].z; v.w += st[k].w; }
     }
     float4* gp = reinterpret_cast<float4*>(a.grads + i);
     if (a.accumulate) {
@@ -1420,7 +1487,8 @@ namespace {
 
 struct TrLayerBufs {
     float *x0, *att, *s1, *s2, *lse2;
-    __bf16 *x0rb, *x0T, *x1rb, *x1T, *attT, *dffnT, *dffnrb, *doT, *dqkvT;
+    __bf16 *x0rb, *x0T, *attT, *doT, *dqkvT;
+    char* stage;
     unsigned char *pmask, *active;
     unsigned short* activeT;
 };
@@ -1429,14 +1497,13 @@ struct TrBufs {
     float *emb, *temb, *hL;
     // backward transients
     float *dh, *datt, *dres[2], *dxp[2], *dtemb, *skp, *vecpart, *part;
-    WgLayer* wg_tab;
     int Mpad, nwg, TS;
     size_t part_stride;
 };
 
 constexpr size_t kSkpFloats = (size_t)1 << 20;
 
-int tr_TS(const fd_score* m) { return 4; }
+int tr_TS(const fd_score* m) { return kMaxTS; }
 
 size_t al(size_t b) { return fd_ws::padded(b); }
 
@@ -1446,6 +1513,7 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
     const size_t T = m->d.max_len, D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, L = m->d.num_layers;
     const size_t M = (size_t)B * T, Mpad = (M + 63) & ~size_t(63);
     const size_t NFT = 16 * (size_t)im->dt, RBW = 32 * (size_t)im->ks1, NP = im->np, NJ = ((T + 15) / 16 + 1) / 2;
+    const size_t stage_bytes = (((size_t)2 * 32 * (RBW + 8) * 2 + (size_t)2 * NFT * 40 * 2) + 1023) & ~size_t(1023);
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al(bytes); return p; };
     TrBufs tb;
@@ -1465,12 +1533,9 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
         b.s2 = (float*)take(sizeof(float) * M * D);
         b.lse2 = (float*)take(sizeof(float) * B * H * T);
         b.x0rb = (__bf16*)take(2 * Mpad * RBW);
-        b.x1rb = (__bf16*)take(2 * Mpad * RBW);
-        b.dffnrb = (__bf16*)take(2 * Mpad * RBW);
+        b.stage = take((Mpad / 32) * stage_bytes + 1024);
         b.x0T = (__bf16*)take(2 * Mpad * NFT);
-        b.x1T = (__bf16*)take(2 * Mpad * NFT);
         b.attT = (__bf16*)take(2 * Mpad * NFT);
-        b.dffnT = (__bf16*)take(2 * Mpad * NFT);
         b.doT = (__bf16*)take(2 * Mpad * NFT);
         b.dqkvT = (__bf16*)take(2 * Mpad * 3 * NP * 16);
         b.pmask = (unsigned char*)take((size_t)B * H * T * NJ * 4);
@@ -1486,7 +1551,6 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
     tb.dtemb = (float*)take(sizeof(float) * B * D);
     tb.skp = (float*)take(sizeof(float) * kSkpFloats);
     tb.vecpart = (float*)take(sizeof(float) * L * tb.nwg * 5 * D);
-    tb.wg_tab = (WgLayer*)take(sizeof(WgLayer) * L);
     tb.part = (float*)take(sizeof(float) * (size_t)tb.TS * (size_t)m->nparams);
     if (out) *out = tb;
     return off + 4096;
@@ -1542,7 +1606,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         FfnFwdArgs fa{};
         fa.x0 = b.x0; fa.att = b.att; fa.s1 = b.s1; fa.s2 = b.s2;
         fa.out = (l + 1 < L) ? tb.layers[l + 1].x0 : tb.hL;
-        fa.x1rb = b.x1rb; fa.x1T = b.x1T;
+        fa.stage = b.stage;
         fa.outrb = (l + 1 < L) ? tb.layers[l + 1].x0rb : nullptr;
         fa.outT = (l + 1 < L) ? tb.layers[l + 1].x0T : nullptr;
         fa.active = b.active; fa.activeT = b.activeT;
@@ -1583,7 +1647,17 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_wgrad<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    std::vector<WgLayer> tab(L);
+    // side stream: the weight gradients of layer l only need that layer's k_tr_ffn_bwd / k_tr_attn_bwd outputs, so they run
+    // beside the input-gradient chain of layers l-1 .. 0 (both are latency-bound and leave most CUs idle on their own)
+    if (!ctx->side_stream) FD_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    while ((int)ctx->side_events.size() < L + 1) {
+        hipEvent_t e;
+        FD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->side_events.push_back(e);
+    }
+    const size_t lds_wg = (size_t)3 * StageL<KS1, DT>::bytes;
+    WgArgs wa{};
+    wa.part = tb.part; wa.nparams = m->nparams; wa.TS = tb.TS; wa.nblk = (M + 31) / 32;
     for (int l = L - 1; l >= 0; --l) {
         const fd_layer_off& lo = m->layers[l];
         TrLayerBufs& b = tb.layers[l];
@@ -1596,7 +1670,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         fa.part_stride = tb.part_stride;
         fa.s1 = b.s1; fa.s2 = b.s2; fa.active = b.active;
         fa.datt = tb.datt; fa.dres = tb.dres[par];
-        fa.dffnT = b.dffnT; fa.dffnrb = b.dffnrb; fa.doT = b.doT;
+        fa.stage = b.stage; fa.doT = b.doT;
         fa.vecpart = tb.vecpart + (size_t)l * tb.nwg * 5 * D;
         fa.bffn = bl + im->boff_ffn; fa.wot = bl + im->boff_wot;
         fa.g1 = P + lo.n1_w; fa.be1 = P + lo.n1_b; fa.g2 = P + lo.n2_w;
@@ -1608,19 +1682,18 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         ab.wk = limg + im->off_wk; ab.wv = limg + im->off_wv; ab.wq = limg + im->off_wq;
         ab.winT = bl + im->boff_win; ab.part_stride = tb.part_stride;
         hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT>), dim3(d.NP, B), dim3(256), lds_ab, s, d, ab);
-        WgLayer& w = tab[l];
-        w.x0T = b.x0T; w.x1T = b.x1T; w.attT = b.attT; w.dffnT = b.dffnT; w.doT = b.doT; w.dqkvT = b.dqkvT;
-        w.x1rb = b.x1rb; w.dffnrb = b.dffnrb; w.activeT = b.activeT;
+        WgLayer w{};
+        w.x0T = b.x0T; w.attT = b.attT; w.doT = b.doT; w.dqkvT = b.dqkvT;
+        w.stage = b.stage; w.activeT = b.activeT;
         w.ffn_img = limg + im->off_ffn; w.bffn = bl + im->boff_ffn;
         w.in_w = lo.in_w; w.in_b = lo.in_b; w.out_w = lo.out_w; w.out_b = lo.out_b; w.l1_w = lo.l1_w; w.l1_b = lo.l1_b; w.l2_w = lo.l2_w;
+        FD_HIP(ctx, hipEventRecord(ctx->side_events[l], s));
+        FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_events[l], 0));
+        hipLaunchKernelGGL((k_tr_wgrad<KS1, DT>), dim3(F / 128 + 4, tb.TS), dim3(256), lds_wg, ctx->side_stream, d, w, wa);
     }
     if (L > 0) {
-        // pageable source: staged by the runtime before the call returns
-        FD_HIP(ctx, hipMemcpyAsync(tb.wg_tab, tab.data(), sizeof(WgLayer) * L, hipMemcpyHostToDevice, s));
-        WgArgs wa{};
-        wa.layers = tb.wg_tab; wa.part = tb.part; wa.nparams = m->nparams; wa.TS = tb.TS; wa.nblk = (M + 31) / 32;
-        const size_t lds_wg = (size_t)3 * (4 * KS1 + 2 * DT) * 1024;
-        hipLaunchKernelGGL((k_tr_wgrad<KS1, DT>), dim3(F / 128 + 4, tb.TS, L), dim3(256), lds_wg, s, d, wa);
+        FD_HIP(ctx, hipEventRecord(ctx->side_events[L], ctx->side_stream));
+        FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[L], 0));
         RedArgs ra{};
         ra.part = tb.part; ra.nparams = m->nparams; ra.TS = tb.TS; ra.vecpart = tb.vecpart; ra.nwg = tb.nwg; ra.D = D; ra.L = L;
         ra.begin = m->layers[0].in_w;
