@@ -16,6 +16,9 @@ N GPUs  : one process per GPU, each samples its own batch of 512 series (the sam
 (127.0.0.1 rendezvous on a free port), so both invocation styles print the same single JSON line from rank 0.
 
 Other workloads (not the headline line; same JSON contract):
+    --mode train                        BASELINE.json configs[2]: nasdaq-synth (T=252, C=6), default transformer, batch 64 per
+                                        GPU, data-parallel: one bench step = one optimizer step (perturb + forward with dropout
+                                        + backward in the bf16 MFMA kernels + flat RCCL gradient all-reduce + clip + fused AdamW)
     --workload mimic --scaling strong   BASELINE.json configs[3]: 4096 series (T=256, C=28), VE-SDE, 2000 predictor
                                         steps, the batch divided over the N ranks (strong scaling: total work fixed)
 """
@@ -46,6 +49,8 @@ WORKLOADS = {
                        "fourier_noise_scaling, 2000 predictor steps"),
 }
 T, CH = WORKLOADS["ecg"]["T"], WORKLOADS["ecg"]["C"]
+TRAIN = dict(T=252, C=6, batch=64, desc="BASELINE.json configs[2]: nasdaq-synth (T=252, C=6), default transformer (d_model=72, "
+             "L=10, H=12, ff=2048), VP-SDE, fourier_noise_scaling, dropout 0.1, AdamW + global-norm clip 1.0")
 
 
 def flops_per_series_forward(T=T, C=CH, D=D, L=L, F=F):
@@ -88,11 +93,112 @@ def cpu_baseline(batch: int, T: int, CH: int, n_timed: int = 3):
     return cb.time_sampler_steps(batch=batch, T=T, C=CH, d_model=D, num_layers=L, n_head=H, n_timed=n_timed)
 
 
+def main_train(args, rank, local_rank, world):
+    """configs[2]: batch-sharded training.  Every rank holds 64 synthetic series (weak scaling); a step = one optimizer step."""
+    T, CH = TRAIN["T"], TRAIN["C"]
+    B = args.batch or TRAIN["batch"]
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("FDIFF_BENCH_BACKEND", "nccl")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist_mod.init_process_group(backend=backend)
+        dist = dist_mod
+    from fourierdiffusion_amd import _C, _rng
+    from fourierdiffusion_amd.models.score_models import ScoreModule
+    from fourierdiffusion_amd.optim import FusedAdamW
+    from fourierdiffusion_amd.parallel import DistEnv, GradExchange
+    from fourierdiffusion_amd.schedulers.sde import VPScheduler
+    from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
+    torch.manual_seed(42)
+    _rng.set_rank(rank)
+    sch = VPScheduler(beta_min=0.1, beta_max=20.0, fourier_noise_scaling=True)
+    sch.set_noise_scaling(T)
+    model = ScoreModule(n_channels=CH, max_len=T, noise_scheduler=sch, fourier_noise_scaling=True, d_model=D, num_layers=L,
+                        n_head=H).to(dev)
+    model.train_precision = "bf16" if args.precision == "bf16" else "fp32"
+    model.train()
+    opt = FusedAdamW(model, lr=1e-3, max_grad_norm=1.0)
+    ex = GradExchange(DistEnv(rank, local_rank, world), backend="rccl" if backend == "nccl" else "torch")
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    X = torch.randn(B, T, CH, generator=g).to(dev)          # each rank its own shard of the global batch
+    ctx, _ = model._engine()
+    lib = _C.lib()
+
+    def one_step(i):
+        model.zero_grad()
+        loss = model.training_step(DiffusableBatch(X=X), i)
+        ex.all_reduce_mean(model.grads)
+        opt.step()
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    steps = args.steps if args.steps != 2 else 50           # (2 is the sampling default: an optimizer step is 1000x shorter)
+    warmup = max(args.warmup, 3)
+    for i in range(warmup):
+        one_step(i)
+    barrier()
+    _C.check(lib.fd_prof_begin(ctx), ctx)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = one_step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(loss).all() and torch.isfinite(model.flat_parameters).all(), "training produced non-finite values"
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        fwd_flops = flops_per_series_forward(T=T, C=CH)
+        out = {
+            "metric": f"training series/sec (T={T}, C={CH})", "value": world * B * steps / elapsed, "unit": "series/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if model.train_mode_effective == "bf16" else "f32",
+            "data": "synthetic (N(0,1) series per rank, random-init weights seed 42)",
+            "config": {"workload": TRAIN["desc"] + f", batch={B}/GPU, one optimizer step per bench step",
+                       "global_batch": world * B, "seq_len": T, "parallelism": f"data parallel x{world}, flat RCCL all-reduce"},
+            "achieved_tflops_whole_step": 3 * fwd_flops * world * B * steps / elapsed / 1e12,
+        }
+        avg_us, cnt, flops = C.c_double(0), C.c_int(0), C.c_double(0)
+        name = C.create_string_buffer(128)
+        roof = None
+        if lib.fd_prof_end(ctx, name, C.byref(avg_us), C.byref(cnt), C.byref(flops)) == 0 and cnt.value > 0:
+            peak = 2500.0 if model.train_mode_effective == "bf16" else 157.3
+            ach = flops.value / (avg_us.value * 1e-6) / 1e12
+            roof = {"bound": "mfma", "kernel": name.value.decode(), "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                    "frac": ach / peak, "traffic": None, "avg_kernel_us": avg_us.value, "launches_timed": cnt.value,
+                    "flops_per_launch": flops.value}
+        out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                from oracle import torch_cpu_baseline as cb
+                out["cpu_baseline"] = cb.time_train_steps(batch=B, T=T, C=CH, d_model=D, num_layers=L, n_head=H)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", default="sample", choices=["sample", "train"])
     ap.add_argument("--workload", default="ecg", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--batch", type=int, default=None, help="series per GPU (weak) / in total (strong)")
@@ -108,6 +214,8 @@ def main():
         raise SystemExit(self_launch(args.gpus))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.mode == "train":
+        return main_train(args, rank, local_rank, world)
     wl = WORKLOADS[args.workload]
     T, CH = wl["T"], wl["C"]
     # one rank per GPU; the modulo only matters for the single-GPU rehearsal of the multi-rank path

@@ -1239,8 +1239,14 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
             // block ib must have landed (this wave's share), then everybody's
             if (ib + 1 < nb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 4) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef FD_TR_ABL_WG_NOBAR
             __syncthreads();
+#endif
+#ifdef FD_TR_ABL_WG_NODMA
+            if (false) {
+#else
             if (ib + 2 < nb) {
+#endif
                 const int bn2 = blk_of(ib + 2);
                 issue(bn2, (ib + 2) % NBUF);
                 if ((ib + 2) % NBUF == 0) load_masks(bn2, mk[0]);
@@ -1613,7 +1619,12 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         fa.wo_img = limg + im->off_wo; fa.ffn_img = limg + im->off_ffn;
         fa.bo = P + lo.out_b; fa.g1 = P + lo.n1_w; fa.be1 = P + lo.n1_b; fa.b2 = P + lo.l2_b; fa.g2 = P + lo.n2_w; fa.be2 = P + lo.n2_b;
         fa.off1 = fd_dropout_site_offset(offset, l, 1); fa.off2 = fd_dropout_site_offset(offset, l, 2); fa.off3 = fd_dropout_site_offset(offset, l, 3);
-        hipLaunchKernelGGL((k_tr_ffn_fwd<KS1, DT, KSO>), dim3(tb.nwg), dim3(TW * 64), lds_ffn, s, d, fa);
+        {
+            // measurement hook (bench.py --mode train): algorithmic flops of this launch = out-projection + FFN of M tokens
+            fd_prof_scope scope(ctx, s, "k_tr_ffn_fwd (out-proj + LN1 + FFN + LN2, training forward)",
+                                (double)M * (4.0 * D * m->d.dim_ff + 2.0 * D * D));
+            hipLaunchKernelGGL((k_tr_ffn_fwd<KS1, DT, KSO>), dim3(tb.nwg), dim3(TW * 64), lds_ffn, s, d, fa);
+        }
     }
     fdgemm::linear_fwd(tb.hL, P + m->un_w, P + m->un_b, out, M, C, D, false, s);
     FD_LAUNCH_CHECK(ctx);

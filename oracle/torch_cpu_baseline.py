@@ -107,6 +107,59 @@ def time_sampler_steps(batch=512, T=100, C=12, d_model=72, num_layers=10, n_head
     }
 
 
+def time_train_steps(batch=64, T=252, C=6, d_model=72, num_layers=10, n_head=12, n_timed=2, n_warm=1):   # noqa: ARG001
+    """The reference's CPU training step as the same torch-op sequence: perturb (VP marginal), train-mode forward of the
+    encoder (dropout 0.1), weighted score-matching loss, autograd backward, clip_grad_norm_(1.0), AdamW (losses.py:39-125,
+    score_models.py:96-130).  A bounded sample: n_timed steps at the probed-best thread count."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.manual_seed(42)
+    net = _CpuScoreNet(C, T, d_model, num_layers, n_head).train()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    G = torch.ones(T) / math.sqrt(2)
+    G[0] = 1.0
+    if T % 2 == 0:
+        G[T // 2] = 1.0
+    x = torch.randn(batch, T, C)
+
+    def one_step():
+        t0 = time.perf_counter()
+        t = torch.rand(batch) * (1.0 - 1e-5) + 1e-5
+        lmc = -0.25 * t ** 2 * (20.0 - 0.1) - 0.5 * t * 0.1
+        mean = torch.exp(lmc)[:, None, None] * x
+        std = torch.sqrt(1.0 - torch.exp(2.0 * lmc))[:, None] * G[None, :]
+        z = torch.randn_like(x)
+        xt = mean + std[:, :, None] * z
+        score = net(xt, t)
+        w = 1.0 / (1.0 / std ** 2).sum(dim=1)
+        loss = (w[:, None, None] * (score + z / std[:, :, None]) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        opt.step()
+        return time.perf_counter() - t0
+
+    # bounded: an optimizer step takes ~8 s on the GPU box's host; probe three thread counts (one step each after one warm-up
+    # at the first), keep the best, time n_timed more -- about a minute in total
+    cands = sorted({c for c in (16, 32, 64) if 1 <= c <= avail}) or [avail]
+    probe = {}
+    torch.set_num_threads(cands[0])
+    one_step()
+    for c in cands:
+        torch.set_num_threads(c)
+        probe[c] = one_step()
+    cores = min(probe, key=probe.get)
+    torch.set_num_threads(cores)
+    times = [one_step() for _ in range(n_timed)]
+    step_s = float(np.mean(times))
+    return {"value": batch / step_s, "unit": "series/s", "cores": cores, "host_cpus_available": avail,
+            "thread_probe_step_s": {str(k): round(v, 3) for k, v in probe.items()}, "kind": "port", "step_ms": step_s * 1e3,
+            "sample": f"{n_timed} timed optimizer steps (after {n_warm} warm-up) at batch={batch}, T={T}, C={C}, default "
+                      f"transformer, fp32, torch {torch.__version__} CPU with {cores} threads"}
+
+
 if __name__ == "__main__":
     import json
     print(json.dumps(time_sampler_steps()))

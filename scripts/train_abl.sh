@@ -1,6 +1,6 @@
 # ablation timing of the training kernels: FDIFF_LIB variants built with -DFD_TR_ABL_* (timing only, wrong results)
 cd $GRAFT_REPO_ROOT
-for v in "" abl_NODMA abl_NOBAR; do
+for v in "" abl_WG_NODMA abl_WG_NOBAR; do
   if [ -n "$v" ]; then export FDIFF_LIB=$GRAFT_REPO_ROOT/fourierdiffusion_amd/libfdiff_$v.so; fi
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_abl -o abl_$v -- python $GRAFT_REPO_ROOT/scripts/shape_bench.py train ecg 64 > /dev/null 2>&1

@@ -119,6 +119,15 @@ def test_bench_two_rank_rehearsal(launcher):
     assert d["metric"] == "sampled series/sec (T=100, C=12)"
 
 
+def test_bench_train_mode_two_rank_rehearsal():
+    """--mode train (BASELINE.json configs[2]): data-parallel optimizer steps, gradient exchange through the GradExchange
+    interface (gloo here; fd_allreduce_grads over RCCL on the 8-GPU node)."""
+    d = _run_bench(["--mode", "train", "--batch", "8", "--steps", "3"], launcher=False)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
+    assert d["metric"] == "training series/sec (T=252, C=6)" and d["value"] > 0 and d["dtype"] == "bf16"
+    assert d["roofline"]["frac"] > 0 and "k_tr_ffn_fwd" in d["roofline"]["kernel"]
+
+
 def test_bench_strong_scaling_rehearsal():
     """--workload mimic --scaling strong (BASELINE.json configs[3]): a fixed total divided over the ranks."""
     d = _run_bench(["--workload", "mimic", "--scaling", "strong", "--batch", "33"], launcher=False)
