@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("FDIFF_LIB", os.path.join(_HERE, "libfdiff_hip.so"))  
 FD_MODE_F32 = 0
 FD_MODE_BF16 = 1
 FD_COMM_ID_BYTES = 128
+FD_BACKBONE_TRANSFORMER, FD_BACKBONE_MLP, FD_BACKBONE_LSTM = 0, 1, 2
 
 
 class FdError(RuntimeError):
@@ -68,6 +69,9 @@ _PROTOS = {
     "fd_score_param_count": (C.c_int64, [C.POINTER(ModelDims)]),
     "fd_score_layout": (C.c_int, [C.POINTER(ModelDims), C.POINTER(ParamEntry), C.POINTER(C.c_int)]),
     "fd_score_create": (C.c_int, [_vp, C.POINTER(ModelDims), C.POINTER(_vp)]),
+    "fd_score_param_count_ex": (C.c_int64, [C.POINTER(ModelDims), C.c_int, C.c_int]),
+    "fd_score_layout_ex": (C.c_int, [C.POINTER(ModelDims), C.c_int, C.c_int, C.POINTER(ParamEntry), C.POINTER(C.c_int)]),
+    "fd_score_create_ex": (C.c_int, [_vp, C.POINTER(ModelDims), C.c_int, C.c_int, C.POINTER(_vp)]),
     "fd_score_destroy": (C.c_int, [_vp]),
     "fd_score_prepare": (C.c_int, [_vp, _vp, _vp]),
     "fd_score_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
@@ -77,6 +81,10 @@ _PROTOS = {
     "fd_score_backward": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "fd_sampler_run": (C.c_int, [_vp, C.POINTER(SdeParams), _vp, _vp, C.c_int, C.c_float, _vp, _vp,
                                  C.c_uint64, C.c_uint64, C.c_int, C.c_int, _vp]),
+    "fd_langevin_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_float, C.c_float, _vp, C.c_int, C.c_int,
+                                   C.c_int, _vp]),
+    "fd_sampler_run_pc": (C.c_int, [_vp, C.POINTER(SdeParams), _vp, _vp, C.c_int, C.c_float, _vp, _vp, _vp, C.c_int, C.c_float,
+                                    C.c_uint64, C.c_uint64, C.c_int, C.c_int, _vp]),
     "fd_grad_sqnorm": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp]),
     "fd_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_float, _vp, C.c_float, C.c_float, C.c_int64,
@@ -164,19 +172,19 @@ def model_dims(n_channels, max_len, d_model, n_head, num_layers, dim_ff=2048) ->
     return ModelDims(int(n_channels), int(max_len), int(d_model), int(n_head), int(num_layers), int(dim_ff))
 
 
-def score_layout(dims: ModelDims):
+def score_layout(dims: ModelDims, backbone: int = 0, d_mlp: int = 0):
     """[(name, offset, numel, shape, trainable)] + total float count, straight from the engine."""
     n = C.c_int(0)
-    rc = lib().fd_score_layout(C.byref(dims), None, C.byref(n))
+    rc = lib().fd_score_layout_ex(C.byref(dims), backbone, d_mlp, None, C.byref(n))
     if rc != 0:
         raise FdError(f"fd_score_layout failed ({rc}): bad model dims")
     arr = (ParamEntry * n.value)()
-    rc = lib().fd_score_layout(C.byref(dims), arr, C.byref(n))
+    rc = lib().fd_score_layout_ex(C.byref(dims), backbone, d_mlp, arr, C.byref(n))
     if rc != 0:
         raise FdError(f"fd_score_layout failed ({rc})")
     out = []
     for e in arr:
         shape = (e.rows, e.cols) if e.cols else (e.rows,)
         out.append((e.name.decode(), int(e.offset), int(e.numel), shape, bool(e.trainable)))
-    total = int(lib().fd_score_param_count(C.byref(dims)))
+    total = int(lib().fd_score_param_count_ex(C.byref(dims), backbone, d_mlp))
     return out, total

@@ -30,14 +30,14 @@ extern "C" int fd_sampler_run(fd_score* m, const fd_sde_params* sde, const float
     if (!m->prepared) return fd_fail(ctx, FD_ERR_STATE, "fd_sampler_run: call fd_score_prepare first");
     hipStream_t s = (hipStream_t)stream;
     FD_REQUIRE(ctx, mode == FD_MODE_F32 || mode == FD_MODE_BF16, "fd_sampler_run: unknown mode %d", mode);
-    if (mode == FD_MODE_BF16 && !getenv("FDIFF_SAMPLER_STEPWISE")) {   // (switch: per-step launches; tests compare the two)
+    if (mode == FD_MODE_BF16 && m->backbone == FD_BACKBONE_TRANSFORMER && !getenv("FDIFF_SAMPLER_STEPWISE")) {   // (switch: per-step launches; tests compare the two)
         const int rc = fd_sampler_run_mega(m, sde, G, timesteps, n_steps, dt, x, z_steps, seed, offset, B, s);
         if (rc != FD_ERR_UNSUPPORTED) return rc;     // ran (or failed loudly); else: step-by-step fallback below
     }
 
     const int T = m->d.max_len, C = m->d.n_channels;
     const size_t n = (size_t)B * T * C;
-    const size_t fwd = fd_score_f32_workspace(m, B, false);
+    const size_t fwd = (m->backbone != FD_BACKBONE_TRANSFORMER) ? fd_bb_workspace(m, B, false) : fd_score_f32_workspace(m, B, false);
     const size_t own = fd_ws::padded(n * sizeof(float)) + fd_ws::padded((size_t)B * sizeof(float));
     if (int rc = fd_ws_reserve(ctx, fwd + own)) return rc;
     float* score = (float*)((char*)ctx->ws + fwd);
@@ -45,12 +45,58 @@ extern "C" int fd_sampler_run(fd_score* m, const fd_sde_params* sde, const float
     const uint64_t per_step = (uint64_t)((n + 3) / 4);
     for (int i = 0; i < n_steps; ++i) {
         hipLaunchKernelGGL(k_fill, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, timesteps[i]);
-        const int rc_f = (mode == FD_MODE_BF16) ? fd_score_forward_bf16(m, x, tvec, score, B, s)
-                                                : fd_score_forward_f32(m, x, tvec, score, B, s, false, 0.f, 0, 0);
+        const int rc_f = fd_score_forward_any(m, x, tvec, score, B, mode, s);
         if (rc_f) return rc_f;
         const float* z = z_steps ? z_steps + (size_t)i * n : nullptr;
         if (int rc = fd_sde_step(ctx, sde, G, x, score, z, seed, offset + (uint64_t)i * per_step,
                                  (double)timesteps[i], dt, x, B, T, C, stream))
+            return rc;
+    }
+    return FD_OK;
+}
+
+// Predictor-corrector variant (not in the reference; BASELINE.json configs[3] says "PC sampler"): n_corr Langevin corrector
+// steps (fd_langevin_step, signal-to-noise ratio snr) before every predictor step.  zc_steps (nullable): injected corrector
+// noise (n_steps, n_corr, B, T, C).  Step-by-step launches (the persistent kernel is predictor-only).
+extern "C" int fd_sampler_run_pc(fd_score* m, const fd_sde_params* sde, const float* G, const float* timesteps, int n_steps,
+                                 float dt, float* x, const float* z_steps, const float* zc_steps, int n_corr, float snr,
+                                 uint64_t seed, uint64_t offset, int B, int mode, void* stream) {
+    if (!m) return FD_ERR_ARG;
+    fd_ctx* ctx = m->ctx;
+    FD_REQUIRE(ctx, sde && G && timesteps && x, "fd_sampler_run_pc: null pointer");
+    FD_REQUIRE(ctx, sde->kind == 0 || sde->kind == 1, "fd_sampler_run_pc: unknown SDE kind %d", sde->kind);
+    FD_REQUIRE(ctx, n_steps > 0 && B > 0 && n_corr >= 0, "fd_sampler_run_pc: n_steps=%d B=%d n_corr=%d", n_steps, B, n_corr);
+    FD_REQUIRE(ctx, dt > 0.f && (n_corr == 0 || snr > 0.f), "fd_sampler_run_pc: dt=%f snr=%f", dt, snr);
+    FD_REQUIRE(ctx, mode == FD_MODE_F32 || mode == FD_MODE_BF16, "fd_sampler_run_pc: unknown mode %d", mode);
+    if (!m->prepared) return fd_fail(ctx, FD_ERR_STATE, "fd_sampler_run_pc: call fd_score_prepare first");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = m->d.max_len, C = m->d.n_channels;
+    const size_t n = (size_t)B * T * C;
+    const size_t fwd = (m->backbone != FD_BACKBONE_TRANSFORMER) ? fd_bb_workspace(m, B, false) : fd_score_f32_workspace(m, B, false);
+    const size_t own = fd_ws::padded(n * sizeof(float)) + fd_ws::padded((size_t)B * sizeof(float));
+    if (int rc = fd_ws_reserve(ctx, fwd + own)) return rc;
+    float* score = (float*)((char*)ctx->ws + fwd);
+    float* tvec = (float*)((char*)score + fd_ws::padded(n * sizeof(float)));
+    const uint64_t per_step = (uint64_t)((n + 3) / 4);
+    // Philox counters: predictor noise of step i at offset + i*per_step (as fd_sampler_run); corrector noise behind them
+    const uint64_t corr_base = offset + (uint64_t)n_steps * per_step;
+    for (int i = 0; i < n_steps; ++i) {
+        hipLaunchKernelGGL(k_fill, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, timesteps[i]);
+        for (int k = 0; k < n_corr; ++k) {
+            if (int rc = fd_score_forward_any(m, x, tvec, score, B, mode, s)) return rc;
+            // alpha_t of Song et al.: 1 - beta(t) dt for the VP-SDE, 1 for the VE-SDE
+            float alpha = 1.0f;
+            if (sde->kind == 0) alpha = 1.0f - (sde->p0 + timesteps[i] * (sde->p1 - sde->p0)) * dt;
+            if (alpha <= 0.f) alpha = 1e-6f;
+            const float* zc = zc_steps ? zc_steps + ((size_t)i * n_corr + k) * n : nullptr;
+            if (int rc = fd_langevin_step(ctx, G, x, score, zc, seed, corr_base + ((uint64_t)i * n_corr + k) * per_step, snr, alpha, x,
+                                          B, T, C, stream))
+                return rc;
+        }
+        if (int rc = fd_score_forward_any(m, x, tvec, score, B, mode, s)) return rc;
+        const float* z = z_steps ? z_steps + (size_t)i * n : nullptr;
+        if (int rc = fd_sde_step(ctx, sde, G, x, score, z, seed, offset + (uint64_t)i * per_step, (double)timesteps[i], dt, x, B, T,
+                                 C, stream))
             return rc;
     }
     return FD_OK;

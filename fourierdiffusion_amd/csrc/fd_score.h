@@ -11,12 +11,22 @@ struct fd_layer_off {
 
 struct fd_bf16_images;   // fd_score_bf16.hip
 
+// parameter offsets of one layer of the MLP / LSTM backbones (fd_backbones.hip):
+//   MLP : a = linear1.weight (d_mlp, D), b = its bias, c = linear2.weight (D, d_mlp), d = its bias
+//   LSTM: a = weight_ih_l0 (4D, D), b = weight_hh_l0 (4D, D), c = bias_ih_l0 (4D), d = bias_hh_l0 (4D)
+struct fd_bb_off {
+    int64_t a, b, c, d;
+};
+
 struct fd_score {
     fd_ctx* ctx = nullptr;
     fd_model_dims d{};
     int64_t nparams = 0;
     int64_t pos = 0, tW = 0, td_w = 0, td_b = 0, emb_w = 0, emb_b = 0, un_w = 0, un_b = 0;
     std::vector<fd_layer_off> layers;
+    int backbone = 0;               // FD_BACKBONE_TRANSFORMER / _MLP / _LSTM
+    int d_mlp = 0;                  // hidden width of the MLP backbone
+    std::vector<fd_bb_off> bb;      // per-layer offsets of the MLP / LSTM backbones
     float* params = nullptr;        // caller-owned flat fp32 masters (set by fd_score_prepare)
     bool prepared = false;
     bool bf16_stale = true;         // bf16 weight images older than the fp32 masters (rebuilt lazily: training never reads them)
@@ -68,6 +78,13 @@ void fd_bf16_destroy(fd_score* m);
 int fd_bf16_prepare(fd_score* m, hipStream_t s);
 int fd_bf16_refresh(fd_score* m, hipStream_t s);   // rebuilds the images if the masters changed since the last build
 int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* out, int B, hipStream_t s);
+// fd_backbones.hip: the reference's other two score backbones (MLPScoreModule / LSTMScoreModule), exact-f32
+int fd_bb_forward(fd_score* m, const float* x, const float* t, float* out, int B, hipStream_t s, bool train, float p,
+                  uint64_t seed, uint64_t offset);
+int fd_bb_backward(fd_score* m, const float* dout, float* grads, int accumulate, hipStream_t s);
+size_t fd_bb_workspace(const fd_score* m, int B, bool train);
+// any backbone, eval mode (sampler loop, fd_score_forward)
+int fd_score_forward_any(fd_score* m, const float* x, const float* t, float* out, int B, int mode, hipStream_t s);
 // fd_train_bf16.hip: bf16 MFMA training path (forward with dropout, backward)
 bool fd_train_bf16_supported(const fd_score* m);
 int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, float* out, int B, float p, uint64_t seed,

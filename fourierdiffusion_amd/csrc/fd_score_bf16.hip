@@ -1089,6 +1089,10 @@ extern "C" int fd_score_plan(fd_score* m, int B, int mode, char* out /* >= 192 b
     fd_ctx* ctx = m->ctx;
     FD_REQUIRE(ctx, out && B > 0, "fd_score_plan: null output or B=%d", B);
     if (series_per_workgroup) *series_per_workgroup = 0;
+    if (m->backbone != FD_BACKBONE_TRANSFORMER) {
+        snprintf(out, 192, "%s backbone: exact-f32 kernels (fd_backbones.hip)", m->backbone == FD_BACKBONE_MLP ? "MLP" : "LSTM");
+        return FD_OK;
+    }
     if (mode == FD_MODE_F32) {
         snprintf(out, 192, "fp32 parity path (per-op kernels, fd_score_f32.hip)");
         return FD_OK;

@@ -490,6 +490,13 @@ extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, i
     FD_REQUIRE(ctx, dout && grads, "fd_score_backward: null pointer");
     if (!m->have_saved) return fd_fail(ctx, FD_ERR_STATE, "fd_score_backward: no training forward to differentiate");
     hipStream_t s = (hipStream_t)stream;
+    if (m->backbone != FD_BACKBONE_TRANSFORMER) {
+        if (ctx->ws_gen != m->saved_ws_gen || ctx->ws != m->saved_ws)
+            return fd_fail(ctx, FD_ERR_STATE, "fd_score_backward: another engine call used the context workspace after "
+                           "fd_score_forward_train (the saved activations live there)");
+        m->have_saved = false;
+        return fd_bb_backward(m, dout, grads, accumulate, s);
+    }
     if (m->saved_bf16) {
         if (ctx->ws_gen != m->saved_ws_gen || ctx->ws != m->saved_ws)
             return fd_fail(ctx, FD_ERR_STATE, "fd_score_backward: another engine call used the context workspace after "

@@ -35,25 +35,48 @@ struct LayoutBuilder {
     }
 };
 
-int64_t build_layout(const fd_model_dims& d, fd_score* m, std::vector<fd_param_entry>* entries) {
+int64_t build_layout(const fd_model_dims& d, fd_score* m, std::vector<fd_param_entry>* entries, int backbone = 0, int d_mlp = 0) {
     LayoutBuilder lb;
     lb.out = entries;
     const int D = d.d_model, C = d.n_channels, T = d.max_len, F = d.dim_ff;
-    int64_t pos = lb.add("pos_encoder.embedding.weight", T, D);
+    // MLP: the series is flattened, embed / unembed work on T*C features; MLP and LSTM have no positional table
+    const int Cin = (backbone == FD_BACKBONE_MLP) ? T * C : C;
+    int64_t pos = (backbone == FD_BACKBONE_TRANSFORMER) ? lb.add("pos_encoder.embedding.weight", T, D) : 0;
     int64_t tW = lb.add("time_encoder.W", (D + 1) / 2, 0, 0);
     int64_t td_w = lb.add("time_encoder.dense.weight", D, D);
     int64_t td_b = lb.add("time_encoder.dense.bias", D, 0);
-    int64_t emb_w = lb.add("embedder.weight", D, C);
+    int64_t emb_w = lb.add("embedder.weight", D, Cin);
     int64_t emb_b = lb.add("embedder.bias", D, 0);
-    int64_t un_w = lb.add("unembedder.weight", C, D);
-    int64_t un_b = lb.add("unembedder.bias", C, 0);
+    int64_t un_w = lb.add("unembedder.weight", Cin, D);
+    int64_t un_b = lb.add("unembedder.bias", Cin, 0);
     if (m) {
         m->pos = pos; m->tW = tW; m->td_w = td_w; m->td_b = td_b;
         m->emb_w = emb_w; m->emb_b = emb_b; m->un_w = un_w; m->un_b = un_b;
         m->layers.clear();
+        m->bb.clear();
     }
     for (int i = 0; i < d.num_layers; ++i) {
         const std::string p = "backbone.layers." + std::to_string(i) + ".";
+        const std::string q = "backbone." + std::to_string(i) + ".";
+        if (backbone == FD_BACKBONE_MLP) {
+            // torchvision.ops.MLP = Sequential(Linear, ReLU, Dropout, Linear, Dropout): parameters at indices 0 and 3
+            fd_bb_off o;
+            o.a = lb.add(q + "0.weight", d_mlp, D);
+            o.b = lb.add(q + "0.bias", d_mlp, 0);
+            o.c = lb.add(q + "3.weight", D, d_mlp);
+            o.d = lb.add(q + "3.bias", D, 0);
+            if (m) m->bb.push_back(o);
+            continue;
+        }
+        if (backbone == FD_BACKBONE_LSTM) {
+            fd_bb_off o;
+            o.a = lb.add(q + "weight_ih_l0", 4 * D, D);
+            o.b = lb.add(q + "weight_hh_l0", 4 * D, D);
+            o.c = lb.add(q + "bias_ih_l0", 4 * D, 0);
+            o.d = lb.add(q + "bias_hh_l0", 4 * D, 0);
+            if (m) m->bb.push_back(o);
+            continue;
+        }
         fd_layer_off lo;
         lo.in_w = lb.add(p + "self_attn.in_proj_weight", 3 * D, D);
         lo.in_b = lb.add(p + "self_attn.in_proj_bias", 3 * D, 0);
@@ -96,24 +119,58 @@ extern "C" int fd_score_layout(const fd_model_dims* dims, fd_param_entry* entrie
     return FD_OK;
 }
 
-extern "C" int fd_score_create(fd_ctx* ctx, const fd_model_dims* dims, fd_score** out) {
+bool bb_ok(const fd_model_dims* d, int backbone, int d_mlp) {
+    if (backbone == FD_BACKBONE_TRANSFORMER) return true;
+    if (backbone == FD_BACKBONE_MLP) return d_mlp > 0 && d->d_model <= 1024;
+    if (backbone == FD_BACKBONE_LSTM) return d->d_model <= 128;      // one thread per gate row, W_hh row in registers
+    return false;
+}
+
+extern "C" int64_t fd_score_param_count_ex(const fd_model_dims* dims, int backbone, int d_mlp) {
+    if (!dims_ok(dims) || !bb_ok(dims, backbone, d_mlp)) return FD_ERR_ARG;
+    return build_layout(*dims, nullptr, nullptr, backbone, d_mlp);
+}
+
+extern "C" int fd_score_layout_ex(const fd_model_dims* dims, int backbone, int d_mlp, fd_param_entry* entries, int* n_entries) {
+    if (!dims_ok(dims) || !n_entries || !bb_ok(dims, backbone, d_mlp)) return FD_ERR_ARG;
+    std::vector<fd_param_entry> v;
+    build_layout(*dims, nullptr, &v, backbone, d_mlp);
+    if (entries) {
+        if (*n_entries < (int)v.size()) return FD_ERR_ARG;
+        memcpy(entries, v.data(), v.size() * sizeof(fd_param_entry));
+    }
+    *n_entries = (int)v.size();
+    return FD_OK;
+}
+
+extern "C" int fd_score_create_ex(fd_ctx* ctx, const fd_model_dims* dims, int backbone, int d_mlp, fd_score** out) {
     if (!ctx) return FD_ERR_ARG;
     FD_REQUIRE(ctx, out != nullptr, "fd_score_create: null out");
     FD_REQUIRE(ctx, dims_ok(dims), "fd_score_create: bad dims (need positive sizes and d_model %% n_head == 0)");
-    FD_REQUIRE(ctx, dims->d_model / dims->n_head <= 64, "fd_score_create: head_dim %d > 64 unsupported",
-               dims->d_model / dims->n_head);
+    FD_REQUIRE(ctx, bb_ok(dims, backbone, d_mlp), "fd_score_create_ex: backbone %d unsupported at d_model=%d d_mlp=%d (MLP: d_mlp > 0; "
+               "LSTM: d_model <= 128)", backbone, dims->d_model, d_mlp);
+    FD_REQUIRE(ctx, backbone != FD_BACKBONE_TRANSFORMER || dims->d_model / dims->n_head <= 64,
+               "fd_score_create: head_dim %d > 64 unsupported", dims->d_model / dims->n_head);
     FD_REQUIRE(ctx, dims->d_model <= 1024, "fd_score_create: d_model %d > 1024 unsupported", dims->d_model);
     fd_score* m = new fd_score();
     m->ctx = ctx;
     m->d = *dims;
-    m->nparams = build_layout(*dims, m, nullptr);
-    int rc = fd_bf16_create(m);
-    if (rc != FD_OK) {
-        delete m;
-        return rc;
+    m->backbone = backbone;
+    m->d_mlp = d_mlp;
+    m->nparams = build_layout(*dims, m, nullptr, backbone, d_mlp);
+    if (backbone == FD_BACKBONE_TRANSFORMER) {
+        int rc = fd_bf16_create(m);
+        if (rc != FD_OK) {
+            delete m;
+            return rc;
+        }
     }
     *out = m;
     return FD_OK;
+}
+
+extern "C" int fd_score_create(fd_ctx* ctx, const fd_model_dims* dims, fd_score** out) {
+    return fd_score_create_ex(ctx, dims, FD_BACKBONE_TRANSFORMER, 0, out);
 }
 
 extern "C" int fd_score_destroy(fd_score* m) {
@@ -193,7 +250,7 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ x, cons
         const float* w = We + (size_t)d * C;
         for (int c = 0; c < C; ++c) acc = fmaf(xr[c], w[c], acc);
     }
-    h[id] = ((acc + be[d]) + pe[(size_t)tt * D + d]) + temb[(size_t)b * D + d];
+    h[id] = ((acc + be[d]) + (pe ? pe[(size_t)tt * D + d] : 0.f)) + temb[(size_t)b * D + d];
 }
 
 // Multi-head attention core for one (b, h, 64-query block): lane per query, online softmax over 32-key tiles in LDS.
@@ -554,8 +611,9 @@ extern "C" int fd_score_prepare(fd_score* m, const float* params, void* stream) 
     m->params = const_cast<float*>(params);
     // The reference renorms the looked-up rows of the positional table in place on every forward
     // (nn.Embedding(max_norm), transformer.py:13-15,27); all T rows are looked up, so do it here once.
-    hipLaunchKernelGGL(k_renorm_rows, dim3(m->d.max_len), dim3(64), 0, (hipStream_t)stream, m->params + m->pos,
-                       m->d.max_len, m->d.d_model, sqrtf((float)m->d.d_model));
+    if (m->backbone == FD_BACKBONE_TRANSFORMER)
+        hipLaunchKernelGGL(k_renorm_rows, dim3(m->d.max_len), dim3(64), 0, (hipStream_t)stream, m->params + m->pos,
+                           m->d.max_len, m->d.d_model, sqrtf((float)m->d.d_model));
     FD_LAUNCH_CHECK(ctx);
     m->bf16_stale = true;     // the bf16 MFMA entry points rebuild their images on first use (fd_bf16_refresh)
     m->prepared = true;
@@ -569,9 +627,14 @@ extern "C" int fd_score_forward(fd_score* m, const float* x, const float* t, flo
     FD_REQUIRE(ctx, x && t && out, "fd_score_forward: null pointer");
     FD_REQUIRE(ctx, B > 0, "fd_score_forward: B=%d", B);
     if (!m->prepared) return fd_fail(ctx, FD_ERR_STATE, "fd_score_forward: call fd_score_prepare first");
-    if (mode == FD_MODE_F32) return fd_score_forward_f32(m, x, t, out, B, (hipStream_t)stream, false, 0.f, 0, 0);
-    if (mode == FD_MODE_BF16) return fd_score_forward_bf16(m, x, t, out, B, (hipStream_t)stream);
-    return fd_fail(ctx, FD_ERR_ARG, "fd_score_forward: unknown mode %d", mode);
+    if (mode != FD_MODE_F32 && mode != FD_MODE_BF16) return fd_fail(ctx, FD_ERR_ARG, "fd_score_forward: unknown mode %d", mode);
+    return fd_score_forward_any(m, x, t, out, B, mode, (hipStream_t)stream);
+}
+
+int fd_score_forward_any(fd_score* m, const float* x, const float* t, float* out, int B, int mode, hipStream_t s) {
+    if (m->backbone != FD_BACKBONE_TRANSFORMER) return fd_bb_forward(m, x, t, out, B, s, false, 0.f, 0, 0);   // one arithmetic: exact f32
+    if (mode == FD_MODE_F32) return fd_score_forward_f32(m, x, t, out, B, s, false, 0.f, 0, 0);
+    return fd_score_forward_bf16(m, x, t, out, B, s);
 }
 
 extern "C" int fd_score_forward_train(fd_score* m, const float* x, const float* t, float* out, int B,
@@ -582,12 +645,14 @@ extern "C" int fd_score_forward_train(fd_score* m, const float* x, const float* 
     FD_REQUIRE(ctx, B > 0, "fd_score_forward_train: B=%d", B);
     FD_REQUIRE(ctx, dropout_p >= 0.f && dropout_p < 1.f, "fd_score_forward_train: dropout_p=%f", dropout_p);
     if (!m->prepared) return fd_fail(ctx, FD_ERR_STATE, "fd_score_forward_train: call fd_score_prepare first");
-    const bool bf16 = m->train_mode == FD_MODE_BF16;
+    const bool bf16 = m->train_mode == FD_MODE_BF16 && m->backbone == FD_BACKBONE_TRANSFORMER;
     if (bf16 && !fd_train_bf16_supported(m))
         return fd_fail(ctx, FD_ERR_UNSUPPORTED, "fd_score_forward_train: bf16 training kernels are not instantiated for this "
                        "model (d_model in {8,24,60,72}, head_dim <= 7, dim_ff %% 128 == 0); select FD_MODE_F32");
-    int rc = bf16 ? fd_score_forward_train_bf16(m, x, t, out, B, dropout_p, seed, offset, (hipStream_t)stream)
-                  : fd_score_forward_f32(m, x, t, out, B, (hipStream_t)stream, true, dropout_p, seed, offset);
+    int rc = (m->backbone != FD_BACKBONE_TRANSFORMER)
+                 ? fd_bb_forward(m, x, t, out, B, (hipStream_t)stream, true, dropout_p, seed, offset)
+                 : (bf16 ? fd_score_forward_train_bf16(m, x, t, out, B, dropout_p, seed, offset, (hipStream_t)stream)
+                         : fd_score_forward_f32(m, x, t, out, B, (hipStream_t)stream, true, dropout_p, seed, offset));
     if (rc == FD_OK) {
         m->saved_bf16 = bf16;
         m->have_saved = true;
@@ -610,7 +675,7 @@ extern "C" int fd_score_set_train_mode(fd_score* m, int mode) {
     if (!m) return FD_ERR_ARG;
     fd_ctx* ctx = m->ctx;
     FD_REQUIRE(ctx, mode == FD_MODE_F32 || mode == FD_MODE_BF16, "fd_score_set_train_mode: unknown mode %d", mode);
-    if (mode == FD_MODE_BF16 && !fd_train_bf16_supported(m))
+    if (mode == FD_MODE_BF16 && (m->backbone != FD_BACKBONE_TRANSFORMER || !fd_train_bf16_supported(m)))
         return fd_fail(ctx, FD_ERR_UNSUPPORTED, "fd_score_set_train_mode: bf16 training kernels not instantiated for this model");
     m->train_mode = mode;
     return FD_OK;

@@ -251,6 +251,71 @@ extern "C" int fd_sde_step(fd_ctx* ctx, const fd_sde_params* sde, const float* G
     return FD_OK;
 }
 
+// Langevin corrector step of a predictor-corrector sampler (Song et al. 2021, Alg. 4/5; NOT in the reference, whose sampler is
+// predictor-only: src/fdiff/sampling/sampler.py:24-43 -- default off, parity unpinned).  In the coordinates whitened by G
+// (x = G x_w, score_w = G score): per series  eps = 2 alpha (snr |z| / |G score|)^2 ;  x <- x + eps G^2 score + sqrt(2 eps) G z.
+// One workgroup per series: two fixed-order norm reductions, then the update.
+namespace {
+__global__ __launch_bounds__(256) void k_langevin(const float* __restrict__ G, const float* __restrict__ x,
+                                                   const float* __restrict__ score, const float* __restrict__ z,
+                                                   float* __restrict__ out, int T, int C, float snr, float alpha, uint64_t seed,
+                                                   uint64_t offset) {
+    __shared__ float red[2][4];
+    const int b = blockIdx.x;
+    const size_t per = (size_t)T * C, base = (size_t)b * per;
+    const size_t ng = (per + 3) / 4;                           // groups of 4 elements: one Philox counter each
+    float sg = 0.f, sz = 0.f;
+    for (size_t gi = threadIdx.x; gi < ng; gi += 256) {
+        float zz[4];
+        if (!z) fd_randn4(offset + (base >> 2) + gi, seed, zz);    // (per % 4 == 0 is required for on-device noise)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t e = gi * 4 + i;
+            if (e < per) {
+                const float gk = G[e / C];
+                const float sv = gk * score[base + e];
+                const float zv = z ? z[base + e] : zz[i];
+                sg += sv * sv;
+                sz += zv * zv;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { sg += __shfl_down(sg, o); sz += __shfl_down(sz, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sg; red[1][threadIdx.x >> 6] = sz; }
+    __syncthreads();
+    const float gn = sqrtf((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    const float zn = sqrtf((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    const float r = snr * zn / fmaxf(gn, 1e-20f);
+    const float eps = 2.0f * alpha * r * r;
+    const float sq = sqrtf(2.0f * eps);
+    for (size_t gi = threadIdx.x; gi < ng; gi += 256) {
+        float zz[4];
+        if (!z) fd_randn4(offset + (base >> 2) + gi, seed, zz);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t e = gi * 4 + i;
+            if (e < per) {
+                const float gk = G[e / C];
+                const float zv = z ? z[base + e] : zz[i];
+                out[base + e] = x[base + e] + eps * (gk * gk) * score[base + e] + sq * (gk * zv);
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int fd_langevin_step(fd_ctx* ctx, const float* G, const float* x, const float* score, const float* z, uint64_t seed,
+                                uint64_t offset, float snr, float alpha, float* out, int B, int T, int C, void* stream) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, G && x && score && out, "fd_langevin_step: null pointer");
+    FD_REQUIRE(ctx, snr > 0.f && alpha > 0.f, "fd_langevin_step: snr=%f alpha=%f", snr, alpha);
+    if (int rc = check_btc(ctx, B, T, C)) return rc;
+    FD_REQUIRE(ctx, z || ((size_t)T * C) % 4 == 0, "fd_langevin_step: on-device noise needs T*C %% 4 == 0 (inject z otherwise)");
+    hipLaunchKernelGGL(k_langevin, dim3(B), dim3(256), 0, (hipStream_t)stream, G, x, score, z, out, T, C, snr, alpha, seed, offset);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
 extern "C" int fd_perturb(fd_ctx* ctx, const fd_sde_params* sde, const float* G, const float* x, const float* t,
                           const float* z, uint64_t seed, uint64_t offset, float* x_noisy, float* target,
                           float* std_out, int B, int T, int C, void* stream) {

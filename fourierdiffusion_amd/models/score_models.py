@@ -36,6 +36,8 @@ class ScoreModule:
     # torch.nn.TransformerEncoderLayer defaults the reference relies on (score_models.py:57-59)
     dim_feedforward = 2048
     dropout = 0.1
+    _backbone = _C.FD_BACKBONE_TRANSFORMER
+    _d_mlp = 0
 
     def __init__(
         self,
@@ -78,7 +80,7 @@ class ScoreModule:
             raise AssertionError("embed_dim must be divisible by num_heads")
         self._dims = _C.model_dims(self.n_channels, self.max_len, self.d_model, self.n_head, self.num_layers,
                                    self.dim_feedforward)
-        self._layout, self._nparams = _C.score_layout(self._dims)
+        self._layout, self._nparams = _C.score_layout(self._dims, self._backbone, self._d_mlp)
         self._flat = torch.zeros(self._nparams, dtype=torch.float32)
         self.grads: Optional[torch.Tensor] = None
         self._views: "OrderedDict[str, torch.Tensor]" = OrderedDict()
@@ -110,11 +112,16 @@ class ScoreModule:
             bound = 1.0 / math.sqrt(w.shape[1]) if w.shape[1] > 0 else 0.0
             init.uniform_(b, -bound, bound)
 
-        init.normal_(v["pos_encoder.embedding.weight"])
+        if "pos_encoder.embedding.weight" in v:
+            init.normal_(v["pos_encoder.embedding.weight"])
         v["time_encoder.W"].copy_(torch.randn((self.d_model + 1) // 2) * 30.0)
         linear("time_encoder.dense")
         linear("embedder")
         linear("unembedder")
+        self._init_backbone(v, linear)
+
+    def _init_backbone(self, v, linear) -> None:
+        init = torch.nn.init
         if self.num_layers > 0:
             p = "backbone.layers.0."
             linear(p + "self_attn.out_proj")
@@ -215,7 +222,7 @@ class ScoreModule:
         ctx = _C.ctx(self._flat.device)
         if self._handle is None:
             h = C.c_void_p()
-            rc = _C.lib().fd_score_create(ctx, C.byref(self._dims), C.byref(h))
+            rc = _C.lib().fd_score_create_ex(ctx, C.byref(self._dims), self._backbone, self._d_mlp, C.byref(h))
             _C.check(rc, ctx)
             self._handle = h
             self._dirty = True
@@ -334,3 +341,56 @@ class ScoreModule:
         if map_location is not None:
             model.to(map_location)
         return model
+
+
+class MLPScoreModule(ScoreModule):
+    """fdiff.models.score_models.MLPScoreModule (score_models.py:169-246) on the engine: the series is flattened to
+    (B, T*C), Linear embed, + time embedding, num_layers x { h += torchvision.ops.MLP(d_model, [d_mlp, d_model], dropout 0.1)(h) },
+    Linear unembed.  Exact-f32 kernels (csrc/fd_backbones.hip); state-dict keys backbone.{i}.0|3.weight|bias."""
+    _backbone = _C.FD_BACKBONE_MLP
+
+    def __init__(self, n_channels: int, max_len: int, noise_scheduler: SDE, fourier_noise_scaling: bool = True, d_model: int = 72,
+                 d_mlp: int = 512, num_layers: int = 3, num_training_steps: int = 1000, lr_max: float = 1e-3,
+                 likelihood_weighting: bool = False) -> None:
+        self._d_mlp = int(d_mlp)
+        self.d_mlp = int(d_mlp)
+        super().__init__(n_channels=n_channels, max_len=max_len, noise_scheduler=noise_scheduler,
+                         fourier_noise_scaling=fourier_noise_scaling, d_model=d_model, num_layers=num_layers, n_head=1,
+                         num_training_steps=num_training_steps, lr_max=lr_max, likelihood_weighting=likelihood_weighting)
+        self.hparams = dict(n_channels=n_channels, max_len=max_len, noise_scheduler=noise_scheduler,
+                            fourier_noise_scaling=fourier_noise_scaling, d_model=d_model, d_mlp=d_mlp, num_layers=num_layers,
+                            num_training_steps=num_training_steps, lr_max=lr_max, likelihood_weighting=likelihood_weighting)
+        self.precision = "fp32"
+        self.train_precision = "fp32"
+
+    def _init_backbone(self, v, linear) -> None:
+        # nn.Linear default initialisation of every layer, drawn independently per block (a ModuleList of fresh MLPs)
+        for i in range(self.num_layers):
+            linear(f"backbone.{i}.0")
+            linear(f"backbone.{i}.3")
+
+
+class LSTMScoreModule(ScoreModule):
+    """fdiff.models.score_models.LSTMScoreModule (score_models.py:249-317) on the engine: Linear embed, + time embedding,
+    num_layers x { h += nn.LSTM(d_model, d_model, batch_first=True)(h)[0] }, Linear unembed.  Exact-f32 kernels; state-dict keys
+    backbone.{i}.weight_ih_l0 | weight_hh_l0 | bias_ih_l0 | bias_hh_l0 (gate order i, f, g, o)."""
+    _backbone = _C.FD_BACKBONE_LSTM
+
+    def __init__(self, n_channels: int, max_len: int, noise_scheduler: SDE, fourier_noise_scaling: bool = True, d_model: int = 72,
+                 num_layers: int = 3, num_training_steps: int = 1000, lr_max: float = 1e-3,
+                 likelihood_weighting: bool = False) -> None:
+        super().__init__(n_channels=n_channels, max_len=max_len, noise_scheduler=noise_scheduler,
+                         fourier_noise_scaling=fourier_noise_scaling, d_model=d_model, num_layers=num_layers, n_head=1,
+                         num_training_steps=num_training_steps, lr_max=lr_max, likelihood_weighting=likelihood_weighting)
+        self.hparams = dict(n_channels=n_channels, max_len=max_len, noise_scheduler=noise_scheduler,
+                            fourier_noise_scaling=fourier_noise_scaling, d_model=d_model, num_layers=num_layers,
+                            num_training_steps=num_training_steps, lr_max=lr_max, likelihood_weighting=likelihood_weighting)
+        self.precision = "fp32"
+        self.train_precision = "fp32"
+
+    def _init_backbone(self, v, linear) -> None:
+        # nn.LSTM.reset_parameters: every tensor U(-1/sqrt(hidden), 1/sqrt(hidden))
+        k = 1.0 / math.sqrt(self.d_model)
+        for i in range(self.num_layers):
+            for nm in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+                torch.nn.init.uniform_(v[f"backbone.{i}.{nm}"], -k, k)

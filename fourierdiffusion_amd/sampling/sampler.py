@@ -21,7 +21,12 @@ from ..utils.dataclasses import DiffusableBatch
 
 
 class DiffusionSampler:
-    def __init__(self, score_model: ScoreModule, sample_batch_size: int) -> None:
+    def __init__(self, score_model: ScoreModule, sample_batch_size: int, corrector_steps: int = 0, snr: float = 0.16) -> None:
+        """corrector_steps > 0 turns the predictor-only sampler of the reference into a predictor-corrector one
+        (`corrector_steps` Langevin steps at signal-to-noise ratio `snr` before every predictor step; an extension, not in
+        the reference: default off)."""
+        self.corrector_steps = int(corrector_steps)
+        self.snr = float(snr)
         self.score_model = score_model
         self.noise_scheduler = score_model.noise_scheduler
         self.sample_batch_size = sample_batch_size
@@ -40,7 +45,8 @@ class DiffusionSampler:
 
     def sample(self, num_samples: int, num_diffusion_steps: Optional[int] = None,
                prior_noise: Optional[Sequence[torch.Tensor]] = None,
-               step_noise: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+               step_noise: Optional[Sequence[torch.Tensor]] = None,
+               corrector_noise: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
         """Returns a CPU tensor (n, max_len, n_channels), n = num_batches * batch_size.
 
         prior_noise[b] (bs,T,C) and step_noise[b] (N,bs,T,C) inject the N(0,1) draws of batch b (parity
@@ -68,8 +74,18 @@ class DiffusionSampler:
                 z = _C.dev_f32(step_noise[b].to(dev), "step_noise")
                 assert tuple(z.shape) == (N, bs, self.max_len, self.n_channels)
             key, off = (0, 0) if z is not None else _rng.stream()
-            rc = _C.lib().fd_sampler_run(h, C.byref(p), G.data_ptr(), ts_arr, N, dt, X.data_ptr(), _C.ptr(z),
-                                         key, off, bs, mode, _C.stream_of(X))
+            if self.corrector_steps > 0:
+                zc = None
+                if corrector_noise is not None:
+                    zc = _C.dev_f32(corrector_noise[b].to(dev), "corrector_noise")
+                    assert tuple(zc.shape) == (N, self.corrector_steps, bs, self.max_len, self.n_channels)
+                if zc is None and z is not None:
+                    key, off = _rng.stream()
+                rc = _C.lib().fd_sampler_run_pc(h, C.byref(p), G.data_ptr(), ts_arr, N, dt, X.data_ptr(), _C.ptr(z), _C.ptr(zc),
+                                                self.corrector_steps, self.snr, key, off, bs, mode, _C.stream_of(X))
+            else:
+                rc = _C.lib().fd_sampler_run(h, C.byref(p), G.data_ptr(), ts_arr, N, dt, X.data_ptr(), _C.ptr(z),
+                                             key, off, bs, mode, _C.stream_of(X))
             _C.check(rc, ctx)
             all_samples.append(X)
         return torch.cat([x.cpu() for x in all_samples], dim=0)

@@ -36,11 +36,15 @@ def flatten_config(cfg) -> Dict[str, Any]:
 
 
 def get_model_type(cfg):
-    """Model class named by cfg.score_model._target_ (:58-76); only the transformer ScoreModule is in scope."""
-    from ..models.score_models import ScoreModule
+    """Model class named by cfg.score_model._target_ (:58-76)."""
+    from ..models.score_models import LSTMScoreModule, MLPScoreModule, ScoreModule
     model_class = cfg["score_model"]["_target_"]
     if model_class == "fdiff.models.score_models.ScoreModule":
         return ScoreModule
+    if model_class == "fdiff.models.score_models.MLPScoreModule":
+        return MLPScoreModule
+    if model_class == "fdiff.models.score_models.LSTMScoreModule":
+        return LSTMScoreModule
     raise NotImplementedError(f"Model class {model_class} not implemented yet.")
 
 

@@ -168,6 +168,23 @@ int64_t fd_score_param_count(const fd_model_dims* dims);
 int fd_score_layout(const fd_model_dims* dims, fd_param_entry* entries, int* n_entries);
 
 int fd_score_create(fd_ctx* ctx, const fd_model_dims* dims, fd_score** out);
+
+/* The reference's other two score backbones, behind the same fd_score handle and entry points
+ * (forward, training pair, sampler loop, optimiser):
+ *   FD_BACKBONE_MLP   replaces fdiff.models.score_models.MLPScoreModule  (score_models.py:169-246): the series is flattened
+ *                     to (B, T*C), Linear embed, + time embedding, num_layers x { h += Linear(relu-dropout(Linear(h))) with
+ *                     torchvision.ops.MLP(hidden=[d_mlp, d_model], dropout 0.1) }, Linear unembed; n_head / dim_ff unused.
+ *   FD_BACKBONE_LSTM  replaces fdiff.models.score_models.LSTMScoreModule (score_models.py:249-317): Linear embed, + time
+ *                     embedding, num_layers x { h += nn.LSTM(d_model, d_model, batch_first)(h) }, Linear unembed.
+ * Both run exact-f32 kernels in either mode (no positional table: pos_encoder is None in the reference).
+ * State-dict names: backbone.{i}.0.weight|bias, backbone.{i}.3.weight|bias (MLP); backbone.{i}.weight_ih_l0,
+ * weight_hh_l0, bias_ih_l0, bias_hh_l0 (LSTM, gate order i|f|g|o). */
+#define FD_BACKBONE_TRANSFORMER 0
+#define FD_BACKBONE_MLP 1
+#define FD_BACKBONE_LSTM 2
+int64_t fd_score_param_count_ex(const fd_model_dims* dims, int backbone, int d_mlp);
+int fd_score_layout_ex(const fd_model_dims* dims, int backbone, int d_mlp, fd_param_entry* entries, int* n_entries);
+int fd_score_create_ex(fd_ctx* ctx, const fd_model_dims* dims, int backbone, int d_mlp, fd_score** out);
 int fd_score_destroy(fd_score* m);
 
 /* Derive the engine-side weight images from the flat fp32 parameters (device pointer):
@@ -214,6 +231,18 @@ int fd_score_backward(fd_score* m, const float* dout, float* grads, int accumula
 int fd_sampler_run(fd_score* m, const fd_sde_params* sde, const float* G, const float* timesteps,
                    int n_steps, float dt, float* x, const float* z_steps, uint64_t seed,
                    uint64_t offset, int B, int mode, void* stream);
+
+/* Predictor-corrector extension (NOT in the reference, whose sampler is predictor-only; default off in the Python surface;
+ * parity unpinned -- follows Song et al. 2021, Alg. 4/5, in the coordinates whitened by G):
+ *   fd_langevin_step : per series eps = 2 alpha (snr |z| / |G score|)^2 ; out = x + eps G^2 score + sqrt(2 eps) G z
+ *                      (z == NULL: on-device Philox noise, needs T*C % 4 == 0; out may alias x)
+ *   fd_sampler_run_pc: fd_sampler_run with n_corr corrector steps (a score evaluation each) before every predictor step;
+ *                      alpha = 1 - beta(t) dt (VP) or 1 (VE); zc_steps (n_steps, n_corr, B, T, C) injected corrector noise or NULL */
+int fd_langevin_step(fd_ctx* ctx, const float* G, const float* x, const float* score, const float* z, uint64_t seed,
+                     uint64_t offset, float snr, float alpha, float* out, int B, int T, int C, void* stream);
+int fd_sampler_run_pc(fd_score* m, const fd_sde_params* sde, const float* G, const float* timesteps, int n_steps, float dt,
+                      float* x, const float* z_steps, const float* zc_steps, int n_corr, float snr, uint64_t seed,
+                      uint64_t offset, int B, int mode, void* stream);
 
 /* ------------------------------------------------------------ a11 optimiser
  * torch.optim.AdamW defaults + diffusers cosine-warmup + Lightning global-norm clip

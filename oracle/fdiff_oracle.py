@@ -375,6 +375,69 @@ def score_forward(p: Dict[str, Array], X: Array, t: Array, n_head: int,
     return out
 
 
+def langevin_step(sde: SDEParams, score: Array, x: Array, z: Array, snr: float, alpha: float) -> Array:
+    """Corrector step of a predictor-corrector sampler.  NOT in the reference (its sampler is predictor-only,
+    sampler.py:24-43): PARITY UNPINNED -- restates Song et al. 2021 (Alg. 4/5) in the coordinates whitened by G:
+    per series eps = 2 alpha (snr |z| / |G score|)^2 ;  x + eps G^2 score + sqrt(2 eps) G z."""
+    x, score, z = (np.asarray(a, dtype=np.float64) for a in (x, score, z))
+    G = np.asarray(sde.G, dtype=np.float64)[None, :, None]
+    gn = np.sqrt(((G * score) ** 2).sum(axis=(1, 2)))
+    zn = np.sqrt((z ** 2).sum(axis=(1, 2)))
+    eps = (2.0 * alpha * (snr * zn / gn) ** 2)[:, None, None]
+    return x + eps * G * G * score + np.sqrt(2.0 * eps) * G * z
+
+
+# --------------------------------------------------------------------------
+# (f)4  the other two score backbones     src/fdiff/models/score_models.py:169-317
+# --------------------------------------------------------------------------
+def mlp_score_forward(p: Dict[str, Array], X: Array, t: Array) -> Array:
+    """MLPScoreModule.forward (score_models.py:220-246), eval mode.  The blocks are torchvision.ops.MLP(in=d_model,
+    hidden=[d_mlp, d_model], dropout=0.1) = Linear -> ReLU -> Dropout -> Linear -> Dropout (torchvision is an unpinned
+    dependency of the reference and absent from the image: PARITY UNPINNED against torchvision itself -- the fixture comes
+    from the reference's class built over a stand-in with that published structure, oracle/make_golden.py)."""
+    X = np.asarray(X, dtype=np.float64)
+    B, T, C = X.shape
+    h = X.reshape(B, T * C) @ _f64(p, "embedder.weight").T + _f64(p, "embedder.bias")
+    D = h.shape[1]
+    emb = gfp_embedding(t, p["time_encoder.W"], D)
+    h = h + (emb @ _f64(p, "time_encoder.dense.weight").T + _f64(p, "time_encoder.dense.bias"))       # use_time_axis=False
+    i = 0
+    while f"backbone.{i}.0.weight" in p:
+        a = np.maximum(h @ _f64(p, f"backbone.{i}.0.weight").T + _f64(p, f"backbone.{i}.0.bias"), 0.0)
+        h = h + (a @ _f64(p, f"backbone.{i}.3.weight").T + _f64(p, f"backbone.{i}.3.bias"))
+        i += 1
+    out = h @ _f64(p, "unembedder.weight").T + _f64(p, "unembedder.bias")
+    return out.reshape(B, T, C)
+
+
+def lstm_score_forward(p: Dict[str, Array], X: Array, t: Array) -> Array:
+    """LSTMScoreModule.forward (score_models.py:291-317), eval mode: Linear embed, + time embedding on the time axis,
+    h += nn.LSTM(D, D, batch_first)(h)[0] per layer (torch gate order i, f, g, o; zero initial state), Linear unembed."""
+    X = np.asarray(X, dtype=np.float64)
+    B, T, C = X.shape
+    h = X @ _f64(p, "embedder.weight").T + _f64(p, "embedder.bias")
+    D = h.shape[-1]
+    emb = gfp_embedding(t, p["time_encoder.W"], D)
+    h = h + (emb @ _f64(p, "time_encoder.dense.weight").T + _f64(p, "time_encoder.dense.bias"))[:, None, :]
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))      # noqa: E731
+    i = 0
+    while f"backbone.{i}.weight_ih_l0" in p:
+        Wih, Whh = _f64(p, f"backbone.{i}.weight_ih_l0"), _f64(p, f"backbone.{i}.weight_hh_l0")
+        bias = _f64(p, f"backbone.{i}.bias_ih_l0") + _f64(p, f"backbone.{i}.bias_hh_l0")
+        hs = np.zeros((B, D))
+        cs = np.zeros((B, D))
+        ys = np.empty_like(h)
+        for tt in range(T):
+            g = h[:, tt] @ Wih.T + hs @ Whh.T + bias
+            ig, fg, gg, og = sig(g[:, :D]), sig(g[:, D:2 * D]), np.tanh(g[:, 2 * D:3 * D]), sig(g[:, 3 * D:])
+            cs = fg * cs + ig * gg
+            hs = og * np.tanh(cs)
+            ys[:, tt] = hs
+        h = h + ys
+        i += 1
+    return h @ _f64(p, "unembedder.weight").T + _f64(p, "unembedder.bias")
+
+
 # --------------------------------------------------------------------------
 # a10  denoising score-matching loss      src/fdiff/utils/losses.py:39-125
 # --------------------------------------------------------------------------

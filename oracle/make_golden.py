@@ -56,8 +56,23 @@ def import_reference():
     stub("pytorch_lightning.utilities.types", OptimizerLRScheduler=object)
     stub("diffusers")
     stub("diffusers.optimization", get_cosine_schedule_with_warmup=lambda **k: None)
+    class StandInMLP(nn.Sequential):
+        """torchvision.ops.MLP is an unpinned dependency of the reference and absent from this image.  Its published
+        structure (torchvision/ops/misc.py: per hidden width Linear -> activation -> Dropout, then Linear -> Dropout) is
+        restated here ONLY so that the reference's MLPScoreModule class can be constructed and run for the fixtures of
+        SURVEY 8(f)4 -- parity of the MLP backbone is therefore pinned to the reference's module code over this stand-in,
+        and UNPINNED against torchvision itself (said so in oracle/fdiff_oracle.py and DESIGN.md)."""
+
+        def __init__(self, in_channels, hidden_channels, dropout=0.0, **unused):
+            layers, d = [], in_channels
+            for hdim in hidden_channels[:-1]:
+                layers += [nn.Linear(d, hdim), nn.ReLU(), nn.Dropout(dropout)]
+                d = hdim
+            layers += [nn.Linear(d, hidden_channels[-1]), nn.Dropout(dropout)]
+            super().__init__(*layers)
+
     stub("torchvision")
-    stub("torchvision.ops", MLP=object)
+    stub("torchvision.ops", MLP=StandInMLP)
     # the reference's `fdiff` is a namespace package (no __init__.py): the repo's own `fdiff` alias package would shadow
     # it from ANY position on sys.path, so the repo root leaves the path while the reference is imported
     saved_path = list(sys.path)
@@ -277,6 +292,50 @@ def gen_loss(R):
     np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
 
 
+CFG_BB = dict(T=20, C=3, D=24, L=2)                   # MLP / LSTM backbone fixtures (d_mlp 64 for the MLP)
+
+
+def gen_backbones(R):
+    """MLPScoreModule / LSTMScoreModule of the reference: eval forward, training loss and autograd gradients
+    (dropout forced to 0, injected t and z) at a small configuration and, forward only, at the hydra configs' width
+    (d_model 72; MLP d_mlp 1024 / 10 layers are cut to 3 layers to keep the fixture small)."""
+    out = {}
+    for kind in ("mlp", "lstm"):
+        for name, cfg, B in (("small", CFG_BB, 4), ("wide", dict(T=50, C=4, D=72, L=3), 3)):
+            d_mlp = 64 if name == "small" else 1024
+            sch = R.sde.VPScheduler(beta_min=0.1, beta_max=20.0, fourier_noise_scaling=True)
+            sch.set_noise_scaling(cfg["T"])
+            if kind == "mlp":
+                m = R.sm.MLPScoreModule(n_channels=cfg["C"], max_len=cfg["T"], noise_scheduler=sch, d_model=cfg["D"], d_mlp=d_mlp,
+                                        num_layers=cfg["L"])
+            else:
+                m = R.sm.LSTMScoreModule(n_channels=cfg["C"], max_len=cfg["T"], noise_scheduler=sch, d_model=cfg["D"],
+                                         num_layers=cfg["L"])
+            sd = W.make_state_dict_backbone(kind, cfg["C"], cfg["T"], cfg["D"], cfg["L"], d_mlp=d_mlp, seed=4321)
+            missing = m.load_state_dict({k: t_(v) for k, v in sd.items()}, strict=False)
+            # the parent constructor's transformer pieces that the subclasses overwrite leave no keys; pos_encoder is None
+            assert not missing.unexpected_keys and all(k.startswith("pos_encoder") for k in missing.missing_keys), missing
+            X = W.randn(f"bb_x_{kind}_{name}", (B, cfg["T"], cfg["C"]), 5)
+            t = W.uniform(f"bb_t_{kind}_{name}", (B,), 5, 0.05, 1.0)
+            z = W.randn(f"bb_z_{kind}_{name}", (B, cfg["T"], cfg["C"]), 5)
+            m.eval()
+            with torch.no_grad():
+                out[f"fwd_{kind}_{name}"] = m(R.dc.DiffusableBatch(X=t_(X), y=None, timesteps=t_(t))).numpy()
+            if name != "small":
+                continue
+            zero_dropout(m)
+            fn_tr = R.losses.get_sde_loss_fn(sch, train=True, likelihood_weighting=False)
+            m.zero_grad()
+            with replay_noise(randn_like_seq=[t_(z)]):
+                lt = fn_tr(m, R.dc.DiffusableBatch(X=t_(X), y=None, timesteps=t_(t)))
+            lt.backward()
+            out[f"loss_{kind}_{name}"] = np.array(lt.item(), np.float64)
+            for k, prm in m.named_parameters():
+                if prm.grad is not None:
+                    out[f"grad_{kind}_{name}/{k}"] = prm.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "backbones.npz"), **out)
+
+
 GRAD_STRIDE = 97      # the default-model gradient fixture keeps every 97th element of each tensor + its norms
 
 
@@ -384,7 +443,7 @@ def main():
     torch.set_num_threads(8)
     R = import_reference()
     gens = dict(dft=gen_dft, spectral=gen_spectral, sde=gen_sde, score=gen_score, ckpt=gen_ckpt, loss=gen_loss, sampler=gen_sampler,
-                dataset=gen_dataset, optim=gen_optim, grad_default=gen_grad_default)
+                dataset=gen_dataset, optim=gen_optim, grad_default=gen_grad_default, backbones=gen_backbones)
     for name in (sys.argv[1:] or list(gens)):                  # `make_golden.py spectral` regenerates one file
         gens[name](R)
     for f in sorted(os.listdir(OUT)):

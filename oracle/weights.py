@@ -83,6 +83,36 @@ def make_state_dict(n_channels: int, max_len: int, d_model: int, num_layers: int
     return sd
 
 
+def make_state_dict_backbone(kind: str, n_channels: int, max_len: int, d_model: int, num_layers: int, d_mlp: int = 512,
+                             seed: int = 1234) -> Dict[str, np.ndarray]:
+    """Weights of the reference's MLPScoreModule / LSTMScoreModule (score_models.py:169-317) with its key names:
+    MLP  : embedder (D, T*C), unembedder (T*C, D), backbone.{i}.0 / .3 (torchvision.ops.MLP = Sequential(Linear, ReLU,
+           Dropout, Linear, Dropout)); LSTM: backbone.{i}.weight_ih_l0 | weight_hh_l0 | bias_ih_l0 | bias_hh_l0."""
+    D, C, T = d_model, n_channels, max_len
+    sd: Dict[str, np.ndarray] = {}
+
+    def lin(name, out_f, in_f):
+        b = 1.0 / math.sqrt(in_f)
+        sd[name + ".weight"] = uniform(name + ".weight", (out_f, in_f), seed, -b, b)
+        sd[name + ".bias"] = uniform(name + ".bias", (out_f,), seed, -b, b)
+
+    sd["time_encoder.W"] = (normal("time_encoder.W", ((D + 1) // 2,), seed) * np.float32(30.0)).astype(np.float32)
+    lin("time_encoder.dense", D, D)
+    cin = T * C if kind == "mlp" else C
+    lin("embedder", D, cin)
+    lin("unembedder", cin, D)
+    for i in range(num_layers):
+        if kind == "mlp":
+            lin(f"backbone.{i}.0", d_mlp, D)
+            lin(f"backbone.{i}.3", D, d_mlp)
+        else:
+            k = 1.0 / math.sqrt(D)
+            for nm, shape in (("weight_ih_l0", (4 * D, D)), ("weight_hh_l0", (4 * D, D)), ("bias_ih_l0", (4 * D,)),
+                              ("bias_hh_l0", (4 * D,))):
+                sd[f"backbone.{i}.{nm}"] = uniform(f"backbone.{i}.{nm}", shape, seed, -k, k)
+    return sd
+
+
 def randn(name: str, shape, seed: int) -> np.ndarray:
     """Deterministic N(0,1) input tensors for tests (same hash family)."""
     return normal("input:" + name, shape, seed)

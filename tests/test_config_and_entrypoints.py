@@ -100,7 +100,7 @@ def test_best_checkpoint_and_model_type(tmp_path):
     assert get_best_checkpoint(tmp_path).name == "epoch=7-val_loss=0.31.ckpt"
     assert get_model_type({"score_model": {"_target_": "fdiff.models.score_models.ScoreModule"}}) is ScoreModule
     with pytest.raises(NotImplementedError):
-        get_model_type({"score_model": {"_target_": "fdiff.models.score_models.LSTMScoreModule"}})
+        get_model_type({"score_model": {"_target_": "fdiff.models.score_models.SomethingElse"}})
 
 
 def test_fdiff_alias_package_resolves_reference_dotted_paths():
@@ -138,3 +138,16 @@ def test_datamodule_statistics_and_sharding(golden):
     assert r0.shape[0] + r1.shape[0] == 50
     merged = torch.cat([r0, r1]).sort(dim=0).values
     assert torch.allclose(merged, whole.sort(dim=0).values)
+
+
+def test_mlp_and_lstm_score_model_configs_compose():
+    """cmd/conf/score_model/{mlp,lstm}.yaml (reference: cmd/conf/score_model/mlp.yaml, lstm.yaml): same keys and values."""
+    from fourierdiffusion_amd.utils.extraction import get_model_type
+    for name, target, extra in (("mlp", "fdiff.models.score_models.MLPScoreModule", {"d_mlp": 1024, "lr_max": 1.0e-4}),
+                                ("lstm", "fdiff.models.score_models.LSTMScoreModule", {"lr_max": 1.0e-3})):
+        cfg = compose(CONF, "train", [f"score_model={name}", "fourier_transform=true"])
+        sm = cfg.score_model
+        assert sm._target_ == target and sm.d_model == 72 and sm.num_layers == 10 and sm.fourier_noise_scaling is True
+        for k, v in extra.items():
+            assert sm[k] == v
+        assert get_model_type(cfg).__name__ == target.rsplit(".", 1)[1]

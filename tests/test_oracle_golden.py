@@ -258,3 +258,19 @@ def test_wasserstein_metric_dicts():
     e = np.zeros(12); e[f] = 1
     Xf, Yf = O.check_flat_array(X), O.check_flat_array(Y)
     np.testing.assert_allclose(mg["marginal_wasserstein_all"][f], math.sqrt(O.emd2_1d(Xf @ e, Yf @ e)), rtol=1e-12)
+
+
+def test_backbone_oracles_match_the_reference_modules(golden):
+    """the numpy restatements of MLPScoreModule / LSTMScoreModule.forward against outputs of the reference's
+    own classes (tests/golden/backbones.npz; the MLP blocks over the documented stand-in for the absent torchvision)."""
+    from oracle import fdiff_oracle as O
+    from oracle import weights as W
+    from oracle.make_golden import CFG_BB
+    g = golden("backbones")
+    for kind, f in (("mlp", O.mlp_score_forward), ("lstm", O.lstm_score_forward)):
+        for name, cfg, B in (("small", CFG_BB, 4), ("wide", dict(T=50, C=4, D=72, L=3), 3)):
+            d_mlp = 64 if name == "small" else 1024
+            sd = W.make_state_dict_backbone(kind, cfg["C"], cfg["T"], cfg["D"], cfg["L"], d_mlp=d_mlp, seed=4321)
+            X = W.randn(f"bb_x_{kind}_{name}", (B, cfg["T"], cfg["C"]), 5)
+            t = W.uniform(f"bb_t_{kind}_{name}", (B,), 5, 0.05, 1.0)
+            np.testing.assert_allclose(f(sd, X, t), g[f"fwd_{kind}_{name}"], atol=5e-6, rtol=0)
