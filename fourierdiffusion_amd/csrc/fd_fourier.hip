@@ -35,32 +35,113 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return float2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
 }
 
-// One Stockham stage, radix r, Ns = product of earlier radices.  Every thread produces one output.
+// One Stockham stage of a LARGE prime radix r (> 31), Ns = product of earlier radices.  Every thread produces the output
+// pair (u, r-u) of one butterfly: W^{u(r-t)} = conj W^{ut}, so with P_t = a_t + a_{r-t}, M_t = a_t - a_{r-t}
+//   X_u = a_0 + sum_{t=1..(r-1)/2} (P_t c_ut + i M_t s_ut),   X_{r-u} = a_0 + sum (P_t c_ut - i M_t s_ut)
+// -- half the LDS reads and a quarter of the multiplies of one direct sum per output.  The inputs arrive pre-twiddled
+// by W_T^(k ktw t) (applied on the fly: one complex multiply per input read).
 __device__ __forceinline__ void stockham_stage(const float2* __restrict__ in, float2* __restrict__ out,
                                                const float2* __restrict__ tw, int T, int Cp, int r, int Ns) {
     const int NT = blockDim.x;
     const int tr = T / r;
     const int ktw = T / (Ns * r);
-    const int total = T * Cp;
-    const float inv_cp = 1.0f / (float)Cp, inv_nsr = 1.0f / (float)(Ns * r), inv_ns = 1.0f / (float)Ns;
+    const int h = (r - 1) >> 1;
+    const int npair = h + 1;                        // u = 0 (alone) and the pairs u = 1..h
+    const int total = tr * npair * Cp;
+    const float inv_cp = 1.0f / (float)Cp, inv_ns = 1.0f / (float)Ns, inv_np = 1.0f / (float)npair;
     for (int id = threadIdx.x; id < total; id += NT) {
         const int q = fdiv(id, inv_cp), p = id - q * Cp;
-        const int blk = fdiv(q, inv_nsr), rem = q - blk * (Ns * r);
-        const int u = fdiv(rem, inv_ns), k = rem - u * Ns;
-        const int j = blk * Ns + k;
-        int step = k * ktw + u * tr;
-        step -= (step >= T) ? T : 0;           // k*ktw < T/r, u*tr < T  ->  < 2T
-        float2 acc = in[j * Cp + p];
-        int e = 0;
-        for (int t = 1; t < r; ++t) {
-            e += step;
+        const int j = fdiv(q, inv_np), u = q - j * npair;           // butterfly j (0 .. T/r), output pair u
+        const int blk = fdiv(j, inv_ns), k = j - blk * Ns;
+        const int step = k * ktw;                                   // pre-twiddle exponent per t: step * t  (< T)
+        const float2 a0 = in[j * Cp + p];
+        float sre = 0.f, sim = 0.f, dre = 0.f, dim = 0.f;
+        int e = 0, f1 = 0, f2 = 0;                                  // e = (u t mod r) * tr ; f1 = step*t ; f2 = step*(r-t)
+        f2 = step * r;                                              // < T
+        for (int t = 1; t <= h; ++t) {
+            e += u * tr;
             e -= (e >= T) ? T : 0;
-            const float2 v = in[(j + t * tr) * Cp + p];
+            f1 += step;
+            f2 -= step;
+            float2 x1 = in[(j + t * tr) * Cp + p], x2 = in[(j + (r - t) * tr) * Cp + p];
+            if (k != 0) {
+                x1 = cmul(x1, tw[f1]);
+                x2 = cmul(x2, tw[f2]);
+            }
             const float2 w = tw[e];
-            acc.x += v.x * w.x - v.y * w.y;
-            acc.y += v.x * w.y + v.y * w.x;
+            const float px = x1.x + x2.x, py = x1.y + x2.y, mx = x1.x - x2.x, my = x1.y - x2.y;
+            sre = fmaf(px, w.x, sre);
+            sim = fmaf(py, w.x, sim);
+            dre = fmaf(mx, w.y, dre);
+            dim = fmaf(my, w.y, dim);
         }
-        out[q * Cp + p] = acc;
+        float2* o = out + ((blk * r) * Ns + k) * Cp + p;            // output v at o[v * Ns * Cp]
+        const int os = Ns * Cp;
+        o[u * os] = float2{a0.x + sre - dim, a0.y + sim + dre};
+        if (u != 0) o[(r - u) * os] = float2{a0.x + sre + dim, a0.y + sim - dre};
+    }
+}
+
+// One Stockham stage of a prime radix R in 11..31 with a whole butterfly per thread, in the paired form above: the R inputs
+// are read (and pre-twiddled) once, the roots of unity live in registers, (R-1)^2 real multiplies per butterfly.
+template <int R>
+__device__ __forceinline__ void stockham_prime(const float2* __restrict__ in, float2* __restrict__ out,
+                                               const float2* __restrict__ tw, int T, int Cp, int Ns) {
+    constexpr int H = (R - 1) / 2;
+    const int NT = blockDim.x;
+    const int tr = T / R;
+    const int ktw = T / (Ns * R);
+    const int total = tr * Cp;
+    const float inv_cp = 1.0f / (float)Cp, inv_ns = 1.0f / (float)Ns;
+    float wc[H + 1], wsn[H + 1];                    // cos / sin of the roots m = 0..H (m > H by symmetry)
+#pragma unroll
+    for (int m = 0; m <= H; ++m) {
+        const float2 w = tw[m * tr];
+        wc[m] = w.x;
+        wsn[m] = w.y;
+    }
+    for (int id = threadIdx.x; id < total; id += NT) {
+        const int j = fdiv(id, inv_cp), p = id - j * Cp;
+        const int blk = fdiv(j, inv_ns), k = j - blk * Ns;
+        float2 a[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) a[t] = in[(j + t * tr) * Cp + p];
+        if (k != 0) {
+            const int step = k * ktw;
+#pragma unroll
+            for (int t = 1; t < R; ++t) a[t] = cmul(a[t], tw[step * t]);
+        }
+        // P_t -> a[t], M_t -> a[R - t]
+#pragma unroll
+        for (int t = 1; t <= H; ++t) {
+            const float2 x1 = a[t], x2 = a[R - t];
+            a[t] = float2{x1.x + x2.x, x1.y + x2.y};
+            a[R - t] = float2{x1.x - x2.x, x1.y - x2.y};
+        }
+        float2* o = out + ((blk * R) * Ns + k) * Cp + p;
+        const int os = Ns * Cp;
+        {
+            float2 acc = a[0];
+#pragma unroll
+            for (int t = 1; t <= H; ++t) { acc.x += a[t].x; acc.y += a[t].y; }
+            o[0] = acc;
+        }
+#pragma unroll
+        for (int u = 1; u <= H; ++u) {
+            float sre = 0.f, sim = 0.f, dre = 0.f, dim = 0.f;
+#pragma unroll
+            for (int t = 1; t <= H; ++t) {
+                const int m = (u * t) % R;                          // compile-time after unrolling
+                const float c = wc[m <= H ? m : R - m];
+                const float sn = (m <= H) ? wsn[m] : -wsn[R - m];
+                sre = fmaf(a[t].x, c, sre);
+                sim = fmaf(a[t].y, c, sim);
+                dre = fmaf(a[R - t].x, sn, dre);
+                dim = fmaf(a[R - t].y, sn, dim);
+            }
+            o[u * os] = float2{a[0].x + sre - dim, a[0].y + sim + dre};
+            o[(R - u) * os] = float2{a[0].x + sre + dim, a[0].y + sim - dre};
+        }
     }
 }
 
@@ -125,7 +206,10 @@ __device__ __forceinline__ void stockham_butterflies(const float2* __restrict__ 
 // BATCHED (single-channel data, C == 1): the workgroup transforms Cc consecutive SERIES instead of Cc channels of one series
 // -- "channel" j is series blockIdx.x * Cc + j, contiguous along time -- so that a (B, T, 1) set (the reference's ECG
 // data, 87 554 x 187 x 1) still fills complex lanes and workgroups (one series per workgroup ran at 0.6 TB/s).
-template <bool INVERSE, bool BATCHED>
+// BIGP: the instantiation that carries the register butterflies of the prime radices 17 / 19 / 23 (34-46 complex registers per
+// thread: they spill at the 1024-thread budget, and a kernel with scratch pays for it in every stage -- (4096, 256, 28) lost
+// 9 % when they lived in the common instantiation); lengths without such a factor run the BIGP = false kernel.
+template <bool INVERSE, bool BATCHED, bool BIGP>
 __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, float* __restrict__ y,
                                                     const float* __restrict__ mean, const float* __restrict__ stdv,
                                                     const float2* __restrict__ tw_fwd, int B, int C, int Cc, FftPlan plan) {
@@ -204,7 +288,12 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
             case 4: stockham_butterflies<4>(src, dst, tw, T, Cp, Ns); break;
             case 5: stockham_butterflies<5>(src, dst, tw, T, Cp, Ns); break;
             case 7: stockham_butterflies<7>(src, dst, tw, T, Cp, Ns); break;
-            default: stockham_stage(src, dst, tw, T, Cp, r, Ns);   // large prime factor: one direct-DFT stage
+            case 11: stockham_prime<11>(src, dst, tw, T, Cp, Ns); break;
+            case 13: stockham_prime<13>(src, dst, tw, T, Cp, Ns); break;
+            case 17: if (BIGP) { stockham_prime<17>(src, dst, tw, T, Cp, Ns); break; }
+            case 19: if (BIGP && r == 19) { stockham_prime<19>(src, dst, tw, T, Cp, Ns); break; }
+            case 23: if (BIGP && r == 23) { stockham_prime<23>(src, dst, tw, T, Cp, Ns); break; }
+            default: stockham_stage(src, dst, tw, T, Cp, r, Ns);   // larger prime factor: one paired direct-DFT stage
         }
         Ns *= r;
         __syncthreads();
@@ -371,11 +460,14 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
     const int nchunks = batched ? 1 : (C + Cc - 1) / Cc;
     const int ngroups = batched ? (B + Cc - 1) / Cc : B;
     const size_t lds = (size_t)T * 8 + 2 * (size_t)T * ((Cc + 1) / 2) * 8;
-    auto kern = batched ? k_fft<INVERSE, true> : k_fft<INVERSE, false>;
-    static bool attr_set[2][2] = {{false, false}, {false, false}};
-    if (!attr_set[INVERSE ? 1 : 0][batched ? 1 : 0]) {
+    bool bigp = false;
+    for (int i = 0; i < plan.nstages; ++i) bigp |= (plan.radix[i] == 17 || plan.radix[i] == 19 || plan.radix[i] == 23);
+    auto kern = bigp ? (batched ? k_fft<INVERSE, true, true> : k_fft<INVERSE, false, true>)
+                     : (batched ? k_fft<INVERSE, true, false> : k_fft<INVERSE, false, false>);
+    static bool attr_set[2][2][2] = {};
+    if (!attr_set[INVERSE ? 1 : 0][batched ? 1 : 0][bigp ? 1 : 0]) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[INVERSE ? 1 : 0][batched ? 1 : 0] = true;
+        attr_set[INVERSE ? 1 : 0][batched ? 1 : 0][bigp ? 1 : 0] = true;
     }
     // twiddle table of this T (cached on the context; a handful of distinct T per process)
     const float2* tw_dev = nullptr;

@@ -16,7 +16,7 @@ def timed(fn, n=20):
     return (time.perf_counter() - t0) / n
 
 
-for (B, T, C) in [(512, 100, 12), (4096, 256, 28), (512, 1024, 16), (4096, 252, 6), (87554, 187, 1), (65536, 256, 1)]:
+for (B, T, C) in [(512, 100, 12), (4096, 256, 28), (512, 1024, 16), (4096, 252, 6), (87554, 187, 1), (65536, 256, 1), (4096, 187, 12), (4096, 365, 8), (4096, 143, 12), (4096, 253, 8)]:
     x = torch.randn(B, T, C, device="cuda")
     n = x.numel()
     td = timed(lambda: dft(x)); ti = timed(lambda: idft(x))
