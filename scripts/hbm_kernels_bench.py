@@ -8,7 +8,9 @@ from fourierdiffusion_amd.schedulers.sde import VPScheduler
 
 
 def timed(fn, n=20):
-    fn(); torch.cuda.synchronize()
+    for _ in range(3):          # (the first call of a kernel variant loads its code object: several ms)
+        fn()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
         fn()

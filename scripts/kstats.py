@@ -1,10 +1,10 @@
-#!/usr/bin/env python3
-"""Print the top kernels of a rocprofv3 --stats CSV (…_kernel_stats.csv)."""
+"""Print the top rows of a rocprofv3 kernel_stats.csv: name, calls, average us, share."""
 import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print(f"total kernel time {tot / 1e6:.2f} ms")
 for r in rows[:n]:
-    print(f"{r['Name'][:72]:72s} calls={r['Calls']:>6s} avg_us={float(r['AverageNs'])/1e3:9.2f} "
-          f"total_ms={float(r['TotalDurationNs'])/1e6:9.3f} {float(r['Percentage']):6.2f}%")
+    print(f'  {r["Name"][:100]:100s} {r["Calls"]:>6s} {float(r["AverageNs"]) / 1e3:10.1f} us {float(r["Percentage"]):6.2f} %')
