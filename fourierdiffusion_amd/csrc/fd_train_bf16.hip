@@ -239,6 +239,36 @@ __device__ __forceinline__ void stage_T(char* __restrict__ stage, int region_off
             col[(size_t)f * SL::TBS] = (__bf16)x;
         }
 }
+// C-layout tile of 16 tokens -> T-layout rows through a wave-private LDS transpose: 4 lanes write one 32-byte run of a
+// feature row (16 tokens x bf16) instead of 64 scattered 2-byte stores per instruction (20 store instructions per tile
+// became 5).  trow0 = &T[row 0][first token of the tile], ts = row stride in elements, tscr = 32 * DT * 16 bytes of LDS.
+template <int DT>
+__device__ __forceinline__ void store_T16(char* tscr, __bf16* __restrict__ trow0, int ts, int lane, int D, const f32x4 (&v)[DT],
+                                          bool ones, bool valid) {
+    const int tok = lane & 15, g = lane >> 4;
+    __bf16* l = reinterpret_cast<__bf16*>(tscr);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 16 * dt + 4 * g + r;
+            float x = 0.f;
+            if (valid) x = (f < D) ? v[dt][r] : ((f == D && ones) ? 1.0f : 0.f);
+            l[f * 16 + tok] = (__bf16)x;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < (16 * DT * 4 + 63) / 64; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < 16 * DT * 4) {
+            const int f = idx >> 2, q = idx & 3;
+            *reinterpret_cast<u32x2*>(trow0 + (size_t)f * ts + 4 * q) = *reinterpret_cast<const u32x2*>(l + f * 16 + 4 * q);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ bf16x8 row_frag(const __bf16* __restrict__ rb, int m, bool valid, int RBW, int ks, int g) {
     if (!valid) return frag_zero();
     return *reinterpret_cast<const bf16x8*>(rb + (size_t)m * RBW + 32 * ks + 8 * g);
@@ -286,15 +316,50 @@ __device__ __forceinline__ void ln_stats(const f32x4 (&v)[DT], int D, int g, flo
         }
     rstd = rsqrtf(group_sum(q) / (float)D + 1e-5f);
 }
-// dropout bits of a (token, D features) row in C layout: three Philox evaluations cover tiles (0,1), (2,3), (4,5)
+// dropout bits of a (token, D features) row in C layout: bytes (m, j, g) written by k_tr_masks, byte j covers the C tiles
+// 2j (low nibble) and 2j+1 (high nibble)
 template <int DT>
-__device__ __forceinline__ void row_drop_bits(const TrDims& d, unsigned long long site_off, int m, int g, unsigned (&bits)[DT]) {
+__device__ __forceinline__ void row_drop_bits(const TrDims& d, const unsigned char* __restrict__ rbits, int m, bool valid, int g,
+                                              unsigned (&bits)[DT]) {
 #pragma unroll
     for (int j = 0; j < (DT + 1) / 2; ++j) {
         unsigned b8 = 0xffu;
-        if (d.p > 0.f) b8 = drop8(site_off + ((unsigned long long)m * ((DT + 1) / 2) + j) * 4ull + (unsigned)g, d.seed, d.thr16);
+        if (d.p > 0.f && valid) b8 = rbits[((size_t)m * ((DT + 1) / 2) + j) * 4 + g];
         bits[2 * j] = b8 & 15u;
         if (2 * j + 1 < DT) bits[2 * j + 1] = b8 >> 4;
+    }
+}
+
+// Every dropout decision of one encoder layer (8 per Philox4x32-10 evaluation), generated AHEAD of the kernels that use
+// them on the context's side stream: the RNG has no data dependency, and inside the latency-bound forward kernels a Philox
+// evaluation (~560 issue cycles) per 32-wide FFN chunk was the longest item of the loop.  Byte layouts:
+//   hkeep (Mpad, 4, F/32)      hidden units of token m, lane group g, chunk: bits 0-3 units 4g+r, bits 4-7 units 16+4g+r
+//   pmask (B, H, T, NJ, 4)     attention probabilities of query t, key block jb, lane group g (keys 4g+r | 16+4g+r)
+//   rb1 / rb3 (Mpad, (DT+1)/2, 4)   out-projection / FFN output rows
+struct MaskArgs {
+    unsigned char* hkeep; unsigned char* pmask; unsigned char* rb1; unsigned char* rb3;
+    unsigned long long off0, off1, off2, off3;
+    long long n_h, n_p, n_r;      // byte counts
+    int NS2;                      // chunks per token (F / 32)
+};
+__global__ __launch_bounds__(256) void k_tr_masks(const TrDims d, const MaskArgs a) {
+    const long long total = a.n_h + a.n_p + 2 * a.n_r;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        if (i < a.n_h) {
+            // byte index (m*4 + g)*NS2 + chunk  <->  counter (m*NS2 + chunk)*4 + g
+            const long long mg = i / a.NS2, chunk = i - mg * a.NS2;
+            const long long m = mg >> 2, g = mg & 3;
+            a.hkeep[i] = (unsigned char)drop8(a.off2 + ((unsigned long long)m * a.NS2 + chunk) * 4ull + (unsigned)g, d.seed, d.thr16);
+        } else if (i < a.n_h + a.n_p) {
+            const long long k = i - a.n_h;
+            a.pmask[k] = (unsigned char)drop8(a.off0 + (unsigned long long)k, d.seed, d.thr16);
+        } else if (i < a.n_h + a.n_p + a.n_r) {
+            const long long k = i - a.n_h - a.n_p;
+            a.rb1[k] = (unsigned char)drop8(a.off1 + (unsigned long long)k, d.seed, d.thr16);
+        } else {
+            const long long k = i - a.n_h - a.n_p - a.n_r;
+            a.rb3[k] = (unsigned char)drop8(a.off3 + (unsigned long long)k, d.seed, d.thr16);
+        }
     }
 }
 
@@ -322,9 +387,8 @@ struct AttnFwdArgs {
     float* att;               // (M, D)
     __bf16* attT;             // T-block, ones row
     float* lse2;              // (B, H, T): row maximum + log2(row sum) of the scaled scores (base-2 logits)
-    unsigned char* pmask;     // (B, H, T, NJ, 4) keep bits of the attention dropout
+    const unsigned char* pmask;   // (B, H, T, NJ, 4) keep bits of the attention dropout (k_tr_masks)
     const char* wk; const char* wv; const char* wq;   // pair images (KS1 blocks per pair)
-    unsigned long long site_off;
 };
 
 template <int KS1>
@@ -416,8 +480,7 @@ __global__ __launch_bounds__(256) void k_tr_attn_fwd(const TrDims d, const AttnF
                 const int head = 2 * pair + hs;
                 const size_t bidx = ((((size_t)b * H + head) * T + (t < T ? t : 0)) * NJ + jb) * 4 + g;
                 unsigned bits = 0xffu;
-                if (d.p > 0.f) bits = drop8(a.site_off + bidx, d.seed, d.thr16);
-                if (t < T && head < H) a.pmask[bidx] = (unsigned char)bits;
+                if (d.p > 0.f && t < T && head < H) bits = a.pmask[bidx];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     pa[r] = (bits >> r) & 1u ? pa[r] : 0.f;
@@ -464,7 +527,7 @@ struct FfnFwdArgs {
     const char* wo_img;       // [DT][KSO]
     const char* ffn_img;      // chunk-major forward image of the layer
     const float* bo; const float* g1; const float* be1; const float* b2; const float* g2; const float* be2;
-    unsigned long long off1, off2, off3;   // Philox counter bases of the three dropout sites
+    const unsigned char* hkeep; const unsigned char* rb1; const unsigned char* rb3;   // dropout decisions (k_tr_masks)
 };
 
 // 8 waves = 4 token tiles (64 tokens) x 2 halves of F.  The weight stream (one 32-wide chunk per F-half per step, 2*NB KiB)
@@ -484,6 +547,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     constexpr int SCR = (TW * KS1 * 1024 > 4 * DT * 1024) ? TW * KS1 * 1024 : 4 * DT * 1024;
     unsigned char* const actB = reinterpret_cast<unsigned char*>(smem + NBUF * WB + SCR) + wave * (64 * NS);   // [64 lanes][NS]
     unsigned short* const actT = reinterpret_cast<unsigned short*>(smem + NBUF * WB + SCR + TW * 64 * NS) + wave * (NS * 32);   // [NS][32]
+    char* const tscr = smem + NBUF * WB + SCR + TW * 64 * NS + TW * NS * 32 * 2 + (wave & 3) * (32 * DT * 16);   // owners' T-store transpose
     const int m = (blockIdx.x * 4 + tile) * 16 + tok;
     const bool valid = m < M;
     const bool owner = fhw == 0;
@@ -525,7 +589,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
                 o[dt] = MFMA(*reinterpret_cast<const bf16x8*>(a.wo_img + ((size_t)(dt * KSO + ks) * 64 + lane) * 16), af, o[dt]);
         }
         unsigned bits[DT];
-        row_drop_bits<DT>(d, a.off1, m, g, bits);
+        row_drop_bits<DT>(d, a.rb1, m, valid, g, bits);
         load_ctile<DT>(a.x0, m, valid, D, g, v);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -538,7 +602,11 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
             }
         }
     }
-    if (owner) store_ctile<DT>(a.s1, m, valid, D, g, v);
+    // (global stores of the prologue are issued AFTER the FFN loop: `s_waitcnt vmcnt(0)` in front of the loop would otherwise
+    // wait for their write acknowledgements -- measured 17 us of a 57 us kernel -- and the data is live in registers anyway)
+    f32x4 s1keep[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) s1keep[dt] = v[dt];
     {
         float mean, rstd;
         ln_stats<DT>(v, D, g, mean, rstd);
@@ -556,12 +624,18 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
             }
         }
     }
-    if (owner) {
-        stage_rows<DT, KS1>(a.stage, StageL<KS1, DT>::off_xr, m, valid, D, g, v, true);
-        stage_T<DT, KS1>(a.stage, StageL<KS1, DT>::off_xT, m, valid, D, g, v, true);
-    }
     bf16x8 xf[KS1];
     ctile_to_frags<DT, KS1>(scratch, lane, D, v, true, xf);
+    // this wave's dropout bytes of its F-half -> LDS (overwritten chunk by chunk with kept-AND-positive), and the epilogue's
+    // dropout bits, fetched now (a dependent global round trip after the loop otherwise)
+    if (d.p > 0.f && valid) {
+        const unsigned char* srcb = a.hkeep + ((size_t)m * 4 + g) * (2 * NS) + fhw * NS;
+        for (int c = 0; c < NS; c += 16) *reinterpret_cast<u32x4*>(actB + lane * NS + c) = *reinterpret_cast<const u32x4*>(srcb + c);
+    } else {
+        for (int c = 0; c < NS; c += 16) *reinterpret_cast<u32x4*>(actB + lane * NS + c) = u32x4{~0u, ~0u, ~0u, ~0u};
+    }
+    unsigned bits3[DT];
+    row_drop_bits<DT>(d, a.rb3, m, valid, g, bits3);
     f32x4 acc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f4zero();
@@ -579,9 +653,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         }
         int ce = c + rot;
         ce -= (ce >= NS) ? NS : 0;
-        const int chunk = fhw * NS + ce;
-        // (thr16 = 0 keeps everything: no branch on p inside the loop -- branches split the MFMA chains into basic blocks)
-        const unsigned bits = drop8(a.off2 + ((unsigned long long)m * (2 * NS) + chunk) * 4ull + (unsigned)g, d.seed, d.thr16);
+        const unsigned bits = actB[lane * NS + ce];               // dropout decisions of this chunk (staged before the loop)
         unsigned act = 0u;
         unsigned long long bal[8];
 #pragma unroll
@@ -609,6 +681,13 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this step's LDS reads are done before the buffer may be refilled
         __builtin_amdgcn_s_barrier();
     }
+    if (owner) {
+        const int m0w = (blockIdx.x * 4 + tile) * 16;
+        store_ctile<DT>(a.s1, m, valid, D, g, s1keep);
+        stage_rows<DT, KS1>(a.stage, StageL<KS1, DT>::off_xr, m, valid, D, g, v, true);
+        store_T16<DT>(tscr, reinterpret_cast<__bf16*>(a.stage + (size_t)(m0w >> 5) * StageL<KS1, DT>::bytes + StageL<KS1, DT>::off_xT) + (m0w & 31),
+                      StageL<KS1, DT>::TBS, lane, D, v, true, valid);
+    }
     // ---- mask bits out: bytes [token][g][chunk] (token-on-lane backward), words [32-token block][half][hidden unit]
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -634,8 +713,6 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] += xch[(tile * DT + dt) * 64 + lane];
     {
-        unsigned bits[DT];
-        row_drop_bits<DT>(d, a.off3, m, g, bits);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d0 = 16 * dt + 4 * g;
@@ -643,7 +720,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
                 const float4 bb = *reinterpret_cast<const float4*>(a.b2 + d0);
                 const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[dt][r] += ((bits[dt] >> r) & 1u) ? (acc[dt][r] + bv[r]) * d.keep_scale : 0.f;
+                for (int r = 0; r < 4; ++r) v[dt][r] += ((bits3[dt] >> r) & 1u) ? (acc[dt][r] + bv[r]) * d.keep_scale : 0.f;
             }
         }
     }
@@ -667,8 +744,9 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     }
     store_ctile<DT>(a.out, m, valid, D, g, v);
     if (a.outrb) {
+        const int m0w = (blockIdx.x * 4 + tile) * 16;
         store_rows<DT, KS1>(a.outrb, m, valid, D, g, v, true);
-        store_T<DT>(a.outT, m, valid, D, g, v, true);
+        store_T16<DT>(tscr, a.outT + ((size_t)(m0w >> 5) * (16 * DT)) * 32 + (m0w & 31), 32, lane, D, v, true, valid);
     }
 }
 
@@ -686,7 +764,7 @@ struct FfnBwdArgs {
     const char* bffn;         // backward FFN image (chunk-major)
     const char* wot;          // [DT][KS1]
     const float* g1; const float* be1; const float* g2;
-    unsigned long long off1, off3;
+    const unsigned char* rb1; const unsigned char* rb3;
 };
 
 // LayerNorm backward on a C-layout tile: dy -> ds (in place), xhat given; returns nothing (column sums done by the caller)
@@ -735,6 +813,8 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     unsigned char* const actB = reinterpret_cast<unsigned char*>(smem + NBUF * WB + SCR) + wave * (64 * NS);
     float* const colred = reinterpret_cast<float*>(smem + NBUF * WB + SCR + TW * 64 * NS);   // [4 tiles][5][16*DT]
     char* const scratch2 = smem + NBUF * WB + SCR + TW * 64 * NS + 4 * 5 * 16 * DT * sizeof(float) + wave * KS1 * 1024;
+    // (the second half of the scratch2 area belongs to the non-owner waves, which never use it: 4 KS1 KiB >= 4 x 512 DT bytes)
+    char* const tscr = smem + NBUF * WB + SCR + TW * 64 * NS + 4 * 5 * 16 * DT * sizeof(float) + 4 * KS1 * 1024 + (wave & 3) * (32 * DT * 16);
     const int m = (blockIdx.x * 4 + tile) * 16 + tok;
     const bool valid = m < M;
     const int rot = (int)((blockIdx.x * 5u) % (unsigned)NS);      // rotated chunk order per workgroup (see k_tr_ffn_fwd)
@@ -803,19 +883,22 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     f32x4 df[DT];
     {
         unsigned bits[DT];
-        row_drop_bits<DT>(d, a.off3, m, g, bits);
+        row_drop_bits<DT>(d, a.rb3, m, valid, g, bits);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) df[dt][r] = ((bits[dt] >> r) & 1u) ? dy[dt][r] * d.keep_scale : 0.f;
     }
     colsum(0, df);                                   // d b2
-    if (owner) {
-        stage_T<DT, KS1>(a.stage, StageL<KS1, DT>::off_dT, m, valid, D, g, df, false);
-        stage_rows<DT, KS1>(a.stage, StageL<KS1, DT>::off_dr, m, valid, D, g, df, false);
-    }
+    // (the stores of d f follow the loop -- see k_tr_ffn_fwd -- and the epilogue's inputs are fetched now)
     bf16x8 dfr[KS1];
     ctile_to_frags<DT, KS1>(scratch, lane, D, df, false, dfr);
+    f32x4 s1t[DT];
+    unsigned bits1[DT];
+    if (owner) {
+        load_ctile<DT>(a.s1, m, valid, D, g, s1t);
+        row_drop_bits<DT>(d, a.rb1, m, valid, g, bits1);
+    }
     f32x4 acc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f4zero();
@@ -858,13 +941,18 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     }
     __syncthreads();
     if (owner) {
+        const int m0w = (blockIdx.x * 4 + tile) * 16;
+        store_T16<DT>(tscr, reinterpret_cast<__bf16*>(a.stage + (size_t)(m0w >> 5) * StageL<KS1, DT>::bytes + StageL<KS1, DT>::off_dT) + (m0w & 31),
+                      StageL<KS1, DT>::TBS, lane, D, df, false, valid);
+        stage_rows<DT, KS1>(a.stage, StageL<KS1, DT>::off_dr, m, valid, D, g, df, false);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dy[dt] += acc[dt] + xch[(tile * DT + dt) * 64 + lane];     // d x1 = residual path + FFN branch
         // ---- LayerNorm1 backward
         float rstd1;
         {
             float mean;
-            load_ctile<DT>(a.s1, m, valid, D, g, xh);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) xh[dt] = s1t[dt];
             ln_stats<DT>(xh, D, g, mean, rstd1);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
@@ -881,15 +969,11 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
         ln_bwd_tile<DT>(dy, xh, a.g1, rstd1, D, g);      // dy = d s1
         store_ctile<DT>(a.dres, m, valid, D, g, dy);
         // ---- d o (out-projection output after its dropout) -> d att = d o W_o
-        {
-            unsigned bits[DT];
-            row_drop_bits<DT>(d, a.off1, m, g, bits);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) df[dt][r] = ((bits[dt] >> r) & 1u) ? dy[dt][r] * d.keep_scale : 0.f;
-        }
-        store_T<DT>(a.doT, m, valid, D, g, df, false);
+            for (int r = 0; r < 4; ++r) df[dt][r] = ((bits1[dt] >> r) & 1u) ? dy[dt][r] * d.keep_scale : 0.f;
+        store_T16<DT>(tscr, a.doT + ((size_t)(m0w >> 5) * (16 * DT)) * 32 + (m0w & 31), 32, lane, D, df, false, valid);
         // (a second scratch: the first one is aliased by the exchange area, which other owners may still be reading)
         ctile_to_frags<DT, KS1>(scratch2, lane, D, df, false, dfr);
 #pragma unroll
@@ -1495,7 +1579,7 @@ struct TrLayerBufs {
     float *x0, *att, *s1, *s2, *lse2;
     __bf16 *x0rb, *x0T, *attT, *doT, *dqkvT;
     char* stage;
-    unsigned char *pmask, *active;
+    unsigned char *pmask, *active, *hkeep, *rb1, *rb3;
     unsigned short* activeT;
 };
 struct TrBufs {
@@ -1546,6 +1630,9 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
         b.dqkvT = (__bf16*)take(2 * Mpad * 3 * NP * 16);
         b.pmask = (unsigned char*)take((size_t)B * H * T * NJ * 4);
         b.active = (unsigned char*)take(Mpad * (F / 32) * 4);
+        b.hkeep = (unsigned char*)take(Mpad * (F / 32) * 4);
+        b.rb1 = (unsigned char*)take(Mpad * ((NFT / 16 + 1) / 2) * 4);
+        b.rb3 = (unsigned char*)take(Mpad * ((NFT / 16 + 1) / 2) * 4);
         b.activeT = (unsigned short*)take((Mpad / 32) * 2 * F * sizeof(unsigned short));
     }
     tb.dh = (float*)take(sizeof(float) * M * D);
@@ -1593,12 +1680,40 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
     const size_t lds_attn = (size_t)d.KT * 16 * 32 + (size_t)d.NJ * 1024;
     const size_t scr = std::max((size_t)TW * KS1 * 1024, (size_t)4 * DT * 1024);
     const size_t NSh = (size_t)m->d.dim_ff / 64;
-    const size_t lds_ffn = (size_t)4 * 2 * (2 * KS1 + DT) * 1024 + scr + (size_t)TW * 64 * NSh + (size_t)TW * NSh * 32 * sizeof(unsigned short);
+    const size_t lds_ffn = (size_t)4 * 2 * (2 * KS1 + DT) * 1024 + scr + (size_t)TW * 64 * NSh + (size_t)TW * NSh * 32 * sizeof(unsigned short) +
+                           (size_t)4 * 32 * DT * 16;
     static bool attr = false;
     if (!attr) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_fwd<KS1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_ffn_fwd<KS1, DT, KSO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
+    }
+    if (p > 0.f) {
+        // dropout decisions of every layer on the side stream, layer by layer, ahead of the kernels that read them
+        if (!ctx->side_stream) FD_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        while ((int)ctx->side_events.size() < L + 2) {
+            hipEvent_t e;
+            FD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->side_events.push_back(e);
+        }
+        // (the buffers were last read by the previous backward on `s`: order the side stream behind it)
+        FD_HIP(ctx, hipEventRecord(ctx->side_events[L + 1], s));
+        FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_events[L + 1], 0));
+        for (int l = 0; l < L; ++l) {
+            TrLayerBufs& b = tb.layers[l];
+            MaskArgs ma{};
+            ma.hkeep = b.hkeep; ma.pmask = b.pmask; ma.rb1 = b.rb1; ma.rb3 = b.rb3;
+            ma.off0 = fd_dropout_site_offset(offset, l, 0); ma.off1 = fd_dropout_site_offset(offset, l, 1);
+            ma.off2 = fd_dropout_site_offset(offset, l, 2); ma.off3 = fd_dropout_site_offset(offset, l, 3);
+            ma.NS2 = m->d.dim_ff / 32;
+            ma.n_h = (long long)tb.Mpad * 4 * ma.NS2;
+            ma.n_p = (long long)B * m->d.n_head * T * d.NJ * 4;
+            ma.n_r = (long long)tb.Mpad * ((DT + 1) / 2) * 4;
+            const long long tot = ma.n_h + ma.n_p + 2 * ma.n_r;
+            const unsigned grid = (unsigned)std::min<long long>((tot + 255) / 256, (long long)ctx->num_cu * 16);
+            hipLaunchKernelGGL(k_tr_masks, dim3(grid), dim3(256), 0, ctx->side_stream, d, ma);
+            FD_HIP(ctx, hipEventRecord(ctx->side_events[l], ctx->side_stream));
+        }
     }
     for (int l = 0; l < L; ++l) {
         const fd_layer_off& lo = m->layers[l];
@@ -1607,7 +1722,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         AttnFwdArgs aa{};
         aa.x0rb = b.x0rb; aa.att = b.att; aa.attT = b.attT; aa.lse2 = b.lse2; aa.pmask = b.pmask;
         aa.wk = limg + im->off_wk; aa.wv = limg + im->off_wv; aa.wq = limg + im->off_wq;
-        aa.site_off = fd_dropout_site_offset(offset, l, 0);
+        if (p > 0.f) FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[l], 0));      // this layer's dropout decisions are ready
         hipLaunchKernelGGL((k_tr_attn_fwd<KS1>), dim3(d.NP, B), dim3(256), lds_attn, s, d, aa);
         FfnFwdArgs fa{};
         fa.x0 = b.x0; fa.att = b.att; fa.s1 = b.s1; fa.s2 = b.s2;
@@ -1618,7 +1733,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         fa.active = b.active; fa.activeT = b.activeT;
         fa.wo_img = limg + im->off_wo; fa.ffn_img = limg + im->off_ffn;
         fa.bo = P + lo.out_b; fa.g1 = P + lo.n1_w; fa.be1 = P + lo.n1_b; fa.b2 = P + lo.l2_b; fa.g2 = P + lo.n2_w; fa.be2 = P + lo.n2_b;
-        fa.off1 = fd_dropout_site_offset(offset, l, 1); fa.off2 = fd_dropout_site_offset(offset, l, 2); fa.off3 = fd_dropout_site_offset(offset, l, 3);
+        fa.hkeep = b.hkeep; fa.rb1 = b.rb1; fa.rb3 = b.rb3;
         {
             // measurement hook (bench.py --mode train): algorithmic flops of this launch = out-projection + FFN of M tokens
             fd_prof_scope scope(ctx, s, "k_tr_ffn_fwd (out-proj + LN1 + FFN + LN2, training forward)",
@@ -1640,7 +1755,6 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     const int M = B * T;
     const float* P = m->params;
     const TrDims d = make_dims(m, B, m->saved_p, m->saved_seed);
-    const uint64_t offset = m->saved_offset;
     if (!accumulate) FD_HIP(ctx, hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(L > 0 ? m->layers[0].in_w : m->nparams), s));
     // ---- unembedder
     fdgemm::linear_bwd_weight(dout, tb.hL, grads + m->un_w, M, C, D, true, s, tb.skp, kSkpFloats);
@@ -1661,7 +1775,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     // side stream: the weight gradients of layer l only need that layer's k_tr_ffn_bwd / k_tr_attn_bwd outputs, so they run
     // beside the input-gradient chain of layers l-1 .. 0 (both are latency-bound and leave most CUs idle on their own)
     if (!ctx->side_stream) FD_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-    while ((int)ctx->side_events.size() < L + 1) {
+    while ((int)ctx->side_events.size() < L + 2) {
         hipEvent_t e;
         FD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->side_events.push_back(e);
@@ -1685,7 +1799,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         fa.vecpart = tb.vecpart + (size_t)l * tb.nwg * 5 * D;
         fa.bffn = bl + im->boff_ffn; fa.wot = bl + im->boff_wot;
         fa.g1 = P + lo.n1_w; fa.be1 = P + lo.n1_b; fa.g2 = P + lo.n2_w;
-        fa.off1 = fd_dropout_site_offset(offset, l, 1); fa.off3 = fd_dropout_site_offset(offset, l, 3);
+        fa.rb1 = b.rb1; fa.rb3 = b.rb3;
         hipLaunchKernelGGL((k_tr_ffn_bwd<KS1, DT>), dim3(tb.nwg), dim3(TW * 64), lds_bwd, s, d, fa);
         AttnBwdArgs ab{};
         ab.x0rb = b.x0rb; ab.att = b.att; ab.datt = tb.datt; ab.lse2 = b.lse2; ab.pmask = b.pmask;
