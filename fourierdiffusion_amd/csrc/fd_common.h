@@ -35,6 +35,7 @@ struct fd_ctx {
     // side stream + events: the training backward runs each layer's weight-gradient kernel beside the (latency-bound)
     // input-gradient chain of the earlier layers
     hipStream_t side_stream = nullptr;
+    hipStream_t side_stream2 = nullptr;   // weight-gradient launches alternate between the two (they are latency-bound on ~80 CUs each)
     std::vector<hipEvent_t> side_events;
     // FFT twiddle tables (T, device pointer), built on first use of a length
     std::vector<std::pair<int, void*>> fft_tw;

@@ -1024,11 +1024,24 @@ __global__ __launch_bounds__(256) void k_tr_attn_bwd(const TrDims d, const AttnB
     char* const qC = oR + RSZ;        char* const kC = qC + CSZ;  char* const oC = kC + CSZ;
     float* const drow = reinterpret_cast<float*>(oC + CSZ);      // [2][NTOK]  rowsum(dO . O) per (head of the pair, query)
     float* const lse = drow + 2 * NTOK;                          // [2][NTOK]
+    // keep bits of the pair's two heads, [2][T][NJ][4] bytes, staged once: the key-owner sweep reads 8 scattered bytes per
+    // (query pair, head) and a global gather there was a dependent L2 round trip per iteration
+    unsigned char* const pm = reinterpret_cast<unsigned char*>(lse + 2 * NTOK);
+    const int PMH = T * NJ * 4;                                  // bytes per head
     const size_t pstride = (size_t)KS1 * 1024;
     auto wfrag = [&](const char* img, int ks) { return *reinterpret_cast<const bf16x8*>(img + pair * pstride + ((size_t)ks * 64 + lane) * 16); };
     auto xfrag = [&](int tile, int ks) { const int t = tile * 16 + tok; return row_frag(a.x0rb, b * T + t, t < T, d.RBW, ks, g); };
     const bool lo_grp = (g >> 1) == 0;
     const int myhead = 2 * pair + (g >> 1);
+    if (d.p > 0.f) {
+        for (int hs = 0; hs < 2; ++hs) {
+            const int head = 2 * pair + hs;
+            if (head >= H) continue;
+            const unsigned char* src = a.pmask + ((size_t)b * H + head) * PMH;        // contiguous per (series, head)
+            for (int i = threadIdx.x * 4; i < PMH; i += 256 * 4)                       // PMH is a multiple of 4
+                *reinterpret_cast<unsigned*>(pm + hs * PMH + i) = *reinterpret_cast<const unsigned*>(src + i);
+        }
+    }
     // ---- stage q, k, v (recomputed), dO, rowsum(dO.O), lse
     {
         bf16x8 wqf[KS1], wkf[KS1], wvf[KS1];
@@ -1131,7 +1144,7 @@ __global__ __launch_bounds__(256) void k_tr_attn_bwd(const TrDims d, const AttnB
                     f32x4 pa = MFMA16(vfa, ob[hs], f4zero()), pb = MFMA16(vfb, ob[hs], f4zero());    // dP (dropped P's gradient)
                     const int head = 2 * pair + hs;
                     unsigned bits = 0xffu;
-                    if (d.p > 0.f && t < T && head < H) bits = a.pmask[((((size_t)b * H + head) * T + t) * NJ + jb) * 4 + g];
+                    if (d.p > 0.f && t < T && head < H) bits = pm[hs * PMH + (t * NJ + jb) * 4 + g];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool va = ka * 16 + 4 * g + r < T, vb = has_b && (kb * 16 + 4 * g + r < T);
@@ -1172,9 +1185,9 @@ __global__ __launch_bounds__(256) void k_tr_attn_bwd(const TrDims d, const AttnB
                         const bool va = qa_i < T && key < T && head < H, vb = has_b && qb_i < T && key < T && head < H;
                         bool ba = true, bb = true;
                         if (d.p > 0.f) {
-                            const size_t base = (((size_t)b * H + (head < H ? head : 0)) * T);
-                            if (va) ba = (a.pmask[((base + qa_i) * NJ + (kt >> 1)) * 4 + (tok >> 2)] >> ((kt & 1) * 4 + (tok & 3))) & 1u;
-                            if (vb) bb = (a.pmask[((base + qb_i) * NJ + (kt >> 1)) * 4 + (tok >> 2)] >> ((kt & 1) * 4 + (tok & 3))) & 1u;
+                            const unsigned char* ph = pm + hs * PMH;
+                            if (va) ba = (ph[(qa_i * NJ + (kt >> 1)) * 4 + (tok >> 2)] >> ((kt & 1) * 4 + (tok & 3))) & 1u;
+                            if (vb) bb = (ph[(qb_i * NJ + (kt >> 1)) * 4 + (tok >> 2)] >> ((kt & 1) * 4 + (tok & 3))) & 1u;
                         }
                         const float Pa = va ? __builtin_amdgcn_exp2f(sa[r] - la[r]) : 0.f;
                         const float Pb = vb ? __builtin_amdgcn_exp2f(sb[r] - lb[r]) : 0.f;
@@ -1691,7 +1704,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
     if (p > 0.f) {
         // dropout decisions of every layer on the side stream, layer by layer, ahead of the kernels that read them
         if (!ctx->side_stream) FD_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-        while ((int)ctx->side_events.size() < L + 2) {
+        while ((int)ctx->side_events.size() < L + 3) {
             hipEvent_t e;
             FD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ctx->side_events.push_back(e);
@@ -1764,7 +1777,8 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     const size_t NSh = (size_t)m->d.dim_ff / 64;
     const size_t lds_bwd = (size_t)4 * 2 * (2 * KS1 + DT) * 1024 + scr + (size_t)TW * 64 * NSh + (size_t)4 * 5 * 16 * DT * sizeof(float) +
                            (size_t)TW * KS1 * 1024;
-    const size_t lds_ab = (size_t)4 * d.KT * 16 * 32 + (size_t)3 * d.NJ * 1024 + (size_t)4 * d.KT * 16 * sizeof(float);
+    const size_t lds_ab = (size_t)4 * d.KT * 16 * 32 + (size_t)3 * d.NJ * 1024 + (size_t)4 * d.KT * 16 * sizeof(float) +
+                          (size_t)2 * d.T * d.NJ * 4;
     static bool attr = false;
     if (!attr) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_ffn_bwd<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1775,7 +1789,8 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     // side stream: the weight gradients of layer l only need that layer's k_tr_ffn_bwd / k_tr_attn_bwd outputs, so they run
     // beside the input-gradient chain of layers l-1 .. 0 (both are latency-bound and leave most CUs idle on their own)
     if (!ctx->side_stream) FD_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-    while ((int)ctx->side_events.size() < L + 2) {
+    if (!ctx->side_stream2) FD_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream2, hipStreamNonBlocking));
+    while ((int)ctx->side_events.size() < L + 3) {
         hipEvent_t e;
         FD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->side_events.push_back(e);
@@ -1812,13 +1827,16 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         w.stage = b.stage; w.activeT = b.activeT;
         w.ffn_img = limg + im->off_ffn; w.bffn = bl + im->boff_ffn;
         w.in_w = lo.in_w; w.in_b = lo.in_b; w.out_w = lo.out_w; w.out_b = lo.out_b; w.l1_w = lo.l1_w; w.l1_b = lo.l1_b; w.l2_w = lo.l2_w;
+        hipStream_t ws = (l & 1) ? ctx->side_stream2 : ctx->side_stream;     // two layers' weight gradients in flight
         FD_HIP(ctx, hipEventRecord(ctx->side_events[l], s));
-        FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_events[l], 0));
-        hipLaunchKernelGGL((k_tr_wgrad<KS1, DT>), dim3(F / 128 + 4, tb.TS), dim3(256), lds_wg, ctx->side_stream, d, w, wa);
+        FD_HIP(ctx, hipStreamWaitEvent(ws, ctx->side_events[l], 0));
+        hipLaunchKernelGGL((k_tr_wgrad<KS1, DT>), dim3(F / 128 + 4, tb.TS), dim3(256), lds_wg, ws, d, w, wa);
     }
     if (L > 0) {
         FD_HIP(ctx, hipEventRecord(ctx->side_events[L], ctx->side_stream));
         FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[L], 0));
+        FD_HIP(ctx, hipEventRecord(ctx->side_events[L + 2], ctx->side_stream2));
+        FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[L + 2], 0));
         RedArgs ra{};
         ra.part = tb.part; ra.nparams = m->nparams; ra.TS = tb.TS; ra.vecpart = tb.vecpart; ra.nwg = tb.nwg; ra.D = D; ra.L = L;
         ra.begin = m->layers[0].in_w;
