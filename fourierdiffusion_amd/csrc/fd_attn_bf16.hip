@@ -27,6 +27,28 @@ namespace {
 
 constexpr float kNegBig = -1.0e30f;
 constexpr int NW = 8, NTH = NW * 64, NQ = 2;
+#ifndef FD_ATTN_LAG
+#define FD_ATTN_LAG 2
+#endif
+#ifndef FD_ATTN_WAVES
+#define FD_ATTN_WAVES 4      // waves per SIMD the register budget is set for (4 = two 8-wave workgroups per CU)
+#endif
+#ifdef FD_ATTN_ABL
+constexpr int ABL = FD_ATTN_ABL;     // ablation builds (scripts/attn_abl.sh): 1 = staging only, 2 = one staged tile per wave, no rescue
+#else
+constexpr int ABL = 0;
+#endif
+#if defined(FD_ATTN_ABL) && FD_ATTN_ABL == 3
+__device__ unsigned long long fd_attn_dbg[8 * 8];   // per wave of workgroup 0: staging, Q setup, key blocks, epilogue, units
+#define ATTN_STAMP(slot, t_prev)                                                                   \
+    do {                                                                                           \
+        const unsigned long long now_ = __builtin_readcyclecounter();                              \
+        if (blockIdx.x == 0 && lane == 0) fd_attn_dbg[wave * 8 + (slot)] += now_ - (t_prev); \
+        (t_prev) = now_;                                                                           \
+    } while (0)
+#else
+#define ATTN_STAMP(slot, t_prev) do { } while (0)
+#endif
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -82,50 +104,53 @@ struct fd_attn_w {
 };
 
 // KS1 == 0: `in` = packed projections qkv (B*T, 3D) fp32 rows [q | k | v].
-// KS1 > 0 : `in` = the layer input h (B*T, D) fp32; Q, K, V of the pair are projected inside the kernel by MFMA (one
-//           launch and the (B*T, 3D) round trip less per layer).
+// KS1 > 0 : `in` = the layer input h (B*T, D) fp32, D % 4 == 0; Q, K, V of the pair are projected inside the kernel by MFMA
+//           (one launch and the (B*T, 3D) round trip less per layer).
 // out (B*T, D) fp32.  grid (query slices, head pairs, B), 512 threads.
+//
+// Phases of a workgroup (in-kernel time stamps at T = 1024, -DFD_ATTN_ABL=3: staging 27 %, per-unit Q set-up 14 %, key
+// blocks 56 % before this form):
+//   1. staging: K, V^T of the whole series and Q of this slice's query tiles -> LDS as bf16 fragments.  The x rows of the
+//      wave's NEXT token tile are in flight (raw fp32 registers) while the current tile runs through the MFMAs.
+//   2. units (2 query tiles x both heads): Q fragments come from LDS (no global round trip per unit); the key loop is ONE
+//      software pipeline over the whole series -- stage A (QK^T MFMA16) of a 128-key block runs while stages B (exp2, pack)
+//      and C (P V MFMA) finish the previous block's last tiles, and the next block's K / V fragments are read from LDS into
+//      the registers that die during the current block.  scripts/ubench/attn_pattern.hip prices the steady state at
+//      ~1.6 K cycles per block and SIMD (VALU: 128 exp2 x 8 + 64 cvt_pk x 4 = 1.28 K); draining and refilling the pipeline at
+//      every block boundary cost 2.0 K.
 template <int KS1>
-__global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restrict__ in, float* __restrict__ out, int T,
+__global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const float* __restrict__ in, float* __restrict__ out, int T,
                                                            int H, int hd, int D, float qscale, int du_per_block, int exact_only,
-                                                           fd_attn_w wimg, size_t pair_stride) {
+                                                           fd_attn_w wimg, size_t pair_stride, int slices, int B) {
     constexpr bool PROJ = KS1 > 0;
+    constexpr int KSN = PROJ ? KS1 : 1;
+    // Workgroup -> (series, head pair, query slice).  Hardware workgroup ids go round-robin over the 8 XCDs; all
+    // NP * slices workgroups of a series are placed on ONE XCD (series s on XCD s % 8), so the series' x rows (and nothing
+    // else) stream through that XCD's L2 once and are re-read from it by the other NP * slices - 1 workgroups.
+    const int NPs = ((H + 1) >> 1) * slices;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / NPs) * 8 + xcd, wsl = slot % NPs;
+    if (b >= B) return;
+    const int pair = wsl / slices, slice = wsl % slices;
     const float* __restrict__ qkv = in;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int KT = (T + 15) >> 4, NJ = (KT + 1) >> 1, NTOK = KT * 16;
-    const int pair = blockIdx.y, b = blockIdx.z;
     char* const kbf = smem;                       // [NTOK][4 g][8 B]: lane group g = 2*hs + (d >> 2), element d & 3
     char* const vbf = smem + (size_t)NTOK * 32;   // [NJ][4 g][16 dim slots][16 B]: (half, r) -> token (2jj+half)*16 + 4g + r
-    unsigned* const kmax = reinterpret_cast<unsigned*>(vbf + (size_t)NJ * 1024);   // [2] max_j |k_j|^2 per head (bits)
+    char* const qbf = vbf + (size_t)NJ * 1024;    // [slice tile][64 lanes][8 B]: Q^T C tile as bf16 (scaled by log2e/sqrt(hd))
+    // [2] max_j |k_j|^2 per head (bits).  With hd < 7 dim slot 7 of V^T is padding: its row feeds only output row 7, which
+    // nobody reads, so the two words live in that row of (group 0, lane group 0) and K + V^T + Q of T = 1024 are exactly
+    // 80 KiB: two workgroups per CU.  hd == 7 (slot 7 = the ones row): 16 bytes behind Q.
+    const bool kmax_in_v = hd < 7;
+    unsigned* const kmax = reinterpret_cast<unsigned*>(kmax_in_v ? vbf + 7 * 16 : qbf + (size_t)du_per_block * NQ * 512);
     const float* base = qkv + (size_t)b * T * (PROJ ? 1 : 3) * D;
-    // activation B fragment of token tile `tile` (PROJ): lane (tok, g) holds features 32ks + 8g .. +7, 1.0 in slot D
-    auto xfrag = [&](int tile, int ks) -> bf16x8 {
-        const int t = tile * 16 + tok, k0 = 32 * ks + 8 * g;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        if (t < T) {
-            if (k0 + 8 <= D) {
-                const float4 a = *reinterpret_cast<const float4*>(base + (size_t)t * D + k0);
-                const float4 c = *reinterpret_cast<const float4*>(base + (size_t)t * D + k0 + 4);
-                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = k0 + e;
-                    if (k < D) v[e] = base[(size_t)t * D + k];
-                    else if (k == D) v[e] = 1.0f;
-                }
-            }
-        }
-        const u32x4 pk = {cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
-        return __builtin_bit_cast(bf16x8, pk);
-    };
-    auto wfrag = [&](const char* img, int ks) -> bf16x8 {
-        return *reinterpret_cast<const bf16x8*>(img + (size_t)pair * pair_stride + ((size_t)ks * 64 + lane) * 16);
-    };
+    const int DUS = (KT + NQ - 1) / NQ;
+    const int du0 = slice * du_per_block, du1 = (ABL == 1) ? du0 : min(DUS, du0 + du_per_block);
+    const int qt0 = du0 * NQ, qt1 = min(KT, (du0 + du_per_block) * NQ);   // this slice's query tiles
+    unsigned long long tprev = __builtin_readcyclecounter();
+    (void)tprev;
 
     // ---- stage K and V^T of this (series, pair) as bf16 fragments; every byte of both regions is written here
     if (threadIdx.x < 2) kmax[threadIdx.x] = 0u;
@@ -133,43 +158,85 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
     if (PROJ) {
         // K^T = W_k x^T (C tile rows = the pair's 16 dim slots) and V = x W_v^T (C tile rows = tokens: already the
         // V^T A-fragment layout; its ones row comes from the bias slot) per token tile, exactly as in fd_mega.hip
-        bf16x8 wkf[PROJ ? KS1 : 1], wvf[PROJ ? KS1 : 1];
+        auto wfrag = [&](const char* img, int ks) -> bf16x8 {
+            return *reinterpret_cast<const bf16x8*>(img + (size_t)pair * pair_stride + ((size_t)ks * 64 + lane) * 16);
+        };
+        bf16x8 wkf[KSN], wvf[KSN], wqf[KSN];
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
             wkf[ks] = wfrag(wimg.wk, ks);
             wvf[ks] = wfrag(wimg.wv, ks);
+            wqf[ks] = wfrag(wimg.wq, ks);
         }
-        for (int kt = wave; kt < KT; kt += NW) {
-            f32x4 a = f4zero(), c = f4zero();
+        // raw x rows of a token tile: lane (tok, g) reads features 32ks + 8g .. +7 (clamped addresses, fixed up in xconv)
+        auto xload = [&](int tile, float4 (&rlo)[KSN], float4 (&rhi)[KSN]) {
+            const int t = min(tile * 16 + tok, T - 1);
+            const float* row = base + (size_t)t * D;
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
-                const bf16x8 xf = xfrag(kt, ks);
+                const int k0 = 32 * ks + 8 * g;
+                rlo[ks] = *reinterpret_cast<const float4*>(row + min(k0, D - 4));
+                rhi[ks] = *reinterpret_cast<const float4*>(row + min(k0 + 4, D - 4));
+            }
+        };
+        // B fragment: features beyond D read 0, slot D the constant 1.0 (bias fold), rows beyond T all 0
+        auto xconv = [&](int tile, float4 a, float4 c, int ks) -> bf16x8 {
+            const bool tv = tile * 16 + tok < T;
+            const int k0 = 32 * ks + 8 * g;
+            const float4 one = {1.f, 0.f, 0.f, 0.f}, zero = {0.f, 0.f, 0.f, 0.f};
+            if (!(tv && k0 + 4 <= D)) a = (tv && k0 == D) ? one : zero;
+            if (!(tv && k0 + 8 <= D)) c = (tv && k0 + 4 == D) ? one : zero;
+            const u32x4 pk = {cvt_pk_bf16(a.x, a.y), cvt_pk_bf16(a.z, a.w), cvt_pk_bf16(c.x, c.y), cvt_pk_bf16(c.z, c.w)};
+            return __builtin_bit_cast(bf16x8, pk);
+        };
+        float4 cur_lo[KSN], cur_hi[KSN], nxt_lo[KSN], nxt_hi[KSN];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) nxt_lo[ks] = nxt_hi[ks] = float4{0.f, 0.f, 0.f, 0.f};
+        if (wave < KT) xload(wave, cur_lo, cur_hi);
+        for (int kt = wave; kt < (ABL == 2 ? min(KT, NW) : KT); kt += NW) {
+            if (kt + NW < KT) xload(kt + NW, nxt_lo, nxt_hi);
+            f32x4 a = f4zero(), c = f4zero(), qa = f4zero();
+            const bool isq = kt >= qt0 && kt < qt1;        // wave-uniform
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const bf16x8 xf = xconv(kt, cur_lo[ks], cur_hi[ks], ks);
                 a = MFMA(wkf[ks], xf, a);
                 c = MFMA(xf, wvf[ks], c);
+                if (isq) qa = MFMA(wqf[ks], xf, qa);
             }
             *reinterpret_cast<u32x2*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8) = u32x2{cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
             char* dst = vbf + ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16;
-            *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = u32x2{cvt_pk_bf16(c[0], c[1]), cvt_pk_bf16(c[2], c[3])};
+            if (!(kmax_in_v && kt == 0 && lane == 7))          // (that row's first 8 bytes hold kmax)
+                *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = u32x2{cvt_pk_bf16(c[0], c[1]), cvt_pk_bf16(c[2], c[3])};
             if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
+            if (isq)
+                *reinterpret_cast<u32x2*>(qbf + ((size_t)(kt - qt0) * 64 + lane) * 8) = u32x2{cvt_pk_bf16(qa[0], qa[1]), cvt_pk_bf16(qa[2], qa[3])};
             float n2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
             float ea, eb;
             swap16(n2, ea, eb);
             n2 = row_max16(ea + eb);
             if (tok == 0 && (g & 1) == 0)
                 __hip_atomic_fetch_max(&kmax[g >> 1], __builtin_bit_cast(unsigned, n2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                cur_lo[ks] = nxt_lo[ks];
+                cur_hi[ks] = nxt_hi[ks];
+            }
         }
     } else {
-    // K: one thread per (token, lane group gq): the 4 dims 4(gq&1)..+3 of head gq>>1 -> one 8-byte row
+    // K: one thread per (token, lane group gq): the 4 dims 4(gq&1)..+3 of head gq>>1 -> one 8-byte row; dim slot hd
+    // carries the constant 1.0 the fast path's shift rides on (Q gets -bound there)
     for (int i = threadIdx.x; i < NTOK * 4; i += NTH) {
         const int t = i >> 2, gq = i & 3, head = 2 * pair + (gq >> 1);
         float kv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int d = 4 * (gq & 1) + r;
-            kv[r] = (t < T && d < hd && head < H) ? base[(size_t)t * 3 * D + D + head * hd + d] : 0.f;
+            kv[r] = (t < T && head < H) ? (d < hd ? base[(size_t)t * 3 * D + D + head * hd + d] : (d == hd ? 1.0f : 0.f)) : 0.f;
         }
         *reinterpret_cast<u32x2*>(kbf + (size_t)i * 8) = u32x2{cvt_pk_bf16(kv[0], kv[1]), cvt_pk_bf16(kv[2], kv[3])};
-        // |k_t|^2 of head gq>>1: the two threads (gq even / odd) holding a token's halves are lane neighbours
+        // |k_t|^2 of head gq>>1 (incl. the constant slot: the bound only grows): the two threads (gq even / odd) holding a
+        // token's halves are lane neighbours
         float n2 = kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2] + kv[3] * kv[3];
         n2 += __shfl_xor(n2, 1);
         // wave maximum per head (lanes with gq>>1 equal): xor-shuffles over the other lane bits
@@ -193,24 +260,35 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
             if (t < T && head < H) x = (d < hd) ? base[(size_t)t * 3 * D + 2 * D + head * hd + d] : (d == hd ? 1.0f : 0.f);
             vv[e] = x;
         }
-        *reinterpret_cast<u32x4*>(vbf + (size_t)i * 16) = u32x4{cvt_pk_bf16(vv[0], vv[1]), cvt_pk_bf16(vv[2], vv[3]),
-                                                               cvt_pk_bf16(vv[4], vv[5]), cvt_pk_bf16(vv[6], vv[7])};
+        if (kmax_in_v && i == 7)                             // (the row's first 8 bytes hold kmax)
+            *reinterpret_cast<u32x2*>(vbf + (size_t)i * 16 + 8) = u32x2{cvt_pk_bf16(vv[4], vv[5]), cvt_pk_bf16(vv[6], vv[7])};
+        else
+            *reinterpret_cast<u32x4*>(vbf + (size_t)i * 16) = u32x4{cvt_pk_bf16(vv[0], vv[1]), cvt_pk_bf16(vv[2], vv[3]),
+                                                                   cvt_pk_bf16(vv[4], vv[5]), cvt_pk_bf16(vv[6], vv[7])};
     }
-    }
-    __syncthreads();
-    bf16x8 wqf[PROJ ? KS1 : 1];
-    if (PROJ) {
+    // Q of this slice's tiles: lane (tok, gq) of tile qt holds dims 4(gq&1)..+3 of head gq>>1, scaled by log2(e)/sqrt(hd)
+    for (int i = threadIdx.x; i < (qt1 - qt0) * 64; i += NTH) {
+        const int ln = i & 63, tl = i >> 6, t = (qt0 + tl) * 16 + (ln & 15), gq = ln >> 4, head = 2 * pair + (gq >> 1);
+        float qv[4];
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) wqf[ks] = wfrag(wimg.wq, ks);
+        for (int r = 0; r < 4; ++r) {
+            const int d = 4 * (gq & 1) + r;
+            qv[r] = (t < T && d < hd && head < H) ? base[(size_t)t * 3 * D + head * hd + d] * qscale : 0.f;
+        }
+        *reinterpret_cast<u32x2*>(qbf + (size_t)i * 8) = u32x2{cvt_pk_bf16(qv[0], qv[1]), cvt_pk_bf16(qv[2], qv[3])};
     }
+    }
+    ATTN_STAMP(0, tprev);
+    __syncthreads();
+    ATTN_STAMP(1, tprev);
 
     const bool lo_grp = (g >> 1) == 0;
     const int myhead = 2 * pair + (g >> 1);
     f32x4 cmask;                                                     // keys beyond T in the ragged last tile
 #pragma unroll
     for (int r = 0; r < 4; ++r) cmask[r] = ((KT - 1) * 16 + 4 * g + r >= T) ? kNegBig : 0.f;
-    const int DUS = (KT + NQ - 1) / NQ;
-    const int du0 = blockIdx.x * du_per_block, du1 = min(DUS, du0 + du_per_block);
+    auto kfrag = [&](int kt) { return *reinterpret_cast<const s16x4*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8); };
+    auto vfrag = [&](int jb) { return *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(jb * 4 + g) * 16 + tok) * 16); };
     for (int du = du0 + wave; du < du1; du += NW) {
         int qt[NQ];
         bool qv[NQ];
@@ -219,78 +297,200 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
             qv[q] = du * NQ + q < KT;
             qt[q] = qv[q] ? du * NQ + q : du * NQ;
         }
-        // Q^T B operands: lane (query tok, g) holds dims 4(g&1)..+3 of head g>>1, pre-scaled by log2(e)/sqrt(hd)
-        s16x4 qb[NQ][2];
+        // Q^T B operands: lane (query tok, g) holds dims 4(g&1)..+3 of head g>>1 (other head's k-slots zero: the K fragment
+        // then serves both heads unmodified)
+        u32x2 qraw[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int t = qt[q] * 16 + tok;
-            float qvv[4];
-            if (PROJ) {
-                f32x4 qa = f4zero();
-#pragma unroll
-                for (int ks = 0; ks < KS1; ++ks) qa = MFMA(wqf[ks], xfrag(qt[q], ks), qa);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) qvv[r] = qa[r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int d = 4 * (g & 1) + r;
-                    qvv[r] = (t < T && d < hd && myhead < H) ? base[(size_t)t * 3 * D + myhead * hd + d] * qscale : 0.f;
-                }
-            }
-            const unsigned q01 = cvt_pk_bf16(qvv[0], qvv[1]), q23 = cvt_pk_bf16(qvv[2], qvv[3]);
-            const u32x2 qe = {lo_grp ? q01 : 0u, lo_grp ? q23 : 0u};
-            const u32x2 qo = {lo_grp ? 0u : q01, lo_grp ? 0u : q23};
-            qb[q][0] = __builtin_bit_cast(s16x4, qe);
-            qb[q][1] = __builtin_bit_cast(s16x4, qo);
-        }
+        for (int q = 0; q < NQ; ++q) qraw[q] = *reinterpret_cast<const u32x2*>(qbf + ((size_t)(qt[q] - qt0) * 64 + lane) * 8);
+        auto qmasked = [&](int q, int hs) -> s16x4 {
+            const bool mine = lo_grp == (hs == 0);
+            const u32x2 w = {mine ? qraw[q][0] : 0u, mine ? qraw[q][1] : 0u};
+            return __builtin_bit_cast(s16x4, w);
+        };
         // Softmax shift: the bound |q| max_j |k_j| >= max_j q.k_j (2 % headroom for the bf16 rounding) instead of a
         // max pass; any shift cancels in P V / sum P.  A row sum below 2^-100 (bound > max + ~100) sends the unit
         // through the exact two-pass form (see fd_mega.hip, tests/test_gpu_baseline_shapes.py).
         float bq[NQ][2];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            // this lane's 4 dims of head g>>1, already scaled and rounded like the MFMA operand
-            const u32x2 qraw = lo_grp ? __builtin_bit_cast(u32x2, qb[q][0]) : __builtin_bit_cast(u32x2, qb[q][1]);
-            const float q0 = __builtin_bit_cast(float, qraw[0] << 16), q1 = __builtin_bit_cast(float, qraw[0] & 0xffff0000u);
-            const float q2 = __builtin_bit_cast(float, qraw[1] << 16), q3 = __builtin_bit_cast(float, qraw[1] & 0xffff0000u);
+            const float q0 = __builtin_bit_cast(float, qraw[q][0] << 16), q1 = __builtin_bit_cast(float, qraw[q][0] & 0xffff0000u);
+            const float q2 = __builtin_bit_cast(float, qraw[q][1] << 16), q3 = __builtin_bit_cast(float, qraw[q][1] & 0xffff0000u);
             float ea, eb;
             swap16(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3, ea, eb);
             const float k2 = __builtin_bit_cast(float, kmax[g >> 1]);
             swap32(__builtin_sqrtf((ea + eb) * k2) * 1.02f, bq[q][0], bq[q][1]);
         }
+        ATTN_STAMP(2, tprev);
         float m2[NQ][2];
         f32x4 o2[NQ][2];
-        auto run_unit = [&](auto exact_c) {
-        constexpr bool EXACT = decltype(exact_c)::value;
+
+        // ------------------------------------------------------------------ fast path: shift = bound, one pipeline
+        auto run_fast = [&]() {
+            // Q with -bound in k-slot hd of its head: K carries a 1.0 there (bias row of the W_k image / staged constant),
+            // so the shift comes out of the contraction and the MFMA's C operand is an inline 0
+            s16x4 qs[NQ][2];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int hs = 0; hs < 2; ++hs) {
+                    u32x2 w = __builtin_bit_cast(u32x2, qmasked(q, hs));
+                    const unsigned nb = cvt_pk_bf16(-bq[q][hs], 0.f) & 0xffffu;
+                    const bool mine = g == 2 * hs + (hd >> 2);
+                    const int dw = (hd & 3) >> 1;
+                    const unsigned old = dw ? w[1] : w[0];
+                    const unsigned patched = (hd & 1) ? ((old & 0x0000ffffu) | (nb << 16)) : ((old & 0xffff0000u) | nb);
+                    if (dw) w[1] = mine ? patched : old;
+                    else w[0] = mine ? patched : old;
+                    qs[q][hs] = __builtin_bit_cast(s16x4, w);
+                }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int hs = 0; hs < 2; ++hs) o2[q][hs] = f4zero();
+            // Tile order inside a 128-key block: k = ((jj * 2 + hs) * NQ + q) * 2 + jl, key tile 2jj + jl
+            constexpr int NKT = 16 * NQ, LAG = FD_ATTN_LAG, HL = LAG / 2;
+            static_assert(NQ == 2 && LAG % 2 == 0 && LAG >= 2 && LAG <= 4, "pipeline carry assumes pairs of tiles, last group only");
+            bf16x8 vprev;
+            f32x4 cpe[LAG];          // carried over the block boundary: scores of the block's last LAG tiles (before exp2),
+            bf16x8 cpk[HL];          // its packed pairs not yet multiplied, and (vprev) its last V^T fragment
+            const int NFULL = KT >> 3;
+            if (NFULL > 0) {
+                // K / V^T fragments are read from LDS one 32-key group (8 slots, ~400 cycles) ahead of their use: two groups of K
+                // and three of V^T are live at a time instead of a whole block's (the kernel must stay under 128 VGPRs: two
+                // workgroups per CU, so that one stages while the other is in its key loop).  kg / vg = group 0 of the block
+                // about to run.
+                s16x4 kg[2] = {kfrag(0), kfrag(1)};
+                bf16x8 vg = vfrag(0);
+#pragma unroll
+                for (int i = 0; i < LAG; ++i) cpe[i] = f32x4{kNegBig, kNegBig, kNegBig, kNegBig};   // exp2 -> 0: the first block's
+#pragma unroll
+                for (int i = 0; i < HL; ++i) cpk[i] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});   // "previous" tiles add 0
+                vprev = vg;
+                auto body = [&](int fb, int nb) {
+                    s16x4 kk[5][2];          // kk[jj] / vv[jj]: group jj of this block; index 4 = group 0 of block nb
+                    bf16x8 vv[5];
+                    kk[0][0] = kg[0];
+                    kk[0][1] = kg[1];
+                    vv[0] = vg;
+                    f32x4 pe[NKT + LAG];
+                    bf16x8 pk[NKT / 2 + LAG];
+#pragma unroll
+                    for (int i = 0; i < LAG; ++i) pe[i] = cpe[i];
+#pragma unroll
+                    for (int i = 0; i < HL; ++i) pk[i] = cpk[i];
+                    const bf16x8 vold = vprev;
+#pragma unroll
+                    for (int k = 0; k < NKT; ++k) {
+                        if ((k & 7) == 0) {     // group start: issue the next group's reads
+                            const int jn = (k >> 3) + 1;
+                            const int kt = (jn < 4) ? fb * 8 + 2 * jn : nb * 8, jb = (jn < 4) ? fb * 4 + jn : nb * 4;
+                            kk[jn][0] = kfrag(kt);
+                            kk[jn][1] = kfrag(kt + 1);
+                            vv[jn] = vfrag(jb);
+                        }
+                        {   // stage A: scores of tile k
+                            const int jl = k & 1, q = (k >> 1) & 1, hs = (k >> 2) & 1, jj = k >> 3;
+                            pe[LAG + k] = MFMA16(kk[jj][jl], qs[q][hs], f4zero());
+                        }
+                        {   // stage B: exp2 + pack of the tile LAG slots back (array slot k)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) pe[k][r] = __builtin_amdgcn_exp2f(pe[k][r]);
+                            if (k & 1) pk[(k >> 1) + HL] = pack8(pe[k - 1], pe[k]);
+                        }
+                        if (k & 1) {   // stage C: P V of the pair 2 LAG slots back (array slot k >> 1)
+                            const int a = k >> 1, p = a - LAG;            // p < 0: pair 16 + p of the previous block (jj = 3)
+                            const int pp = p < 0 ? 16 + p : p;
+                            const int q = pp & 1, hs = (pp >> 1) & 1, jj = pp >> 2;
+                            o2[q][hs] = MFMA(p < 0 ? vold : vv[jj], pk[a], o2[q][hs]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    vprev = vv[3];
+                    kg[0] = kk[4][0];
+                    kg[1] = kk[4][1];
+                    vg = vv[4];
+#pragma unroll
+                    for (int i = 0; i < LAG; ++i) cpe[i] = pe[NKT + i];
+#pragma unroll
+                    for (int i = 0; i < HL; ++i) cpk[i] = pk[NKT / 2 + i];
+                };
+                int fb = 0;
+                for (; fb + 1 < NFULL; fb += 2) {       // (two blocks per trip: half the register moves at the back edge)
+                    body(fb, fb + 1);
+                    body(fb + 1, min(fb + 2, NFULL - 1));
+                }
+                if (fb < NFULL) body(fb, fb);
+                // drain: the last block's final tiles
+                {
+                    f32x4 pe[LAG];
+                    bf16x8 pk[LAG];
+#pragma unroll
+                    for (int i = 0; i < LAG; ++i) pe[i] = cpe[i];
+#pragma unroll
+                    for (int i = 0; i < HL; ++i) pk[i] = cpk[i];
+#pragma unroll
+                    for (int k = 0; k < LAG; ++k) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pe[k][r] = __builtin_amdgcn_exp2f(pe[k][r]);
+                        if (k & 1) pk[(k >> 1) + HL] = pack8(pe[k - 1], pe[k]);
+                    }
+#pragma unroll
+                    for (int a = 0; a < LAG; ++a) {
+                        const int pp = 16 - LAG + a;
+                        o2[pp & 1][(pp >> 1) & 1] = MFMA(vprev, pk[a], o2[pp & 1][(pp >> 1) & 1]);
+                    }
+                }
+            }
+            // The series' last, partial key block (1-7 tiles): a rolled loop over key-tile PAIRS with a static body.  Keys
+            // beyond T need no mask here: their K rows, V rows and ones-row entries are all 0 (exp2(0) * 0).
+            for (int jb = NFULL * 4; jb < NJ; ++jb) {
+                const int ka = 2 * jb, kb2 = (2 * jb + 1 < KT) ? 2 * jb + 1 : ka;
+                const s16x4 kfa = kfrag(ka), kfb = kfrag(kb2);
+                const bf16x8 vfj = vfrag(jb);           // (a missing odd tile: its V^T half was staged as zeros)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int hs = 0; hs < 2; ++hs) {
+                        f32x4 pa = MFMA16(kfa, qs[q][hs], f4zero());
+                        f32x4 pb = MFMA16(kfb, qs[q][hs], f4zero());
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            pa[r] = __builtin_amdgcn_exp2f(pa[r]);
+                            pb[r] = __builtin_amdgcn_exp2f(pb[r]);
+                        }
+                        o2[q][hs] = MFMA(vfj, pack8(pa, pb), o2[q][hs]);
+                    }
+            }
+        };
+
+        // ------------------------------------------------------------------ exact path: two passes per 128-key block
+        auto run_exact = [&]() {
+        s16x4 qb[NQ][2];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int hs = 0; hs < 2; ++hs) {
-                m2[q][hs] = EXACT ? kNegBig : bq[q][hs];
+                qb[q][hs] = qmasked(q, hs);
+                m2[q][hs] = kNegBig;
                 o2[q][hs] = f4zero();
             }
         // One 128-key block.  FULL (8 key tiles) and LAST (the block holds the series' final, possibly ragged tile) are
         // compile-time: with run-time tile guards every MFMA sits in its own basic block and the hand-made software
         // pipeline below falls apart (measured 3x slower).
-        auto key_block = [&](int kb, auto full_c, auto last_c) {
-            constexpr bool FULL = decltype(full_c)::value, LAST = decltype(last_c)::value;
+        auto key_block = [&](int kb, auto last_c) {
+            constexpr bool LAST = decltype(last_c)::value;
             s16x4 kf[8];
             bf16x8 vf[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (FULL || kb + j < KT) kf[j] = *reinterpret_cast<const s16x4*>(kbf + ((size_t)((kb + j) * 16 + tok) * 4 + g) * 8);
+            for (int j = 0; j < 8; ++j) kf[j] = kfrag(kb + j);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                if (FULL || (kb >> 1) + jj < NJ)
-                    vf[jj] = *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(((kb >> 1) + jj) * 4 + g) * 16 + tok) * 16);
-            const int nk = FULL ? 8 : min(8, KT - kb);
+            for (int jj = 0; jj < 4; ++jj) vf[jj] = vfrag((kb >> 1) + jj);
             constexpr int NKT = 16 * NQ;          // score tiles per block: k = ((hs*4 + jj)*NQ + q)*2 + jl, key tile 2jj+jl
-            // pass 1 (exact path only): row maxima of this key block (software-pipelined by hand, see fd_mega.hip)
+            // pass 1: row maxima of this key block (software-pipelined by hand, see fd_mega.hip)
             float bm[NQ][2];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) bm[q][0] = bm[q][1] = kNegBig;
-            if (EXACT) {
+            {
                 constexpr int LAG = 3;
                 f32x4 t4[NKT];
 #pragma unroll
@@ -298,18 +498,16 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
                     if (k < NKT) {
                         const int jl = k & 1, q = (k >> 1) % NQ, jj = ((k >> 1) / NQ) & 3, hs = (k >> 1) / NQ >> 2;
                         const int j = 2 * jj + jl;
-                        if (j < nk) t4[k] = MFMA16(kf[j], qb[q][hs], (LAST && kb + j == KT - 1) ? cmask : f4zero());
+                        t4[k] = MFMA16(kf[j], qb[q][hs], (LAST && j == 7) ? cmask : f4zero());
                     }
                     if (k >= LAG) {
                         const int e = k - LAG;
-                        const int jl = e & 1, q = (e >> 1) % NQ, jj = ((e >> 1) / NQ) & 3, hs = (e >> 1) / NQ >> 2;
-                        if (2 * jj + jl < nk) {
-                            const f32x4 v = t4[e];
-                            float bb = bm[q][hs];
-                            bb = fmaxf(fmaxf(bb, v[0]), v[1]);
-                            bb = fmaxf(fmaxf(bb, v[2]), v[3]);
-                            bm[q][hs] = bb;
-                        }
+                        const int q = (e >> 1) % NQ, hs = (e >> 1) / NQ >> 2;
+                        const f32x4 v = t4[e];
+                        float bb = bm[q][hs];
+                        bb = fmaxf(fmaxf(bb, v[0]), v[1]);
+                        bb = fmaxf(fmaxf(bb, v[2]), v[3]);
+                        bm[q][hs] = bb;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -319,17 +517,14 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int hs = 0; hs < 2; ++hs) {
-                    float mnew = m2[q][hs];
-                    if (EXACT) {
-                        mnew = fmaxf(m2[q][hs], group_max(bm[q][hs]));
-                        const float alpha = __builtin_amdgcn_exp2f(m2[q][hs] - mnew);
-                        o2[q][hs] = o2[q][hs] * alpha;
-                        m2[q][hs] = mnew;
-                    }
+                    const float mnew = fmaxf(m2[q][hs], group_max(bm[q][hs]));
+                    const float alpha = __builtin_amdgcn_exp2f(m2[q][hs] - mnew);
+                    o2[q][hs] = o2[q][hs] * alpha;
+                    m2[q][hs] = mnew;
                     negm[q][hs] = f32x4{-mnew, -mnew, -mnew, -mnew};
                     clast[q][hs] = cmask - mnew;
                 }
-            // pass 2: P = exp2(S - max), packed to bf16 B fragments, then P V
+            // pass 2: P = exp2(S - max) (-max rides in the MFMA's C operand), packed to bf16 B fragments, then P V
             {
                 constexpr int LAG = 2;
                 f32x4 pe[NKT];
@@ -339,22 +534,18 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
                     if (k < NKT) {
                         const int jl = k & 1, q = (k >> 1) % NQ, jj = ((k >> 1) / NQ) & 3, hs = (k >> 1) / NQ >> 2;
                         const int j = 2 * jj + jl;
-                        if (j < nk) pe[k] = MFMA16(kf[j], qb[q][hs], (LAST && kb + j == KT - 1) ? clast[q][hs] : negm[q][hs]);
-                        else pe[k] = f4zero();
+                        pe[k] = MFMA16(kf[j], qb[q][hs], (LAST && j == 7) ? clast[q][hs] : negm[q][hs]);
                     }
                     if (k >= LAG && k - LAG < NKT) {
                         const int e = k - LAG;
-                        const int jl = e & 1, jj = ((e >> 1) / NQ) & 3;
-                        if (2 * jj + jl < nk) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) pe[e][r] = __builtin_amdgcn_exp2f(pe[e][r]);
-                        }
-                        if (jl) pk[e >> 1] = pack8(pe[e - 1], pe[e]);
+                        for (int r = 0; r < 4; ++r) pe[e][r] = __builtin_amdgcn_exp2f(pe[e][r]);
+                        if (e & 1) pk[e >> 1] = pack8(pe[e - 1], pe[e]);
                     }
                     if (k >= 2 * LAG && ((k - 2 * LAG) & 1)) {
                         const int e = k - 2 * LAG;
                         const int q = (e >> 1) % NQ, jj = ((e >> 1) / NQ) & 3, hs = (e >> 1) / NQ >> 2;
-                        if (2 * jj < nk) o2[q][hs] = MFMA(vf[jj], pk[e >> 1], o2[q][hs]);
+                        o2[q][hs] = MFMA(vf[jj], pk[e >> 1], o2[q][hs]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -365,41 +556,35 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
         // unrolled pipeline -- same finding as in fd_mega.hip's run-time-shape path.
         auto ragged_block = [&](int kb) {
             const f32x4 allneg = {kNegBig, kNegBig, kNegBig, kNegBig};
-            auto kfrag = [&](int kt) { return *reinterpret_cast<const s16x4*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8); };
             f32x4 negm[NQ][2];
-            if (EXACT) {
-                float bm[NQ][2];
+            float bm[NQ][2];
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) bm[q][0] = bm[q][1] = kNegBig;
-                for (int kt = kb; kt < KT; ++kt) {
-                    const s16x4 kfa = kfrag(kt);
-                    const f32x4 ca = (kt == KT - 1) ? cmask : f4zero();
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                        for (int hs = 0; hs < 2; ++hs) {
-                            const f32x4 v = MFMA16(kfa, qb[q][hs], ca);
-                            bm[q][hs] = fmaxf(fmaxf(fmaxf(bm[q][hs], v[0]), v[1]), fmaxf(v[2], v[3]));
-                        }
-                }
+            for (int q = 0; q < NQ; ++q) bm[q][0] = bm[q][1] = kNegBig;
+            for (int kt = kb; kt < KT; ++kt) {
+                const s16x4 kfa = kfrag(kt);
+                const f32x4 ca = (kt == KT - 1) ? cmask : f4zero();
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
 #pragma unroll
                     for (int hs = 0; hs < 2; ++hs) {
-                        const float mnew = fmaxf(m2[q][hs], group_max(bm[q][hs]));
-                        const float alpha = __builtin_amdgcn_exp2f(m2[q][hs] - mnew);
-                        o2[q][hs] = o2[q][hs] * alpha;
-                        m2[q][hs] = mnew;
+                        const f32x4 v = MFMA16(kfa, qb[q][hs], ca);
+                        bm[q][hs] = fmaxf(fmaxf(fmaxf(bm[q][hs], v[0]), v[1]), fmaxf(v[2], v[3]));
                     }
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int hs = 0; hs < 2; ++hs) negm[q][hs] = f32x4{-m2[q][hs], -m2[q][hs], -m2[q][hs], -m2[q][hs]};
+                for (int hs = 0; hs < 2; ++hs) {
+                    const float mnew = fmaxf(m2[q][hs], group_max(bm[q][hs]));
+                    const float alpha = __builtin_amdgcn_exp2f(m2[q][hs] - mnew);
+                    o2[q][hs] = o2[q][hs] * alpha;
+                    m2[q][hs] = mnew;
+                    negm[q][hs] = f32x4{-mnew, -mnew, -mnew, -mnew};
+                }
             for (int jb = kb >> 1; jb < NJ; ++jb) {
                 const int ka = 2 * jb, kb2 = (2 * jb + 1 < KT) ? 2 * jb + 1 : ka;
                 const s16x4 kfa = kfrag(ka), kfb = kfrag(kb2);
-                const bf16x8 vfj = *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(jb * 4 + g) * 16 + tok) * 16);
+                const bf16x8 vfj = vfrag(jb);
                 const f32x4 ma = (ka == KT - 1) ? cmask : f4zero();
                 const f32x4 mb = (2 * jb + 1 >= KT) ? allneg : ((kb2 == KT - 1) ? cmask : f4zero());
 #pragma unroll
@@ -419,8 +604,8 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
         };
         {
             int kb = 0;
-            for (; kb + 8 < KT; kb += 8) key_block(kb, std::true_type{}, std::false_type{});
-            if (kb + 8 == KT) key_block(kb, std::true_type{}, std::true_type{});
+            for (; kb + 8 < KT; kb += 8) key_block(kb, std::false_type{});
+            if (kb + 8 == KT) key_block(kb, std::true_type{});
             else ragged_block(kb);
         }
         };
@@ -441,15 +626,16 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
             return bad;
         };
         if (exact_only) {
-            run_unit(std::true_type{});
+            run_exact();
             (void)row_sums();
         } else {
-            run_unit(std::false_type{});
-            if (__builtin_amdgcn_ballot_w64(row_sums()) != 0ull) {
-                run_unit(std::true_type{});
+            run_fast();
+            if (__builtin_amdgcn_ballot_w64(row_sums()) != 0ull && ABL != 2) {
+                run_exact();
                 (void)row_sums();
             }
         }
+        ATTN_STAMP(3, tprev);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             float o_sel[4];
@@ -465,6 +651,7 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
                 }
             }
         }
+        ATTN_STAMP(4, tprev);
     }
 }
 
@@ -477,33 +664,56 @@ __global__ __launch_bounds__(NTH, 2) void k_attention_bf16(const float* __restri
 int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, int H, int hd, hipStream_t s, const char* wk,
                       const char* wv, const char* wq, int ks1) {
     const int KT = (T + 15) / 16, NJ = (KT + 1) / 2, D = H * hd;
-    const size_t lds = (size_t)KT * 16 * 32 + (size_t)NJ * 1024 + 16;
-    if (hd > 7 || lds > 160 * 1024) return FD_ERR_UNSUPPORTED;
+    const size_t lds_kv = (size_t)KT * 16 * 32 + (size_t)NJ * 1024 + (hd == 7 ? 16 : 0);
+    if (hd > 7 || lds_kv + NQ * 512 > 160 * 1024) return FD_ERR_UNSUPPORTED;
     const bool proj = wk != nullptr;
-    if (proj && ks1 != 3 && ks1 != 2) return FD_ERR_UNSUPPORTED;
+    if (proj && ((ks1 != 3 && ks1 != 2) || (D & 3))) return FD_ERR_UNSUPPORTED;   // (raw x rows are read as float4)
     const void* kern = proj ? (ks1 == 3 ? (const void*)k_attention_bf16<3> : (const void*)k_attention_bf16<2>)
                             : (const void*)k_attention_bf16<0>;
     FD_HIP(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int NP = (H + 1) / 2, DUS = (KT + NQ - 1) / NQ;
-    // Query slices per (series, pair): every slice restages K/V (~10 % of a full slice's work); pick the count that
-    // minimises rounds x work per round (one workgroup per CU: 8 waves at the 256-VGPR budget).
-    int slices = 1;
+    // Query slices per (series, pair): every slice restages K/V (~16 % of a full slice's work) and keeps its own Q tiles in
+    // LDS (512 B per tile); pick the count that minimises rounds x work per round among those that fit (two workgroups per
+    // CU when one needs <= 80 KiB).
+    static const int force_slices = getenv("FDIFF_ATTN_SLICES") ? atoi(getenv("FDIFF_ATTN_SLICES")) : 0;
+    int slices = 0;
     double best = 1e30;
-    for (int sl = 1; sl <= 8; sl *= 2) {
-        if (sl > 1 && DUS / sl < NW) break;                  // at least one unit per wave
+    auto fits = [&](int sl) { return lds_kv + (size_t)((DUS + sl - 1) / sl) * NQ * 512 <= 160 * 1024; };
+    for (int sl = 1; sl <= 16 && (sl == 1 || sl <= DUS); sl *= 2) {
+        if (!fits(sl)) continue;
+        if (slices && DUS / sl < NW) break;                  // at least one unit per wave, unless nothing coarser fits
+        // time of a slice's workgroup ~ staging (the whole series: 0.3 of a full key loop, measured at T = 1024) + its share
+        // of the key loop; workgroups that fit twice on a CU (<= 80 KiB, 128 VGPRs) overlap by ~12 % only, so the model
+        // counts CU slots as one workgroup each
         const double rounds = (double)(((size_t)B * NP * sl + ctx->num_cu - 1) / ctx->num_cu);
-        const double cost = rounds * (1.0 / sl + 0.1);
+        const double cost = rounds * (1.0 / sl + 0.3);
         if (cost < best - 1e-9) { best = cost; slices = sl; }
     }
+    if (force_slices > 0 && force_slices <= DUS && fits(force_slices)) slices = force_slices;
+    if (!slices) return FD_ERR_UNSUPPORTED;
     const int du_per_block = (DUS + slices - 1) / slices;
+    const size_t lds = lds_kv + (size_t)du_per_block * NQ * 512;
     const float qscale = 1.4426950408889634f / sqrtf((float)hd);
     const int exact = getenv("FDIFF_ATTN_EXACT") ? 1 : 0;
     const fd_attn_w w{wk, wv, wq};
     const size_t pair_stride = (size_t)ks1 * 1024;
-    const dim3 grid(slices, NP, B), block(NTH);
-    if (!proj) hipLaunchKernelGGL(k_attention_bf16<0>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride);
-    else if (ks1 == 3) hipLaunchKernelGGL(k_attention_bf16<3>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride);
-    else hipLaunchKernelGGL(k_attention_bf16<2>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride);
+    const dim3 grid((unsigned)(((B + 7) / 8) * 8 * NP * slices)), block(NTH);
+    if (!proj) hipLaunchKernelGGL(k_attention_bf16<0>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B);
+    else if (ks1 == 3) hipLaunchKernelGGL(k_attention_bf16<3>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B);
+    else hipLaunchKernelGGL(k_attention_bf16<2>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B);
     FD_LAUNCH_CHECK(ctx);
+#if defined(FD_ATTN_ABL) && FD_ATTN_ABL == 3
+    {
+        static int calls = 0;
+        if (++calls == 30) {
+            unsigned long long h[64];
+            hipStreamSynchronize(s);
+            hipMemcpyFromSymbol(h, HIP_SYMBOL(fd_attn_dbg), sizeof(h));
+            for (int w = 0; w < 8; ++w)
+                fprintf(stderr, "[attn dbg] wave %d over %d launches: staging %llu, barrier %llu, q-setup %llu, key blocks %llu, epilogue %llu cycles (100 MHz ticks?)\n",
+                        w, calls, h[w * 8 + 0] / calls, h[w * 8 + 1] / calls, h[w * 8 + 2] / calls, h[w * 8 + 3] / calls, h[w * 8 + 4] / calls);
+        }
+    }
+#endif
     return FD_OK;
 }

@@ -560,7 +560,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             const float part = qa[q][0] * qa[q][0] + qa[q][1] * qa[q][1] + qa[q][2] * qa[q][2] + qa[q][3] * qa[q][3];
                             float ea, eb;
                             swap16(part, ea, eb);                     // the two lane groups of a head
-                            const float bnd = __builtin_sqrtf((ea + eb) * k2) * 1.02f;
+                            const float bnd = __builtin_amdgcn_sqrtf((ea + eb) * k2) * 1.02f;   // (v_sqrt_f32, 1 ulp: the 2 % headroom covers it; the IEEE form is 15 instructions)
                             swap32(bnd, bq[q][0], bq[q][1]);          // head 0 bound | head 1 bound, in every lane
                         }
                     }
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         float o_sel[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o_sel[r] = lo_grp ? o2[q][0][r] : o2[q][1][r];
-                        const float inv = 1.0f / lrow[q];
+                        const float inv = __builtin_amdgcn_rcpf(lrow[q]);    // (v_rcp_f32, 1 ulp, instead of the 10-instruction IEEE division: the result is rounded to bf16)
                         // head = 2*(pg+pr) + (g>>1); its 8 dims are one 16-B k-slot group of the out-proj B fragment
                         const int head = 2 * (pg + pr) + (g >> 1);
                         u32x2 pk = {cvt_pk_bf16(o_sel[0] * inv, o_sel[1] * inv), cvt_pk_bf16(o_sel[2] * inv, o_sel[3] * inv)};

@@ -8,14 +8,18 @@ from fourierdiffusion_amd.schedulers.sde import VPScheduler
 
 
 def timed(fn, n=20):
+    """Median over n calls of the event-bracketed device time (a mean over host wall time picks up the caching allocator's
+    occasional hipMalloc: one 70-90 ms stall in 20 calls, seen at a different row in every run)."""
     for _ in range(3):          # (the first call of a kernel variant loads its code object: several ms)
         fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    ts.sort()
+    return ts[n // 2]
 
 
 for (B, T, C) in [(512, 100, 12), (4096, 256, 28), (512, 1024, 16), (4096, 252, 6), (87554, 187, 1), (65536, 256, 1), (4096, 187, 12), (4096, 365, 8), (4096, 143, 12), (4096, 253, 8)]:
