@@ -675,7 +675,8 @@ int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, in
     // Query slices per (series, pair): every slice restages K/V (~16 % of a full slice's work) and keeps its own Q tiles in
     // LDS (512 B per tile); pick the count that minimises rounds x work per round among those that fit (two workgroups per
     // CU when one needs <= 80 KiB).
-    static const int force_slices = getenv("FDIFF_ATTN_SLICES") ? atoi(getenv("FDIFF_ATTN_SLICES")) : 0;
+    const char* fs_env = getenv("FDIFF_ATTN_SLICES");        // (tests: force the query-slice count)
+    const int force_slices = fs_env ? atoi(fs_env) : 0;
     int slices = 0;
     double best = 1e30;
     auto fits = [&](int sl) { return lds_kv + (size_t)((DUS + sl - 1) / sl) * NQ * 512 <= 160 * 1024; };

@@ -13,11 +13,11 @@ def timed(fn, n=20):
     for _ in range(3):          # (the first call of a kernel variant loads its code object: several ms)
         fn()
     torch.cuda.synchronize()
-    ts = []
-    for _ in range(n):
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); e1.synchronize()
-        ts.append(e0.elapsed_time(e1) * 1e-3)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for e0, e1 in ev:           # back to back (no host sync in between): the events bracket the kernel on the device time line
+        e0.record(); fn(); e1.record()
+    torch.cuda.synchronize()
+    ts = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev]
     ts.sort()
     return ts[n // 2]
 

@@ -184,3 +184,44 @@ def test_softmax_shift_fallback_equals_exact_path():
         outs[scale] = (fast, exact)
         np.testing.assert_allclose(fast, exact, atol=2e-3 * np.abs(exact).max(), rtol=0)
     assert np.abs(outs[40.0][1] - outs[1.0][1]).max() > 1e-2, "scaled projection must change the output"
+
+
+ATTN_SHAPES = {
+    # long-series attention kernel (fd_attn_bf16.hip): full 128-key blocks + ragged tail (T=365: 23 key tiles), odd tile count,
+    # head_dim 5 and 7 (7: the ones row sits in V^T's last slot, max|k|^2 words move out of it), d_model 56 = two k-steps
+    "drought": dict(T=365, C=1, D=72, L=2, H=12),
+    "hd5": dict(T=400, C=7, D=60, L=2, H=12),
+    "hd7_ks2": dict(T=300, C=3, D=56, L=2, H=8),
+    "blocks_only": dict(T=512, C=2, D=72, L=1, H=12),
+}
+
+
+@pytest.mark.parametrize("env", [{}, {"FDIFF_ATTN_UNFUSED": "1"}, {"FDIFF_ATTN_SLICES": "4"}, {"FDIFF_ATTN_SLICES": "1"},
+                                 {"FDIFF_ATTN_EXACT": "1"}, {"FDIFF_ATTN_UNFUSED": "1", "FDIFF_ATTN_SLICES": "2"}],
+                         ids=lambda e: ",".join(f"{k[6:]}={v}" for k, v in e.items()) or "default")
+@pytest.mark.parametrize("name", sorted(ATTN_SHAPES))
+def test_layer_attention_kernel_variants(name, env):
+    """Every instantiation / launch shape of k_attention_bf16 against the oracle: projections fused (the persistent kernel's
+    weight images) or packed q|k|v input (FDIFF_ATTN_UNFUSED), 1 / 2 / 4 query slices per (series, head pair), the exact two-pass
+    softmax, and the bound-shifted fast path (default)."""
+    cfg = ATTN_SHAPES[name]
+    B = 2
+    saved = {k: os.environ.get(k) for k in ("FDIFF_ATTN_UNFUSED", "FDIFF_ATTN_SLICES", "FDIFF_ATTN_EXACT")}
+    try:
+        for k in saved:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        m, _, sd = make_model(cfg, precision="bf16")
+        assert "per-layer" in m.plan(B)[0], m.plan(B)
+        X = W.randn(f"at_x_{name}", (B, cfg["T"], cfg["C"]), 2)
+        t = W.uniform(f"at_t_{name}", (B,), 2, 1e-5, 1.0)
+        out = run(m, X, t)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    ref = O.score_forward(sd, X, t, cfg["H"])
+    err, rms = report_err(f"forward bf16 layer-attention {name} {env}", out, ref)
+    assert err <= 2e-2 and rms <= 1e-2, (err, rms)
