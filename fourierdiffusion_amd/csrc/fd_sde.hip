@@ -86,7 +86,8 @@ __global__ __launch_bounds__(kBlock) void k_sde_step(const float* __restrict__ G
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const size_t ei = e + i;
-            const int t = (int)((ei / (size_t)C) % (size_t)T);
+            // (64-bit integer division is ~100 instructions: below 2^32 elements the 32-bit form, wave-uniform choice)
+            const int t = (n >> 32) ? (int)((ei / (size_t)C) % (size_t)T) : (int)(((unsigned)ei / (unsigned)C) % (unsigned)T);
             o[i] = fd_sde_apply(xs[i], ss[i], z[i], G[t], cf);
         }
         st4(out, e, n, float4{o[0], o[1], o[2], o[3]});
