@@ -534,15 +534,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     // S^T tiles contract over 16 k-slots (8 dims x 2 heads): the K=16 MFMA takes the 8-byte K rows
                     // as they lie in LDS (no zero-padded upper half to materialise)
                     const bool lo_grp = (g >> 1) == 0;
-                    s16x4 qb[NQ][2];
+                    u32x2 qraw[NQ];          // this lane's 4 dims of its own head (head g>>1), bf16
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        const unsigned q01 = cvt_pk_bf16(qa[q][0], qa[q][1]), q23 = cvt_pk_bf16(qa[q][2], qa[q][3]);
-                        const u32x2 qe = {lo_grp ? q01 : 0u, lo_grp ? q23 : 0u};
-                        const u32x2 qo = {lo_grp ? 0u : q01, lo_grp ? 0u : q23};
-                        qb[q][0] = __builtin_bit_cast(s16x4, qe);
-                        qb[q][1] = __builtin_bit_cast(s16x4, qo);
-                    }
+                    for (int q = 0; q < NQ; ++q) qraw[q] = u32x2{cvt_pk_bf16(qa[q][0], qa[q][1]), cvt_pk_bf16(qa[q][2], qa[q][3])};
+                    auto qmasked = [&](int q, int hs) -> s16x4 {      // head hs's operand: the other head's lane groups zeroed
+                        const bool mine = lo_grp == (hs == 0);
+                        const u32x2 w = {mine ? qraw[q][0] : 0u, mine ? qraw[q][1] : 0u};
+                        return __builtin_bit_cast(s16x4, w);
+                    };
                     // keys beyond T in the ragged last tile: masked through the MFMA's C operand
                     f32x4 cmask;
 #pragma unroll
@@ -552,42 +551,43 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     // as nothing overflows (bound >= max) or flushes to zero; P keeps the fp32 exponent range in bf16.
                     // If a row sum comes out below 2^-100 (bound > max + ~100: not seen with real weights) the unit is
                     // redone with the exact two-pass maximum.
-                    float bq[NQ][2];
+                    // Q with -bound in k-slot hd of its head: lane group 2hs + (hd >> 2), element hd & 3.  Every lane patches
+                    // its OWN head's bound into its own words first (one convert + merge per query tile), the per-head
+                    // operands are then two masked copies: 14 VALU instructions fewer per unit than masking first and
+                    // patching each copy, and only the 4 raw words stay live for the exact path.
+                    s16x4 qs[NQ][2];
                     {
                         const float k2 = reinterpret_cast<const float*>(kmax)[(pr * S + ser) * 2 + (g >> 1)];
+                        const bool slot_here = (g & 1) == (hd >> 2);
+                        const int dw = (hd & 3) >> 1;
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) {
                             const float part = qa[q][0] * qa[q][0] + qa[q][1] * qa[q][1] + qa[q][2] * qa[q][2] + qa[q][3] * qa[q][3];
                             float ea, eb;
                             swap16(part, ea, eb);                     // the two lane groups of a head
                             const float bnd = __builtin_amdgcn_sqrtf((ea + eb) * k2) * 1.02f;   // (v_sqrt_f32, 1 ulp: the 2 % headroom covers it; the IEEE form is 15 instructions)
-                            swap32(bnd, bq[q][0], bq[q][1]);          // head 0 bound | head 1 bound, in every lane
+                            const unsigned nb = cvt_pk_bf16(-bnd, 0.f) & 0xffffu;
+                            const unsigned old = dw ? qraw[q][1] : qraw[q][0];
+                            const unsigned patched = (hd & 1) ? ((old & 0x0000ffffu) | (nb << 16)) : ((old & 0xffff0000u) | nb);
+                            const unsigned neww = slot_here ? patched : old;
+                            const unsigned w0 = dw ? qraw[q][0] : neww, w1 = dw ? neww : qraw[q][1];
+                            const u32x2 qe = {lo_grp ? w0 : 0u, lo_grp ? w1 : 0u};
+                            const u32x2 qo = {lo_grp ? 0u : w0, lo_grp ? 0u : w1};
+                            qs[q][0] = __builtin_bit_cast(s16x4, qe);
+                            qs[q][1] = __builtin_bit_cast(s16x4, qo);
                         }
                     }
-                    // Q with -bound in k-slot hd of its head (fast path): lane group 2hs + (hd >> 2), element hd & 3
-                    s16x4 qs[NQ][2];
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                        for (int hs = 0; hs < 2; ++hs) {
-                            u32x2 w = __builtin_bit_cast(u32x2, qb[q][hs]);
-                            const unsigned nb = cvt_pk_bf16(-bq[q][hs], 0.f) & 0xffffu;
-                            const bool mine = g == 2 * hs + (hd >> 2);
-                            const int dw = (hd & 3) >> 1;
-                            const unsigned old = w[dw];
-                            const unsigned patched = (hd & 1) ? ((old & 0x0000ffffu) | (nb << 16)) : ((old & 0xffff0000u) | nb);
-                            w[dw] = mine ? patched : old;
-                            qs[q][hs] = __builtin_bit_cast(s16x4, w);
-                        }
                     float m2[NQ][2];
                     f32x4 o2[NQ][2];
                     auto run_unit = [&](auto exact_c) {
                     constexpr bool EXACT = decltype(exact_c)::value;
+                    s16x4 qb[NQ][2];         // unpatched operands: exact path only
 #pragma unroll
                     for (int q = 0; q < NQ; ++q)
 #pragma unroll
                         for (int hs = 0; hs < 2; ++hs) {
-                            m2[q][hs] = EXACT ? kNegBig : bq[q][hs];
+                            if (EXACT) qb[q][hs] = qmasked(q, hs);
+                            m2[q][hs] = kNegBig;
                             o2[q][hs] = f4zero();
                         }
                     if (SH::KT == 0 || FD_ROLLED_ATTN) {
