@@ -54,6 +54,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #ifndef FD_NO_PROF
 #define FD_NO_PROF 0
 #endif
+#ifndef FD_STATIC_UNITS
+#define FD_STATIC_UNITS 1
+#endif
 #ifndef FD_PROF_UNITS
 #define FD_PROF_UNITS 0
 #endif
@@ -273,7 +276,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
             if (16 * dt + 4 * g < D) s += (v[dt][0] + v[dt][1]) + (v[dt][2] + v[dt][3]);
-        const float mean = group_sum(s) / (float)D;
+        const float invD = 1.0f / (float)D;          // (a multiply instead of two IEEE divisions per call)
+        const float mean = group_sum(s) * invD;
         float q = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     q += c * c;
                 }
             }
-        const float rstd = rsqrtf(group_sum(q) / (float)D + 1e-5f);
+        const float rstd = __builtin_amdgcn_rsqf(group_sum(q) * invD + 1e-5f);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d0 = 16 * dt + 4 * g;
@@ -815,11 +819,18 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                 {
                     const int DF = KT >> 1;                            // two-tile units per (pair, series)
                     const int ND = npg * S * DF, NU = ND + ((KT & 1) ? npg * S : 0);
+#if FD_STATIC_UNITS
+                    // Static hand-out: wave w runs units w, w + NW, ...  (The dynamic LDS counter balanced the per-wave times
+                    // but never changed the phase time -- a wave left alone on its SIMD runs at nearly the throughput of two --
+                    // and cost an LDS atomic round trip, ~12 VALU instructions and a wait for the weight prefetch per unit.)
+                    for (int u = wave; u < NU; u += NW) {
+#else
                     for (;;) {
                         int u = 0;
                         if (lane == 0) u = (int)__hip_atomic_fetch_add(ucnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         u = __builtin_amdgcn_readfirstlane(u);
                         if (u >= NU) break;
+#endif
                         if (u < ND) {
                             const int pr = u / (S * DF), ur = u - pr * (S * DF);
                             const int ser = ur / DF, du = ur - ser * DF;
