@@ -42,6 +42,8 @@ struct fd_mega_params {
     const char* img_layers;
     size_t layer_stride;
     size_t off_wk, off_wv, off_wq, off_wo, off_ffn;
+    size_t off_lpar;                     // fp32 block [6][D] (bo, b2, g1, b1, g2, b2) of the layer, nlp KiB: fetched by DMA
+    int nlp;
     // sampler
     const float* G;
     const fd_sde_step_coef* steps;       // device array [nsteps]

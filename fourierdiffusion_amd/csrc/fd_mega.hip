@@ -224,8 +224,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
     char* const afr = smem + P.lds_afr;                       // [NTILE][KSO][64][16 B]  attention-output fragments
     char* const ring = wsl;                                   // FFN weight ring + exchange alias W/K/V(/afr)
     float* const temb = reinterpret_cast<float*>(smem + P.lds_temb);   // [S][D] + emb scratch [S][D]
-    float* const lpar = temb + 2 * S * D;                              // [6][D] bo, b2, g1, b1, g2, b2 of the layer
-    unsigned* const kmax2 = reinterpret_cast<unsigned*>(lpar + 6 * D); // [2 parities][NPG][S][2] max_j |k_j|^2 per head (bits)
+    float* const lpar = temb + ((2 * S * D + 3) & ~3);                 // [6][D] bo, b2, g1, b1, g2, b2 of the layer (nlp KiB by DMA)
+    unsigned* const kmax2 = reinterpret_cast<unsigned*>(lpar + P.nlp * 256); // [2 parities][NPG][S][2] max_j |k_j|^2 per head (bits)
     unsigned* const ucnt = kmax2 + 4 * NPG * S;                        // next attention unit of the group (dynamic hand-out)
 
     // ---- token-tile ownership (same split as the FFN: quarters mq, F-halves fh; fh waves rotated)
@@ -429,13 +429,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
         for (int l = 0; l < SHP(L); ++l) {
             const char* limg = layer_ptr(l);
             refresh_lane();
-            if (wave == NW - 1) {   // small fp32 vectors of this layer -> LDS (first read after several barriers)
-                const fd_mega_layer_f32 lp = P.layers[l];
-                const long long offs[6] = {lp.out_b, lp.l2_b, lp.n1_w, lp.n1_b, lp.n2_w, lp.n2_b};
-#pragma unroll
-                for (int v = 0; v < 6; ++v)
-                    for (int d = lane; d < D; d += 64) lpar[v * D + d] = P.params[offs[v] + d];
-            }
+            // (the small fp32 vectors of the layer ride in the layer image and arrive with the first group's weight DMA below.
+            //  One wave loading them -- offset table, then the vectors, then its share of the weight DMA: three dependent
+            //  round trips in front of the layer's first barrier -- was most of a phase that took 8.6 K cycles per layer.)
 
             // -------- attention, one group of head pairs at a time
             for (int pg = 0; pg < NP; pg += NPG) {
@@ -453,6 +449,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     dma_blocks(limg + P.off_wk, wk, npg * KS1);
                     dma_blocks(limg + P.off_wv, wv, npg * KS1);
                     dma_blocks(limg + P.off_wq, wq, npg * KS1);
+                    dma_blocks(limg + P.off_lpar, reinterpret_cast<char*>(lpar), P.nlp);
                     for (int i = threadIdx.x; i < NPG * S * 2; i += NTH) kmax[i] = 0u;
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();

@@ -178,11 +178,11 @@ __device__ void build_win_block(const float* __restrict__ Win, __bf16* __restric
 struct fd_img_build {
     const float* P;
     const long long* lofs;     // [L][12] fd_layer_off
-    char* mimg; size_t off_layers, layer_stride, off_wk, off_wv, off_wq, off_wo, off_ffn;
+    char* mimg; size_t off_layers, layer_stride, off_wk, off_wv, off_wq, off_wo, off_ffn, off_lpar;
     char* ffn; size_t ffn_layer_bytes;
     char* bimg; size_t b_layer_stride, boff_ffn, boff_wot, boff_win;
     int D, F, H, hd, KS1, DT, KSO, NP;
-    int n_qkv, n_wo, n_ffn, n_wot, n_win;   // block counts per layer (n_qkv = NP*KS1 per matrix)
+    int n_qkv, n_wo, n_ffn, n_wot, n_win, n_lp;   // block counts per layer (n_qkv = NP*KS1 per matrix)
     int mega, train;
     float qscale;
 };
@@ -209,6 +209,18 @@ __global__ __launch_bounds__(64) void k_build_layer_images(const fd_img_build B)
     blk -= B.n_wo;
     if (blk < B.n_ffn) { build_ffn_block(P + lo[4], P + lo[5], P + lo[6], (__bf16*)(limg + B.off_ffn), B.D, B.F, B.KS1, B.DT, 1, blk, lane); return; }
     blk -= B.n_ffn;
+    if (blk < B.n_lp) {   // the layer's small fp32 vectors as one DMA-able block: [6][D] out_b, l2_b, n1_w, n1_b, n2_w, n2_b
+        const int vsel[6] = {3, 7, 8, 9, 10, 11};
+        float4 v;
+        float* ve = reinterpret_cast<float*>(&v);
+        for (int e = 0; e < 4; ++e) {
+            const int i = (blk * 64 + lane) * 4 + e, vi = i / B.D, d = i - vi * B.D;
+            ve[e] = (vi < 6) ? P[lo[vsel[vi]] + d] : 0.f;
+        }
+        *reinterpret_cast<float4*>(limg + B.off_lpar + ((size_t)blk * 64 + lane) * 16) = v;
+        return;
+    }
+    blk -= B.n_lp;
     if (!B.train) return;
     char* bl = B.bimg + (size_t)l * B.b_layer_stride;
     if (blk < B.n_ffn) { build_ffn_bwd_block(P + lo[4], P + lo[6], (__bf16*)(bl + B.boff_ffn), B.D, B.F, B.KS1, B.DT, blk, lane); return; }
@@ -680,7 +692,9 @@ int fd_bf16_create(fd_score* m) {
         im->off_wq = im->off_wv + (size_t)im->np * im->ks1 * KB;
         im->off_wo = im->off_wq + (size_t)im->np * im->ks1 * KB;
         im->off_ffn = im->off_wo + (size_t)im->dt * im->kso * KB;
-        im->layer_stride = im->off_ffn + im->ffn_layer_bytes;
+        im->off_lpar = im->off_ffn + im->ffn_layer_bytes;
+        im->nlp = (24 * D + 1023) / 1024;
+        im->layer_stride = im->off_lpar + (size_t)im->nlp * KB;
         const size_t total = im->off_layers + im->layer_stride * L;
         if (hipMalloc((void**)&im->mimg, total) != hipSuccess ||
             hipMalloc((void**)&im->layer_tab, sizeof(fd_mega_layer_f32) * L) != hipSuccess) {
@@ -747,6 +761,7 @@ int fd_bf16_prepare(fd_score* m, hipStream_t s) {
     B.P = P; B.lofs = im->layer_off_tab;
     B.mimg = im->mimg; B.off_layers = im->off_layers; B.layer_stride = im->layer_stride;
     B.off_wk = im->off_wk; B.off_wv = im->off_wv; B.off_wq = im->off_wq; B.off_wo = im->off_wo; B.off_ffn = im->off_ffn;
+    B.off_lpar = im->off_lpar; B.n_lp = im->mega ? im->nlp : 0;
     B.ffn = im->ffn; B.ffn_layer_bytes = im->ffn_layer_bytes;
     B.bimg = im->bimg; B.b_layer_stride = im->b_layer_stride; B.boff_ffn = im->boff_ffn; B.boff_wot = im->boff_wot; B.boff_win = im->boff_win;
     B.D = D; B.F = F; B.H = H; B.hd = hd; B.KS1 = im->ks1; B.DT = im->dt; B.KSO = im->kso; B.NP = im->np;
@@ -755,7 +770,7 @@ int fd_bf16_prepare(fd_score* m, hipStream_t s) {
     // softmax scale and log2(e) folded into W_q / b_q: the kernels' softmax is exp2(s - max)
     B.qscale = (float)(1.4426950408889634 / std::sqrt((double)hd));
     int per_layer = B.n_ffn;
-    if (B.mega) per_layer += 3 * B.n_qkv + B.n_wo + B.n_ffn;
+    if (B.mega) per_layer += 3 * B.n_qkv + B.n_wo + B.n_ffn + B.n_lp;
     if (B.mega && B.train) per_layer += B.n_ffn + B.n_wot + B.n_win;
     if (L > 0) hipLaunchKernelGGL(k_build_layer_images, dim3(per_layer, L), dim3(64), 0, s, B);
     if (im->mega) {
@@ -808,7 +823,8 @@ static MegaPlan plan_mega_nw(const fd_score* m, int B, int nw) {
             const size_t front = std::max(wkv, half_ring);
             const size_t mid = std::max(front + afr, std::max(ring, xch));
             // time embedding + its scratch, the layer's fp32 vectors, max|K| table of the attention group
-            const size_t temb = (((size_t)(2 * S + 6) * D + (size_t)npg * S * 16) * sizeof(float) + 15) & ~size_t(15);
+            // (the layer vectors arrive by DMA: whole KiB blocks at a 16-byte aligned offset -- fd_mega.hip's LDS map)
+            const size_t temb = (((size_t)((2 * S * D + 3) & ~3) + (size_t)im->nlp * 256 + (size_t)npg * S * 16) * sizeof(float) + 15) & ~size_t(15);
             const size_t total = xfr + mid + temb;
             if (total > lds_cap) continue;
             pl.ok = true;
@@ -857,6 +873,7 @@ static int fill_mega_params(const fd_score* m, const MegaPlan& pl, int B, fd_meg
     P.img_layers = im->mimg + im->off_layers;
     P.layer_stride = im->layer_stride;
     P.off_wk = im->off_wk; P.off_wv = im->off_wv; P.off_wq = im->off_wq; P.off_wo = im->off_wo; P.off_ffn = im->off_ffn;
+    P.off_lpar = im->off_lpar; P.nlp = im->nlp;
     return FD_OK;
 }
 
