@@ -48,8 +48,13 @@ struct fd_mega_params {
     const float* G;
     const fd_sde_step_coef* steps;       // device array [nsteps]
     const float* z_steps;                // injected noise (nsteps, B, T, C) or null
+    const float* temb_table;             // (nsteps, D) time embedding of every step's t (sampler mode: t is shared by all
+                                         // series, fd_mega_temb_table fills it before the launch) or null
     unsigned long long seed, offset, ctr_per_step, n_elem;
 };
+
+// time embedding (transformer.py:80-89) of every step's t, same arithmetic as inside the kernel: table (nsteps, D)
+void fd_mega_temb_table(const fd_mega_params& P, float* table, hipStream_t s);
 
 int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int kso, int mt, int nw, int grid, size_t lds,
                    hipStream_t s, char* describe = nullptr);

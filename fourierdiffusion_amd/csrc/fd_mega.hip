@@ -171,6 +171,31 @@ struct ShapeModel {
 };
 #define SHP(name) (SH::name != 0 ? SH::name : P.name)
 
+// time embedding of one t by one wave: Gaussian Fourier features (LDS scratch `emb`, D floats) then the dense layer -> out[D]
+__device__ __forceinline__ void time_embed_wave(float tv, const float* __restrict__ params, long long tW, long long td_w,
+                                                long long td_b, float* emb, float* out, int D, int lane) {
+    const int half = (D + 1) / 2;
+    for (int j = lane; j < D; j += 64) {
+        const int jj = (j < half) ? j : j - half;
+        const float ph = ((tv * params[tW + jj]) * 2.0f) * 3.14159274101257324f;
+        emb[j] = (j < half) ? sinf(ph) : cosf(ph);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int d = lane; d < D; d += 64) {
+        float a = params[td_b + d];
+        const float* w = params + td_w + (size_t)d * D;
+        for (int j = 0; j < D; ++j) a = fmaf(w[j], emb[j], a);
+        out[d] = a;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_temb_table(const float* __restrict__ params, long long tW, long long td_w, long long td_b,
+                                                   const fd_sde_step_coef* __restrict__ steps, float* __restrict__ table, int D) {
+    extern __shared__ float emb_sh[];
+    time_embed_wave(steps[blockIdx.x].t, params, tW, td_w, td_b, emb_sh, table + (size_t)blockIdx.x * D, D, threadIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // NW = waves per workgroup (8: one workgroup per CU, up to 16 token tiles).  A 4-wave form (two co-resident
 // workgroups per CU, one series each) was measured: the younger workgroup of each CU loses issue arbitration and
@@ -350,25 +375,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
     for (int step = 0; step < nsteps; ++step) {
         mark(0, step);
         refresh_lane();
-        // ============================ time embedding (transformer.py:80-89), one wave per series
-        for (int sw = wave; sw < S; sw += NW) {
-            const int b = b0 + sw;
-            float tv = 0.f;
-            if (b < P.B) tv = (P.mode == FD_MEGA_SAMPLE) ? P.steps[step].t : P.tvec[b];
-            const int half = (D + 1) / 2;
-            float* emb = temb + (S + sw) * D;
-            for (int j = lane; j < D; j += 64) {
-                const int jj = (j < half) ? j : j - half;
-                const float ph = ((tv * P.params[P.tW + jj]) * 2.0f) * 3.14159274101257324f;
-                emb[j] = (j < half) ? sinf(ph) : cosf(ph);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            for (int d = lane; d < D; d += 64) {
-                float a = P.params[P.td_b + d];
-                const float* w = P.params + P.td_w + (size_t)d * D;
-                for (int j = 0; j < D; ++j) a = fmaf(w[j], emb[j], a);
-                temb[sw * D + d] = a;
+        // ============================ time embedding (transformer.py:80-89)
+        if (P.temb_table) {
+            // sampler mode: every series has the step's t -- the embedding of all steps was computed before the launch
+            // (fd_mega_temb_table): one load instead of a Fourier-feature + dense chain that two waves ran while six waited
+            for (int i = threadIdx.x; i < S * D; i += NTH) temb[i] = P.temb_table[(size_t)step * D + (i % D)];
+        } else {
+            for (int sw = wave; sw < S; sw += NW) {       // one wave per series
+                const int b = b0 + sw;
+                const float tv = (b < P.B) ? P.tvec[b] : 0.f;
+                time_embed_wave(tv, P.params, P.tW, P.td_w, P.td_b, temb + (S + sw) * D, temb + sw * D, D, lane);
             }
         }
         __syncthreads();
@@ -1176,6 +1192,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ host side
+void fd_mega_temb_table(const fd_mega_params& P, float* table, hipStream_t s) {
+    hipLaunchKernelGGL(k_temb_table, dim3(P.nsteps), dim3(64), (size_t)P.D * sizeof(float), s, P.params, P.tW, P.td_w, P.td_b, P.steps,
+                       table, P.D);
+}
+
 template <int KS1, int DT, int KSO, int MT, class SH, int NW = 8>
 static int launch_mega_t(fd_ctx* ctx, const fd_mega_params& P, int grid, size_t lds, hipStream_t s) {
     auto kern = k_mega<KS1, DT, KSO, MT, SH, NW>;

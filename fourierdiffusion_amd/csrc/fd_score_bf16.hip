@@ -991,7 +991,8 @@ int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, c
     if (!pl.ok || getenv("FDIFF_NO_MEGA")) return FD_ERR_UNSUPPORTED;
     if (int rc = fd_bf16_refresh(m, s)) return rc;
     const size_t tab_bytes = fd_ws::padded(sizeof(fd_sde_step_coef) * (size_t)n_steps);
-    if (int rc = fd_ws_reserve(ctx, tab_bytes)) return rc;
+    const size_t temb_bytes = fd_ws::padded(sizeof(float) * (size_t)n_steps * m->d.d_model);
+    if (int rc = fd_ws_reserve(ctx, tab_bytes + temb_bytes)) return rc;
     std::vector<fd_sde_step_coef> tab(n_steps);
     for (int i = 0; i < n_steps; ++i) {
         const SdeCoef c = fd_sde_coef(*sde, (double)timesteps[i], dt);
@@ -1011,6 +1012,11 @@ int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, c
     MP.offset = offset;
     MP.n_elem = (unsigned long long)B * m->d.max_len * m->d.n_channels;
     MP.ctr_per_step = (MP.n_elem + 3) / 4;
+    if (!getenv("FDIFF_MEGA_NO_TEMB_TABLE")) {     // (switch: compute the time embedding inside the kernel every step, as in forward mode)
+        float* table = reinterpret_cast<float*>((char*)ctx->ws + tab_bytes);
+        fd_mega_temb_table(MP, table, s);
+        MP.temb_table = table;
+    }
     if (getenv("FDIFF_MEGA_PROF")) {      // profiling aid: per-phase cycle breakdown of workgroup 0 / wave 0
         const size_t nent = 8300;
         unsigned long long* pb = nullptr;
