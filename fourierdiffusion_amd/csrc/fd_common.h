@@ -37,6 +37,7 @@ struct fd_ctx {
     hipStream_t side_stream = nullptr;
     hipStream_t side_stream2 = nullptr;   // weight-gradient launches alternate between the two (they are latency-bound on ~80 CUs each)
     std::vector<hipEvent_t> side_events;
+    bool tr_readers_event_valid = false;   // side_events[L + 1] has been recorded behind the last reader of the dropout-decision buffers
     // FFT twiddle tables (T, device pointer), built on first use of a length
     std::vector<std::pair<int, void*>> fft_tw;
     // measurement hooks (fd_prof_begin / fd_prof_end)

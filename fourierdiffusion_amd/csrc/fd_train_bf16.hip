@@ -303,7 +303,8 @@ __device__ __forceinline__ void ln_stats(const f32x4 (&v)[DT], int D, int g, flo
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
         if (16 * dt + 4 * g < D) s += (v[dt][0] + v[dt][1]) + (v[dt][2] + v[dt][3]);
-    mean = group_sum(s) / (float)D;
+    const float invD = 1.0f / (float)D;      // (one reciprocal instead of two IEEE divisions on the serial path)
+    mean = group_sum(s) * invD;
     float q = 0.f;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -314,7 +315,7 @@ __device__ __forceinline__ void ln_stats(const f32x4 (&v)[DT], int D, int g, flo
                 q += c * c;
             }
         }
-    rstd = rsqrtf(group_sum(q) / (float)D + 1e-5f);
+    rstd = __builtin_amdgcn_rsqf(group_sum(q) * invD + 1e-5f);
 }
 // dropout bits of a (token, D features) row in C layout: bytes (m, j, g) written by k_tr_masks, byte j covers the C tiles
 // 2j (low nibble) and 2j+1 (high nibble)
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(256) void k_tr_attn_fwd(const TrDims d, const AttnF
 #pragma unroll
         for (int hs = 0; hs < 2; ++hs) ls[hs] = group_sum(ls[hs]);
         const float lmine = lo_grp ? ls[0] : ls[1], mmine = lo_grp ? mx[0] : mx[1];
-        const float inv = d.keep_scale / lmine;
+        const float inv = d.keep_scale * __builtin_amdgcn_rcpf(lmine);     // (v_rcp_f32, 1 ulp; the product is rounded to bf16)
         const int m = b * T + t;
         if (t < T && myhead < H) {
 #pragma unroll
@@ -788,7 +789,8 @@ __device__ __forceinline__ void ln_bwd_tile(f32x4 (&dy)[DT], const f32x4 (&xhat)
             dy[dt] = f4zero();
         }
     }
-    const float m1 = group_sum(s1) / (float)D, m2 = group_sum(s2) / (float)D;
+    const float invD = 1.0f / (float)D;
+    const float m1 = group_sum(s1) * invD, m2 = group_sum(s2) * invD;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
         if (16 * dt + 4 * g < D) {
@@ -1113,7 +1115,7 @@ __global__ __launch_bounds__(256) void k_tr_attn_bwd(const TrDims d, const AttnB
         return __builtin_bit_cast(s16x4, u32x2{mine ? u[0] : 0u, mine ? u[1] : 0u});
     };
     const float ln2 = 0.6931471805599453f;
-    const float inv_sqrt_hd = 1.0f / sqrtf((float)hd);
+    const float inv_sqrt_hd = __builtin_amdgcn_rsqf((float)hd);
     // each wave owns token tiles tt = wave, wave+4, ...: as QUERY tile (d q), then as KEY tile (d k, d v), then the
     // input gradient of in_proj for those 16 tokens
     for (int tt = wave; tt < KT; tt += 4) {
@@ -1709,9 +1711,11 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             FD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ctx->side_events.push_back(e);
         }
-        // (the buffers were last read by the previous backward on `s`: order the side stream behind it)
-        FD_HIP(ctx, hipEventRecord(ctx->side_events[L + 1], s));
-        FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_events[L + 1], 0));
+        // The mask buffers were last read by the previous training forward / backward on `s`: side_events[L + 1] was recorded
+        // behind that reader (tr_readers_done), so the decisions of this step are generated while `s` still runs this step's
+        // prologue kernels (perturbation, weight-image rebuild, embedding).  Recording the event HERE made the first
+        // attention kernel wait for a cross-stream hand-off plus the first mask kernel: an 80 us hole in every step.
+        if (ctx->tr_readers_event_valid) FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_events[L + 1], 0));
         for (int l = 0; l < L; ++l) {
             TrLayerBufs& b = tb.layers[l];
             MaskArgs ma{};
@@ -1756,6 +1760,10 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
     }
     fdgemm::linear_fwd(tb.hL, P + m->un_w, P + m->un_b, out, M, C, D, false, s);
     FD_LAUNCH_CHECK(ctx);
+    if (p > 0.f) {      // the dropout-decision buffers may be rewritten once everything enqueued so far has run
+        FD_HIP(ctx, hipEventRecord(ctx->side_events[L + 1], s));
+        ctx->tr_readers_event_valid = true;
+    }
     return FD_OK;
 }
 
@@ -1832,6 +1840,20 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         FD_HIP(ctx, hipStreamWaitEvent(ws, ctx->side_events[l], 0));
         hipLaunchKernelGGL((k_tr_wgrad<KS1, DT>), dim3(F / 128 + 4, tb.TS), dim3(256), lds_wg, ws, d, w, wa);
     }
+    if (m->saved_p > 0.f && L > 0) {      // last reader of the dropout-decision buffers on `s` (layer 0's attention backward)
+        FD_HIP(ctx, hipEventRecord(ctx->side_events[L + 1], s));
+        ctx->tr_readers_event_valid = true;
+    }
+    // The input-gradient chain is complete; the last weight-gradient launches are still running on the side streams.  The
+    // embedding-side backward (first layer's input gradient, positional / time / embedder gradients: ~60 us of small kernels)
+    // needs none of them and runs first, the fixed-order reduce of the weight-gradient partials after the side streams join.
+    if (L > 0) {
+        // gradient of the first layer's input = residual path + the pairs' in_proj contributions
+        const size_t nn = (size_t)M * D;
+        hipLaunchKernelGGL(k_tr_sum_parts, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, tb.dres[0], tb.dxp[0], d.NP,
+                           tb.part_stride, tb.dh, nn);
+    }
+    if (int rc = fd_embed_backward(m, tb.dh, tb.emb, tb.dtemb, grads, B, tb.skp, kSkpFloats, s)) return rc;
     if (L > 0) {
         FD_HIP(ctx, hipEventRecord(ctx->side_events[L], ctx->side_stream));
         FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[L], 0));
@@ -1850,12 +1872,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         ra.grads = grads; ra.accumulate = accumulate;
         const long long n = m->nparams - ra.begin;
         hipLaunchKernelGGL(k_tr_reduce, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, ra);
-        // gradient of the first layer's input = residual path + the pairs' in_proj contributions
-        const size_t nn = (size_t)M * D;
-        hipLaunchKernelGGL(k_tr_sum_parts, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, tb.dres[0], tb.dxp[0], d.NP,
-                           tb.part_stride, tb.dh, nn);
     }
-    if (int rc = fd_embed_backward(m, tb.dh, tb.emb, tb.dtemb, grads, B, tb.skp, kSkpFloats, s)) return rc;
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }
