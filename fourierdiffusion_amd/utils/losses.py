@@ -42,8 +42,10 @@ def get_sde_loss_fn(
         X = _C.dev_f32(batch.X.to(dev), "batch.X")
         timesteps = batch.timesteps
         if timesteps is None:
-            # t ~ U[eps, T] per sample (losses.py:59-63); host-side draw from torch's generator is plumbing
-            timesteps = torch.rand(X.shape[0]) * (scheduler.T - scheduler.eps) + scheduler.eps
+            # t ~ U[eps, T] per sample, drawn on X's device like the reference (losses.py:59-63: torch.rand(..., device=X.device)).
+            # A host-side draw + .to(device) is a blocking copy from pageable memory: it stalled the host behind the previous
+            # optimizer step in every iteration, so the GPU idled through the next step's first ~35 launches (~0.2 ms per step).
+            timesteps = torch.rand(X.shape[0], device=dev) * (scheduler.T - scheduler.eps) + scheduler.eps
         timesteps = _C.dev_f32(timesteps.to(dev), "timesteps")
         x_noisy, target, std = scheduler.perturb(X, timesteps, noise=noise)
         if train:
