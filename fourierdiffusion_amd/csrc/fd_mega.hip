@@ -54,6 +54,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #ifndef FD_NO_PROF
 #define FD_NO_PROF 0
 #endif
+#ifndef FD_KV_TILE_MAJOR
+#define FD_KV_TILE_MAJOR 1
+#endif
 #ifndef FD_STATIC_UNITS
 #define FD_STATIC_UNITS 1
 #endif
@@ -475,6 +478,73 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                 mark(2, step);
                 // ---- K projection (K^T rows pair-major, 8 rows per head) and V projection (non-transposed, so the
                 //      C tile is already the V^T A-fragment) for every token tile -> kbf / vbf
+#if FD_KV_TILE_MAJOR
+                // Tile-major: a wave takes whole token tiles and runs the group's pairs over ONE read of the tile's x fragments
+                // (a (pair, tile) item per trip re-read them for every pair and had two MFMA chains to hide its LDS round trip
+                // behind; here 2 x npg chains are in flight).  Same worst case per wave (2 tiles x 3 pairs at T = 100, S = 2).
+                // (static group size: the group's W_k | W_v fragments stay in registers across the wave's tiles -- re-reading
+                //  them per tile made the phase LDS-bandwidth bound: 14 tiles x 18 KiB per group)
+                constexpr int NPGS = SH::NPG > 0 ? SH::NPG : 1;
+                bf16x8 wkf[NPGS][KS1], wvf[NPGS][KS1];
+                if (SH::NPG > 0) {
+#pragma unroll
+                    for (int pr = 0; pr < NPGS; ++pr)
+#pragma unroll
+                        for (int ks = 0; ks < KS1; ++ks) {
+                            wkf[pr][ks] = *reinterpret_cast<const bf16x8*>(wk + ((pr * KS1 + ks) * 64 + lane) * 16);
+                            wvf[pr][ks] = *reinterpret_cast<const bf16x8*>(wv + ((pr * KS1 + ks) * 64 + lane) * 16);
+                        }
+                }
+                for (int tile = wave; tile < NTILE; tile += NW) {
+                    bf16x8 xf[KS1];
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks) xf[ks] = xfrag(tile, ks);
+                    const int ser = tile / KT, kt = tile - ser * KT;
+                    f32x4 a[SH::NPG > 0 ? SH::NPG : 1], b[SH::NPG > 0 ? SH::NPG : 1];
+                    auto proj = [&](int pr, f32x4& ka, f32x4& vb) {
+                        ka = f4zero();
+                        vb = f4zero();
+#pragma unroll
+                        for (int ks = 0; ks < KS1; ++ks) {
+                            if (SH::NPG > 0) {
+                                ka = MFMA(wkf[pr][ks], xf[ks], ka);
+                                vb = MFMA(xf[ks], wvf[pr][ks], vb);
+                            } else {
+                                ka = MFMA(*reinterpret_cast<const bf16x8*>(wk + ((pr * KS1 + ks) * 64 + lane) * 16), xf[ks], ka);
+                                vb = MFMA(xf[ks], *reinterpret_cast<const bf16x8*>(wv + ((pr * KS1 + ks) * 64 + lane) * 16), vb);
+                            }
+                        }
+                    };
+                    auto store = [&](int pr, const f32x4& ka, const f32x4& vb) {
+                        u32x2 pk = {cvt_pk_bf16(ka[0], ka[1]), cvt_pk_bf16(ka[2], ka[3])};
+                        *reinterpret_cast<u32x2*>(kbf + ((size_t)(pr * NTOK + tile * 16 + tok) * 4 + g) * 8) = pk;
+                        float n2 = ka[0] * ka[0] + ka[1] * ka[1] + ka[2] * ka[2] + ka[3] * ka[3];
+                        float ea, eb;
+                        swap16(n2, ea, eb);                           // the two lane groups of a head
+                        n2 = row_max16(ea + eb);
+                        if (tok == 0 && (g & 1) == 0)
+                            __hip_atomic_fetch_max(&kmax[(pr * S + ser) * 2 + (g >> 1)], __builtin_bit_cast(unsigned, n2),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        u32x2 pv = {cvt_pk_bf16(vb[0], vb[1]), cvt_pk_bf16(vb[2], vb[3])};
+                        char* dst = vbf + ((size_t)(((pr * S + ser) * NJ + (kt >> 1)) * 4 + g) * 16 + tok) * 16;
+                        *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = pv;
+                        if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
+                    };
+                    if (SH::NPG > 0) {            // static group size: all pairs' chains issued before the first result is used
+#pragma unroll
+                        for (int pr = 0; pr < (SH::NPG > 0 ? SH::NPG : 1); ++pr)
+                            if (pr < npg) proj(pr, a[pr], b[pr]);
+#pragma unroll
+                        for (int pr = 0; pr < (SH::NPG > 0 ? SH::NPG : 1); ++pr)
+                            if (pr < npg) store(pr, a[pr], b[pr]);
+                    } else {
+                        for (int pr = 0; pr < npg; ++pr) {
+                            proj(pr, a[0], b[0]);
+                            store(pr, a[0], b[0]);
+                        }
+                    }
+                }
+#else
                 for (int u = wave; u < npg * NTILE; u += NW) {
                     const int pr = u / NTILE, tile = u - pr * NTILE;
                     f32x4 a = f4zero(), b = f4zero();
@@ -504,6 +574,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = pv;
                     if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
                 }
+#endif
                 if (threadIdx.x == 0) *ucnt = 0u;                     // (the previous group's units ended with a barrier)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // W_q of this group
                 __syncthreads();
