@@ -386,7 +386,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
         } else {
             for (int sw = wave; sw < S; sw += NW) {       // one wave per series
                 const int b = b0 + sw;
-                const float tv = (b < P.B) ? P.tvec[b] : 0.f;
+                float tv = 0.f;
+                if (b < P.B) tv = (P.mode == FD_MEGA_SAMPLE) ? P.steps[step].t : P.tvec[b];
                 time_embed_wave(tv, P.params, P.tW, P.td_w, P.td_b, temb + (S + sw) * D, temb + sw * D, D, lane);
             }
         }

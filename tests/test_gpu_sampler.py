@@ -130,3 +130,31 @@ def test_persistent_sampler_equals_stepwise_launches_bf16(C):
     assert np.isfinite(outs[0]).all()
     # identical network kernel and noise; only the fusion of the SDE step differs (fp32 rounding of the update)
     np.testing.assert_allclose(outs[0], outs[1], atol=5e-5 * max(1.0, np.abs(outs[1]).max()), rtol=0)
+
+
+def test_precomputed_time_embedding_table_is_bit_identical():
+    """Sampler mode reads the time embedding of every step from a table filled before the launch (fd_mega_temb_table: all
+    series share the step's t); FDIFF_MEGA_NO_TEMB_TABLE computes it inside the kernel every step as forward mode does.
+    Same arithmetic, so the samples must be bit-identical -- on a two-series-per-workgroup shape and a dynamic one."""
+    import os
+    from fourierdiffusion_amd.sampling.sampler import DiffusionSampler
+    for cfg, B in ((dict(T=100, C=12, D=72, L=2, H=12), 512), (dict(T=40, C=3, D=24, L=2, H=4), 7)):
+        outs = []
+        for no_table in (False, True):
+            m, _, _ = make_model(cfg, precision="bf16")
+            sampler = DiffusionSampler(score_model=m, sample_batch_size=B)
+            old = os.environ.get("FDIFF_MEGA_NO_TEMB_TABLE")
+            try:
+                if no_table:
+                    os.environ["FDIFF_MEGA_NO_TEMB_TABLE"] = "1"
+                else:
+                    os.environ.pop("FDIFF_MEGA_NO_TEMB_TABLE", None)
+                torch.manual_seed(5)
+                outs.append(sampler.sample(num_samples=B, num_diffusion_steps=6).numpy())
+            finally:
+                if old is None:
+                    os.environ.pop("FDIFF_MEGA_NO_TEMB_TABLE", None)
+                else:
+                    os.environ["FDIFF_MEGA_NO_TEMB_TABLE"] = old
+        assert np.isfinite(outs[0]).all()
+        assert np.array_equal(outs[0], outs[1])
