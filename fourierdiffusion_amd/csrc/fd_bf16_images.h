@@ -17,7 +17,6 @@ struct fd_bf16_images {
     size_t off_wk = 0, off_wv = 0, off_wq = 0, off_wo = 0, off_ffn = 0;
     size_t off_lpar = 0;        // fp32 [6][D] out_b, l2_b, n1_w, n1_b, n2_w, n2_b of the layer, zero-padded to nlp KiB
     int nlp = 0;
-    fd_mega_layer_f32* layer_tab = nullptr;   // device [L]
     // ---- training (fd_train_bf16.hip): transposed-weight images of the backward pass, built lazily with the others
     bool train = false;         // bf16 training kernels instantiated for this model
     char* bimg = nullptr;       // per layer: FFN backward blocks (chunk-major, same block count as the forward image),

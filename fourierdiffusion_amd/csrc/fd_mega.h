@@ -9,10 +9,6 @@ struct fd_sde_step_coef {
     float a_x, g, dt, sqrt_dt, t;   // SdeCoef of fd_sde.h + the timestep itself (time embedding)
 };
 
-struct fd_mega_layer_f32 {          // offsets (floats) into the flat fp32 parameter buffer
-    long long out_b, l2_b, n1_w, n1_b, n2_w, n2_b;
-};
-
 struct fd_mega_params {
     // shapes
     int B, T, KT /* ceil(T/16) */, C, D, H, hd, L, F;
@@ -35,7 +31,6 @@ struct fd_mega_params {
     const float* tvec;
     const float* params;
     long long pos, tW, td_w, td_b;
-    const fd_mega_layer_f32* layers;     // device array [L]
     // bf16 fragment images
     const char* img_emb;
     const char* img_unemb;

@@ -696,19 +696,9 @@ int fd_bf16_create(fd_score* m) {
         im->nlp = (24 * D + 1023) / 1024;
         im->layer_stride = im->off_lpar + (size_t)im->nlp * KB;
         const size_t total = im->off_layers + im->layer_stride * L;
-        if (hipMalloc((void**)&im->mimg, total) != hipSuccess ||
-            hipMalloc((void**)&im->layer_tab, sizeof(fd_mega_layer_f32) * L) != hipSuccess) {
+        if (hipMalloc((void**)&im->mimg, total) != hipSuccess) {
             fd_bf16_destroy(m);
             return fd_fail(m->ctx, FD_ERR_HIP, "fd_bf16_create: hipMalloc of the persistent-kernel images failed");
-        }
-        std::vector<fd_mega_layer_f32> tab(L);
-        for (int i = 0; i < L; ++i) {
-            const fd_layer_off& lo = m->layers[i];
-            tab[i] = fd_mega_layer_f32{lo.out_b, lo.l2_b, lo.n1_w, lo.n1_b, lo.n2_w, lo.n2_b};
-        }
-        if (hipMemcpy(im->layer_tab, tab.data(), sizeof(fd_mega_layer_f32) * L, hipMemcpyHostToDevice) != hipSuccess) {
-            fd_bf16_destroy(m);
-            return fd_fail(m->ctx, FD_ERR_HIP, "fd_bf16_create: upload of the layer table failed");
         }
     }
     {   // parameter offsets of every layer for the single-launch image build
@@ -744,7 +734,6 @@ void fd_bf16_destroy(fd_score* m) {
     if (!m->bf16) return;
     if (m->bf16->ffn) (void)hipFree(m->bf16->ffn);
     if (m->bf16->mimg) (void)hipFree(m->bf16->mimg);
-    if (m->bf16->layer_tab) (void)hipFree(m->bf16->layer_tab);
     if (m->bf16->layer_off_tab) (void)hipFree(m->bf16->layer_off_tab);
     if (m->bf16->bimg) (void)hipFree(m->bf16->bimg);
     delete m->bf16;
@@ -867,7 +856,6 @@ static int fill_mega_params(const fd_score* m, const MegaPlan& pl, int B, fd_meg
     P.lds_temb = pl.lds_temb; P.lds_afr = pl.lds_afr; P.num_cu = m->ctx->num_cu;
     P.params = m->params;
     P.pos = m->pos; P.tW = m->tW; P.td_w = m->td_w; P.td_b = m->td_b;
-    P.layers = im->layer_tab;
     P.img_emb = im->mimg + im->off_emb;
     P.img_unemb = im->mimg + im->off_unemb;
     P.img_layers = im->mimg + im->off_layers;
