@@ -298,37 +298,47 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
     };
     auto layer_ptr = [&](int l) -> const char* { return P.img_layers + (size_t)l * P.layer_stride; };
 
-    // LayerNorm of v (C layout, DT tiles) over the D features of token lane&15, in place
-    auto layer_norm = [&](f32x4 (&v)[DT], const float* __restrict__ gamma, const float* __restrict__ beta) {
-        float s = 0.f;
+    // LayerNorm of two C-layout tiles (DT row tiles each) over the D features of token lane&15, in place; both tiles in one
+    // basic block so that their reductions and LDS reads interleave
+    auto layer_norm2 = [&](f32x4 (&va)[DT], f32x4 (&vb)[DT], const float* __restrict__ gamma, const float* __restrict__ beta) {
+        float sa = 0.f, sb = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
-            if (16 * dt + 4 * g < D) s += (v[dt][0] + v[dt][1]) + (v[dt][2] + v[dt][3]);
-        const float invD = 1.0f / (float)D;          // (a multiply instead of two IEEE divisions per call)
-        const float mean = group_sum(s) * invD;
-        float q = 0.f;
+            if (16 * dt + 4 * g < D) {
+                sa += (va[dt][0] + va[dt][1]) + (va[dt][2] + va[dt][3]);
+                sb += (vb[dt][0] + vb[dt][1]) + (vb[dt][2] + vb[dt][3]);
+            }
+        const float invD = 1.0f / (float)D;
+        const float ma = group_sum(sa) * invD, mb = group_sum(sb) * invD;
+        float qa = 0.f, qb = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
             if (16 * dt + 4 * g < D) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float c = v[dt][r] - mean;
-                    q += c * c;
+                    const float ca = va[dt][r] - ma, cb = vb[dt][r] - mb;
+                    qa += ca * ca;
+                    qb += cb * cb;
                 }
             }
-        const float rstd = __builtin_amdgcn_rsqf(group_sum(q) * invD + 1e-5f);
+        const float ra = __builtin_amdgcn_rsqf(group_sum(qa) * invD + 1e-5f), rb2 = __builtin_amdgcn_rsqf(group_sum(qb) * invD + 1e-5f);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d0 = 16 * dt + 4 * g;
             if (d0 < D) {
                 const float4 gm = *reinterpret_cast<const float4*>(gamma + d0);
                 const float4 bt = *reinterpret_cast<const float4*>(beta + d0);
-                v[dt][0] = (v[dt][0] - mean) * rstd * gm.x + bt.x;
-                v[dt][1] = (v[dt][1] - mean) * rstd * gm.y + bt.y;
-                v[dt][2] = (v[dt][2] - mean) * rstd * gm.z + bt.z;
-                v[dt][3] = (v[dt][3] - mean) * rstd * gm.w + bt.w;
+                va[dt][0] = (va[dt][0] - ma) * ra * gm.x + bt.x;
+                va[dt][1] = (va[dt][1] - ma) * ra * gm.y + bt.y;
+                va[dt][2] = (va[dt][2] - ma) * ra * gm.z + bt.z;
+                va[dt][3] = (va[dt][3] - ma) * ra * gm.w + bt.w;
+                vb[dt][0] = (vb[dt][0] - mb) * rb2 * gm.x + bt.x;
+                vb[dt][1] = (vb[dt][1] - mb) * rb2 * gm.y + bt.y;
+                vb[dt][2] = (vb[dt][2] - mb) * rb2 * gm.z + bt.z;
+                vb[dt][3] = (vb[dt][3] - mb) * rb2 * gm.w + bt.w;
             } else {
-                v[dt] = f4zero();
+                va[dt] = f4zero();
+                vb[dt] = f4zero();
             }
         }
     };
@@ -998,34 +1008,48 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                 for (int ks = 0; ks < KSO; ++ks)
                     wo[dt][ks] = WO_LDS ? *reinterpret_cast<const bf16x8*>(wsl + ((dt * KSO + ks) * 64 + lane) * 16)
                                         : gfrag(limg + P.off_wo, dt * KSO + ks);
+            {
+                // Both owned tiles in ONE basic block (a wave that owns a single tile runs its first tile twice and skips the
+                // second write): behind a `tt < ntile` branch each tile's out-proj -> residual -> LayerNorm -> fragment chain
+                // ran strictly after the other's (2.9 K cycles per tile in the sub-phase marks, no latency hidden).
+                bool ok[2];
+                int tl[2];
 #pragma unroll
-            for (int oi = 0; oi < 2; ++oi) {
-                const int tt = fh + 2 * oi;
-                if (tt < ntile) {
-                    const int tile = tile0 + tt;
-                    f32x4 acc[DT];
+                for (int oi = 0; oi < 2; ++oi) {
+                    const int tt = fh + 2 * oi;
+                    ok[oi] = tt < ntile;
+                    tl[oi] = tile0 + (ok[oi] ? tt : 0);
+                }
+                f32x4 acc[2][DT];
 #pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) acc[dt] = f4zero();
+                for (int oi = 0; oi < 2; ++oi)
 #pragma unroll
-                    for (int ks = 0; ks < KSO; ++ks) {
-                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(afr + ((tile * KSO + ks) * 64 + lane) * 16);
+                    for (int dt = 0; dt < DT; ++dt) acc[oi][dt] = f4zero();
 #pragma unroll
-                        for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(wo[dt][ks], af, acc[dt]);
+                for (int ks = 0; ks < KSO; ++ks)
+#pragma unroll
+                    for (int oi = 0; oi < 2; ++oi) {
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(afr + ((tl[oi] * KSO + ks) * 64 + lane) * 16);
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) acc[oi][dt] = MFMA(wo[dt][ks], af, acc[oi][dt]);
                     }
+#pragma unroll
+                for (int oi = 0; oi < 2; ++oi)
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) {
                         const int d0 = 16 * dt + 4 * g;
                         if (d0 < D) {
                             const float4 bo = *reinterpret_cast<const float4*>(lpar + 0 * D + d0);
-                            res[oi][dt][0] += acc[dt][0] + bo.x;
-                            res[oi][dt][1] += acc[dt][1] + bo.y;
-                            res[oi][dt][2] += acc[dt][2] + bo.z;
-                            res[oi][dt][3] += acc[dt][3] + bo.w;
+                            res[oi][dt][0] += acc[oi][dt][0] + bo.x;
+                            res[oi][dt][1] += acc[oi][dt][1] + bo.y;
+                            res[oi][dt][2] += acc[oi][dt][2] + bo.z;
+                            res[oi][dt][3] += acc[oi][dt][3] + bo.w;
                         }
                     }
-                    layer_norm(res[oi], lpar + 2 * D, lpar + 3 * D);
-                    write_xfrags(tile, res[oi]);
-                }
+                layer_norm2(res[0], res[1], lpar + 2 * D, lpar + 3 * D);
+#pragma unroll
+                for (int oi = 0; oi < 2; ++oi)
+                    if (ok[oi]) write_xfrags(tl[oi], res[oi]);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1154,10 +1178,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         for (int dt = 0; dt < DT; ++dt) xch[((mq * MT + tt) * DT + dt) * 64 + lane] = acc[dt][tt];
                     }
                 __syncthreads();
+                {
+                    // both owned tiles in one basic block (see the out-proj phase): a missing second tile is computed from the
+                    // first one's operands and zeroed afterwards
+                    bool okc[2];
 #pragma unroll
-                for (int oi = 0; oi < 2; ++oi) {
-                    const int ttc = FH + 2 * oi;                     // owned tile: a constant after unrolling
-                    if (ttc < MT && ttc < ntile) {
+                    for (int oi = 0; oi < 2; ++oi) {
+                        const int ttc = FH + 2 * oi;                 // owned tile: a constant after unrolling
+                        okc[oi] = ttc < MT && ttc < ntile;
+                        const int tts = okc[oi] ? ttc : FH;          // (tile FH of the quarter always exists when ntile > FH)
 #pragma unroll
                         for (int dt = 0; dt < DT; ++dt) {
                             const int d0 = 16 * dt + 4 * g;
@@ -1165,18 +1194,22 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             // keep the pre-FFN residual live across the whole loop (it cost 32 spilled registers)
                             const int dr = (d0 < D) ? d0 : 0;
                             const f32x4 mine = acc[dt][ttc < MT ? ttc : 0];          // already contains the residual
-                            const f32x4 other = xch[((mq * MT + ttc) * DT + dt) * 64 + lane];
+                            const f32x4 other = xch[((mq * MT + tts) * DT + dt) * 64 + lane];
                             const float4 b2 = *reinterpret_cast<const float4*>(lpar + 1 * D + dr);
                             res[oi][dt][0] = mine[0] + other[0] + b2.x;              // lanes with d0 >= D: zeroed by layer_norm
                             res[oi][dt][1] = mine[1] + other[1] + b2.y;
                             res[oi][dt][2] = mine[2] + other[2] + b2.z;
                             res[oi][dt][3] = mine[3] + other[3] + b2.w;
                         }
-                        layer_norm(res[oi], lpar + 4 * D, lpar + 5 * D);
-                        write_xfrags(tile0 + ttc, res[oi]);
-                    } else {
+                    }
+                    layer_norm2(res[0], res[1], lpar + 4 * D, lpar + 5 * D);
 #pragma unroll
-                        for (int dt = 0; dt < DT; ++dt) res[oi][dt] = f4zero();
+                    for (int oi = 0; oi < 2; ++oi) {
+                        if (okc[oi]) write_xfrags(tile0 + FH + 2 * oi, res[oi]);
+                        else {
+#pragma unroll
+                            for (int dt = 0; dt < DT; ++dt) res[oi][dt] = f4zero();
+                        }
                     }
                 }
                 __syncthreads();
