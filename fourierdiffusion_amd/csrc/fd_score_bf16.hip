@@ -462,6 +462,11 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // The chunk loop is instantiated for "every tile present" (the common case: one basic block per chunk, the tiles' LDS reads /
+    // MFMAs / relu interleave) and once with the per-tile guard; with the guard alone every tile was its own basic block and
+    // ran H -> relu -> W2 strictly in sequence (the finding of fd_mega.hip's FFN loop, never applied here).
+    auto chunk_loop = [&](auto fullc) {
+    constexpr bool FULL = decltype(fullc)::value;
     int buf = 0;
     for (int st = 0; st < NS; ++st) {
 #ifndef FD_ABLATE_NODMA
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
                 w2[dt] = *reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024);
 #pragma unroll
             for (int tt = 0; tt < MT; ++tt) {
-                if (tt < ntile) {
+                if (FULL || tt < ntile) {
                     f32x4 h0 = f32x4{0.f, 0.f, 0.f, 0.f}, h1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < KS1; ++ks) {
@@ -510,6 +515,9 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
         buf ^= 1;
 #endif
     }
+    };
+    if (ntile == MT) chunk_loop(std::true_type{});
+    else chunk_loop(std::false_type{});
 
 #ifdef FD_ABLATE_NOEPI
     if (acc[0][0][0] != 12345.678f) return;
