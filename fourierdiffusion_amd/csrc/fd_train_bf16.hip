@@ -137,17 +137,22 @@ struct TrDims {
 };
 
 // ------------------------------------------------------------------------------------------------ shared device pieces
-// C-layout tile (features 16dt+4g+r of token `m`) <- fp32 rows
+// C-layout tile (features 16dt+4g+r of token `m`) <- fp32 rows.  Unconditional loads from clamped addresses (row 0 for an
+// invalid token, D % 4 == 0) and a select afterwards: a load inside a divergent branch makes hipcc wait for it (vmcnt(0)) at
+// the end of the branch -- one exposed L2 round trip per row tile, ~25 of them in the prologue of k_tr_ffn_bwd.
 template <int DT>
 __device__ __forceinline__ void load_ctile(const float* __restrict__ base, int m, bool valid, int D, int g, f32x4 (&v)[DT]) {
+    const int mc = valid ? m : 0;
+    float4 raw[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
         const int d0 = 16 * dt + 4 * g;
-        v[dt] = f4zero();
-        if (valid && d0 < D) {
-            const float4 a = *reinterpret_cast<const float4*>(base + (size_t)m * D + d0);
-            v[dt] = f32x4{a.x, a.y, a.z, a.w};
-        }
+        raw[dt] = *reinterpret_cast<const float4*>(base + (size_t)mc * D + (d0 < D ? d0 : D - 4));
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const bool ok = valid && (16 * dt + 4 * g < D);
+        v[dt] = f32x4{ok ? raw[dt].x : 0.f, ok ? raw[dt].y : 0.f, ok ? raw[dt].z : 0.f, ok ? raw[dt].w : 0.f};
     }
 }
 template <int DT>
@@ -321,11 +326,14 @@ __device__ __forceinline__ void ln_stats(const f32x4 (&v)[DT], int D, int g, flo
 // 2j (low nibble) and 2j+1 (high nibble)
 template <int DT>
 __device__ __forceinline__ void row_drop_bits(const TrDims& d, const unsigned char* __restrict__ rbits, int m, bool valid, int g,
-                                              unsigned (&bits)[DT]) {
+                                              unsigned (&bits)[DT]) {      // (unconditional loads + select, see load_ctile)
+    const int mc = valid ? m : 0;
+    unsigned char raw[(DT + 1) / 2];
+#pragma unroll
+    for (int j = 0; j < (DT + 1) / 2; ++j) raw[j] = rbits[((size_t)mc * ((DT + 1) / 2) + j) * 4 + g];
 #pragma unroll
     for (int j = 0; j < (DT + 1) / 2; ++j) {
-        unsigned b8 = 0xffu;
-        if (d.p > 0.f && valid) b8 = rbits[((size_t)m * ((DT + 1) / 2) + j) * 4 + g];
+        const unsigned b8 = (d.p > 0.f && valid) ? (unsigned)raw[j] : 0xffu;
         bits[2 * j] = b8 & 15u;
         if (2 * j + 1 < DT) bits[2 * j + 1] = b8 >> 4;
     }
@@ -572,32 +580,57 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     if (NS > 1) issue(1);
     if (NS > 2) issue(2);
     // ---- out-projection + bias + dropout + residual -> s1  (both waves of a tile compute it; the owner stores)
+    // Every global read of the prologue is issued before the first MFMA waits (attention rows, W_o fragments, residual rows,
+    // dropout bytes, bias and LayerNorm vectors): read where they were used, hipcc put an `s_waitcnt vmcnt(0)` behind each
+    // group -- about ten dependent L2 round trips in front of the chunk loop of a kernel whose 100 workgroups cannot hide them.
     f32x4 v[DT];
+    float4 bo4[DT], g14[DT], be14[DT];
     {
-        f32x4 o[DT];
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[dt] = f4zero();
+        float e8[KSO][8];
+        bf16x8 wof[DT][KSO];
+        const int mc = valid ? m : 0;                      // (clamped row: unconditional loads, selected afterwards)
 #pragma unroll
         for (int ks = 0; ks < KSO; ++ks) {
-            const int head = 4 * ks + g;
-            float e8[8];
+            const int head = 4 * ks + g, hc = head < d.H ? head : d.H - 1;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) e8[e] = (valid && head < d.H && e < d.hd) ? a.att[(size_t)m * D + head * d.hd + e] : 0.f;
-            const u32x4 pk = {cvt_pk_bf16(e8[0], e8[1]), cvt_pk_bf16(e8[2], e8[3]), cvt_pk_bf16(e8[4], e8[5]), cvt_pk_bf16(e8[6], e8[7])};
-            const bf16x8 af = __builtin_bit_cast(bf16x8, pk);
+            for (int e = 0; e < 8; ++e) e8[ks][e] = a.att[(size_t)mc * D + hc * d.hd + (e < d.hd ? e : 0)];
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-                o[dt] = MFMA(*reinterpret_cast<const bf16x8*>(a.wo_img + ((size_t)(dt * KSO + ks) * 64 + lane) * 16), af, o[dt]);
+                wof[dt][ks] = *reinterpret_cast<const bf16x8*>(a.wo_img + ((size_t)(dt * KSO + ks) * 64 + lane) * 16);
         }
         unsigned bits[DT];
         row_drop_bits<DT>(d, a.rb1, m, valid, g, bits);
         load_ctile<DT>(a.x0, m, valid, D, g, v);
 #pragma unroll
+        for (int ks = 0; ks < KSO; ++ks) {
+            const int head = 4 * ks + g;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) e8[ks][e] = (valid && head < d.H && e < d.hd) ? e8[ks][e] : 0.f;
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = 16 * dt + 4 * g, dr = d0 < D ? d0 : 0;
+            bo4[dt] = *reinterpret_cast<const float4*>(a.bo + dr);
+            g14[dt] = *reinterpret_cast<const float4*>(a.g1 + dr);
+            be14[dt] = *reinterpret_cast<const float4*>(a.be1 + dr);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = f4zero();
+#pragma unroll
+        for (int ks = 0; ks < KSO; ++ks) {
+            const u32x4 pk = {cvt_pk_bf16(e8[ks][0], e8[ks][1]), cvt_pk_bf16(e8[ks][2], e8[ks][3]), cvt_pk_bf16(e8[ks][4], e8[ks][5]),
+                              cvt_pk_bf16(e8[ks][6], e8[ks][7])};
+            const bf16x8 af = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[dt] = MFMA(wof[dt][ks], af, o[dt]);
+        }
+#pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d0 = 16 * dt + 4 * g;
             if (d0 < D) {
-                const float4 bb = *reinterpret_cast<const float4*>(a.bo + d0);
-                const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+                const float bv[4] = {bo4[dt].x, bo4[dt].y, bo4[dt].z, bo4[dt].w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[dt][r] += ((bits[dt] >> r) & 1u) ? (o[dt][r] + bv[r]) * d.keep_scale : 0.f;
             }
@@ -615,7 +648,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         for (int dt = 0; dt < DT; ++dt) {
             const int d0 = 16 * dt + 4 * g;
             if (d0 < D) {
-                const float4 gm = *reinterpret_cast<const float4*>(a.g1 + d0), bt = *reinterpret_cast<const float4*>(a.be1 + d0);
+                const float4 gm = g14[dt], bt = be14[dt];
                 v[dt][0] = (v[dt][0] - mean) * rstd * gm.x + bt.x;
                 v[dt][1] = (v[dt][1] - mean) * rstd * gm.y + bt.y;
                 v[dt][2] = (v[dt][2] - mean) * rstd * gm.z + bt.z;
