@@ -1,7 +1,7 @@
 """Debug aid: compare the persistent kernel against the oracle layer by layer (FDIFF_MEGA_LAYERS=k)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import fdiff_oracle as O, weights as W
 from oracle.make_golden import CFG_DEFAULT, CFG_TINY, CFG_ODD
 from tests.gpu_util import make_model, dev, host
