@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import torch
 
-_state = {"rank_base": 0}
+_state = {"rank_base": 0, "keys_drawn": 0}
 
 
 def set_rank(rank: int) -> None:
@@ -22,6 +22,7 @@ def set_rank(rank: int) -> None:
 
 def next_key() -> int:
     """A fresh Philox key from torch's global CPU generator."""
+    _state["keys_drawn"] += 1
     return int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())
 
 
@@ -32,3 +33,14 @@ def base_offset() -> int:
 def stream():
     """(key, offset) for one engine call."""
     return next_key(), _state["rank_base"]
+
+
+def keys_drawn() -> int:
+    """Keys drawn so far in this process (the Trainer measures how many a training step takes, so that a rank whose slice of
+    a global batch is empty can discard as many and keep torch's generator in step with the other ranks)."""
+    return _state["keys_drawn"]
+
+
+def discard_keys(n: int) -> None:
+    for _ in range(int(n)):
+        next_key()

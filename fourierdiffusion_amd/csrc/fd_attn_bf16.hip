@@ -670,7 +670,9 @@ int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, in
     if (proj && ((ks1 != 3 && ks1 != 2) || (D & 3))) return FD_ERR_UNSUPPORTED;   // (raw x rows are read as float4)
     const void* kern = proj ? (ks1 == 3 ? (const void*)k_attention_bf16<3> : (const void*)k_attention_bf16<2>)
                             : (const void*)k_attention_bf16<0>;
-    FD_HIP(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    static unsigned long long attr[3] = {};
+    if (fd_first_on_device(attr[proj ? (ks1 == 3 ? 2 : 1) : 0], ctx->device))
+        FD_HIP(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int NP = (H + 1) / 2, DUS = (KT + NQ - 1) / NQ;
     // Query slices per (series, pair): every slice restages K/V (~16 % of a full slice's work) and keeps its own Q tiles in
     // LDS (512 B per tile); pick the count that minimises rounds x work per round among those that fit (two workgroups per

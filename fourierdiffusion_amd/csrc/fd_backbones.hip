@@ -341,12 +341,15 @@ int fd_bb_backward(fd_score* m, const float* dout, float* grads, int accumulate,
         } else {
             const int G = 4 * D;
             const size_t lds = ((size_t)G * D + G + 4 * D) * sizeof(float);
+            static unsigned long long attr[2] = {};
             if (D <= 72) {
-                FD_HIP(ctx, hipFuncSetAttribute((const void*)k_lstm_bwd_rec<72>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                if (fd_first_on_device(attr[0], ctx->device))
+                    FD_HIP(ctx, hipFuncSetAttribute((const void*)k_lstm_bwd_rec<72>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 hipLaunchKernelGGL((k_lstm_bwd_rec<72>), dim3(B), dim3(4 * 72), lds, s, b.dh, b.act[i], b.aux[i], P + o.b, b.dact, T, D);
             } else {
                 if (lds > 160 * 1024) return fd_fail(ctx, FD_ERR_UNSUPPORTED, "LSTM backward: W_hh of d_model %d exceeds the LDS", D);
-                FD_HIP(ctx, hipFuncSetAttribute((const void*)k_lstm_bwd_rec<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                if (fd_first_on_device(attr[1], ctx->device))
+                    FD_HIP(ctx, hipFuncSetAttribute((const void*)k_lstm_bwd_rec<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 hipLaunchKernelGGL((k_lstm_bwd_rec<128>), dim3(B), dim3(4 * 128), lds, s, b.dh, b.act[i], b.aux[i], P + o.b, b.dact, T, D);
             }
             // b_ih and b_hh enter the pre-activations identically

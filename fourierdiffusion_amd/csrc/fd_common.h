@@ -15,6 +15,9 @@
 struct fd_ctx {
     int device = 0;
     std::string err;
+    // first error raised by a void helper deep inside a multi-launch call (fixed-order reductions whose scratch could not be
+    // allocated): the enclosing API call returns it (fd_take_deferred) instead of FD_OK with gradients partly unwritten
+    int deferred_rc = 0;
     // grow-only scratch arena; carved per call by fd_ws
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -37,7 +40,12 @@ struct fd_ctx {
     hipStream_t side_stream = nullptr;
     hipStream_t side_stream2 = nullptr;   // weight-gradient launches alternate between the two (they are latency-bound on ~80 CUs each)
     std::vector<hipEvent_t> side_events;
-    bool tr_readers_event_valid = false;   // side_events[L + 1] has been recorded behind the last reader of the dropout-decision buffers
+    // recorded behind the last reader (training forward / backward) of the dropout-decision buffers, which live in the arena;
+    // tr_readers_gen = ws_gen at that moment: a different ws_gen at the next training forward means some other call carved the
+    // arena in between and may still be running on the caller's stream, so the side stream must wait for a FRESH event
+    hipEvent_t tr_readers_event = nullptr;
+    bool tr_readers_event_valid = false;
+    uint64_t tr_readers_gen = 0;
     // FFT twiddle tables (T, device pointer), built on first use of a length
     std::vector<std::pair<int, void*>> fft_tw;
     // measurement hooks (fd_prof_begin / fd_prof_end)
@@ -81,6 +89,24 @@ inline int fd_fail(fd_ctx* ctx, int code, const char* fmt, ...) {
     va_end(ap);
     if (ctx) ctx->err = buf;
     return code;
+}
+
+// hipFuncSetAttribute is per device: a call site keeps one `static` mask with a bit per device ordinal and sets the attribute
+// the first time it sees a device (not on every launch: it is a driver call)
+inline bool fd_first_on_device(unsigned long long& mask, int device) {
+    const unsigned long long bit = 1ull << (device & 63);
+    if (mask & bit) return false;
+    mask |= bit;
+    return true;
+}
+
+inline void fd_defer(fd_ctx* ctx, int rc) {
+    if (rc && ctx && !ctx->deferred_rc) ctx->deferred_rc = rc;
+}
+inline int fd_take_deferred(fd_ctx* ctx) {
+    const int rc = ctx->deferred_rc;
+    ctx->deferred_rc = 0;
+    return rc;
 }
 
 #define FD_HIP(ctx, expr)                                                                     \

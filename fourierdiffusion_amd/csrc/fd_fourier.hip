@@ -464,11 +464,9 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
     for (int i = 0; i < plan.nstages; ++i) bigp |= (plan.radix[i] == 17 || plan.radix[i] == 19 || plan.radix[i] == 23);
     auto kern = bigp ? (batched ? k_fft<INVERSE, true, true> : k_fft<INVERSE, false, true>)
                      : (batched ? k_fft<INVERSE, true, false> : k_fft<INVERSE, false, false>);
-    static bool attr_set[2][2][2] = {};
-    if (!attr_set[INVERSE ? 1 : 0][batched ? 1 : 0][bigp ? 1 : 0]) {
+    static unsigned long long attr_set[2][2][2] = {};
+    if (fd_first_on_device(attr_set[INVERSE ? 1 : 0][batched ? 1 : 0][bigp ? 1 : 0], ctx->device))
         FD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[INVERSE ? 1 : 0][batched ? 1 : 0][bigp ? 1 : 0] = true;
-    }
     // twiddle table of this T (cached on the context; a handful of distinct T per process)
     const float2* tw_dev = nullptr;
     for (auto& e : ctx->fft_tw)

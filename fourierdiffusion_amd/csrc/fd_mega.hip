@@ -1305,11 +1305,9 @@ void fd_mega_temb_table(const fd_mega_params& P, float* table, hipStream_t s) {
 template <int KS1, int DT, int KSO, int MT, class SH, int NW = 8>
 static int launch_mega_t(fd_ctx* ctx, const fd_mega_params& P, int grid, size_t lds, hipStream_t s) {
     auto kern = k_mega<KS1, DT, KSO, MT, SH, NW>;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr = 0;
+    if (fd_first_on_device(attr, ctx->device))
         FD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (NW == 8 ? 160 : 80) * 1024));
-        attr = true;
-    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, P);
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;

@@ -600,11 +600,9 @@ int launch_ffn(fd_ctx* ctx, const float* x, float* out, const char* wimg, const 
     constexpr size_t lds_xfr = KSO > 0 ? (size_t)4 * MT * KS1 * 1024 : 0;   // fused prologue: x fragments behind the ring
     const size_t lds = (lds_main > lds_xch ? lds_main : lds_xch) + lds_xfr;
     auto kern = k_ffn_ln<KS1, DT, MT, KSO>;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr = 0;
+    if (fd_first_on_device(attr, ctx->device))
         FD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
     const int grid = (M + tok_per_wg - 1) / tok_per_wg;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, x, out, wimg, b2, gamma, beta, M, D, F, tok_per_wg, pre);
     FD_LAUNCH_CHECK(ctx);

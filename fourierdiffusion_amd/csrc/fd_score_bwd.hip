@@ -402,7 +402,7 @@ inline unsigned ew_grid(fd_ctx* ctx, size_t n) {
     return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
-void colsum(fd_ctx* ctx, const float* x, float* out, int M, int N, hipStream_t s) { (void)fd_colsum_det(ctx, x, out, M, N, s); }
+void colsum(fd_ctx* ctx, const float* x, float* out, int M, int N, hipStream_t s) { fd_defer(ctx, fd_colsum_det(ctx, x, out, M, N, s)); }
 
 // tmp = dropout-backward(src) (site mask), bias gradient += column sums of tmp (fixed-order reduction)
 void dropout_bwd_colsum(fd_ctx* ctx, const float* src, float* tmp, int M, int N, float p, uint64_t seed, uint64_t offset,
@@ -419,7 +419,10 @@ void ln_bwd(fd_ctx* ctx, const float* dy, const float* x, const float* mr, const
     tokens_per_block = std::min(64, std::max(8, (tokens_per_block + 3) & ~3));
     const int nblk = (M + tokens_per_block - 1) / tokens_per_block;
     float* part = fd_red_scratch(ctx, (size_t)nblk * 2 * D);
-    if (!part) return;                       // (allocation failure surfaces as a HIP error at the launch check)
+    if (!part) {                             // nothing is launched, so no launch check would see it: the API call returns it
+        fd_defer(ctx, fd_fail(ctx, FD_ERR_HIP, "ln_bwd: reduction scratch allocation failed"));
+        return;
+    }
     hipLaunchKernelGGL(k_ln_bwd, dim3(nblk), dim3(256), 8 * D * sizeof(float), s, dy, x, mr, gamma, dx, part, M, D, tokens_per_block);
     // rows are [dgamma | dbeta]: two strided sums
     hipLaunchKernelGGL(k_sum_rows_strided, dim3((D + 255) / 256), dim3(256), 0, s, part, nblk, 2 * D, 0, D, dgamma);
@@ -481,7 +484,7 @@ int fd_embed_backward(fd_score* m, const float* dh, const float* emb, float* dte
     fdgemm::linear_bwd_weight(dtemb, emb, grads + m->td_w, B, D, D, true, s, skp, skp_floats);
     colsum(ctx, dtemb, grads + m->td_b, B, D, s);
     FD_LAUNCH_CHECK(ctx);
-    return FD_OK;
+    return fd_take_deferred(ctx);
 }
 
 extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, int accumulate, void* stream) {
@@ -583,5 +586,5 @@ extern "C" int fd_score_backward(fd_score* m, const float* dout, float* grads, i
 
     if (int rc = fd_embed_backward(m, dh, sv.emb, dtemb, grads, B, skp, kSplitKFloats, s)) return rc;
     FD_LAUNCH_CHECK(ctx);
-    return FD_OK;
+    return fd_take_deferred(ctx);
 }

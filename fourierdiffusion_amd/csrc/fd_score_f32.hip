@@ -122,7 +122,9 @@ extern "C" int fd_score_layout(const fd_model_dims* dims, fd_param_entry* entrie
 bool bb_ok(const fd_model_dims* d, int backbone, int d_mlp) {
     if (backbone == FD_BACKBONE_TRANSFORMER) return true;
     if (backbone == FD_BACKBONE_MLP) return d_mlp > 0 && d->d_model <= 1024;
-    if (backbone == FD_BACKBONE_LSTM) return d->d_model <= 128;      // one thread per gate row, W_hh row in registers
+    // one thread per gate row, W_hh row in registers; the backward through time keeps W_hh (4 D^2 floats) + 8 D floats in the
+    // 160 KiB LDS, which holds up to d_model = 100 -- wider models would run forward and fail in their first training step
+    if (backbone == FD_BACKBONE_LSTM) return d->d_model <= 100;
     return false;
 }
 
@@ -659,7 +661,8 @@ extern "C" int fd_score_forward_train(fd_score* m, const float* x, const float* 
     const bool bf16 = m->train_mode == FD_MODE_BF16 && m->backbone == FD_BACKBONE_TRANSFORMER;
     if (bf16 && !fd_train_bf16_supported(m))
         return fd_fail(ctx, FD_ERR_UNSUPPORTED, "fd_score_forward_train: bf16 training kernels are not instantiated for this "
-                       "model (d_model in {8,24,60,72}, head_dim <= 7, dim_ff %% 128 == 0); select FD_MODE_F32");
+                       "model (needs bf16 weight images -- fd_score_plan says which widths have them --, dim_ff %% 1024 == 0, dim_ff <= 2048, "
+                       "max_len <= 1024); select FD_MODE_F32");
     int rc = (m->backbone != FD_BACKBONE_TRANSFORMER)
                  ? fd_bb_forward(m, x, t, out, B, (hipStream_t)stream, true, dropout_p, seed, offset)
                  : (bf16 ? fd_score_forward_train_bf16(m, x, t, out, B, dropout_p, seed, offset, (hipStream_t)stream)

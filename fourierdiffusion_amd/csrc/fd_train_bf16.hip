@@ -1712,7 +1712,7 @@ TrDims make_dims(const fd_score* m, int B, float p, uint64_t seed) {
 
 template <int KS1, int DT, int KSO>
 int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B, float p, uint64_t seed, uint64_t offset,
-                 hipStream_t s, TrBufs& tb) {
+                 hipStream_t s, TrBufs& tb, uint64_t gen_in) {
     fd_ctx* ctx = m->ctx;
     const fd_bf16_images* im = m->bf16;
     const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model, L = m->d.num_layers;
@@ -1730,11 +1730,10 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
     const size_t NSh = (size_t)m->d.dim_ff / 64;
     const size_t lds_ffn = (size_t)4 * 2 * (2 * KS1 + DT) * 1024 + scr + (size_t)TW * 64 * NSh + (size_t)TW * NSh * 32 * sizeof(unsigned short) +
                            (size_t)4 * 32 * DT * 16;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr = 0;
+    if (fd_first_on_device(attr, ctx->device)) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_fwd<KS1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_ffn_fwd<KS1, DT, KSO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     if (p > 0.f) {
         // dropout decisions of every layer on the side stream, layer by layer, ahead of the kernels that read them
@@ -1744,11 +1743,15 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             FD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ctx->side_events.push_back(e);
         }
-        // The mask buffers were last read by the previous training forward / backward on `s`: side_events[L + 1] was recorded
-        // behind that reader (tr_readers_done), so the decisions of this step are generated while `s` still runs this step's
-        // prologue kernels (perturbation, weight-image rebuild, embedding).  Recording the event HERE made the first
-        // attention kernel wait for a cross-stream hand-off plus the first mask kernel: an 80 us hole in every step.
-        if (ctx->tr_readers_event_valid) FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_events[L + 1], 0));
+        // The mask buffers were last read by the previous training forward / backward on `s`: tr_readers_event was recorded
+        // behind that reader, so the decisions of this step are generated while `s` still runs this step's prologue kernels
+        // (perturbation, weight-image rebuild, embedding).  Recording an event HERE makes the first attention kernel wait for
+        // a cross-stream hand-off plus the first mask kernel (an 80 us hole in every step), so that is only done when some
+        // other call has carved the arena since (an eval forward, the sampler, another model on this context: gen_in differs)
+        // and may still be running on `s`.
+        if (!ctx->tr_readers_event) FD_HIP(ctx, hipEventCreateWithFlags(&ctx->tr_readers_event, hipEventDisableTiming));
+        if (!ctx->tr_readers_event_valid || gen_in != ctx->tr_readers_gen) FD_HIP(ctx, hipEventRecord(ctx->tr_readers_event, s));
+        FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->tr_readers_event, 0));
         for (int l = 0; l < L; ++l) {
             TrLayerBufs& b = tb.layers[l];
             MaskArgs ma{};
@@ -1794,8 +1797,9 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
     fdgemm::linear_fwd(tb.hL, P + m->un_w, P + m->un_b, out, M, C, D, false, s);
     FD_LAUNCH_CHECK(ctx);
     if (p > 0.f) {      // the dropout-decision buffers may be rewritten once everything enqueued so far has run
-        FD_HIP(ctx, hipEventRecord(ctx->side_events[L + 1], s));
+        FD_HIP(ctx, hipEventRecord(ctx->tr_readers_event, s));
         ctx->tr_readers_event_valid = true;
+        ctx->tr_readers_gen = ctx->ws_gen;
     }
     return FD_OK;
 }
@@ -1812,7 +1816,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     if (!accumulate) FD_HIP(ctx, hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(L > 0 ? m->layers[0].in_w : m->nparams), s));
     // ---- unembedder
     fdgemm::linear_bwd_weight(dout, tb.hL, grads + m->un_w, M, C, D, true, s, tb.skp, kSkpFloats);
-    fd_colsum_det(ctx, dout, grads + m->un_b, M, C, s);
+    if (int rc = fd_colsum_det(ctx, dout, grads + m->un_b, M, C, s)) return rc;
     fdgemm::linear_bwd_input(dout, P + m->un_w, tb.dh, M, C, D, false, s);
     const size_t scr = std::max((size_t)TW * KS1 * 1024, (size_t)4 * DT * 1024);
     const size_t NSh = (size_t)m->d.dim_ff / 64;
@@ -1820,12 +1824,11 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
                            (size_t)TW * KS1 * 1024;
     const size_t lds_ab = (size_t)4 * d.KT * 16 * 32 + (size_t)3 * d.NJ * 1024 + (size_t)4 * d.KT * 16 * sizeof(float) +
                           (size_t)2 * d.T * d.NJ * 4;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr = 0;
+    if (fd_first_on_device(attr, ctx->device)) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_ffn_bwd<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_bwd<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_wgrad<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     // side stream: the weight gradients of layer l only need that layer's k_tr_ffn_bwd / k_tr_attn_bwd outputs, so they run
     // beside the input-gradient chain of layers l-1 .. 0 (both are latency-bound and leave most CUs idle on their own)
@@ -1874,8 +1877,10 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         hipLaunchKernelGGL((k_tr_wgrad<KS1, DT>), dim3(F / 128 + 4, tb.TS), dim3(256), lds_wg, ws, d, w, wa);
     }
     if (m->saved_p > 0.f && L > 0) {      // last reader of the dropout-decision buffers on `s` (layer 0's attention backward)
-        FD_HIP(ctx, hipEventRecord(ctx->side_events[L + 1], s));
+        if (!ctx->tr_readers_event) FD_HIP(ctx, hipEventCreateWithFlags(&ctx->tr_readers_event, hipEventDisableTiming));
+        FD_HIP(ctx, hipEventRecord(ctx->tr_readers_event, s));
         ctx->tr_readers_event_valid = true;
+        ctx->tr_readers_gen = ctx->ws_gen;
     }
     // The input-gradient chain is complete; the last weight-gradient launches are still running on the side streams.  The
     // embedding-side backward (first layer's input gradient, positional / time / embedder gradients: ~60 us of small kernels)
@@ -1886,7 +1891,14 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         hipLaunchKernelGGL(k_tr_sum_parts, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, tb.dres[0], tb.dxp[0], d.NP,
                            tb.part_stride, tb.dh, nn);
     }
-    if (int rc = fd_embed_backward(m, tb.dh, tb.emb, tb.dtemb, grads, B, tb.skp, kSkpFloats, s)) return rc;
+    const int rc_embed = fd_embed_backward(m, tb.dh, tb.emb, tb.dtemb, grads, B, tb.skp, kSkpFloats, s);
+    if (rc_embed) {
+        // the weight-gradient launches on the side streams are still writing tb.part (arena memory): let them finish before the
+        // caller sees the error and reuses or frees the arena
+        (void)hipStreamSynchronize(ctx->side_stream);
+        (void)hipStreamSynchronize(ctx->side_stream2);
+        return rc_embed;
+    }
     if (L > 0) {
         FD_HIP(ctx, hipEventRecord(ctx->side_events[L], ctx->side_stream));
         FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[L], 0));
@@ -1937,11 +1949,16 @@ int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, flo
     if (!fd_train_bf16_supported(m)) return fd_fail(ctx, FD_ERR_UNSUPPORTED, "bf16 training path unsupported for this model");
     if (int rc = fd_bf16_refresh(m, s)) return rc;
     const size_t need = fd_train_bf16_workspace(m, B);
+    // ws_gen before this call touches the arena; the reserve + carve below advance it by exactly two, so "nobody else used the
+    // arena since the last training reader" reads gen_in == tr_readers_gen
+    const uint64_t gen_in = ctx->ws_gen;
+    const void* ws_before = ctx->ws;
     if (int rc = fd_ws_reserve(ctx, need)) return rc;
     fd_ws ws(ctx);
+    if (ctx->ws != ws_before) ctx->tr_readers_event_valid = false;      // regrown: the reserve synchronised the device
     TrBufs tb;
     tr_carve(m, B, (char*)ctx->ws, &tb);
-#define CALL_F(K, T_, O) tr_forward_t<K, T_, O>(m, x, t, out, B, p, seed, offset, s, tb)
+#define CALL_F(K, T_, O) tr_forward_t<K, T_, O>(m, x, t, out, B, p, seed, offset, s, tb, gen_in)
     FD_TR_DISPATCH(CALL_F);
 #undef CALL_F
 }

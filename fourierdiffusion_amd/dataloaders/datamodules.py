@@ -72,8 +72,11 @@ class BatchLoader:
     the collective counts of the ranks can never diverge.  Each item carries `global_size` (samples of the global batch)
     so that the exchange can weight a rank by n_local / n_global (unequal slices would otherwise bias the mean)."""
 
-    def __init__(self, dataset: DiffusionDataset, batch_size: int, shuffle: bool, rank: int = 0, world: int = 1) -> None:
+    def __init__(self, dataset: DiffusionDataset, batch_size: int, shuffle: bool, rank: int = 0, world: int = 1,
+                 epoch: int = 0) -> None:
         self.dataset, self.batch_size, self.shuffle, self.rank, self.world = dataset, batch_size, shuffle, rank, world
+        self.epoch = epoch                                  # advances with every pass over the loader
+        self.shuffle_seed = int(torch.initial_seed())      # torch.manual_seed(cfg.random_seed): the same on every rank
 
     def __len__(self) -> int:
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
@@ -81,7 +84,16 @@ class BatchLoader:
     def __iter__(self) -> Iterator[DiffusableBatch]:
         n = len(self.dataset)
         Xs = self.dataset.standardized()
-        order = torch.randperm(n) if self.shuffle else torch.arange(n)      # torch's generator: same on every rank
+        if not self.shuffle:
+            order = torch.arange(n)
+        else:
+            # Data-parallel ranks must cut the SAME permutation.  It comes from a generator of its own, seeded by (seed, epoch)
+            # -- like the per-epoch generator of torch's RandomSampler -- so it cannot depend on how much of torch's global
+            # generator a rank has consumed (a rank with an empty slice of a small last batch runs no training step:
+            # 87 553 % 64 == 1 in the reference's ECG set), and a single process shuffles exactly as N ranks do
+            g = torch.Generator(device="cpu").manual_seed((self.shuffle_seed * 1000003 + self.epoch) & ((1 << 62) - 1))
+            order = torch.randperm(n, generator=g)
+        self.epoch += 1
         for i in range(0, n, self.batch_size):
             idx = order[i:i + self.batch_size]
             n_global = int(idx.numel())
@@ -141,7 +153,9 @@ class Datamodule:
         return self._train_set
 
     def train_dataloader(self) -> BatchLoader:
-        return BatchLoader(self._train_dataset(), self.batch_size, shuffle=True, rank=self.rank, world=self.world)
+        epoch = getattr(self, "_train_epoch", 0)           # one loader per epoch (Trainer.fit): the epoch seeds its shuffle
+        self._train_epoch = epoch + 1
+        return BatchLoader(self._train_dataset(), self.batch_size, shuffle=True, rank=self.rank, world=self.world, epoch=epoch)
 
     def test_dataloader(self) -> BatchLoader:
         ds = DiffusionDataset(X=self.X_test, y=self.y_test, fourier_transform=self.fourier_transform)

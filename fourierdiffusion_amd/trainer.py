@@ -79,6 +79,7 @@ class Trainer:
         self.history: List[Dict[str, float]] = []
         self.dist = DistEnv()
         self.optimizer: Optional[FusedAdamW] = None
+        self._keys_per_step = 2                 # perturbation + dropout key; re-measured on every non-empty step
 
     # ------------------------------------------------------------------
     def fit(self, model, datamodule) -> None:
@@ -122,9 +123,15 @@ class Trainer:
                 n_global = int(getattr(batch, "global_size", n_local * self.dist.world))
                 weight = n_local * self.dist.world / max(1, n_global)
                 if n_local > 0:
+                    k0 = _rng.keys_drawn()
                     loss = model.training_step(batch, bi, grad_weight=weight)   # forward + backward inside the engine
+                    self._keys_per_step = _rng.keys_drawn() - k0
                     losses.append(loss * weight)
                 else:
+                    # the other ranks draw Philox keys (perturbation noise, dropout) from torch's global CPU generator in
+                    # this step: draw and discard as many, or the generators -- seeded alike on every rank -- drift apart
+                    # and everything derived from them later (sampling callbacks, a re-seeded shuffle) differs per rank
+                    _rng.discard_keys(self._keys_per_step)
                     if model.grads is None:
                         model.grads = torch.zeros_like(model.flat_parameters)
                     losses.append(torch.zeros((), device=model.device))

@@ -205,3 +205,61 @@ def test_batchloader_every_rank_yields_every_global_batch():
         counts.append([len(b) for b in items])
         assert [b.global_size for b in items] == [64, 1]
     assert counts == [[16, 1], [16, 0], [16, 0], [16, 0]]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a rank whose slice of a small last batch is empty runs no training step and so draws no Philox keys
+# from torch's global generator; the shuffle of the next epoch must not depend on that, and the generators must stay in step.
+class _KeyDrawingModel(_QuadModel):
+    """Like ScoreModule.training_step: one key for the perturbation noise, one for the dropout masks."""
+
+    def __init__(self, dim):
+        super().__init__(dim)
+        self.seen = []
+
+    def training_step(self, batch, bi, grad_weight=1.0):
+        from fourierdiffusion_amd import _rng
+        _rng.stream()
+        _rng.stream()
+        self.seen.append(batch.X[:, 0, 0].clone())
+        return super().training_step(batch, bi, grad_weight)
+
+
+def _rng_fit_worker(rank, world, port, out_dir, n, bs, epochs):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), FDIFF_DIST_BACKEND="gloo", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    import torch.distributed as dist
+    from fourierdiffusion_amd import _rng
+    from fourierdiffusion_amd.dataloaders.datamodules import TensorDatamodule
+    from fourierdiffusion_amd.trainer import Trainer
+    X = torch.arange(n * 3 * 2, dtype=torch.float32).reshape(n, 3, 2)          # X[i, 0, 0] = 6 i identifies the sample
+    dm = TensorDatamodule(X_train=X, X_test=X[:4], batch_size=bs)
+    model = _KeyDrawingModel(6)
+    tr = Trainer(max_epochs=epochs, grad_exchange="torch", enable_progress_bar=False)
+    torch.manual_seed(77)
+    tr.fit(model, dm)
+    per_epoch = len(model.seen) // epochs if rank == 0 else None
+    torch.save({"seen": model.seen, "next_key": _rng.next_key(), "w": model.flat_parameters}, os.path.join(out_dir, f"rng_{rank}.pt"))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_world2_empty_slice_keeps_generators_and_shuffle_in_step(tmp_path):
+    """n = 17, batch 8, world 2: the last global batch of every epoch has one sample, rank 1's slice is empty.  Over three
+    epochs the two ranks must (a) cut the same permutation -- the union of their slices is every sample exactly once per
+    epoch -- and (b) leave torch's global generator in the same state."""
+    world, n, bs, epochs = 2, 17, 8, 3
+    mp.spawn(_rng_fit_worker, args=(world, _free_port(), str(tmp_path), n, bs, epochs), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"rng_{r}.pt") for r in range(world)]
+    assert res[0]["next_key"] == res[1]["next_key"], "torch's CPU generator drifted apart between the ranks"
+    assert torch.equal(res[0]["w"], res[1]["w"])
+    nb = (n + bs - 1) // bs
+    # rank 0 ran nb steps per epoch, rank 1 nb - 1 (its slice of the last batch is empty)
+    assert len(res[0]["seen"]) == epochs * nb and len(res[1]["seen"]) == epochs * (nb - 1)
+    for e in range(epochs):
+        ids = torch.cat(res[0]["seen"][e * nb:(e + 1) * nb] + res[1]["seen"][e * (nb - 1):(e + 1) * (nb - 1)])
+        assert torch.equal(ids.sort().values, torch.arange(n, dtype=torch.float32) * 6), f"epoch {e}: samples duplicated or dropped"
+    # epochs are shuffled differently
+    assert not torch.equal(torch.cat(res[0]["seen"][:nb]), torch.cat(res[0]["seen"][nb:2 * nb]))
