@@ -44,15 +44,19 @@ struct fd_ctx {
     // tr_readers_gen = ws_gen at that moment: a different ws_gen at the next training forward means some other call carved the
     // arena in between and may still be running on the caller's stream, so the side stream must wait for a FRESH event
     hipEvent_t tr_readers_event = nullptr;
+    hipEvent_t tr_masksT_event = nullptr;      // behind the key-oriented copies of the attention keep bits (read by the backward only)
     bool tr_readers_event_valid = false;
     uint64_t tr_readers_gen = 0;
     // FFT twiddle tables (T, device pointer), built on first use of a length
     std::vector<std::pair<int, void*>> fft_tw;
     // measurement hooks (fd_prof_begin / fd_prof_end)
+    // several kernels may be bracketed in one window (the training step brackets its forward FFN kernel and the weight-gradient
+    // kernel); fd_prof_end reports the one with the largest TOTAL time
     bool prof_on = false;
-    std::string prof_name;
-    double prof_flops = 0.0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    struct prof_kernel { std::string name; double flops; };
+    std::vector<prof_kernel> prof_kernels;
+    struct prof_event { int kernel; hipEvent_t a, b; };
+    std::vector<prof_event> prof_events;
 };
 
 float* fd_gemm_scratch(fd_ctx* ctx, size_t* n_floats);   // fd_ctx.hip
@@ -67,17 +71,20 @@ struct fd_prof_scope {
     fd_ctx* ctx;
     hipStream_t s;
     hipEvent_t a = nullptr, b = nullptr;
+    int kernel = -1;
     fd_prof_scope(fd_ctx* c, hipStream_t st, const char* name, double flops) : ctx(c), s(st) {
-        if (!ctx->prof_on || ctx->prof_events.size() >= 4096) { ctx = nullptr; return; }
+        if (!ctx->prof_on || ctx->prof_events.size() >= 8192) { ctx = nullptr; return; }
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { ctx = nullptr; return; }
-        ctx->prof_name = name;
-        ctx->prof_flops = flops;
+        for (size_t i = 0; i < ctx->prof_kernels.size(); ++i)
+            if (ctx->prof_kernels[i].name == name) kernel = (int)i;
+        if (kernel < 0) { ctx->prof_kernels.push_back({name, flops}); kernel = (int)ctx->prof_kernels.size() - 1; }
+        ctx->prof_kernels[kernel].flops = flops;
         (void)hipEventRecord(a, s);
     }
     ~fd_prof_scope() {
         if (!ctx) return;
         (void)hipEventRecord(b, s);
-        ctx->prof_events.emplace_back(a, b);
+        ctx->prof_events.push_back({kernel, a, b});
     }
 };
 

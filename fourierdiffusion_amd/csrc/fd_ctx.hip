@@ -29,6 +29,7 @@ extern "C" int fd_ctx_destroy(fd_ctx* ctx) {
     if (ctx->red_scratch) (void)hipFree(ctx->red_scratch);
     for (hipEvent_t e : ctx->side_events) (void)hipEventDestroy(e);
     if (ctx->tr_readers_event) (void)hipEventDestroy(ctx->tr_readers_event);
+    if (ctx->tr_masksT_event) (void)hipEventDestroy(ctx->tr_masksT_event);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->side_stream2) (void)hipStreamDestroy(ctx->side_stream2);
     for (auto& e : ctx->fft_tw) (void)hipFree(e.second);
@@ -91,12 +92,11 @@ float* fd_gemm_scratch(fd_ctx* ctx, size_t* n_floats) {
 extern "C" int fd_prof_begin(fd_ctx* ctx) {
     if (!ctx) return FD_ERR_ARG;
     for (auto& e : ctx->prof_events) {
-        (void)hipEventDestroy(e.first);
-        (void)hipEventDestroy(e.second);
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
     }
     ctx->prof_events.clear();
-    ctx->prof_name.clear();
-    ctx->prof_flops = 0.0;
+    ctx->prof_kernels.clear();
     ctx->prof_on = true;
     return FD_OK;
 }
@@ -105,21 +105,28 @@ extern "C" int fd_prof_end(fd_ctx* ctx, char* name_out, double* avg_us, int* lau
     if (!ctx) return FD_ERR_ARG;
     FD_REQUIRE(ctx, name_out && avg_us && launches && flops_per_launch, "fd_prof_end: null output");
     ctx->prof_on = false;
-    double total_ms = 0.0;
-    int n = 0;
+    std::vector<double> total_ms(ctx->prof_kernels.size(), 0.0);
+    std::vector<int> n(ctx->prof_kernels.size(), 0);
     for (auto& e : ctx->prof_events) {
         float ms = 0.f;
-        if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
-            total_ms += ms;
-            ++n;
+        if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            total_ms[e.kernel] += ms;
+            ++n[e.kernel];
         }
-        (void)hipEventDestroy(e.first);
-        (void)hipEventDestroy(e.second);
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
     }
     ctx->prof_events.clear();
-    snprintf(name_out, 128, "%s", ctx->prof_name.c_str());
-    *launches = n;
-    *avg_us = n ? 1e3 * total_ms / n : 0.0;
-    *flops_per_launch = ctx->prof_flops;
+    int best = -1;                        // the bracketed kernel with the largest total time in the window
+    for (size_t k = 0; k < total_ms.size(); ++k)
+        if (n[k] > 0 && (best < 0 || total_ms[k] > total_ms[best])) best = (int)k;
+    if (best < 0) {
+        name_out[0] = 0; *launches = 0; *avg_us = 0.0; *flops_per_launch = 0.0;
+        return FD_OK;
+    }
+    snprintf(name_out, 128, "%s", ctx->prof_kernels[best].name.c_str());
+    *launches = n[best];
+    *avg_us = 1e3 * total_ms[best] / n[best];
+    *flops_per_launch = ctx->prof_kernels[best].flops;
     return FD_OK;
 }

@@ -33,22 +33,42 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ x
     if (sub == 0 && n < N)
         part[(size_t)blockIdx.y * N + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+// 64 columns x 4 row strands per block; a strand adds rows strand, strand + 4, ... in ascending order with eight loads in
+// flight, the strands are combined in a fixed order (one thread per column walking R rows was a chain of R dependent round
+// trips on 72 threads: 14-32 us for the 126 partial rows of a 16 128-token batch).
+__device__ __forceinline__ float sum_rows_strand(const float* __restrict__ p, int R, size_t stride, int sub) {
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.f;
+    int r = sub;
+    for (; r + 28 < R; r += 32) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += p[(size_t)(r + 4 * k) * stride];
+    }
+    for (; r < R; r += 4) a[0] += p[(size_t)r * stride];
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
 __global__ __launch_bounds__(256) void k_sum_rows(const float* __restrict__ part, int R, int N, float* __restrict__ out, int accumulate) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    float v = 0.f;
-    for (int r = 0; r < R; ++r) v += part[(size_t)r * N + n];
-    out[n] = accumulate ? out[n] + v : v;
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + col;
+    red[sub][col] = (n < N) ? sum_rows_strand(part + n, R, (size_t)N, sub) : 0.f;
+    __syncthreads();
+    if (sub == 0 && n < N) {
+        const float v = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        out[n] = accumulate ? out[n] + v : v;
+    }
 }
 
 // out[n] += sum_r part[r * stride + col0 + n], n < N
 __global__ __launch_bounds__(256) void k_sum_rows_strided(const float* __restrict__ part, int R, int stride, int col0, int N,
                                                            float* __restrict__ out) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    float v = 0.f;
-    for (int r = 0; r < R; ++r) v += part[(size_t)r * stride + col0 + n];
-    out[n] += v;
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + col;
+    red[sub][col] = (n < N) ? sum_rows_strand(part + col0 + n, R, (size_t)stride, sub) : 0.f;
+    __syncthreads();
+    if (sub == 0 && n < N) out[n] += (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
 // out = dropout(in) with the forward's mask (same Philox stream as fd_k_dropout: 4 elements per counter)
@@ -367,32 +387,32 @@ __global__ __launch_bounds__(64 * NWV) void k_attn_bwd_kv(const float* __restric
 // Four independent strands per output (loads in flight instead of one dependent chain), combined in a fixed order.
 __global__ __launch_bounds__(256) void k_embed_reduce(const float* __restrict__ dh, float* __restrict__ dpos,
                                                        float* __restrict__ dtemb, int B, int T, int D) {
-    const size_t id = blockIdx.x * (size_t)256 + threadIdx.x;
-    if (id < (size_t)T * D) {
-        const int t = (int)(id / D), d = (int)(id % D);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // grid: blocks [0, nb_pos) own the positional-table gradient, the rest the time-embedding gradient; eight loads in flight
+    // per output (four left the longer of the two sums a chain of T / 4 dependent round trips on B * D threads)
+    const int nb_pos = (T * D + 255) / 256;
+    if ((int)blockIdx.x < nb_pos) {
+        const size_t id = blockIdx.x * (size_t)256 + threadIdx.x;
+        if (id >= (size_t)T * D) return;
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = 0.f;
         int b = 0;
-        for (; b + 3 < B; b += 4) {
-            a0 += dh[((size_t)(b + 0) * T + t) * D + d];
-            a1 += dh[((size_t)(b + 1) * T + t) * D + d];
-            a2 += dh[((size_t)(b + 2) * T + t) * D + d];
-            a3 += dh[((size_t)(b + 3) * T + t) * D + d];
+        for (; b + 7 < B; b += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += dh[(size_t)(b + k) * T * D + id];
         }
-        for (; b < B; ++b) a0 += dh[((size_t)b * T + t) * D + d];
-        dpos[id] += (a0 + a1) + (a2 + a3);
-    }
-    if (id < (size_t)B * D) {
-        const int b = (int)(id / D), d = (int)(id % D);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int t = 0;
-        for (; t + 3 < T; t += 4) {
-            a0 += dh[((size_t)b * T + t + 0) * D + d];
-            a1 += dh[((size_t)b * T + t + 1) * D + d];
-            a2 += dh[((size_t)b * T + t + 2) * D + d];
-            a3 += dh[((size_t)b * T + t + 3) * D + d];
-        }
-        for (; t < T; ++t) a0 += dh[((size_t)b * T + t) * D + d];
-        dtemb[id] = (a0 + a1) + (a2 + a3);
+        for (; b < B; ++b) a[0] += dh[(size_t)b * T * D + id];
+        dpos[id] += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    } else {
+        // 64 columns x 4 strands of t per block, fixed-order combine
+        __shared__ float red[4][64];
+        const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+        const size_t id = (size_t)(blockIdx.x - nb_pos) * 64 + col;          // (b, d) flattened
+        const bool ok = id < (size_t)B * D;
+        const int b = ok ? (int)(id / D) : 0, d = ok ? (int)(id % D) : 0;
+        red[sub][col] = ok ? sum_rows_strand(dh + (size_t)b * T * D + d, T, (size_t)D, sub) : 0.f;
+        __syncthreads();
+        if (sub == 0 && ok) dtemb[id] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
     }
 }
 
@@ -425,8 +445,8 @@ void ln_bwd(fd_ctx* ctx, const float* dy, const float* x, const float* mr, const
     }
     hipLaunchKernelGGL(k_ln_bwd, dim3(nblk), dim3(256), 8 * D * sizeof(float), s, dy, x, mr, gamma, dx, part, M, D, tokens_per_block);
     // rows are [dgamma | dbeta]: two strided sums
-    hipLaunchKernelGGL(k_sum_rows_strided, dim3((D + 255) / 256), dim3(256), 0, s, part, nblk, 2 * D, 0, D, dgamma);
-    hipLaunchKernelGGL(k_sum_rows_strided, dim3((D + 255) / 256), dim3(256), 0, s, part, nblk, 2 * D, D, D, dbeta);
+    hipLaunchKernelGGL(k_sum_rows_strided, dim3((D + 63) / 64), dim3(256), 0, s, part, nblk, 2 * D, 0, D, dgamma);
+    hipLaunchKernelGGL(k_sum_rows_strided, dim3((D + 63) / 64), dim3(256), 0, s, part, nblk, 2 * D, D, D, dbeta);
 }
 
 template <int HDP>
@@ -444,7 +464,7 @@ void attn_bwd_t(const float* qkv, const float* dO, const float* lse, const float
 }  // namespace
 
 void fd_sum_rows(const float* part, int R, int N, float* out, bool accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(k_sum_rows, dim3((N + 255) / 256), dim3(256), 0, s, part, R, N, out, accumulate ? 1 : 0);
+    hipLaunchKernelGGL(k_sum_rows, dim3((N + 63) / 64), dim3(256), 0, s, part, R, N, out, accumulate ? 1 : 0);
 }
 
 int fd_colsum_det(fd_ctx* ctx, const float* x, float* out, int M, int N, hipStream_t s) {
@@ -477,10 +497,8 @@ int fd_embed_backward(fd_score* m, const float* dh, const float* emb, float* dte
     const int M = B * T;
     fdgemm::linear_bwd_weight(dh, m->saved_x, grads + m->emb_w, M, D, C, true, s, skp, skp_floats);
     colsum(ctx, dh, grads + m->emb_b, M, D, s);
-    {
-        const size_t n = std::max((size_t)T * D, (size_t)B * D);
-        hipLaunchKernelGGL(k_embed_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dh, grads + m->pos, dtemb, B, T, D);
-    }
+    hipLaunchKernelGGL(k_embed_reduce, dim3((unsigned)((T * D + 255) / 256 + (B * D + 63) / 64)), dim3(256), 0, s, dh, grads + m->pos,
+                       dtemb, B, T, D);
     fdgemm::linear_bwd_weight(dtemb, emb, grads + m->td_w, B, D, D, true, s, skp, skp_floats);
     colsum(ctx, dtemb, grads + m->td_b, B, D, s);
     FD_LAUNCH_CHECK(ctx);

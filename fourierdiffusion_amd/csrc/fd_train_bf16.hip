@@ -25,6 +25,7 @@
 // feature on lane) cannot both be regenerated from one counter layout without 4x the Philox evaluations.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 #include "fd_bf16_images.h"
 #include "fd_gemm_f32.h"
@@ -372,6 +373,39 @@ __global__ __launch_bounds__(256) void k_tr_masks(const TrDims d, const MaskArgs
     }
 }
 
+// Key-oriented copy of the attention keep bits for the backward's key-owner sweep (d K, d V): the forward and the query-owner
+// sweep read byte [(b, head)][query][jb][g] = bits of keys 32 jb + 4 g + r (bit r) and 32 jb + 16 + 4 g + r (bit 4 + r); the
+// key-owner sweep needs, per key, the bits of eight QUERIES.  Gathering them there cost eight LDS byte reads with their
+// address arithmetic per (query block, head) in a VALU-bound loop (280 VALU against 153 in the query-owner loop); here it
+// is a side-stream kernel off the critical path.  Same bits, second layout: byte [(b, head)][key][jq][g] = bits of queries
+// 32 jq + 4 g + r (bit r) and 32 jq + 16 + 4 g + r (bit 4 + r).  One workgroup per ((b, head), jq): the 32 queries' rows
+// (32 x NJ x 4 bytes) go through LDS.
+__global__ __launch_bounds__(256) void k_tr_masks_T(const unsigned char* __restrict__ pmask, unsigned char* __restrict__ pmaskT,
+                                                     int T, int NJ) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char srow[];      // [32 queries][NJ * 4]
+    const int jq = blockIdx.x;
+    const size_t bh = blockIdx.y;
+    const int RB = NJ * 4;
+    for (int i = threadIdx.x * 4; i < 32 * RB; i += 256 * 4) {
+        const int q = 32 * jq + i / RB;
+        unsigned w = 0u;
+        if (q < T) w = *reinterpret_cast<const unsigned*>(pmask + (bh * T + q) * RB + (i % RB));
+        *reinterpret_cast<unsigned*>(srow + i) = w;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < T * 4; o += 256) {
+        const int key = o >> 2, gq = o & 3;
+        const int col = (key >> 5) * 4 + ((key >> 2) & 3), sh = ((key >> 4) & 1) * 4 + (key & 3);
+        unsigned out = 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ql = (e >> 2) * 16 + 4 * gq + (e & 3);
+            out |= ((srow[ql * RB + col] >> sh) & 1u) << e;
+        }
+        pmaskT[((bh * T + key) * NJ + jq) * 4 + gq] = (unsigned char)out;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ layer-input preparation
 // fp32 (M, D) -> bf16 rows (ones in slot D) + T-block (ones row), for the first layer's input (the embedding kernel is the
 // exact-f32 one).  One wave per 16-token tile.
@@ -400,8 +434,14 @@ struct AttnFwdArgs {
     const char* wk; const char* wv; const char* wq;   // pair images (KS1 blocks per pair)
 };
 
-template <int KS1>
-__global__ __launch_bounds__(256) void k_tr_attn_fwd(const TrDims d, const AttnFwdArgs a) {
+// NW waves per workgroup: a wave owns the token tiles wave, wave + NW, ... (NW = 8 from five tiles on: the kernels are latency-
+// bound chains per tile, so twice the waves per (series, head pair) halve the critical path at T = 100 and double the waves
+// per SIMD that hide each other's LDS / MFMA / exp latencies at T = 252)
+#ifndef FD_TR_ATTN_MINW
+#define FD_TR_ATTN_MINW 2
+#endif
+template <int KS1, int NW>
+__global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const AttnFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -416,7 +456,7 @@ __global__ __launch_bounds__(256) void k_tr_attn_fwd(const TrDims d, const AttnF
         bf16x8 wkf[KS1], wvf[KS1];
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) { wkf[ks] = wfrag(a.wk, ks); wvf[ks] = wfrag(a.wv, ks); }
-        for (int kt = wave; kt < KT; kt += 4) {
+        for (int kt = wave; kt < KT; kt += NW) {
             f32x4 ka = f4zero(), vc = f4zero();
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
@@ -441,7 +481,7 @@ __global__ __launch_bounds__(256) void k_tr_attn_fwd(const TrDims d, const AttnF
     for (int r = 0; r < 4; ++r) cmask[r] = ((KT - 1) * 16 + 4 * g + r >= T) ? kNegBig : 0.f;
     const f32x4 allneg = {kNegBig, kNegBig, kNegBig, kNegBig};
     auto kfrag = [&](int kt) { return *reinterpret_cast<const s16x4*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8); };
-    for (int qt = wave; qt < KT; qt += 4) {
+    for (int qt = wave; qt < KT; qt += NW) {
         const int t = qt * 16 + tok;
         f32x4 qa = f4zero();
 #pragma unroll
@@ -1038,6 +1078,7 @@ struct AttnBwdArgs {
     const float* datt;        // (M, D)
     const float* lse2;
     const unsigned char* pmask;
+    const unsigned char* pmaskT;   // key-oriented copy (k_tr_masks_T)
     float* dxp;               // [NP][M, D]: this pair's contribution to the layer-input gradient
     __bf16* dqkvT;            // T-block with 3*NP*16 rows: row which*(NP*16) + pair*16 + (8 hs + dim)
     const char* wk; const char* wv; const char* wq;
@@ -1045,8 +1086,8 @@ struct AttnBwdArgs {
     size_t part_stride;
 };
 
-template <int KS1, int DT>
-__global__ __launch_bounds__(256) void k_tr_attn_bwd(const TrDims d, const AttnBwdArgs a) {
+template <int KS1, int DT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_attn_bwd(const TrDims d, const AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1073,7 +1114,7 @@ __global__ __launch_bounds__(256) void k_tr_attn_bwd(const TrDims d, const AttnB
             const int head = 2 * pair + hs;
             if (head >= H) continue;
             const unsigned char* src = a.pmask + ((size_t)b * H + head) * PMH;        // contiguous per (series, head)
-            for (int i = threadIdx.x * 4; i < PMH; i += 256 * 4)                       // PMH is a multiple of 4
+            for (int i = threadIdx.x * 4; i < PMH; i += NW * 64 * 4)                       // PMH is a multiple of 4
                 *reinterpret_cast<unsigned*>(pm + hs * PMH + i) = *reinterpret_cast<const unsigned*>(src + i);
         }
     }
@@ -1082,7 +1123,7 @@ __global__ __launch_bounds__(256) void k_tr_attn_bwd(const TrDims d, const AttnB
         bf16x8 wqf[KS1], wkf[KS1], wvf[KS1];
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) { wqf[ks] = wfrag(a.wq, ks); wkf[ks] = wfrag(a.wk, ks); wvf[ks] = wfrag(a.wv, ks); }
-        for (int kt = wave; kt < KT; kt += 4) {
+        for (int kt = wave; kt < KT; kt += NW) {
             f32x4 qr = f4zero(), kr = f4zero(), vr = f4zero(), qc = f4zero(), kc = f4zero();
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
@@ -1123,7 +1164,9 @@ __global__ __launch_bounds__(256) void k_tr_attn_bwd(const TrDims d, const AttnB
             swap16(part, ea, eb);
             if ((g & 1) == 0) {
                 drow[(g >> 1) * NTOK + kt * 16 + tok] = ea + eb;
-                lse[(g >> 1) * NTOK + kt * 16 + tok] = (t < T && myhead < H) ? a.lse2[((size_t)b * H + myhead) * T + t] : 0.f;
+                // padded queries / a missing odd head: lse = +1e30 makes every P = exp2(s - lse) of that row exactly 0, so the
+                // sweeps need no validity selects (padded KEYS have all-zero K / V / dO operands instead)
+                lse[(g >> 1) * NTOK + kt * 16 + tok] = (t < T && myhead < H) ? a.lse2[((size_t)b * H + myhead) * T + t] : 1.0e30f;
             }
             // dO column form: lane (dim row = tok, g) holds tokens 4g+r of this tile
             {
@@ -1151,7 +1194,7 @@ __global__ __launch_bounds__(256) void k_tr_attn_bwd(const TrDims d, const AttnB
     const float inv_sqrt_hd = __builtin_amdgcn_rsqf((float)hd);
     // each wave owns token tiles tt = wave, wave+4, ...: as QUERY tile (d q), then as KEY tile (d k, d v), then the
     // input gradient of in_proj for those 16 tokens
-    for (int tt = wave; tt < KT; tt += 4) {
+    for (int tt = wave; tt < KT; tt += NW) {
         f32x4 dq[2] = {f4zero(), f4zero()}, dk[2] = {f4zero(), f4zero()}, dv[2] = {f4zero(), f4zero()};
         // ---------------- as query tile: S^T tiles [key rows 4g+r][query col]
         {
@@ -1168,27 +1211,27 @@ __global__ __launch_bounds__(256) void k_tr_attn_bwd(const TrDims d, const AttnB
                     dr[hs] = drow[hs * NTOK + tt * 16 + tok];
                 }
             }
+            const int tcl = t < T ? t : T - 1;                       // (padded query columns are discarded at the end)
             for (int jb = 0; jb < NJ; ++jb) {
+                // a missing odd key tile re-reads tile ka: its half of the K column block is zero, so it adds nothing to d q;
+                // padded keys likewise (zero K columns); no per-score validity selects
                 const int ka = 2 * jb, kb = (2 * jb + 1 < KT) ? 2 * jb + 1 : ka;
-                const bool has_b = 2 * jb + 1 < KT;
                 const s16x4 kfa = rfrag(kR, ka), kfb = rfrag(kR, kb), vfa = rfrag(vR, ka), vfb = rfrag(vR, kb);
                 const bf16x8 kcf = cfrag(kC, jb);
 #pragma unroll
                 for (int hs = 0; hs < 2; ++hs) {
                     f32x4 sa = MFMA16(kfa, qb[hs], f4zero()), sb = MFMA16(kfb, qb[hs], f4zero());
                     f32x4 pa = MFMA16(vfa, ob[hs], f4zero()), pb = MFMA16(vfb, ob[hs], f4zero());    // dP (dropped P's gradient)
-                    const int head = 2 * pair + hs;
                     unsigned bits = 0xffu;
-                    if (d.p > 0.f && t < T && head < H) bits = pm[hs * PMH + (t * NJ + jb) * 4 + g];
+                    if (d.p > 0.f) bits = pm[hs * PMH + (tcl * NJ + jb) * 4 + g];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const bool va = ka * 16 + 4 * g + r < T, vb = has_b && (kb * 16 + 4 * g + r < T);
-                        const float Pa = va ? __builtin_amdgcn_exp2f(sa[r] - lq[hs]) : 0.f;
-                        const float Pb = vb ? __builtin_amdgcn_exp2f(sb[r] - lq[hs]) : 0.f;
-                        const float ga = ((bits >> r) & 1u) ? pa[r] * d.keep_scale : 0.f;
-                        const float gb = ((bits >> (4 + r)) & 1u) ? pb[r] * d.keep_scale : 0.f;
-                        sa[r] = Pa * (ga - dr[hs]);
-                        sb[r] = Pb * (gb - dr[hs]);
+                        const float Pa = __builtin_amdgcn_exp2f(sa[r] - lq[hs]);
+                        const float Pb = __builtin_amdgcn_exp2f(sb[r] - lq[hs]);
+                        const float ma = ((bits >> r) & 1u) ? d.keep_scale : 0.f;          // keep multiplier of this score
+                        const float mb = ((bits >> (4 + r)) & 1u) ? d.keep_scale : 0.f;
+                        sa[r] = Pa * __builtin_fmaf(pa[r], ma, -dr[hs]);
+                        sb[r] = Pb * __builtin_fmaf(pb[r], mb, -dr[hs]);
                     }
                     dq[hs] = MFMA(kcf, pack8(sa, sb), dq[hs]);       // [dim rows][query col] += K^T dS^T
                 }
@@ -1197,39 +1240,55 @@ __global__ __launch_bounds__(256) void k_tr_attn_bwd(const TrDims d, const AttnB
         // ---------------- as key tile: S tiles [query rows 4g+r][key col]
         {
             const int kt = tt;
-            const s16x4 kf = rfrag(kR, kt), vf = rfrag(vR, kt);
-            const int key = kt * 16 + tok;
+            // the head's k-slots are selected on the key side once per tile (masking either operand of the contraction does)
+            s16x4 kfh[2], vfh[2];
+            {
+                const s16x4 kf = rfrag(kR, kt), vf = rfrag(vR, kt);
+#pragma unroll
+                for (int hs = 0; hs < 2; ++hs) { kfh[hs] = headmask(kf, hs); vfh[hs] = headmask(vf, hs); }
+            }
+            const int key = kt * 16 + tok, keycl = key < T ? key : T - 1;       // (padded key columns are discarded at the end)
+            // keep bits in the key-oriented layout: one 32-bit word per (key, query block) and head holds the four lane groups'
+            // bytes; the next block's words are in flight during the current one
+            const unsigned char* pt[2];
+#pragma unroll
+            for (int hs = 0; hs < 2; ++hs) {
+                const int head = min(2 * pair + hs, H - 1);
+                pt[hs] = a.pmaskT + (((size_t)b * H + head) * T + keycl) * NJ * 4;
+            }
+            unsigned wn[2] = {0xffffffffu, 0xffffffffu};
+            if (d.p > 0.f) { wn[0] = *reinterpret_cast<const unsigned*>(pt[0]); wn[1] = *reinterpret_cast<const unsigned*>(pt[1]); }
             for (int jq = 0; jq < NJ; ++jq) {
                 const int qa_t = 2 * jq, qb_t = (2 * jq + 1 < KT) ? 2 * jq + 1 : qa_t;
-                const bool has_b = 2 * jq + 1 < KT;
+                const unsigned wc[2] = {wn[0], wn[1]};
+                if (d.p > 0.f && jq + 1 < NJ) {
+                    wn[0] = *reinterpret_cast<const unsigned*>(pt[0] + (jq + 1) * 4);
+                    wn[1] = *reinterpret_cast<const unsigned*>(pt[1] + (jq + 1) * 4);
+                }
                 const s16x4 qfa = rfrag(qR, qa_t), qfb = rfrag(qR, qb_t), ofa = rfrag(oR, qa_t), ofb = rfrag(oR, qb_t);
                 const bf16x8 qcf = cfrag(qC, jq), ocf = cfrag(oC, jq);
 #pragma unroll
                 for (int hs = 0; hs < 2; ++hs) {
-                    f32x4 sa = MFMA16(headmask(qfa, hs), kf, f4zero()), sb = MFMA16(headmask(qfb, hs), kf, f4zero());
-                    f32x4 pa = MFMA16(headmask(ofa, hs), vf, f4zero()), pb = MFMA16(headmask(ofb, hs), vf, f4zero());
-                    const int head = 2 * pair + hs;
+                    f32x4 sa = MFMA16(qfa, kfh[hs], f4zero()), sb = MFMA16(qfb, kfh[hs], f4zero());
+                    f32x4 pa = MFMA16(ofa, vfh[hs], f4zero()), pb = MFMA16(ofb, vfh[hs], f4zero());
+                    // padded query rows carry lse = 1e30 (P = 0); a missing odd query tile re-reads tile qa_t against zero halves
+                    // of the Q / dO column blocks
                     const f32x4 la = *reinterpret_cast<const f32x4*>(lse + hs * NTOK + qa_t * 16 + 4 * g);
                     const f32x4 lb = *reinterpret_cast<const f32x4*>(lse + hs * NTOK + qb_t * 16 + 4 * g);
                     const f32x4 da = *reinterpret_cast<const f32x4*>(drow + hs * NTOK + qa_t * 16 + 4 * g);
                     const f32x4 db = *reinterpret_cast<const f32x4*>(drow + hs * NTOK + qb_t * 16 + 4 * g);
+                    const unsigned bits = (wc[hs] >> (8 * g)) & 0xffu;
                     f32x4 pda, pdb;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int qa_i = qa_t * 16 + 4 * g + r, qb_i = qb_t * 16 + 4 * g + r;
-                        const bool va = qa_i < T && key < T && head < H, vb = has_b && qb_i < T && key < T && head < H;
-                        bool ba = true, bb = true;
-                        if (d.p > 0.f) {
-                            const unsigned char* ph = pm + hs * PMH;
-                            if (va) ba = (ph[(qa_i * NJ + (kt >> 1)) * 4 + (tok >> 2)] >> ((kt & 1) * 4 + (tok & 3))) & 1u;
-                            if (vb) bb = (ph[(qb_i * NJ + (kt >> 1)) * 4 + (tok >> 2)] >> ((kt & 1) * 4 + (tok & 3))) & 1u;
-                        }
-                        const float Pa = va ? __builtin_amdgcn_exp2f(sa[r] - la[r]) : 0.f;
-                        const float Pb = vb ? __builtin_amdgcn_exp2f(sb[r] - lb[r]) : 0.f;
-                        pda[r] = ba ? Pa * d.keep_scale : 0.f;
-                        pdb[r] = bb ? Pb * d.keep_scale : 0.f;
-                        sa[r] = Pa * ((ba ? pa[r] * d.keep_scale : 0.f) - da[r]);
-                        sb[r] = Pb * ((bb ? pb[r] * d.keep_scale : 0.f) - db[r]);
+                        const float ma = ((bits >> r) & 1u) ? d.keep_scale : 0.f;          // keep multiplier of this score
+                        const float mb = ((bits >> (4 + r)) & 1u) ? d.keep_scale : 0.f;
+                        const float Pa = __builtin_amdgcn_exp2f(sa[r] - la[r]);
+                        const float Pb = __builtin_amdgcn_exp2f(sb[r] - lb[r]);
+                        pda[r] = Pa * ma;
+                        pdb[r] = Pb * mb;
+                        sa[r] = Pa * __builtin_fmaf(pa[r], ma, -da[r]);
+                        sb[r] = Pb * __builtin_fmaf(pb[r], mb, -db[r]);
                     }
                     dv[hs] = MFMA(ocf, pack8(pda, pdb), dv[hs]);     // [dim rows][key col] += dO^T P_drop
                     dk[hs] = MFMA(qcf, pack8(sa, sb), dk[hs]);       // += Q^T dS
@@ -1296,7 +1355,8 @@ struct WgArgs {
 __device__ __forceinline__ bf16x8 t_frag(const __bf16* __restrict__ tb, int blk, int NF, int rt, int lane, int nvalid) {
     const int row = lane & 15, g = lane >> 4;
     u32x4 v = *reinterpret_cast<const u32x4*>(tb + ((size_t)blk * NF + 16 * rt + row) * 32 + 8 * g);
-    if (nvalid < 32) {
+    if (nvalid < 32) {       // only the very last block of the batch; the empty asm keeps hipcc from if-converting the (uniform)
+        asm volatile("");    // branch into 16 selects executed for every fragment of every block
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             if (8 * g + e >= nvalid) v[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
@@ -1366,8 +1426,13 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
         auto blk_of = [&](int ib) { int bq = ib + brot; bq -= (bq >= nb) ? nb : 0; return blk0 + bq; };
         if (nb > 0) { issue(blk_of(0), 0); load_masks(blk_of(0), mk[0]); }
         if (nb > 1) { issue(blk_of(1), 1); load_masks(blk_of(1), mk[1]); }
-        for (int ib = 0; ib < nb; ++ib) {
-            const int blk = blk_of(ib), slot = ib % NBUF;
+        // One block: the ring slot is a compile-time constant (the loop below is unrolled by NBUF), so neither the mask words
+        // nor the LDS addresses go through run-time selects.  Tokens beyond M need no masking here: k_tr_ffn_fwd / k_tr_ffn_bwd
+        // write ZERO rows and T-block columns for them into the stage records (every workgroup covers 64 tokens up to Mpad), and
+        // a zero x1 / d f column contributes nothing to either gradient.  The dropout keep scale is linear in both products and
+        // is applied once to the accumulators after the loop.
+        auto block = [&](int ib, auto slot_c) {
+            constexpr int slot = decltype(slot_c)::value;
             // block ib must have landed (this wave's share), then everybody's
             if (ib + 1 < nb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 4) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1380,19 +1445,13 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
             if (ib + 2 < nb) {
 #endif
                 const int bn2 = blk_of(ib + 2);
-                issue(bn2, (ib + 2) % NBUF);
-                if ((ib + 2) % NBUF == 0) load_masks(bn2, mk[0]);
-                else if ((ib + 2) % NBUF == 1) load_masks(bn2, mk[1]);
-                else load_masks(bn2, mk[2]);
+                issue(bn2, (slot + 2) % NBUF);
+                load_masks(bn2, mk[(slot + 2) % NBUF]);
             }
             const char* sx = smem + slot * SB + SL::off_xr;
             const char* sd = smem + slot * SB + SL::off_dr;
             const char* tx = smem + slot * SB + SL::off_xT;
             const char* td = smem + slot * SB + SL::off_dT;
-            const int nvalid = min(32, M - blk * 32);
-            unsigned short mks[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mks[i] = (slot == 0) ? mk[0][i] : (slot == 1 ? mk[1][i] : mk[2][i]);
             f32x4 hh[2][2], dh[2][2];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -1410,12 +1469,12 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
                 }
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft) {
-                    const unsigned mw = mks[half * 2 + ft];
+                    const unsigned mw = mk[slot][half * 2 + ft];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool on = (mw >> (4 * g + r)) & 1u;
-                        h[ft][r] = on ? h[ft][r] * d.keep_scale : 0.f;
-                        e[ft][r] = on ? e[ft][r] * d.keep_scale : 0.f;
+                        h[ft][r] = on ? h[ft][r] : 0.f;
+                        e[ft][r] = on ? e[ft][r] : 0.f;
                     }
                     hh[ft][half] = h[ft];
                     dh[ft][half] = e[ft];
@@ -1428,27 +1487,28 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
             for (int dt = 0; dt < DT; ++dt) {
                 // T-block A operands in the token order of the packed C tiles: slots 0-3 = tokens 4g.., slots 4-7 = tokens 16+4g..
                 const char* px = tx + (size_t)(16 * dt + tok) * (SL::TBS * 2), *pd = td + (size_t)(16 * dt + tok) * (SL::TBS * 2);
-                u32x2 xl = *reinterpret_cast<const u32x2*>(px + 8 * g), xh = *reinterpret_cast<const u32x2*>(px + 32 + 8 * g);
-                u32x2 dl = *reinterpret_cast<const u32x2*>(pd + 8 * g), dhh = *reinterpret_cast<const u32x2*>(pd + 32 + 8 * g);
-                u32x4 xv = {xl[0], xl[1], xh[0], xh[1]}, dv = {dl[0], dl[1], dhh[0], dhh[1]};
-                if (nvalid < 32) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int tk = (e < 4) ? 4 * g + e : 16 + 4 * g + (e - 4);
-                        if (tk >= nvalid) {
-                            xv[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
-                            dv[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
-                        }
-                    }
-                }
-                const bf16x8 ax = __builtin_bit_cast(bf16x8, xv), ad = __builtin_bit_cast(bf16x8, dv);
+                const u32x2 xl = *reinterpret_cast<const u32x2*>(px + 8 * g), xh = *reinterpret_cast<const u32x2*>(px + 32 + 8 * g);
+                const u32x2 dl = *reinterpret_cast<const u32x2*>(pd + 8 * g), dhh = *reinterpret_cast<const u32x2*>(pd + 32 + 8 * g);
+                const bf16x8 ax = __builtin_bit_cast(bf16x8, u32x4{xl[0], xl[1], xh[0], xh[1]});
+                const bf16x8 ad = __builtin_bit_cast(bf16x8, u32x4{dl[0], dl[1], dhh[0], dhh[1]});
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft) {
                     a2[ft][dt] = MFMA(ad, hB[ft], a2[ft][dt]);        // d W2[d][f]
                     a1[ft][dt] = MFMA(ax, dB[ft], a1[ft][dt]);        // d W1[f][d], row D = d b1[f]
                 }
             }
+        };
+        for (int ib = 0; ib < nb; ib += NBUF) {
+            block(ib, std::integral_constant<int, 0>{});
+            if (ib + 1 < nb) block(ib + 1, std::integral_constant<int, 1>{});
+            if (ib + 2 < nb) block(ib + 2, std::integral_constant<int, 2>{});
         }
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a1[ft][dt][r] *= d.keep_scale; a2[ft][dt][r] *= d.keep_scale; }
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
             const int f = chunk * 32 + ft * 16 + tok;
@@ -1483,29 +1543,39 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
         if (nr == 0 || blk1 <= blk0) {
             // (nothing owned: still nothing to write -- every output element has exactly one owner wave)
         } else {
-            bf16x8 bn[DT], an[MAXR];
-            auto fetch = [&](int blk) {
+            // operands straight from the T-blocks in global memory (L2 / Infinity Cache: ~2 us per round trip and only 2-10
+            // MFMAs per block to hide it behind), so the fragments of the next PF blocks are in flight in registers
+            constexpr int PF = 3;
+            bf16x8 bn[PF][DT], an[PF][MAXR];
+            auto fetch = [&](int blk, bf16x8 (&bq)[DT], bf16x8 (&aq)[MAXR]) {
                 const int nvalid = min(32, M - blk * 32);
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) bn[dt] = t_frag(Bt, blk, NFT, dt, lane, nvalid);
+                for (int dt = 0; dt < DT; ++dt) bq[dt] = t_frag(Bt, blk, NFT, dt, lane, nvalid);
 #pragma unroll
                 for (int i = 0; i < MAXR; ++i)
-                    if (i < nr) an[i] = t_frag(At, blk, ANF, rt_base + wave + 4 * i, lane, nvalid);
+                    if (i < nr) aq[i] = t_frag(At, blk, ANF, rt_base + wave + 4 * i, lane, nvalid);
             };
-            fetch(blk0);
-            for (int blk = blk0; blk < blk1; ++blk) {
-                bf16x8 bc[DT], ac[MAXR];
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) bc[dt] = bn[dt];
+            for (int q = 0; q < PF; ++q)
+                if (blk0 + q < blk1) fetch(blk0 + q, bn[q], an[q]);
+            for (int blk = blk0; blk < blk1; blk += PF) {
 #pragma unroll
-                for (int i = 0; i < MAXR; ++i) ac[i] = an[i];
-                if (blk + 1 < blk1) fetch(blk + 1);
+                for (int q = 0; q < PF; ++q) {
+                    if (blk + q < blk1) {
+                        bf16x8 bc[DT], ac[MAXR];
 #pragma unroll
-                for (int i = 0; i < MAXR; ++i)
-                    if (i < nr) {
+                        for (int dt = 0; dt < DT; ++dt) bc[dt] = bn[q][dt];
 #pragma unroll
-                        for (int dt = 0; dt < DT; ++dt) acc[i][dt] = MFMA(ac[i], bc[dt], acc[i][dt]);
+                        for (int i = 0; i < MAXR; ++i) ac[i] = an[q][i];
+                        if (blk + q + PF < blk1) fetch(blk + q + PF, bn[q], an[q]);
+#pragma unroll
+                        for (int i = 0; i < MAXR; ++i)
+                            if (i < nr) {
+#pragma unroll
+                                for (int dt = 0; dt < DT; ++dt) acc[i][dt] = MFMA(ac[i], bc[dt], acc[i][dt]);
+                            }
                     }
+                }
             }
         }
 #pragma unroll
@@ -1542,26 +1612,28 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
     }
 }
 
-// grads[i] (+)= sum over the token splits (fixed order) for the matrices / biases the weight-gradient kernel owns, the
-// per-workgroup column sums (fixed order) for the five vector parameters of the FFN-side backward, and 0 for everything
-// else in the layer range (alignment gaps of the flat layout: the fused AdamW and the gradient norm run over them).
-constexpr int kMaxTS = 4;
+// grads[i] (+)= sum over the token splits (fixed order) for the matrices / biases the weight-gradient kernel owns and 0 for the
+// alignment gaps of the flat layout (the fused AdamW and the gradient norm run over them).  ONE LAYER per launch, on the side
+// stream right behind that layer's k_tr_wgrad (its partials are still in the Infinity Cache).  The five vector parameters of
+// the FFN-side backward (per-workgroup column sums) are reduced by k_tr_vecreduce.
+constexpr int kMaxTS = 32;
 struct RedArgs {
-    const float* part; long long nparams; int TS;
-    const float* vecpart;      // [L][nwg][5][D]
-    int nwg, D, L;
-    long long begin;           // first layer parameter
-    long long layer_stride;    // parameters per layer
+    const float* part; long long nparams; int TS;      // nparams = parameters per layer (the stride of a split's partials)
+    int D;
     long long rel[5];          // offsets of l2_b, n2_b, n2_w, n1_b, n1_w relative to the layer's first parameter
     long long wrel[7], wnum[7];   // in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w: offsets / element counts
-    float* grads; int accumulate;
+    float* grads; int accumulate;                       // grads = the layer's first parameter
 };
 __global__ __launch_bounds__(256) void k_tr_reduce(const RedArgs a) {
     // 4 consecutive parameters per thread: every tensor of the flat layout starts on a 16-byte boundary and every owned range
     // has a multiple of 4 elements (d_model % 4 == 0), so a group is owned / vector / gap as a whole
-    const long long i = a.begin + ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= a.nparams) return;
-    const long long li = (i - a.begin) / a.layer_stride, rel = (i - a.begin) - li * a.layer_stride;
+    const long long rel = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (rel >= a.nparams) return;
+#pragma unroll
+    for (int sidx = 0; sidx < 5; ++sidx) {
+        const long long o = rel - a.rel[sidx];
+        if (o >= 0 && o < a.D) return;                 // k_tr_vecreduce owns these
+    }
     float4 v = {0.f, 0.f, 0.f, 0.f};
     bool owned = false;
 #pragma unroll
@@ -1571,39 +1643,53 @@ __global__ __launch_bounds__(256) void k_tr_reduce(const RedArgs a) {
         float4 p4[kMaxTS];
 #pragma unroll
         for (int t = 0; t < kMaxTS; ++t)
-            p4[t] = (t < a.TS) ? *reinterpret_cast<const float4*>(a.part + (size_t)t * a.nparams + i) : float4{0.f, 0.f, 0.f, 0.f};
+            p4[t] = (t < a.TS) ? *reinterpret_cast<const float4*>(a.part + (size_t)t * a.nparams + rel) : float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < kMaxTS; ++t) { v.x += p4[t].x; v.y += p4[t].y; v.z += p4[t].z; v.w += p4[t].w; }
     }
-    int vs = -1;
-    long long vo = 0;
-#pragma unroll
-    for (int sidx = 0; sidx < 5; ++sidx) {
-        const long long o = rel - a.rel[sidx];
-        if (o >= 0 && o < a.D) { vs = sidx; vo = o; }
-    }
-    if (vs >= 0) {
-        owned = true;
-        const float* vp = a.vecpart + ((size_t)li * a.nwg * 5 + vs) * a.D + vo;
-        // 8 strands (workgroup index mod 8), each in ascending order, combined in a fixed order: 8 loads in flight
-        float4 st[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) st[k] = float4{0.f, 0.f, 0.f, 0.f};
-        for (int w0 = 0; w0 < a.nwg; w0 += 8) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (w0 + k < a.nwg) {
-                    const float4 q4 = *reinterpret_cast<const float4*>(vp + (size_t)(w0 + k) * 5 * a.D);
-                    st[k].x += q4.x; st[k].y += q4.y; st[k].z += q4.z; st[k].w += q4.w;
-                }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { v.x += st[k].x; v.y += st[k].y; v.z += st[k].z; v.w += st[k].w; }
-    }
-    float4* gp = reinterpret_cast<float4*>(a.grads + i);
+    float4* gp = reinterpret_cast<float4*>(a.grads + rel);
     if (a.accumulate) {
         if (owned) { const float4 g4 = *gp; *gp = float4{g4.x + v.x, g4.y + v.y, g4.z + v.z, g4.w + v.w}; }
     } else {
+        *gp = v;
+    }
+}
+
+// The five vector parameters per layer whose gradients k_tr_ffn_bwd leaves as per-workgroup column sums (l2_b, n2_b, n2_w,
+// n1_b, n1_w): grid (5, L), 1024 threads = 32 float4 columns x 32 strands.  A strand adds workgroups strand, strand + 32, ... in
+// ascending order (all of its loads in flight), the strands are combined through LDS in ascending order: fixed order, no
+// atomics.  (As one thread per column group inside k_tr_reduce this was a serial chain of nwg / 8 dependent round trips:
+// 110 us at 252 workgroups.)
+struct VecRedArgs {
+    const float* vecpart;      // [L][nwg][5][D]
+    int nwg, D;
+    long long begin, layer_stride;
+    long long rel[5];
+    float* grads; int accumulate;
+};
+__global__ __launch_bounds__(1024) void k_tr_vecreduce(const VecRedArgs a) {
+    __shared__ float4 red[32][32];
+    const int vs = blockIdx.x, li = blockIdx.y;
+    const int col = threadIdx.x & 31, strand = threadIdx.x >> 5;
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (4 * col < a.D) {
+        const float* vp = a.vecpart + ((size_t)li * a.nwg * 5 + vs) * a.D + 4 * col;
+        for (int w0 = strand; w0 < a.nwg; w0 += 32 * 4) {
+            float4 q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                q[k] = (w0 + 32 * k < a.nwg) ? *reinterpret_cast<const float4*>(vp + (size_t)(w0 + 32 * k) * 5 * a.D) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc.x += q[k].x; acc.y += q[k].y; acc.z += q[k].z; acc.w += q[k].w; }
+        }
+    }
+    red[strand][col] = acc;
+    __syncthreads();
+    if (strand == 0 && 4 * col < a.D) {
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 32; ++k) { const float4 q = red[k][col]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        float4* gp = reinterpret_cast<float4*>(a.grads + a.begin + (long long)li * a.layer_stride + a.rel[vs] + 4 * col);
+        if (a.accumulate) { const float4 g4 = *gp; v.x += g4.x; v.y += g4.y; v.z += g4.z; v.w += g4.w; }
         *gp = v;
     }
 }
@@ -1627,7 +1713,7 @@ struct TrLayerBufs {
     float *x0, *att, *s1, *s2, *lse2;
     __bf16 *x0rb, *x0T, *attT, *doT, *dqkvT;
     char* stage;
-    unsigned char *pmask, *active, *hkeep, *rb1, *rb3;
+    unsigned char *pmask, *pmaskT, *active, *hkeep, *rb1, *rb3;
     unsigned short* activeT;
 };
 struct TrBufs {
@@ -1636,12 +1722,21 @@ struct TrBufs {
     // backward transients
     float *dh, *datt, *dres[2], *dxp[2], *dtemb, *skp, *vecpart, *part;
     int Mpad, nwg, TS;
-    size_t part_stride;
+    size_t part_stride, layer_params;
 };
 
 constexpr size_t kSkpFloats = (size_t)1 << 20;
 
-int tr_TS(const fd_score* m) { return kMaxTS; }
+// Token splits of the weight-gradient launch: (F/128 + 4) x TS workgroups of 4 waves.  The kernel is latency-bound (one
+// L2 / Infinity-Cache round trip per 32-token block and wave), so it wants every SIMD of the chip to hold a wave: 16 splits
+// give 320 workgroups at dim_ff 2048 (round 2 ran 4 = 80 workgroups on 256 CUs: 277 us per layer at 16 128 tokens).  At
+// least 6 blocks per split so that the per-workgroup prologue (64 KiB of weight fragments) stays amortised.
+int tr_TS(const fd_score* m, int B) {
+    const long long nblk = ((long long)B * m->d.max_len + 31) / 32;
+    int ts = (int)std::min<long long>(16, std::max<long long>(1, nblk / 6));
+    if (const char* e = getenv("FDIFF_TR_TS")) ts = std::max(1, std::min(kMaxTS, atoi(e)));     // experiments
+    return ts;
+}
 
 size_t al(size_t b) { return fd_ws::padded(b); }
 
@@ -1657,7 +1752,7 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
     TrBufs tb;
     tb.Mpad = (int)Mpad;
     tb.nwg = (int)(Mpad / 64);
-    tb.TS = tr_TS(m);
+    tb.TS = tr_TS(m, B);
     tb.part_stride = M * D;
     tb.emb = (float*)take(sizeof(float) * B * D);
     tb.temb = (float*)take(sizeof(float) * B * D);
@@ -1677,6 +1772,7 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
         b.doT = (__bf16*)take(2 * Mpad * NFT);
         b.dqkvT = (__bf16*)take(2 * Mpad * 3 * NP * 16);
         b.pmask = (unsigned char*)take((size_t)B * H * T * NJ * 4);
+        b.pmaskT = (unsigned char*)take((size_t)B * H * T * NJ * 4);
         b.active = (unsigned char*)take(Mpad * (F / 32) * 4);
         b.hkeep = (unsigned char*)take(Mpad * (F / 32) * 4);
         b.rb1 = (unsigned char*)take(Mpad * ((NFT / 16 + 1) / 2) * 4);
@@ -1692,9 +1788,25 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
     tb.dtemb = (float*)take(sizeof(float) * B * D);
     tb.skp = (float*)take(sizeof(float) * kSkpFloats);
     tb.vecpart = (float*)take(sizeof(float) * L * tb.nwg * 5 * D);
-    tb.part = (float*)take(sizeof(float) * (size_t)tb.TS * (size_t)m->nparams);
+    // per-split partials of ONE layer's weight gradients, one buffer per side stream (two layers in flight)
+    tb.layer_params = L > 1 ? (size_t)(m->layers[1].in_w - m->layers[0].in_w) : (size_t)(m->nparams - (L ? m->layers[0].in_w : 0));
+    tb.part = (float*)take(sizeof(float) * 2 * (size_t)kMaxTS * tb.layer_params);
     if (out) *out = tb;
     return off + 4096;
+}
+
+// Side streams carry work that is OFF the step's critical path (dropout decisions one layer ahead, weight gradients behind the
+// input-gradient chain): lowest priority, so that the dispatcher hands free CU slots to the chain's workgroups first.
+hipError_t side_stream_create(hipStream_t* st) {
+    int least = 0, greatest = 0;
+    if (!getenv("FDIFF_TR_NOPRIO") && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+        return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least);
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+
+int tr_attn_waves(int KT) {
+    if (const char* e = getenv("FDIFF_TR_ATTN_NW")) return atoi(e) == 8 ? 8 : 4;     // experiments
+    return KT > 4 ? 8 : 4;
 }
 
 TrDims make_dims(const fd_score* m, int B, float p, uint64_t seed) {
@@ -1712,7 +1824,7 @@ TrDims make_dims(const fd_score* m, int B, float p, uint64_t seed) {
 
 template <int KS1, int DT, int KSO>
 int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B, float p, uint64_t seed, uint64_t offset,
-                 hipStream_t s, TrBufs& tb, uint64_t gen_in) {
+                 hipStream_t s, TrBufs& tb, uint64_t gen_in, bool img_forked) {
     fd_ctx* ctx = m->ctx;
     const fd_bf16_images* im = m->bf16;
     const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model, L = m->d.num_layers;
@@ -1725,19 +1837,22 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
     if (L > 0)
         hipLaunchKernelGGL((k_tr_prep<KS1, DT>), dim3((tb.Mpad / 16 + 3) / 4), dim3(256), 0, s, h0, tb.layers[0].x0rb, tb.layers[0].x0T,
                            M, tb.Mpad, D);
+    if (img_forked) FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[L + 2], 0));      // weight images rebuilt (side stream 2)
     const size_t lds_attn = (size_t)d.KT * 16 * 32 + (size_t)d.NJ * 1024;
+    const int attn_nw = tr_attn_waves(d.KT);
     const size_t scr = std::max((size_t)TW * KS1 * 1024, (size_t)4 * DT * 1024);
     const size_t NSh = (size_t)m->d.dim_ff / 64;
     const size_t lds_ffn = (size_t)4 * 2 * (2 * KS1 + DT) * 1024 + scr + (size_t)TW * 64 * NSh + (size_t)TW * NSh * 32 * sizeof(unsigned short) +
                            (size_t)4 * 32 * DT * 16;
     static unsigned long long attr = 0;
     if (fd_first_on_device(attr, ctx->device)) {
-        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_fwd<KS1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_fwd<KS1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_fwd<KS1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_ffn_fwd<KS1, DT, KSO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     if (p > 0.f) {
         // dropout decisions of every layer on the side stream, layer by layer, ahead of the kernels that read them
-        if (!ctx->side_stream) FD_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        if (!ctx->side_stream) FD_HIP(ctx, side_stream_create(&ctx->side_stream));
         while ((int)ctx->side_events.size() < L + 3) {
             hipEvent_t e;
             FD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1767,6 +1882,13 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             hipLaunchKernelGGL(k_tr_masks, dim3(grid), dim3(256), 0, ctx->side_stream, d, ma);
             FD_HIP(ctx, hipEventRecord(ctx->side_events[l], ctx->side_stream));
         }
+        // key-oriented copies of the attention keep bits: only the backward reads them, so they queue behind the decisions of
+        // every layer (the forward never waits for them); last layer first, the order the backward wants them in
+        for (int l = L - 1; l >= 0; --l)
+            hipLaunchKernelGGL(k_tr_masks_T, dim3(d.NJ, B * m->d.n_head), dim3(256), (size_t)32 * d.NJ * 4, ctx->side_stream,
+                               tb.layers[l].pmask, tb.layers[l].pmaskT, T, d.NJ);
+        if (!ctx->tr_masksT_event) FD_HIP(ctx, hipEventCreateWithFlags(&ctx->tr_masksT_event, hipEventDisableTiming));
+        FD_HIP(ctx, hipEventRecord(ctx->tr_masksT_event, ctx->side_stream));
     }
     for (int l = 0; l < L; ++l) {
         const fd_layer_off& lo = m->layers[l];
@@ -1776,7 +1898,8 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         aa.x0rb = b.x0rb; aa.att = b.att; aa.attT = b.attT; aa.lse2 = b.lse2; aa.pmask = b.pmask;
         aa.wk = limg + im->off_wk; aa.wv = limg + im->off_wv; aa.wq = limg + im->off_wq;
         if (p > 0.f) FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[l], 0));      // this layer's dropout decisions are ready
-        hipLaunchKernelGGL((k_tr_attn_fwd<KS1>), dim3(d.NP, B), dim3(256), lds_attn, s, d, aa);
+        if (attn_nw == 8) hipLaunchKernelGGL((k_tr_attn_fwd<KS1, 8>), dim3(d.NP, B), dim3(512), lds_attn, s, d, aa);
+        else hipLaunchKernelGGL((k_tr_attn_fwd<KS1, 4>), dim3(d.NP, B), dim3(256), lds_attn, s, d, aa);
         FfnFwdArgs fa{};
         fa.x0 = b.x0; fa.att = b.att; fa.s1 = b.s1; fa.s2 = b.s2;
         fa.out = (l + 1 < L) ? tb.layers[l + 1].x0 : tb.hL;
@@ -1822,26 +1945,40 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     const size_t NSh = (size_t)m->d.dim_ff / 64;
     const size_t lds_bwd = (size_t)4 * 2 * (2 * KS1 + DT) * 1024 + scr + (size_t)TW * 64 * NSh + (size_t)4 * 5 * 16 * DT * sizeof(float) +
                            (size_t)TW * KS1 * 1024;
+    const int attn_nw = tr_attn_waves(d.KT);
     const size_t lds_ab = (size_t)4 * d.KT * 16 * 32 + (size_t)3 * d.NJ * 1024 + (size_t)4 * d.KT * 16 * sizeof(float) +
                           (size_t)2 * d.T * d.NJ * 4;
     static unsigned long long attr = 0;
     if (fd_first_on_device(attr, ctx->device)) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_ffn_bwd<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_bwd<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_bwd<KS1, DT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_bwd<KS1, DT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_wgrad<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     // side stream: the weight gradients of layer l only need that layer's k_tr_ffn_bwd / k_tr_attn_bwd outputs, so they run
     // beside the input-gradient chain of layers l-1 .. 0 (both are latency-bound and leave most CUs idle on their own)
-    if (!ctx->side_stream) FD_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-    if (!ctx->side_stream2) FD_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream2, hipStreamNonBlocking));
+    if (!ctx->side_stream) FD_HIP(ctx, side_stream_create(&ctx->side_stream));
+    if (!ctx->side_stream2) FD_HIP(ctx, side_stream_create(&ctx->side_stream2));
     while ((int)ctx->side_events.size() < L + 3) {
         hipEvent_t e;
         FD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->side_events.push_back(e);
     }
     const size_t lds_wg = (size_t)3 * StageL<KS1, DT>::bytes;
+    static const bool serial = getenv("FDIFF_TR_SERIAL") != nullptr;
     WgArgs wa{};
-    wa.part = tb.part; wa.nparams = m->nparams; wa.TS = tb.TS; wa.nblk = (M + 31) / 32;
+    wa.nparams = (long long)tb.layer_params; wa.TS = tb.TS; wa.nblk = (M + 31) / 32;
+    RedArgs ra{};
+    ra.nparams = (long long)tb.layer_params; ra.TS = tb.TS; ra.D = D; ra.accumulate = accumulate;
+    if (L > 0) {
+        const fd_layer_off& l0 = m->layers[0];
+        ra.rel[0] = l0.l2_b - l0.in_w; ra.rel[1] = l0.n2_b - l0.in_w; ra.rel[2] = l0.n2_w - l0.in_w;
+        ra.rel[3] = l0.n1_b - l0.in_w; ra.rel[4] = l0.n1_w - l0.in_w;
+        const long long wr[7] = {0, l0.in_b - l0.in_w, l0.out_w - l0.in_w, l0.out_b - l0.in_w, l0.l1_w - l0.in_w, l0.l1_b - l0.in_w, l0.l2_w - l0.in_w};
+        const long long wn[7] = {3LL * D * D, 3LL * D, (long long)D * D, D, (long long)F * D, F, (long long)D * F};
+        for (int k = 0; k < 7; ++k) { ra.wrel[k] = wr[k]; ra.wnum[k] = wn[k]; }
+    }
+    if (m->saved_p > 0.f && ctx->tr_masksT_event) FD_HIP(ctx, hipStreamWaitEvent(s, ctx->tr_masksT_event, 0));
     for (int l = L - 1; l >= 0; --l) {
         const fd_layer_off& lo = m->layers[l];
         TrLayerBufs& b = tb.layers[l];
@@ -1861,20 +1998,34 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         fa.rb1 = b.rb1; fa.rb3 = b.rb3;
         hipLaunchKernelGGL((k_tr_ffn_bwd<KS1, DT>), dim3(tb.nwg), dim3(TW * 64), lds_bwd, s, d, fa);
         AttnBwdArgs ab{};
-        ab.x0rb = b.x0rb; ab.att = b.att; ab.datt = tb.datt; ab.lse2 = b.lse2; ab.pmask = b.pmask;
+        ab.x0rb = b.x0rb; ab.att = b.att; ab.datt = tb.datt; ab.lse2 = b.lse2; ab.pmask = b.pmask; ab.pmaskT = b.pmaskT;
         ab.dxp = tb.dxp[par]; ab.dqkvT = b.dqkvT;
         ab.wk = limg + im->off_wk; ab.wv = limg + im->off_wv; ab.wq = limg + im->off_wq;
         ab.winT = bl + im->boff_win; ab.part_stride = tb.part_stride;
-        hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT>), dim3(d.NP, B), dim3(256), lds_ab, s, d, ab);
+        if (attn_nw == 8) hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 8>), dim3(d.NP, B), dim3(512), lds_ab, s, d, ab);
+        else hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 4>), dim3(d.NP, B), dim3(256), lds_ab, s, d, ab);
         WgLayer w{};
         w.x0T = b.x0T; w.attT = b.attT; w.doT = b.doT; w.dqkvT = b.dqkvT;
         w.stage = b.stage; w.activeT = b.activeT;
         w.ffn_img = limg + im->off_ffn; w.bffn = bl + im->boff_ffn;
-        w.in_w = lo.in_w; w.in_b = lo.in_b; w.out_w = lo.out_w; w.out_b = lo.out_b; w.l1_w = lo.l1_w; w.l1_b = lo.l1_b; w.l2_w = lo.l2_w;
+        // offsets relative to the layer's first parameter: the partials hold one layer
+        w.in_w = 0; w.in_b = lo.in_b - lo.in_w; w.out_w = lo.out_w - lo.in_w; w.out_b = lo.out_b - lo.in_w;
+        w.l1_w = lo.l1_w - lo.in_w; w.l1_b = lo.l1_b - lo.in_w; w.l2_w = lo.l2_w - lo.in_w;
         hipStream_t ws = (l & 1) ? ctx->side_stream2 : ctx->side_stream;     // two layers' weight gradients in flight
+        if (serial) ws = s;                                                   // measurement: solo kernel times
+        wa.part = tb.part + (size_t)(l & 1) * kMaxTS * tb.layer_params;
         FD_HIP(ctx, hipEventRecord(ctx->side_events[l], s));
         FD_HIP(ctx, hipStreamWaitEvent(ws, ctx->side_events[l], 0));
-        hipLaunchKernelGGL((k_tr_wgrad<KS1, DT>), dim3(F / 128 + 4, tb.TS), dim3(256), lds_wg, ws, d, w, wa);
+        {
+            // measurement hook (bench.py --mode train): every weight gradient of one layer -- in_proj 2 M 3D D, out_proj 2 M D D,
+            // linear1 + linear2 2 x 2 M D F (the recomputation of the hidden / d hidden blocks is not algorithmic work)
+            fd_prof_scope scope(ctx, ws, "k_tr_wgrad (all weight gradients of one encoder layer, training backward)",
+                                (double)M * (8.0 * D * D + 4.0 * D * F));
+            hipLaunchKernelGGL((k_tr_wgrad<KS1, DT>), dim3(F / 128 + 4, tb.TS), dim3(256), lds_wg, ws, d, w, wa);
+        }
+        ra.part = wa.part;
+        ra.grads = grads + lo.in_w;
+        hipLaunchKernelGGL(k_tr_reduce, dim3((unsigned)((tb.layer_params / 4 + 255) / 256)), dim3(256), 0, ws, ra);
     }
     if (m->saved_p > 0.f && L > 0) {      // last reader of the dropout-decision buffers on `s` (layer 0's attention backward)
         if (!ctx->tr_readers_event) FD_HIP(ctx, hipEventCreateWithFlags(&ctx->tr_readers_event, hipEventDisableTiming));
@@ -1891,6 +2042,13 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         hipLaunchKernelGGL(k_tr_sum_parts, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, tb.dres[0], tb.dxp[0], d.NP,
                            tb.part_stride, tb.dh, nn);
     }
+    if (L > 0) {
+        VecRedArgs va{};
+        va.vecpart = tb.vecpart; va.nwg = tb.nwg; va.D = D; va.begin = m->layers[0].in_w; va.layer_stride = (long long)tb.layer_params;
+        for (int k = 0; k < 5; ++k) va.rel[k] = ra.rel[k];
+        va.grads = grads; va.accumulate = accumulate;
+        hipLaunchKernelGGL(k_tr_vecreduce, dim3(5, L), dim3(1024), 0, s, va);
+    }
     const int rc_embed = fd_embed_backward(m, tb.dh, tb.emb, tb.dtemb, grads, B, tb.skp, kSkpFloats, s);
     if (rc_embed) {
         // the weight-gradient launches on the side streams are still writing tb.part (arena memory): let them finish before the
@@ -1904,19 +2062,6 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[L], 0));
         FD_HIP(ctx, hipEventRecord(ctx->side_events[L + 2], ctx->side_stream2));
         FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[L + 2], 0));
-        RedArgs ra{};
-        ra.part = tb.part; ra.nparams = m->nparams; ra.TS = tb.TS; ra.vecpart = tb.vecpart; ra.nwg = tb.nwg; ra.D = D; ra.L = L;
-        ra.begin = m->layers[0].in_w;
-        ra.layer_stride = (L > 1) ? (m->layers[1].in_w - m->layers[0].in_w) : (m->nparams - m->layers[0].in_w);
-        const fd_layer_off& l0 = m->layers[0];
-        ra.rel[0] = l0.l2_b - l0.in_w; ra.rel[1] = l0.n2_b - l0.in_w; ra.rel[2] = l0.n2_w - l0.in_w;
-        ra.rel[3] = l0.n1_b - l0.in_w; ra.rel[4] = l0.n1_w - l0.in_w;
-        const long long wr[7] = {0, l0.in_b - l0.in_w, l0.out_w - l0.in_w, l0.out_b - l0.in_w, l0.l1_w - l0.in_w, l0.l1_b - l0.in_w, l0.l2_w - l0.in_w};
-        const long long wn[7] = {3LL * D * D, 3LL * D, (long long)D * D, D, (long long)F * D, F, (long long)D * F};
-        for (int k = 0; k < 7; ++k) { ra.wrel[k] = wr[k]; ra.wnum[k] = wn[k]; }
-        ra.grads = grads; ra.accumulate = accumulate;
-        const long long n = m->nparams - ra.begin;
-        hipLaunchKernelGGL(k_tr_reduce, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, ra);
     }
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
@@ -1947,7 +2092,25 @@ int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, flo
                                 uint64_t offset, hipStream_t s) {
     fd_ctx* ctx = m->ctx;
     if (!fd_train_bf16_supported(m)) return fd_fail(ctx, FD_ERR_UNSUPPORTED, "bf16 training path unsupported for this model");
-    if (int rc = fd_bf16_refresh(m, s)) return rc;
+    // The optimizer step made the bf16 weight images stale.  Rebuilding them (~50 us of small kernels) needs nothing but the
+    // parameters, and the step's prologue on `s` (time embedding, embedding, first layer's operand preparation) does not need
+    // the images: the rebuild runs beside it on the second side stream and joins `s` in front of the first attention kernel.
+    bool img_forked = false;
+    if (m->bf16_stale && m->d.num_layers > 0 && !getenv("FDIFF_TR_SERIAL")) {
+        if (!ctx->side_stream2) FD_HIP(ctx, side_stream_create(&ctx->side_stream2));
+        while ((int)ctx->side_events.size() < m->d.num_layers + 3) {
+            hipEvent_t e;
+            FD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->side_events.push_back(e);
+        }
+        FD_HIP(ctx, hipEventRecord(ctx->side_events[m->d.num_layers], s));
+        FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream2, ctx->side_events[m->d.num_layers], 0));
+        if (int rc = fd_bf16_refresh(m, ctx->side_stream2)) return rc;
+        FD_HIP(ctx, hipEventRecord(ctx->side_events[m->d.num_layers + 2], ctx->side_stream2));
+        img_forked = true;
+    } else if (int rc = fd_bf16_refresh(m, s)) {
+        return rc;
+    }
     const size_t need = fd_train_bf16_workspace(m, B);
     // ws_gen before this call touches the arena; the reserve + carve below advance it by exactly two, so "nobody else used the
     // arena since the last training reader" reads gen_in == tr_readers_gen
@@ -1958,7 +2121,7 @@ int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, flo
     if (ctx->ws != ws_before) ctx->tr_readers_event_valid = false;      // regrown: the reserve synchronised the device
     TrBufs tb;
     tr_carve(m, B, (char*)ctx->ws, &tb);
-#define CALL_F(K, T_, O) tr_forward_t<K, T_, O>(m, x, t, out, B, p, seed, offset, s, tb, gen_in)
+#define CALL_F(K, T_, O) tr_forward_t<K, T_, O>(m, x, t, out, B, p, seed, offset, s, tb, gen_in, img_forked)
     FD_TR_DISPATCH(CALL_F);
 #undef CALL_F
 }

@@ -242,12 +242,30 @@ class ScoreModule:
             self._train_mode_set = self.train_precision
         return ctx, self._handle
 
+    @property
+    def precision_effective(self) -> str:
+        """The arithmetic eval / sampling really runs in: ``precision`` unless it asks for bf16 and this model's dimensions
+        have no bf16 MFMA instantiation (fd_score_plan answers FD_ERR_UNSUPPORTED) -- then the exact-f32 kernels run, the same
+        way ``train_mode_effective`` reports the training fallback.  The reference takes any d_model / n_head
+        (score_models.py:23-65); a width the MFMA path does not cover must still sample."""
+        if self.precision != "bf16":
+            return self.precision
+        ctx, h = self._engine()
+        key = (int(h.value or 0), self.precision)
+        if getattr(self, "_precision_probe", (None, None))[0] != key:
+            buf = C.create_string_buffer(192)
+            rc = _C.lib().fd_score_plan(h, 1, _C.FD_MODE_BF16, buf, None)
+            if rc not in (0, -5):
+                _C.check(rc, ctx)
+            self._precision_probe = (key, "bf16" if rc == 0 else "fp32")
+        return self._precision_probe[1]
+
     def plan(self, batch_size: int, precision: Optional[str] = None) -> Tuple[str, int]:
         """(description of the kernel path a batch of this size takes, series per workgroup) -- fd_score_plan."""
         ctx, h = self._engine()
         buf = C.create_string_buffer(192)
         spw = C.c_int(0)
-        rc = _C.lib().fd_score_plan(h, int(batch_size), _PRECISIONS[precision or self.precision], buf, C.byref(spw))
+        rc = _C.lib().fd_score_plan(h, int(batch_size), _PRECISIONS[precision or self.precision_effective], buf, C.byref(spw))
         _C.check(rc, ctx)
         return buf.value.decode(), spw.value
 
@@ -270,7 +288,7 @@ class ScoreModule:
                                                  key, off, _C.stream_of(Xd))
             self._train_inputs = (Xd, td)       # the engine reads them again in backward
         else:
-            mode = _PRECISIONS[self.precision]
+            mode = _PRECISIONS[self.precision_effective]
             rc = _C.lib().fd_score_forward(h, Xd.data_ptr(), td.data_ptr(), out.data_ptr(), B, mode,
                                            _C.stream_of(Xd))
         _C.check(rc, ctx)

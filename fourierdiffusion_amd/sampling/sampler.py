@@ -64,7 +64,7 @@ class DiffusionSampler:
         dt = float(sch.step_size)
         p = sch._c_params()
         G = sch.G_on(dev)
-        mode = _PRECISIONS[model.precision]
+        mode = _PRECISIONS[model.precision_effective]     # fp32 when the model's width has no bf16 instantiation
         all_samples: List[torch.Tensor] = []
         for b in range(num_batches):
             bs = min(num_samples - b * self.sample_batch_size, self.sample_batch_size)
