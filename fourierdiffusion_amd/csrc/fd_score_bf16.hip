@@ -609,22 +609,26 @@ int launch_ffn(fd_ctx* ctx, const float* x, float* out, const char* wimg, const 
     return FD_OK;
 }
 
-// tokens per workgroup: whole "rounds" of one workgroup per CU, each WG at most 4*MT tiles (256 tokens)
-template <int KS1, int DT, int KSO>
+// tokens per workgroup: whole "rounds" of one workgroup per CU, each WG at most 4*MTMAX tiles.  MTMAX = 4 (256 tokens) for the
+// widths up to d_model 95; the wider classes hold DT x MT accumulator tiles + MT x KS1 fragments per wave in 256 VGPRs only
+// with fewer token tiles per wave (d_model 96..127: 3, d_model 128..143: 2).
+template <int KS1, int DT, int KSO, int MTMAX = 4>
 int dispatch_ffn(fd_ctx* ctx, const float* x, float* out, const char* wimg, const float* b2, const float* gamma,
                  const float* beta, int M, int D, int F, const fd_ffn_pre& pre, hipStream_t s) {
-    const long long cap = 256LL * ctx->num_cu;
+    const long long tcap = 64LL * MTMAX;
+    const long long cap = tcap * ctx->num_cu;
     const int rounds = (int)((M + cap - 1) / cap);
     int tok = (int)((M + (long long)rounds * ctx->num_cu - 1) / ((long long)rounds * ctx->num_cu));
-    if (tok > 256) tok = 256;
+    if (tok > tcap) tok = (int)tcap;
     if (tok < 16) tok = 16;
     const int mt = ((tok + 15) / 16 + 3) / 4;       // tiles of the fullest token quarter
-    switch (mt) {
-        case 1: return launch_ffn<KS1, DT, 1, KSO>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, pre, s);
-        case 2: return launch_ffn<KS1, DT, 2, KSO>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, pre, s);
-        case 3: return launch_ffn<KS1, DT, 3, KSO>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, pre, s);
-        default: return launch_ffn<KS1, DT, 4, KSO>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, pre, s);
+    if (mt <= 1) return launch_ffn<KS1, DT, 1, KSO>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, pre, s);
+    if (mt == 2) return launch_ffn<KS1, DT, 2, KSO>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, pre, s);
+    if constexpr (MTMAX >= 3) {
+        if (mt == 3) return launch_ffn<KS1, DT, 3, KSO>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, pre, s);
     }
+    if constexpr (MTMAX >= 4) return launch_ffn<KS1, DT, 4, KSO>(ctx, x, out, wimg, b2, gamma, beta, M, D, F, tok, pre, s);
+    return fd_fail(ctx, FD_ERR_UNSUPPORTED, "k_ffn_ln: %d token tiles per wave exceed this width class", mt);
 }
 
 // x != nullptr: out = LN2(x + FFN(x)).  x == nullptr: x = LN1(h0 + att Wo^T + bo) is computed in the kernel (fused
@@ -649,13 +653,19 @@ int run_ffn(fd_score* m, const float* x, float* out, int layer, int M, hipStream
             return dispatch_ffn<2, 4, 3>(ctx, x, out, wimg, P + lo.l2_b, P + lo.n2_w, P + lo.n2_b, M, D, F, pre, s);
         return fd_fail(ctx, FD_ERR_UNSUPPORTED, "fused out-proj + FFN kernel not instantiated for d_model=%d", D);
     }
-#define FD_FFN_CASE(K, T_)                                                                                     \
+#define FD_FFN_CASE(K, T_, MTMAX_)                                                                             \
     if (im->ks1 == K && im->dt == T_)                                                                          \
-        return dispatch_ffn<K, T_, 0>(ctx, x, out, wimg, P + lo.l2_b, P + lo.n2_w, P + lo.n2_b, M, D, F, pre, s);
-    FD_FFN_CASE(3, 5)   // d_model 72 (hydra default)
-    FD_FFN_CASE(2, 4)   // d_model 60 (class default)
-    FD_FFN_CASE(1, 2)   // d_model 24
-    FD_FFN_CASE(1, 1)   // d_model 8
+        return dispatch_ffn<K, T_, 0, MTMAX_>(ctx, x, out, wimg, P + lo.l2_b, P + lo.n2_w, P + lo.n2_b, M, D, F, pre, s);
+    // (KS1, DT) = (k-steps of d_model + 1 bias slot, 16-row tiles of d_model + 1 ones row): every d_model % 4 == 0 up to 143
+    FD_FFN_CASE(3, 5, 4)   // d_model 64 .. 79 (72: hydra default)
+    FD_FFN_CASE(2, 4, 4)   // d_model 48 .. 63 (60: class default)
+    FD_FFN_CASE(1, 2, 4)   // d_model 16 .. 31
+    FD_FFN_CASE(1, 1, 4)   // d_model  4 .. 15
+    FD_FFN_CASE(2, 3, 4)   // d_model 32 .. 47
+    FD_FFN_CASE(3, 6, 4)   // d_model 80 .. 95
+    FD_FFN_CASE(4, 7, 3)   // d_model 96 .. 111
+    FD_FFN_CASE(4, 8, 3)   // d_model 112 .. 127
+    FD_FFN_CASE(5, 9, 2)   // d_model 128 .. 143
 #undef FD_FFN_CASE
     return fd_fail(ctx, FD_ERR_UNSUPPORTED, "bf16 FFN kernel not instantiated for d_model=%d", D);
 }
@@ -668,13 +678,20 @@ int fd_bf16_create(fd_score* m) {
     const int D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, C = m->d.n_channels, L = m->d.num_layers;
     const int hd = D / H;
     im->ks1 = (D + 1 + 31) / 32;
-    im->dt = (D + 15) / 16;
+    // 16-row tiles of the d_model features PLUS the ones row (bias column of the weight gradients, softmax denominator row ...):
+    // always one spare row, so d_model = 16, 48, 64, ... share the class of the next larger widths instead of having none
+    im->dt = (D + 1 + 15) / 16;
     im->kso = (8 * H + 31) / 32;
     im->kse = (C + 1 + 31) / 32;
     im->ct = (C + 15) / 16;
     im->np = (H + 1) / 2;
+    // FFN kernel instantiations (run_ffn): every d_model % 4 == 0 up to 143; the persistent kernel, the fused attention
+    // kernel and the bf16 training kernels exist for the four classes of `inst_mega` and head_dim <= 7 -- outside them the
+    // bf16 mode runs fp32-MFMA projections + (head_dim <= 7: bf16, else exact-f32) attention + the bf16 FFN kernel
     const bool inst = (im->ks1 == 3 && im->dt == 5) || (im->ks1 == 2 && im->dt == 4) ||
-                      (im->ks1 == 1 && im->dt == 2) || (im->ks1 == 1 && im->dt == 1);
+                      (im->ks1 == 1 && im->dt == 2) || (im->ks1 == 1 && im->dt == 1) ||
+                      (im->ks1 == 2 && im->dt == 3) || (im->ks1 == 3 && im->dt == 6) ||
+                      (im->ks1 == 4 && im->dt == 7) || (im->ks1 == 4 && im->dt == 8) || (im->ks1 == 5 && im->dt == 9);
     im->supported = inst && (D % 4 == 0) && (F % 128 == 0) && L > 0;
     const bool inst_mega = (im->ks1 == 3 && im->dt == 5 && im->kso == 3) || (im->ks1 == 2 && im->dt == 4 && im->kso == 3) ||
                            (im->ks1 == 1 && im->dt == 2 && im->kso == 1) || (im->ks1 == 1 && im->dt == 1 && im->kso == 1);
@@ -892,7 +909,7 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
     fd_ctx* ctx = m->ctx;
     if (!m->bf16 || !m->bf16->supported)
         return fd_fail(ctx, FD_ERR_UNSUPPORTED,
-                       "bf16 MFMA path supports d_model in {8,24,60,72} with dim_ff %% 128 == 0; use FD_MODE_F32");
+                       "bf16 MFMA path supports d_model %% 4 == 0, d_model <= 143, dim_ff %% 128 == 0; use FD_MODE_F32");
     if (int rc = fd_bf16_refresh(m, s)) return rc;
     {
         const MegaPlan pl = plan_mega(m, B);
@@ -1123,6 +1140,14 @@ extern "C" int fd_score_plan(fd_score* m, int B, int mode, char* out /* >= 192 b
         if (series_per_workgroup) *series_per_workgroup = pl.S;
         return fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.nw, pl.grid, pl.lds, nullptr, out);
     }
-    snprintf(out, 192, "per-layer bf16 kernels (k_attention_bf16 + k_ffn_ln)");
+    {
+        const fd_bf16_images* im = m->bf16;
+        const int hd = m->d.d_model / m->d.n_head;
+        const bool fuse = im->mega && im->kso == 3 && (im->ks1 == 3 || im->ks1 == 2);
+        snprintf(out, 192, "per-layer bf16 kernels (k_attention_bf16 + k_ffn_ln): attention %s, k_ffn_ln<%d,%d>%s",
+                 hd > 7 ? "exact-f32 kernel (head_dim > 7) on fp32-MFMA projections"
+                        : (im->mega ? "bf16 with fused Q/K/V projections" : "bf16 on fp32-MFMA projections"),
+                 im->ks1, im->dt, fuse ? " with fused out-proj + LN1" : "");
+    }
     return FD_OK;
 }
