@@ -29,6 +29,16 @@ struct FftPlan {
 // n / d for 0 <= n < 2^22 through the float pipe (4 VALU instead of the ~40 of a 32-bit integer division; the index
 // arithmetic, not the butterflies, dominated this kernel): (n + 0.5) * (1/d) is at least 0.5/d away from an integer
 // and carries an absolute error below n * 2^-23.
+// Global accessors of the load / store passes.  Nontemporal scalar accesses were measured and are NOT the default: (4096, 256, 28)
+// 2.81 -> 2.40 TB/s, (512, 1024, 16) 1.67 -> 1.01 (-DFDIFF_FFT_NONTEMPORAL builds that form)
+#ifdef FDIFF_FFT_NONTEMPORAL
+__device__ __forceinline__ float ldg(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stg(float* p, float v) { __builtin_nontemporal_store(v, p); }
+#else
+__device__ __forceinline__ float ldg(const float* p) { return *p; }
+__device__ __forceinline__ void stg(float* p, float v) { *p = v; }
+#endif
+
 __device__ __forceinline__ int fdiv(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -246,8 +256,8 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
         const bool has_b = (2 * p + 1) < cc;
         float2 z;
         if (!INVERSE) {
-            z.x = xb[(size_t)n * rstep + ca * cstep];
-            z.y = has_b ? xb[(size_t)n * rstep + (ca + 1) * cstep] : 0.f;
+            z.x = ldg(xb + (size_t)n * rstep + ca * cstep);
+            z.y = has_b ? ldg(xb + (size_t)n * rstep + (ca + 1) * cstep) : 0.f;
         } else {
             // Hermitian extension of the packed half spectrum (fourier.py:62-77): X[T-k] = conj X[k]
             const int kk = (n <= T / 2) ? n : T - n;
@@ -255,8 +265,8 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
             const float sg = (n <= T / 2) ? 1.0f : -1.0f;
             const size_t ire = (size_t)kk * rstep, iim = (size_t)(n_real + kk - 1) * rstep;
             const size_t oa = ca * cstep, ob = (ca + 1) * cstep;
-            float are = xb[ire + oa], aim = has_im ? xb[iim + oa] : 0.f;
-            float bre = has_b ? xb[ire + ob] : 0.f, bim = (has_b && has_im) ? xb[iim + ob] : 0.f;
+            float are = ldg(xb + ire + oa), aim = has_im ? ldg(xb + iim + oa) : 0.f;
+            float bre = has_b ? ldg(xb + ire + ob) : 0.f, bim = (has_b && has_im) ? ldg(xb + iim + ob) : 0.f;
             if (mean) {   // de-standardise in the frequency domain (cmd/sample.py:76-78)
                 const size_t mre = (size_t)kk * C, mim = (size_t)(n_real + kk - 1) * C, ma = ca * mstep, mb = (ca + 1) * mstep;
                 are = are * stdv[mre + ma] + mean[mre + ma];
@@ -327,11 +337,11 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
                     if (has_im) bim = (bim - mean[mim + mb]) / stdv[mim + mb];
                 }
             }
-            yb[ire + oa] = are;
-            if (has_b) yb[ire + ob] = bre;
+            stg(yb + ire + oa, are);
+            if (has_b) stg(yb + ire + ob, bre);
             if (has_im) {
-                yb[iim + oa] = aim;
-                if (has_b) yb[iim + ob] = bim;
+                stg(yb + iim + oa, aim);
+                if (has_b) stg(yb + iim + ob, bim);
             }
         }
     } else {
@@ -340,8 +350,8 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
             if (BATCHED) { p = fdiv(id, inv_t); n = id - p * T; } else { n = fdiv(id, inv_cp); p = id - n * Cp; }
             const int ca = c0 + 2 * p;
             const float2 z = src[n * Cp + p];
-            yb[(size_t)n * rstep + ca * cstep] = z.x * scale;
-            if ((2 * p + 1) < cc) yb[(size_t)n * rstep + (ca + 1) * cstep] = z.y * scale;
+            stg(yb + (size_t)n * rstep + ca * cstep, z.x * scale);
+            if ((2 * p + 1) < cc) stg(yb + (size_t)n * rstep + (ca + 1) * cstep, z.y * scale);
         }
     }
 }
@@ -445,7 +455,8 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
     int max_pairs = (int)((lds_cap - (size_t)T * 8) / ((size_t)T * 16));
     // prefer <= 72 KiB per workgroup (two resident workgroups per CU overlap each other's load / store passes) as long
     // as a chunk keeps at least 8 channels = one 32-byte sector per time step
-    const int pairs_2wg = (int)(((size_t)72 * 1024 - (size_t)T * 8) / ((size_t)T * 16));
+    static const int lds_target_kb = getenv("FDIFF_FFT_LDS_KB") ? atoi(getenv("FDIFF_FFT_LDS_KB")) : 72;
+    const int pairs_2wg = (int)(((size_t)lds_target_kb * 1024 - (size_t)T * 8) / ((size_t)T * 16));
     if (pairs_2wg >= 4 && pairs_2wg < max_pairs) max_pairs = pairs_2wg;
     int Cc = C;
     if ((C + 1) / 2 > max_pairs) Cc = max_pairs * 2;

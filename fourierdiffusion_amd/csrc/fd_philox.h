@@ -33,11 +33,13 @@ __device__ __forceinline__ float fd_u01(uint32_t r) { return ((float)(r >> 8) + 
 
 __device__ __forceinline__ void fd_box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
     const float u1 = fd_u01(a), u2 = fd_u01(b);
-    const float r = sqrtf(-2.0f * __logf(u1));
-    float s, c;
-    sincospif(2.0f * u2, &s, &c);
-    n0 = r * c;
-    n1 = r * s;
+    // v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32 (1 ulp; the sine unit takes its argument in revolutions, i.e. computes
+    // sin(2 pi u2) from u2 directly): ~12 instructions per pair of normals instead of ~90 with the range-reducing sincospif and
+    // the IEEE square root -- the draws are N(0,1) to 1e-6, which is what the sampler needs (the reference's torch.randn is
+    // not bit-matched anyway: SURVEY 7.2)
+    const float r = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1));
+    n0 = r * __builtin_amdgcn_cosf(u2);
+    n1 = r * __builtin_amdgcn_sinf(u2);
 }
 
 __device__ __forceinline__ void fd_randn4(uint64_t counter, uint64_t seed, float (&n)[4]) {

@@ -63,34 +63,86 @@ __global__ __launch_bounds__(kBlock) void k_prior(const float* __restrict__ G, c
     }
 }
 
-// Euler-Maruyama reverse step (sde.py:129-165, 215-246), one pass.
+// Time index t of the four elements of group e .. e+3 of a (B, T, C) tensor: ONE division for the row and one for its remainder
+// by T, then carries (eight runtime divisions per group were ~200 VALU instructions, more than the Philox evaluation).
+__device__ __forceinline__ void group_rows(size_t e, size_t n, int T, int C, int (&t)[4]) {
+    if ((n >> 32) == 0 && C >= 4) {           // wave-uniform
+        const unsigned e32 = (unsigned)e;
+        const unsigned row = e32 / (unsigned)C;
+        unsigned c = e32 - row * (unsigned)C;
+        unsigned tt = row % (unsigned)T;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            t[i] = (int)tt;
+            if (++c == (unsigned)C) { c = 0; tt = (tt + 1 == (unsigned)T) ? 0u : tt + 1; }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = (int)(((e + i) / (size_t)C) % (size_t)T);
+    }
+}
+
+// Euler-Maruyama reverse step (sde.py:129-165, 215-246), one pass: 12 bytes per element (x, score in; x' out), noise from the
+// Philox stream.  Two 16-byte groups per thread and iteration, all four loads issued before the first Philox round, so that
+// the ~350 VALU instructions of two counters run under the loads' latency (one group per iteration left the kernel at 3.3 TB/s
+// where the 28-byte-per-parameter AdamW pass streams 5.0).
+typedef __attribute__((ext_vector_type(4))) float f32x4_nt;
+__device__ __forceinline__ float4 ldnt4(const float* p) {
+    const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+    return float4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ void stnt4(float* p, float a, float b, float c, float d) {
+    __builtin_nontemporal_store(f32x4_nt{a, b, c, d}, reinterpret_cast<f32x4_nt*>(p));
+}
+
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void k_sde_step(const float* __restrict__ G, const float* __restrict__ x,
                                                        const float* __restrict__ score,
                                                        const float* __restrict__ zin, float* __restrict__ out,
                                                        size_t n, int T, int C, SdeCoef cf, uint64_t seed,
                                                        uint64_t offset) {
     const size_t ngroups = (n + 3) / 4;
-    for (size_t g = blockIdx.x * (size_t)kBlock + threadIdx.x; g < ngroups; g += (size_t)gridDim.x * kBlock) {
-        const size_t e = g * 4;
-        const float4 xv = ld4(x, e, n), sv = ld4(score, e, n);
-        float z[4];
-        if (zin) {
-            const float4 v = ld4(zin, e, n);
-            z[0] = v.x; z[1] = v.y; z[2] = v.z; z[3] = v.w;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t g0 = blockIdx.x * (size_t)kBlock + threadIdx.x; g0 < ngroups; g0 += 2 * stride) {
+        const size_t g1 = g0 + stride;
+        const bool two = g1 < ngroups;
+        const size_t e0 = g0 * 4, e1 = (two ? g1 : g0) * 4;
+        const bool full = e0 + 4 <= n && e1 + 4 <= n;
+        float4 xv0, sv0, xv1, sv1;
+        if (NT && full) {       // streamed once: keep the lines out of the way of the score network's weights in L2 / MALL
+            xv0 = ldnt4(x + e0); sv0 = ldnt4(score + e0);
+            xv1 = ldnt4(x + e1); sv1 = ldnt4(score + e1);
         } else {
-            fd_randn4(offset + g, seed, z);
+            xv0 = ld4(x, e0, n); sv0 = ld4(score, e0, n);
+            xv1 = ld4(x, e1, n); sv1 = ld4(score, e1, n);
         }
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        const float ss[4] = {sv.x, sv.y, sv.z, sv.w};
-        float o[4];
+        float z0[4], z1[4];
+        if (zin) {
+            const float4 v0 = ld4(zin, e0, n), v1 = ld4(zin, e1, n);
+            z0[0] = v0.x; z0[1] = v0.y; z0[2] = v0.z; z0[3] = v0.w;
+            z1[0] = v1.x; z1[1] = v1.y; z1[2] = v1.z; z1[3] = v1.w;
+        } else {
+            fd_randn4(offset + g0, seed, z0);
+            fd_randn4(offset + (two ? g1 : g0), seed, z1);
+        }
+        int t0[4], t1[4];
+        group_rows(e0, n, T, C, t0);
+        group_rows(e1, n, T, C, t1);
+        const float xs0[4] = {xv0.x, xv0.y, xv0.z, xv0.w}, ss0[4] = {sv0.x, sv0.y, sv0.z, sv0.w};
+        const float xs1[4] = {xv1.x, xv1.y, xv1.z, xv1.w}, ss1[4] = {sv1.x, sv1.y, sv1.z, sv1.w};
+        float o0[4], o1[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const size_t ei = e + i;
-            // (64-bit integer division is ~100 instructions: below 2^32 elements the 32-bit form, wave-uniform choice)
-            const int t = (n >> 32) ? (int)((ei / (size_t)C) % (size_t)T) : (int)(((unsigned)ei / (unsigned)C) % (unsigned)T);
-            o[i] = fd_sde_apply(xs[i], ss[i], z[i], G[t], cf);
+            o0[i] = fd_sde_apply(xs0[i], ss0[i], z0[i], G[t0[i]], cf);
+            o1[i] = fd_sde_apply(xs1[i], ss1[i], z1[i], G[t1[i]], cf);
         }
-        st4(out, e, n, float4{o[0], o[1], o[2], o[3]});
+        if (NT && full) {
+            stnt4(out + e0, o0[0], o0[1], o0[2], o0[3]);
+            if (two) stnt4(out + e1, o1[0], o1[1], o1[2], o1[3]);
+        } else {
+            st4(out, e0, n, float4{o0[0], o0[1], o0[2], o0[3]});
+            if (two) st4(out, e1, n, float4{o1[0], o1[1], o1[2], o1[3]});
+        }
     }
 }
 
@@ -200,7 +252,8 @@ __global__ __launch_bounds__(64) void k_loss_sum(const float* __restrict__ parti
 
 inline int grid_for(size_t ngroups, int num_cu) {
     size_t blocks = (ngroups + kBlock - 1) / kBlock;
-    size_t cap = (size_t)num_cu * 8;
+    static const int mult = getenv("FDIFF_SDE_GRIDMULT") ? atoi(getenv("FDIFF_SDE_GRIDMULT")) : 64;
+    size_t cap = (size_t)num_cu * mult;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
@@ -246,8 +299,16 @@ extern "C" int fd_sde_step(fd_ctx* ctx, const fd_sde_params* sde, const float* G
     if (int rc = check_btc(ctx, B, T, C)) return rc;
     const size_t n = (size_t)B * T * C;
     const SdeCoef cf = fd_sde_coef(*sde, t, dt);
-    hipLaunchKernelGGL(k_sde_step, dim3(grid_for((n + 3) / 4, ctx->num_cu)), dim3(kBlock), 0,
-                       (hipStream_t)stream, G, x, score, z, out, n, T, C, cf, seed, offset);
+    // nontemporal loads / stores when the three streams exceed what the 256 MB Infinity Cache can hold between kernels
+    // ((4096, 256, 28) = 352 MB: 3.6 -> 4.4 TB/s); smaller steps -- the sampler's x and score were just written by the score
+    // network and are still cache resident -- run 15-25 % faster with ordinary accesses.  FDIFF_SDE_NT=0/1 forces either form.
+    const char* nte = getenv("FDIFF_SDE_NT");
+    const bool nt = nte ? nte[0] == '1' : (12.0 * (double)n > 160.0e6);
+    const size_t ngroups2 = ((n + 3) / 4 + 1) / 2;                  // two groups per thread and iteration
+    if (nt) hipLaunchKernelGGL(k_sde_step<true>, dim3(grid_for(ngroups2, ctx->num_cu)), dim3(kBlock), 0,
+                               (hipStream_t)stream, G, x, score, z, out, n, T, C, cf, seed, offset);
+    else hipLaunchKernelGGL(k_sde_step<false>, dim3(grid_for(ngroups2, ctx->num_cu)), dim3(kBlock), 0,
+                            (hipStream_t)stream, G, x, score, z, out, n, T, C, cf, seed, offset);
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }
