@@ -93,6 +93,22 @@ def cpu_baseline(batch: int, T: int, CH: int, n_timed: int = 3):
     return cb.time_sampler_steps(batch=batch, T=T, C=CH, d_model=D, num_layers=L, n_head=H, n_timed=n_timed)
 
 
+def rank_report(dist, rank, world, dev_index):
+    """FDIFF_BENCH_REPORT_RANKS=1 (scripts/scale_check.sh): every rank's device binding and Philox counter base, gathered on
+    rank 0 -- one process per GPU and disjoint noise streams are checked on the real node, not assumed."""
+    if not os.environ.get("FDIFF_BENCH_REPORT_RANKS"):
+        return None
+    from fourierdiffusion_amd import _rng
+    props = torch.cuda.get_device_properties(dev_index)
+    me = {"rank": rank, "device": dev_index, "uuid": str(getattr(props, "uuid", "")), "philox_base": _rng.base_offset(),
+          "pid": os.getpid()}
+    if dist is None:
+        return [me]
+    out = [None] * world
+    dist.all_gather_object(out, me)
+    return out
+
+
 def main_train(args, rank, local_rank, world):
     """configs[2]: batch-sharded training.  Every rank holds 64 synthetic series (weak scaling); a step = one optimizer step."""
     T, CH = TRAIN["T"], TRAIN["C"]
@@ -160,6 +176,7 @@ def main_train(args, rank, local_rank, world):
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    ranks_info = rank_report(dist, rank, world, dev_index)
     if rank == 0:
         fwd_flops = flops_per_series_forward(T=T, C=CH)
         out = {
@@ -182,6 +199,8 @@ def main_train(args, rank, local_rank, world):
                     "frac": ach / peak, "traffic": None, "avg_kernel_us": avg_us.value, "launches_timed": cnt.value,
                     "flops_per_launch": flops.value}
         out["roofline"] = roof
+        if ranks_info is not None:
+            out["ranks"] = ranks_info
         if world == 1 and not args.no_cpu_baseline:
             try:
                 from oracle import torch_cpu_baseline as cb
@@ -300,6 +319,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    ranks_info = rank_report(dist, rank, world, dev_index)
     if rank == 0:
         series = total_series * args.steps
         value = series / elapsed
@@ -342,6 +362,8 @@ def main():
                         "avg_kernel_us": avg_us.value, "launches_timed": cnt.value,
                         "flops_per_launch": flops.value}
         out["roofline"] = roof
+        if ranks_info is not None:
+            out["ranks"] = ranks_info
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(B, T, CH)

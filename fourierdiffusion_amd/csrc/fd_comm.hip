@@ -63,10 +63,27 @@ extern "C" int fd_comm_init(fd_ctx* ctx, int rank, int nranks, const void* uniqu
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
     ncclComm_t comm;
+    // The two set-up mistakes that show up here rather than earlier: (1) dmabuf IPC -- this host driver only supports it, and
+    // without HSA_ENABLE_IPC_MODE_LEGACY=0 in EVERY rank's environment RCCL's buffer exchange fails with
+    // "hipIpcGetMemHandle: invalid argument"; (2) a rank bound to a device another rank already holds, or to one the
+    // launcher's *_VISIBLE_DEVICES hid (one process per GPU: device = LOCAL_RANK).  Both are named in the message.
+    int ndev = 0;
+    (void)hipGetDeviceCount(&ndev);
+    if (nranks > 1 && ndev > 0 && nranks > ndev && !getenv("FDIFF_ALLOW_SHARED_GPU"))
+        return fd_fail(ctx, FD_ERR_COMM, "fd_comm_init: %d ranks but only %d visible GPU(s) in this process (rank %d on device %d); "
+                       "check HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES -- RCCL needs one GPU per rank",
+                       nranks, ndev, rank, ctx->device);
     ncclResult_t r = g_rccl.CommInitRank(&comm, nranks, id, rank);
-    if (r != ncclSuccess)
-        return fd_fail(ctx, FD_ERR_COMM, "ncclCommInitRank failed: %s",
-                       g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    if (r != ncclSuccess) {
+        const char* ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+        const char* hv = getenv("HIP_VISIBLE_DEVICES");
+        const char* rv = getenv("ROCR_VISIBLE_DEVICES");
+        return fd_fail(ctx, FD_ERR_COMM, "ncclCommInitRank failed: %s (rank %d / %d on device %d of %d visible; "
+                       "HSA_ENABLE_IPC_MODE_LEGACY=%s%s, HIP_VISIBLE_DEVICES=%s, ROCR_VISIBLE_DEVICES=%s)",
+                       g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?", rank, nranks, ctx->device, ndev,
+                       ipc ? ipc : "<unset>", (ipc && ipc[0] == '0') ? "" : " -- must be 0 on this host (dmabuf IPC only)",
+                       hv ? hv : "<unset>", rv ? rv : "<unset>");
+    }
     ctx->comm = comm;
     ctx->rank = rank;
     ctx->nranks = nranks;
