@@ -93,5 +93,7 @@ int fd_score_backward_bf16(fd_score* m, const float* dout, float* grads, int acc
 int fd_embed_backward(fd_score* m, const float* dh, const float* emb, float* dtemb, float* grads, int B, float* skp,
                       size_t skp_floats, hipStream_t s);   // fd_score_bwd.hip
 // fd_attn_bf16.hip
+// head_dim 8 .. 32, one head per contraction (fd_attn_wide.hip); qkv = packed projections (B*T, 3D)
+int fd_attention_bf16_wide(fd_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int hd, hipStream_t s);
 int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, int H, int hd, hipStream_t s,
                       const char* wk = nullptr, const char* wv = nullptr, const char* wq = nullptr, int ks1 = 0);

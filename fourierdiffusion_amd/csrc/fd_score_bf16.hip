@@ -968,6 +968,8 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
         if (arc == FD_ERR_UNSUPPORTED) {
             fdgemm::linear_fwd(h0, P + lo.in_w, P + lo.in_b, qkv, M, 3 * D, D, false, s);
             arc = getenv("FDIFF_ATTN_F32") ? FD_ERR_UNSUPPORTED : fd_attention_bf16(ctx, qkv, att, B, T, H, hd, s);
+            if (arc == FD_ERR_UNSUPPORTED && hd > 7 && !getenv("FDIFF_ATTN_F32"))       // head_dim 8 .. 32: one head per contraction
+                arc = fd_attention_bf16_wide(ctx, qkv, att, B, T, H, hd, s);
             if (arc == FD_ERR_UNSUPPORTED) {
                 fd_attention_f32(qkv, att, nullptr, B, T, H, hd, 0.f, 0, 0, s);
                 arc = FD_OK;
@@ -1145,7 +1147,8 @@ extern "C" int fd_score_plan(fd_score* m, int B, int mode, char* out /* >= 192 b
         const int hd = m->d.d_model / m->d.n_head;
         const bool fuse = im->mega && im->kso == 3 && (im->ks1 == 3 || im->ks1 == 2);
         snprintf(out, 192, "per-layer bf16 kernels (k_attention_bf16 + k_ffn_ln): attention %s, k_ffn_ln<%d,%d>%s",
-                 hd > 7 ? "exact-f32 kernel (head_dim > 7) on fp32-MFMA projections"
+                 hd > 32 ? "exact-f32 kernel (head_dim > 32) on fp32-MFMA projections"
+                 : hd > 7 ? "bf16 k_attention_wide (one head per contraction) on fp32-MFMA projections"
                         : (im->mega ? "bf16 with fused Q/K/V projections" : "bf16 on fp32-MFMA projections"),
                  im->ks1, im->dt, fuse ? " with fused out-proj + LN1" : "");
     }
