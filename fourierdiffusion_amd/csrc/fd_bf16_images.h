@@ -22,5 +22,10 @@ struct fd_bf16_images {
     char* bimg = nullptr;       // per layer: FFN backward blocks (chunk-major, same block count as the forward image),
                                 // W_o^T, and the per-pair W_q|W_k|W_v^T blocks of the attention backward
     size_t b_layer_stride = 0, boff_ffn = 0, boff_wot = 0, boff_win = 0;
+    // ---- widths outside the persistent kernel's family: projection images of the step-by-step path (fd_linear_bf16.hip),
+    // per layer [W_in: nrt_in row tiles x ks1][W_o: dt row tiles x ks1] 1 KiB blocks (rows of W, bias in k-slot d_model)
+    char* pimg = nullptr;
+    size_t p_layer_stride = 0, poff_wo = 0;
+    int nrt_in = 0;
     long long* layer_off_tab = nullptr;   // device [L][12]: fd_layer_off of every layer (single-launch image build)
 };

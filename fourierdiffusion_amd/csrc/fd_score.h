@@ -93,6 +93,10 @@ int fd_score_backward_bf16(fd_score* m, const float* dout, float* grads, int acc
 int fd_embed_backward(fd_score* m, const float* dh, const float* emb, float* dtemb, float* grads, int B, float* skp,
                       size_t skp_floats, hipStream_t s);   // fd_score_bwd.hip
 // fd_attn_bf16.hip
+// fd_linear_bf16.hip: bf16 MFMA projections of the step-by-step path (weight images [row tile][k-step], bias in k-slot K)
+int fd_linear_bf16(fd_ctx* ctx, const float* x, const char* img, float* out, int M, int N, int K, int ks, hipStream_t s);
+int fd_linear_res_ln_bf16(fd_ctx* ctx, const float* x, const char* img, const float* res, const float* gamma, const float* beta,
+                          float* out, int M, int D, int ks, int dt, hipStream_t s);
 // head_dim 8 .. 32, one head per contraction (fd_attn_wide.hip); qkv = packed projections (B*T, 3D)
 int fd_attention_bf16_wide(fd_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int hd, hipStream_t s);
 int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, int H, int hd, hipStream_t s,

@@ -737,6 +737,15 @@ int fd_bf16_create(fd_score* m) {
             return fd_fail(m->ctx, FD_ERR_HIP, "fd_bf16_create: upload of the layer offset table failed");
         }
     }
+    if (!im->mega) {
+        im->nrt_in = (3 * D + 15) / 16;
+        im->poff_wo = (size_t)im->nrt_in * im->ks1 * 1024;
+        im->p_layer_stride = im->poff_wo + (size_t)im->dt * im->ks1 * 1024;
+        if (hipMalloc((void**)&im->pimg, im->p_layer_stride * L) != hipSuccess) {
+            fd_bf16_destroy(m);
+            return fd_fail(m->ctx, FD_ERR_HIP, "fd_bf16_create: hipMalloc of the projection images failed");
+        }
+    }
     // bf16 training kernels (fd_train_bf16.hip) exist for the persistent kernel's model family; their transposed-weight
     // images: FFN backward (same block count as the forward image) | W_o^T (dt x ks1) | in_proj^T half-blocks (np x 3 x dt)
     im->train = im->mega;
@@ -759,6 +768,7 @@ void fd_bf16_destroy(fd_score* m) {
     if (m->bf16->mimg) (void)hipFree(m->bf16->mimg);
     if (m->bf16->layer_off_tab) (void)hipFree(m->bf16->layer_off_tab);
     if (m->bf16->bimg) (void)hipFree(m->bf16->bimg);
+    if (m->bf16->pimg) (void)hipFree(m->bf16->pimg);
     delete m->bf16;
     m->bf16 = nullptr;
 }
@@ -785,6 +795,16 @@ int fd_bf16_prepare(fd_score* m, hipStream_t s) {
     if (B.mega) per_layer += 3 * B.n_qkv + B.n_wo + B.n_ffn + B.n_lp;
     if (B.mega && B.train) per_layer += B.n_ffn + B.n_wot + B.n_win;
     if (L > 0) hipLaunchKernelGGL(k_build_layer_images, dim3(per_layer, L), dim3(64), 0, s, B);
+    if (im->pimg) {
+        for (int i = 0; i < L; ++i) {
+            const fd_layer_off& lo = m->layers[i];
+            char* pl = im->pimg + (size_t)i * im->p_layer_stride;
+            hipLaunchKernelGGL(k_build_image, dim3(im->nrt_in * im->ks1), dim3(64), 0, s, IMG_EMB, P + lo.in_w, P + lo.in_b, (__bf16*)pl,
+                               im->ks1, 3 * D, D, H, hd, D, 1.f);
+            hipLaunchKernelGGL(k_build_image, dim3(im->dt * im->ks1), dim3(64), 0, s, IMG_EMB, P + lo.out_w, P + lo.out_b,
+                               (__bf16*)(pl + im->poff_wo), im->ks1, D, D, H, hd, D, 1.f);
+        }
+    }
     if (im->mega) {
         hipLaunchKernelGGL(k_build_image, dim3(im->dt * im->kse), dim3(64), 0, s, IMG_EMB, P + m->emb_w, P + m->emb_b,
                            (__bf16*)(im->mimg + im->off_emb), im->kse, D, C, H, hd, D, 1.f);
@@ -966,7 +986,11 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
             arc = fd_attention_bf16(ctx, h0, att, B, T, H, hd, s, limg + imq->off_wk, limg + imq->off_wv, limg + imq->off_wq, imq->ks1);
         }
         if (arc == FD_ERR_UNSUPPORTED) {
-            fdgemm::linear_fwd(h0, P + lo.in_w, P + lo.in_b, qkv, M, 3 * D, D, false, s);
+            const bool pbf = imq->pimg && !getenv("FDIFF_PROJ_F32");       // bf16 MFMA projections (fd_linear_bf16.hip)
+            int prc = FD_ERR_UNSUPPORTED;
+            if (pbf) prc = fd_linear_bf16(ctx, h0, imq->pimg + (size_t)i * imq->p_layer_stride, qkv, M, 3 * D, D, imq->ks1, s);
+            if (prc == FD_ERR_UNSUPPORTED) fdgemm::linear_fwd(h0, P + lo.in_w, P + lo.in_b, qkv, M, 3 * D, D, false, s);
+            else if (prc != FD_OK) return prc;
             arc = getenv("FDIFF_ATTN_F32") ? FD_ERR_UNSUPPORTED : fd_attention_bf16(ctx, qkv, att, B, T, H, hd, s);
             if (arc == FD_ERR_UNSUPPORTED && hd > 7 && !getenv("FDIFF_ATTN_F32"))       // head_dim 8 .. 32: one head per contraction
                 arc = fd_attention_bf16_wide(ctx, qkv, att, B, T, H, hd, s);
@@ -984,8 +1008,16 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
             if (int rc = run_ffn(m, nullptr, h1, i, M, s, att, h0)) return rc;
             std::swap(h0, h1);
         } else {
-            fdgemm::linear_fwd(att, P + lo.out_w, P + lo.out_b, tmp, M, D, D, false, s);
-            fdf32::add_layernorm(h0, tmp, P + lo.n1_w, P + lo.n1_b, h1, M, D, s);
+            int orc = FD_ERR_UNSUPPORTED;
+            if (im->pimg && !getenv("FDIFF_PROJ_F32"))
+                orc = fd_linear_res_ln_bf16(ctx, att, im->pimg + (size_t)i * im->p_layer_stride + im->poff_wo, h0, P + lo.n1_w, P + lo.n1_b, h1,
+                                            M, D, im->ks1, im->dt, s);
+            if (orc == FD_ERR_UNSUPPORTED) {
+                fdgemm::linear_fwd(att, P + lo.out_w, P + lo.out_b, tmp, M, D, D, false, s);
+                fdf32::add_layernorm(h0, tmp, P + lo.n1_w, P + lo.n1_b, h1, M, D, s);
+            } else if (orc != FD_OK) {
+                return orc;
+            }
             if (int rc = run_ffn(m, h1, h0, i, M, s)) return rc;
         }
     }
@@ -1147,9 +1179,9 @@ extern "C" int fd_score_plan(fd_score* m, int B, int mode, char* out /* >= 192 b
         const int hd = m->d.d_model / m->d.n_head;
         const bool fuse = im->mega && im->kso == 3 && (im->ks1 == 3 || im->ks1 == 2);
         snprintf(out, 192, "per-layer bf16 kernels (k_attention_bf16 + k_ffn_ln): attention %s, k_ffn_ln<%d,%d>%s",
-                 hd > 32 ? "exact-f32 kernel (head_dim > 32) on fp32-MFMA projections"
-                 : hd > 7 ? "bf16 k_attention_wide (one head per contraction) on fp32-MFMA projections"
-                        : (im->mega ? "bf16 with fused Q/K/V projections" : "bf16 on fp32-MFMA projections"),
+                 hd > 32 ? "exact-f32 kernel (head_dim > 32) on bf16-MFMA projections"
+                 : hd > 7 ? "bf16 k_attention_wide (one head per contraction) on bf16-MFMA projections"
+                        : (im->mega ? "bf16 with fused Q/K/V projections" : "bf16 on bf16-MFMA projections"),
                  im->ks1, im->dt, fuse ? " with fused out-proj + LN1" : "");
     }
     return FD_OK;
