@@ -127,9 +127,13 @@ def test_persistent_sampler_equals_stepwise_launches_bf16(C):
                 os.environ.pop("FDIFF_SAMPLER_STEPWISE", None)
             else:
                 os.environ["FDIFF_SAMPLER_STEPWISE"] = old
-    assert np.isfinite(outs[0]).all()
-    # identical network kernel and noise; only the fusion of the SDE step differs (fp32 rounding of the update)
-    np.testing.assert_allclose(outs[0], outs[1], atol=5e-5 * max(1.0, np.abs(outs[1]).max()), rtol=0)
+    bad = ~np.isfinite(outs[0])
+    assert not bad.any(), f"{int(bad.sum())} non-finite samples of {bad.size} at {np.argwhere(bad)[:8].tolist()}; stepwise non-finite: {int((~np.isfinite(outs[1])).sum())}"
+    # identical network kernel and noise; only the fusion of the SDE step differs (fp32 rounding of the update).  In bf16
+    # mode a 1e-7 change of x can flip an activation's bf16 rounding (2^-9 relative) in the next forward, and this toy model's
+    # trajectories grow to |x| ~ 300, so the two loops agree to bf16 noise, not to fp32 rounding: 2e-3 of the scale as in
+    # test_gpu_bench_instantiation.py (measured 1.8e-4; a wrong lane -> Philox-counter map gives O(1): independent normals)
+    np.testing.assert_allclose(outs[0], outs[1], atol=2e-3 * max(1.0, np.abs(outs[1]).max()), rtol=0)
 
 
 def test_precomputed_time_embedding_table_is_bit_identical():
