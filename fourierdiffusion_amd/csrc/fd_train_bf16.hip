@@ -383,8 +383,8 @@ __global__ __launch_bounds__(256) void k_tr_masks(const TrDims d, const MaskArgs
 __global__ __launch_bounds__(256) void k_tr_masks_T(const unsigned char* __restrict__ pmask, unsigned char* __restrict__ pmaskT,
                                                      int T, int NJ) {
     extern __shared__ __attribute__((aligned(16))) unsigned char srow[];      // [32 queries][NJ * 4]
-    const int jq = blockIdx.x;
-    const size_t bh = blockIdx.y;
+    const int jq = blockIdx.y;
+    const size_t bh = blockIdx.x;                 // (series, head) on the x axis: no 65 535 limit
     const int RB = NJ * 4;
     for (int i = threadIdx.x * 4; i < 32 * RB; i += 256 * 4) {
         const int q = 32 * jq + i / RB;
@@ -1885,7 +1885,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         // key-oriented copies of the attention keep bits: only the backward reads them, so they queue behind the decisions of
         // every layer (the forward never waits for them); last layer first, the order the backward wants them in
         for (int l = L - 1; l >= 0; --l)
-            hipLaunchKernelGGL(k_tr_masks_T, dim3(d.NJ, B * m->d.n_head), dim3(256), (size_t)32 * d.NJ * 4, ctx->side_stream,
+            hipLaunchKernelGGL(k_tr_masks_T, dim3(B * m->d.n_head, d.NJ), dim3(256), (size_t)32 * d.NJ * 4, ctx->side_stream,
                                tb.layers[l].pmask, tb.layers[l].pmaskT, T, d.NJ);
         if (!ctx->tr_masksT_event) FD_HIP(ctx, hipEventCreateWithFlags(&ctx->tr_masksT_event, hipEventDisableTiming));
         FD_HIP(ctx, hipEventRecord(ctx->tr_masksT_event, ctx->side_stream));

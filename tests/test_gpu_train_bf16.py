@@ -192,6 +192,56 @@ def test_dropout_forward_backward_consistency_bf16():
     assert abs(fd - an) <= 0.1 * max(abs(fd), abs(an)) + 1e-4, (fd, an)
 
 
+def test_dropout_on_gradients_per_tensor_bf16():
+    """Dropout ON (p = 0.1), bf16 path, per parameter tensor: the directional derivative of the (same-key) loss along the
+    tensor's own gradient block u_k = g_k / |g_k| must equal |g_k| -- a wrong keep-bit orientation, a missing keep scale or a
+    gradient that ignores the masks in ONE tensor (the weight-gradient kernel and the two input-gradient kernels read the
+    bits in three different layouts) changes that tensor's projection while the whole-gradient check above can still pass.
+    Central differences with a 10 % loss change per side; 15 % tolerance (bf16 forward noise + curvature)."""
+    from fourierdiffusion_amd.utils.losses import get_sde_loss_fn
+    cfg = dict(T=40, C=4, D=72, L=2, H=12)
+    m, sch, _ = make_model(cfg, precision="bf16")
+    B = 32
+    X = W.randn("drt_x", (B, cfg["T"], cfg["C"]), 3)
+    z = W.randn("drt_z", (B, cfg["T"], cfg["C"]), 3)
+    t = W.uniform("drt_t", (B,), 3, 0.2, 1.0)
+    fn = get_sde_loss_fn(sch, train=True)
+
+    def loss_at(backward):
+        torch.manual_seed(21)
+        return fn(m, batch_of(X, t), noise=dev(z), backward=backward).item()
+
+    m.zero_grad()
+    l0 = loss_at(True)
+    assert m.train_mode_effective == "bf16" and m.dropout == pytest.approx(0.1)
+    grads = m.grads.clone()
+    base = m.flat_parameters.clone()
+    views = {name: (off, numel) for name, off, numel, shape, _ in m._layout}
+    keys = ["backbone.layers.0.linear1.weight", "backbone.layers.1.linear2.weight", "backbone.layers.0.self_attn.in_proj_weight",
+            "backbone.layers.1.self_attn.out_proj.weight", "backbone.layers.0.norm1.weight", "backbone.layers.1.linear1.bias",
+            "embedder.weight", "pos_encoder.embedding.weight", "unembedder.weight"]
+    worst = 0.0
+    for k in keys:
+        off, numel = views[k]
+        gk = grads[off:off + numel]
+        nk = float(gk.norm())
+        assert nk > 0, k
+        eps = 0.1 * abs(l0) / nk
+        v = torch.zeros_like(base)
+        v[off:off + numel] = gk / nk
+        m.flat_parameters.copy_(base + eps * v); m.mark_parameters_changed()
+        lp = loss_at(False)
+        m.flat_parameters.copy_(base - eps * v); m.mark_parameters_changed()
+        lm = loss_at(False)
+        fd = (lp - lm) / (2 * eps)
+        rel = abs(fd - nk) / nk
+        worst = max(worst, rel)
+        _log(f"[parity] bf16 dropout-on gradient of {k}: central difference {fd:.4e} vs |g_k| {nk:.4e} (rel {rel:.3e})")
+        assert rel <= 0.15, (k, fd, nk)
+    m.flat_parameters.copy_(base); m.mark_parameters_changed()
+    _log(f"[parity] bf16 dropout-on per-tensor directional derivatives: worst relative deviation {worst:.3e}")
+
+
 def test_short_optimisation_run_bf16_tracks_f32():
     """40 AdamW steps on a fixed synthetic batch with the bf16 and the exact-f32 training kernels (dropout 0, same t, z per
     step): both losses fall, and the bf16 loss curve stays within 5 % of the f32 one."""
