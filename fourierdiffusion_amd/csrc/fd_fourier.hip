@@ -24,6 +24,9 @@ struct FftPlan {
     int T;
     int nstages;
     int radix[kMaxStages];
+    int vec_ok;        // C even, even chunk starts, 8-byte aligned x / y: channel pairs move as float2
+    int stagger;       // phase stagger of the first resident round: sixteenths of a period in units of 1024 cycles (0 = off)
+    int resident;      // workgroups resident at once
 };
 
 // n / d for 0 <= n < 2^22 through the float pipe (4 VALU instead of the ~40 of a 32-bit integer division; the index
@@ -40,6 +43,10 @@ __device__ __forceinline__ void stg(float* p, float v) { *p = v; }
 #endif
 
 __device__ __forceinline__ int fdiv(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
+// a * b for 0 <= a, b < 2^24 by v_mul_u32_u24 (full rate); the 32-bit v_mul_lo_u32 hipcc emits for plain `int * int` is
+// quarter rate, and the index arithmetic of a stage -- not its butterflies -- is most of this kernel's VALU time (every index
+// of the LDS-resident transform is below 2^22, every factor below 2^24)
+__device__ __forceinline__ int m24(int a, int b) { return (int)__umul24((unsigned)a, (unsigned)b); }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return float2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
@@ -171,18 +178,20 @@ __device__ __forceinline__ void stockham_butterflies(const float2* __restrict__ 
     float2 wr[R];                                   // R-th roots of unity in the transform's direction
 #pragma unroll
     for (int m = 0; m < R; ++m) wr[m] = tw[m * tr];
+    const int trC = tr * Cp, RNs = R * Ns;          // (wave-uniform products: scalar unit)
     for (int id = threadIdx.x; id < total; id += NT) {
-        const int j = fdiv(id, inv_cp), p = id - j * Cp;
-        const int blk = fdiv(j, inv_ns), k = j - blk * Ns;
+        const int j = fdiv(id, inv_cp), p = id - m24(j, Cp);
+        const int blk = fdiv(j, inv_ns), k = j - m24(blk, Ns);
         float2 a[R];
+        const float2* i0 = in + (id - 0);           // in[j * Cp + p] == in[id]: the butterfly's inputs are id + t * tr * Cp
 #pragma unroll
-        for (int t = 0; t < R; ++t) a[t] = in[(j + t * tr) * Cp + p];
+        for (int t = 0; t < R; ++t) a[t] = i0[t * trC];
         if (k != 0) {
-            const int step = k * ktw;               // < T / R
+            const int step = m24(k, ktw);           // < T / R
 #pragma unroll
-            for (int t = 1; t < R; ++t) a[t] = cmul(a[t], tw[step * t]);   // step * t < T
+            for (int t = 1; t < R; ++t) a[t] = cmul(a[t], tw[step * t]);   // step * t < T (t is a literal: shifts / adds)
         }
-        float2* o = out + ((blk * R) * Ns + k) * Cp + p;                     // output u at o[u * Ns * Cp]
+        float2* o = out + m24(m24(blk, RNs) + k, Cp) + p;                    // output u at o[u * Ns * Cp]
         const int os = Ns * Cp;
         if (R == 2) {
             o[0] = float2{a[0].x + a[1].x, a[0].y + a[1].y};
@@ -211,6 +220,64 @@ __device__ __forceinline__ void stockham_butterflies(const float2* __restrict__ 
     }
 }
 
+// In-place decimation-in-frequency stage of small radix R on sub-transforms of length Lc (Gentleman-Sande): the butterfly of
+// (block, j), j < m = Lc / R, reads X[base + j + t m], t < R, and writes  b_u = (sum_t a_t W_R^(u t)) W_Lc^(j u)  back to
+// X[base + j + u m] -- the same R places, so ONE LDS image serves the whole transform (the Stockham form needs two) and four
+// instead of two workgroups fit a CU at (T, C) = (256, 28).  After the last stage X_k sits at the digit-reversed place
+// rev[k]; the store pass reads through that table.
+template <int R>
+__device__ __forceinline__ void dif_butterflies(float2* __restrict__ X, const float2* __restrict__ tw, int T, int Cp, int Lc) {
+    const int NT = blockDim.x;
+    const int m = Lc / R;
+    const int tr = T / R;
+    const int ktw = T / Lc;                         // W_Lc = W_T^ktw
+    const int total = tr * Cp;
+    const float inv_cp = 1.0f / (float)Cp, inv_m = 1.0f / (float)m;
+    float2 wr[R];                                   // R-th roots of unity in the transform's direction
+#pragma unroll
+    for (int q = 0; q < R; ++q) wr[q] = tw[q * tr];
+    const int ms = m * Cp;
+    for (int id = threadIdx.x; id < total; id += NT) {
+        const int bj = fdiv(id, inv_cp), p = id - m24(bj, Cp);
+        const int blk = fdiv(bj, inv_m), j = bj - m24(blk, m);
+        float2* x0 = X + m24(m24(blk, Lc) + j, Cp) + p;                      // input / output t at x0[t * m * Cp]
+        float2 a[R], b[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) a[t] = x0[t * ms];
+        if (R == 2) {
+            b[0] = float2{a[0].x + a[1].x, a[0].y + a[1].y};
+            b[1] = float2{a[0].x - a[1].x, a[0].y - a[1].y};
+        } else if (R == 4) {
+            const float2 s02 = {a[0].x + a[2].x, a[0].y + a[2].y}, d02 = {a[0].x - a[2].x, a[0].y - a[2].y};
+            const float2 s13 = {a[1].x + a[3].x, a[1].y + a[3].y}, d13 = {a[1].x - a[3].x, a[1].y - a[3].y};
+            const float2 rot = cmul(d13, wr[1]);    // (a1 - a3) * W_4   (W_4 = -i forward, +i inverse)
+            b[0] = float2{s02.x + s13.x, s02.y + s13.y};
+            b[1] = float2{d02.x + rot.x, d02.y + rot.y};
+            b[2] = float2{s02.x - s13.x, s02.y - s13.y};
+            b[3] = float2{d02.x - rot.x, d02.y - rot.y};
+        } else {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                float2 acc = a[0];
+#pragma unroll
+                for (int t = 1; t < R; ++t) {
+                    const float2 w = wr[(u * t) % R];
+                    acc.x += a[t].x * w.x - a[t].y * w.y;
+                    acc.y += a[t].x * w.y + a[t].y * w.x;
+                }
+                b[u] = acc;
+            }
+        }
+        if (j != 0 && m > 1) {
+            const int step = m24(j, ktw);           // j u ktw < m R ktw = T
+#pragma unroll
+            for (int u = 1; u < R; ++u) b[u] = cmul(b[u], tw[step * u]);
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) x0[u * ms] = b[u];
+    }
+}
+
 // INVERSE == false : x (time)  -> y (packed spectrum), optional (y - mean)/std
 // INVERSE == true  : x (packed spectrum), optional x*std + mean  -> y (time)
 // BATCHED (single-channel data, C == 1): the workgroup transforms Cc consecutive SERIES instead of Cc channels of one series
@@ -219,10 +286,21 @@ __device__ __forceinline__ void stockham_butterflies(const float2* __restrict__ 
 // BIGP: the instantiation that carries the register butterflies of the prime radices 17 / 19 / 23 (34-46 complex registers per
 // thread: they spill at the 1024-thread budget, and a kernel with scratch pays for it in every stage -- (4096, 256, 28) lost
 // 9 % when they lived in the common instantiation); lengths without such a factor run the BIGP = false kernel.
-template <bool INVERSE, bool BATCHED, bool BIGP>
+template <bool INVERSE, bool BATCHED, bool BIGP, bool INPLACE = false>
 __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, float* __restrict__ y,
                                                     const float* __restrict__ mean, const float* __restrict__ stdv,
                                                     const float2* __restrict__ tw_fwd, int B, int C, int Cc, FftPlan plan) {
+    // Phase stagger (plan.stagger > 0): every workgroup of the launch takes the same time, so without it the whole chip loads,
+    // computes and stores in lockstep round after round -- HBM idle during the stages, the SIMDs idle during the transfers
+    // (measured: kernel time = transfer time + stage time, also at four workgroups per CU).  The first resident round starts
+    // spread over one period; later workgroups inherit the spread through the slots they take over.
+    if (plan.stagger > 0) {
+        const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+        if (lin < (unsigned)plan.resident) {
+            const unsigned slots = ((lin * 2654435761u) >> 16) % 16u;          // 0 .. 15 sixteenths of the period
+            for (unsigned i = 0; i < slots * (unsigned)plan.stagger; ++i) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NT = blockDim.x;
     const int T = plan.T;
@@ -232,7 +310,22 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
     const int Cp = (cc + 1) >> 1;            // complex lanes (channel pairs)
     float2* tw = reinterpret_cast<float2*>(smem);
     float2* bufA = tw + T;
-    float2* bufB = bufA + (size_t)T * ((Cc + 1) >> 1);
+    float2* bufB = bufA + (size_t)T * ((Cc + 1) >> 1);          // Stockham ping-pong partner; INPLACE: the digit-reversal table
+    unsigned short* rev = reinterpret_cast<unsigned short*>(bufB);
+    if (INPLACE) {
+        // rev[k] = place of X_k after the DIF stages: place = sum_s d_s m_s (m_s = T / (r_0 .. r_s)), k = sum_s d_s (r_0 .. r_{s-1})
+        for (int k = threadIdx.x; k < T; k += blockDim.x) {
+            int rem = k, place = 0, mcur = T;
+            for (int st = 0; st < plan.nstages; ++st) {
+                const int r = plan.radix[st];
+                mcur /= r;
+                const int dgt = rem % r;
+                rem /= r;
+                place += dgt * mcur;
+            }
+            rev[k] = (unsigned short)place;
+        }
+    }
     // W_T^k = exp(-2 pi i k / T), built once per T on the host in double precision (a per-workgroup sincospi in double
     // was a third of the kernel's time); the inverse transform conjugates
     for (int k = threadIdx.x; k < T; k += NT) {
@@ -245,30 +338,45 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
     const bool even = (T & 1) == 0;
     const float scale = rsqrtf((float)T);
     // offset of (row, channel) in xb / yb, and in the (T, C) mean / std tables; BATCHED: channel = series, rows contiguous
-    const size_t cstep = BATCHED ? (size_t)T : 1, rstep = BATCHED ? 1 : (size_t)C, mstep = BATCHED ? 0 : 1;
+    // (32-bit offsets inside one series / series group: T * C * Cc < 2^31 is checked on the host; factors < 2^24 for m24)
+    const int cstep = BATCHED ? T : 1, rstep = BATCHED ? 1 : C, mstep = BATCHED ? 0 : 1;
+    // channel pairs as 8-byte accesses: rows of an even number of channels, chunks start at even channels and the tensor base is
+    // 8-byte aligned (the host passes `vec_ok`): half the memory instructions and address arithmetic of the load / store passes
+    const bool vec2 = !BATCHED && plan.vec_ok != 0;
 
     // ---- load pass: build z[n][p]  (thread order: channel pairs fastest, BATCHED: rows fastest = contiguous in memory)
     const float inv_cp = 1.0f / (float)Cp, inv_t = 1.0f / (float)T, inv_nr = 1.0f / (float)n_real;
     for (int id = threadIdx.x; id < T * Cp; id += NT) {
         int n, p;
-        if (BATCHED) { p = fdiv(id, inv_t); n = id - p * T; } else { n = fdiv(id, inv_cp); p = id - n * Cp; }
+        if (BATCHED) { p = fdiv(id, inv_t); n = id - m24(p, T); } else { n = fdiv(id, inv_cp); p = id - m24(n, Cp); }
         const int ca = c0 + 2 * p;
         const bool has_b = (2 * p + 1) < cc;
         float2 z;
         if (!INVERSE) {
-            z.x = ldg(xb + (size_t)n * rstep + ca * cstep);
-            z.y = has_b ? ldg(xb + (size_t)n * rstep + (ca + 1) * cstep) : 0.f;
+            if (vec2) {           // both channels of the pair in one 8-byte access (C even: 8-byte aligned)
+                z = *reinterpret_cast<const float2*>(xb + m24(n, rstep) + ca);
+            } else {
+                z.x = ldg(xb + m24(n, rstep) + m24(ca, cstep));
+                z.y = has_b ? ldg(xb + m24(n, rstep) + m24(ca + 1, cstep)) : 0.f;
+            }
         } else {
             // Hermitian extension of the packed half spectrum (fourier.py:62-77): X[T-k] = conj X[k]
             const int kk = (n <= T / 2) ? n : T - n;
             const bool has_im = (kk != 0) && !(even && kk == T / 2);
             const float sg = (n <= T / 2) ? 1.0f : -1.0f;
-            const size_t ire = (size_t)kk * rstep, iim = (size_t)(n_real + kk - 1) * rstep;
-            const size_t oa = ca * cstep, ob = (ca + 1) * cstep;
-            float are = ldg(xb + ire + oa), aim = has_im ? ldg(xb + iim + oa) : 0.f;
-            float bre = has_b ? ldg(xb + ire + ob) : 0.f, bim = (has_b && has_im) ? ldg(xb + iim + ob) : 0.f;
+            const int ire = m24(kk, rstep), iim = m24(n_real + kk - 1, rstep);
+            const int oa = m24(ca, cstep), ob = m24(ca + 1, cstep);
+            float are, aim, bre, bim;
+            if (vec2) {
+                const float2 re2 = *reinterpret_cast<const float2*>(xb + ire + oa);
+                const float2 im2 = has_im ? *reinterpret_cast<const float2*>(xb + iim + oa) : float2{0.f, 0.f};
+                are = re2.x; bre = re2.y; aim = im2.x; bim = im2.y;
+            } else {
+                are = ldg(xb + ire + oa); aim = has_im ? ldg(xb + iim + oa) : 0.f;
+                bre = has_b ? ldg(xb + ire + ob) : 0.f; bim = (has_b && has_im) ? ldg(xb + iim + ob) : 0.f;
+            }
             if (mean) {   // de-standardise in the frequency domain (cmd/sample.py:76-78)
-                const size_t mre = (size_t)kk * C, mim = (size_t)(n_real + kk - 1) * C, ma = ca * mstep, mb = (ca + 1) * mstep;
+                const int mre = m24(kk, C), mim = m24(n_real + kk - 1, C), ma = ca * mstep, mb = (ca + 1) * mstep;
                 are = are * stdv[mre + ma] + mean[mre + ma];
                 if (has_im) aim = aim * stdv[mim + ma] + mean[mim + ma];
                 if (has_b) {
@@ -282,13 +390,28 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
             z.x = are - bim;
             z.y = aim + bre;
         }
-        bufA[n * Cp + p] = z;
+        bufA[BATCHED ? m24(n, Cp) + p : id] = z;        // (non-batched: id == n * Cp + p)
     }
     __syncthreads();
 
-    // ---- Stockham stages (ping-pong)
+    // ---- stages: Stockham ping-pong, or in place (INPLACE: smooth lengths only, radices 2 / 3 / 4 / 5 / 7)
     float2* src = bufA;
     float2* dst = bufB;
+    if (INPLACE) {
+        int Lc = T;
+        for (int s = 0; s < plan.nstages; ++s) {
+            const int r = plan.radix[s];
+            switch (r) {
+                case 2: dif_butterflies<2>(bufA, tw, T, Cp, Lc); break;
+                case 3: dif_butterflies<3>(bufA, tw, T, Cp, Lc); break;
+                case 4: dif_butterflies<4>(bufA, tw, T, Cp, Lc); break;
+                case 5: dif_butterflies<5>(bufA, tw, T, Cp, Lc); break;
+                default: dif_butterflies<7>(bufA, tw, T, Cp, Lc); break;
+            }
+            Lc /= r;
+            __syncthreads();
+        }
+    } else {
     int Ns = 1;
 #if defined(FD_FFT_ABL) && FD_FFT_ABL == 1
     for (int s = 0; s < 0; ++s) {
@@ -315,25 +438,28 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
         src = dst;
         dst = tmp;
     }
+    }
+    // place of coefficient / sample k in `src` (identity for the autosort form)
+    auto at = [&](int k) { return INPLACE ? (int)rev[k] : k; };
 
     // ---- store pass
     if (!INVERSE) {
         // X_a[k] = (Z[k] + conj Z[T-k]) / 2 ,  X_b[k] = (Z[k] - conj Z[T-k]) / (2i)
         for (int id = threadIdx.x; id < n_real * Cp; id += NT) {
             int k, p;
-            if (BATCHED) { p = fdiv(id, inv_nr); k = id - p * n_real; } else { k = fdiv(id, inv_cp); p = id - k * Cp; }
+            if (BATCHED) { p = fdiv(id, inv_nr); k = id - m24(p, n_real); } else { k = fdiv(id, inv_cp); p = id - m24(k, Cp); }
             const int ca = c0 + 2 * p;
             const bool has_b = (2 * p + 1) < cc;
-            const float2 zk = src[k * Cp + p];
-            const float2 zm = src[((k == 0) ? 0 : (T - k)) * Cp + p];
+            const float2 zk = src[m24(at(k), Cp) + p];
+            const float2 zm = src[m24(at((k == 0) ? 0 : (T - k)), Cp) + p];
             const float h = 0.5f * scale;
             float are = (zk.x + zm.x) * h, aim = (zk.y - zm.y) * h;
             float bre = (zk.y + zm.y) * h, bim = (zm.x - zk.x) * h;
             const bool has_im = (k != 0) && !(even && k == T / 2);   // fourier.py:26-37 drop exact zeros
-            const size_t ire = (size_t)k * rstep, iim = (size_t)(n_real + k - 1) * rstep;
-            const size_t oa = ca * cstep, ob = (ca + 1) * cstep;
+            const int ire = m24(k, rstep), iim = m24(n_real + k - 1, rstep);
+            const int oa = m24(ca, cstep), ob = m24(ca + 1, cstep);
             if (mean) {   // standardise (datamodules.py:61-62)
-                const size_t mre = (size_t)k * C, mim = (size_t)(n_real + k - 1) * C, ma = ca * mstep, mb = (ca + 1) * mstep;
+                const int mre = m24(k, C), mim = m24(n_real + k - 1, C), ma = ca * mstep, mb = (ca + 1) * mstep;
                 are = (are - mean[mre + ma]) / stdv[mre + ma];
                 if (has_im) aim = (aim - mean[mim + ma]) / stdv[mim + ma];
                 if (has_b) {
@@ -341,21 +467,30 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
                     if (has_im) bim = (bim - mean[mim + mb]) / stdv[mim + mb];
                 }
             }
-            stg(yb + ire + oa, are);
-            if (has_b) stg(yb + ire + ob, bre);
-            if (has_im) {
-                stg(yb + iim + oa, aim);
-                if (has_b) stg(yb + iim + ob, bim);
+            if (vec2) {
+                *reinterpret_cast<float2*>(yb + ire + oa) = float2{are, bre};
+                if (has_im) *reinterpret_cast<float2*>(yb + iim + oa) = float2{aim, bim};
+            } else {
+                stg(yb + ire + oa, are);
+                if (has_b) stg(yb + ire + ob, bre);
+                if (has_im) {
+                    stg(yb + iim + oa, aim);
+                    if (has_b) stg(yb + iim + ob, bim);
+                }
             }
         }
     } else {
         for (int id = threadIdx.x; id < T * Cp; id += NT) {
             int n, p;
-            if (BATCHED) { p = fdiv(id, inv_t); n = id - p * T; } else { n = fdiv(id, inv_cp); p = id - n * Cp; }
+            if (BATCHED) { p = fdiv(id, inv_t); n = id - m24(p, T); } else { n = fdiv(id, inv_cp); p = id - m24(n, Cp); }
             const int ca = c0 + 2 * p;
-            const float2 z = src[n * Cp + p];
-            stg(yb + (size_t)n * rstep + ca * cstep, z.x * scale);
-            if ((2 * p + 1) < cc) stg(yb + (size_t)n * rstep + (ca + 1) * cstep, z.y * scale);
+            const float2 z = src[m24(at(n), Cp) + p];
+            if (vec2) {
+                *reinterpret_cast<float2*>(yb + m24(n, rstep) + ca) = float2{z.x * scale, z.y * scale};
+            } else {
+                stg(yb + m24(n, rstep) + m24(ca, cstep), z.x * scale);
+                if ((2 * p + 1) < cc) stg(yb + m24(n, rstep) + m24(ca + 1, cstep), z.y * scale);
+            }
         }
     }
 }
@@ -431,6 +566,8 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
     FD_REQUIRE(ctx, B > 0 && T > 0 && C > 0, "%s: bad shape B=%d T=%d C=%d", who, B, T, C);
     FD_REQUIRE(ctx, (mean == nullptr) == (stdv == nullptr), "%s: mean and std must come together", who);
     FD_REQUIRE(ctx, B <= 2147483647 / 2, "%s: batch too large", who);
+    FD_REQUIRE(ctx, C < (1 << 24) && (long long)T * C < 2147483647LL, "%s: one series (T * C = %lld elements) exceeds the 32-bit "
+               "in-series offsets of the kernel", who, (long long)T * C);
     FftPlan plan;
     FD_REQUIRE(ctx, make_plan(T, plan), "%s: T=%d has too many prime factors", who, T);
     // A length dominated by one large prime factor p runs that factor as a direct-DFT stage, O(T p) per transform; from
@@ -452,16 +589,31 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
             }
         }
     }
-    // LDS: twiddles (8T) + two complex images of T * ceil(Cc/2) float2
+    // In-place form (one LDS image + the digit-reversal table instead of two images) for smooth lengths: radices 2 / 3 / 4 / 5 / 7
+    // only.  Measured (profiles/r03_fft_experiments.txt): with whole rows in one chunk either way it is 5-12 % SLOWER than the
+    // autosort form although four instead of two workgroups fit a CU (the kernel is bound by its instruction count, 55 % VALU
+    // busy, not by residency), but where the autosort form has to split the channels of a row over several workgroups
+    // ((512, 1024, 16): two chunks of 8) the single image keeps rows whole: iRFFT 48.2 -> 41.6 us.  So: in place exactly when that
+    // saves a channel split.  FDIFF_FFT_INPLACE=0 / 1 forces either form where both exist (the parity tests run both).
+    bool smooth = T < 65536;
+    for (int i = 0; i < plan.nstages; ++i) smooth &= (plan.radix[i] <= 5 || plan.radix[i] == 7);
+    static const int lds_target_kb0 = getenv("FDIFF_FFT_LDS_KB") ? atoi(getenv("FDIFF_FFT_LDS_KB")) : 72;
+    const long long auto_pairs = ((long long)lds_target_kb0 * 1024 - (long long)T * 8) / ((long long)T * 16);
+    bool inplace = smooth && C > 1 && auto_pairs >= 4 && (C + 1) / 2 > auto_pairs;
+    if (const char* e = getenv("FDIFF_FFT_INPLACE")) inplace = smooth && e[0] != '0';
+    // LDS: twiddles (8T) + complex images of T * ceil(Cc/2) float2: two (Stockham ping-pong) or one + 2T bytes (in place)
     const size_t lds_cap = 128 * 1024;
+    const size_t fixed = (size_t)T * 8 + (inplace ? (size_t)T * 2 + 16 : 0), per_pair = (size_t)T * (inplace ? 8 : 16);
     FD_REQUIRE(ctx, (size_t)T * 8 + 2 * (size_t)T * 8 <= lds_cap, "%s: T=%d too long for the LDS-resident transform",
                who, T);   // (also keeps every index below 2^22, the range of fdiv)
-    int max_pairs = (int)((lds_cap - (size_t)T * 8) / ((size_t)T * 16));
-    // prefer <= 72 KiB per workgroup (two resident workgroups per CU overlap each other's load / store passes) as long
-    // as a chunk keeps at least 8 channels = one 32-byte sector per time step
+    int max_pairs = (int)((lds_cap - fixed) / per_pair);
+    // prefer <= 72 KiB per workgroup (two resident workgroups per CU overlap each other's load / store passes; the in-place
+    // form then fits four) as long as a chunk keeps at least 8 channels = one 32-byte sector per time step
     static const int lds_target_kb = getenv("FDIFF_FFT_LDS_KB") ? atoi(getenv("FDIFF_FFT_LDS_KB")) : 72;
-    const int pairs_2wg = (int)(((size_t)lds_target_kb * 1024 - (size_t)T * 8) / ((size_t)T * 16));
-    if (pairs_2wg >= 4 && pairs_2wg < max_pairs) max_pairs = pairs_2wg;
+    const size_t target = (size_t)lds_target_kb * 1024;
+    const int pairs_2wg = target > fixed ? (int)((target - fixed) / per_pair) : 0;
+    // (in place: whole rows in one chunk whenever they fit at all -- that is what this form is selected for)
+    if (pairs_2wg >= 4 && pairs_2wg < max_pairs && !(inplace && (C + 1) / 2 <= max_pairs)) max_pairs = pairs_2wg;
     int Cc = C;
     if ((C + 1) / 2 > max_pairs) Cc = max_pairs * 2;
     // single-channel sets: Cc consecutive series per workgroup (BATCHED), as many as keep >= 2 workgroups per CU busy,
@@ -474,13 +626,15 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
     }
     const int nchunks = batched ? 1 : (C + Cc - 1) / Cc;
     const int ngroups = batched ? (B + Cc - 1) / Cc : B;
-    const size_t lds = (size_t)T * 8 + 2 * (size_t)T * ((Cc + 1) / 2) * 8;
+    const size_t lds = fixed + (inplace ? 1 : 2) * (size_t)T * ((Cc + 1) / 2) * 8;
     bool bigp = false;
     for (int i = 0; i < plan.nstages; ++i) bigp |= (plan.radix[i] == 17 || plan.radix[i] == 19 || plan.radix[i] == 23);
-    auto kern = bigp ? (batched ? k_fft<INVERSE, true, true> : k_fft<INVERSE, false, true>)
+    void (*kern)(const float*, float*, const float*, const float*, const float2*, int, int, int, FftPlan);
+    if (inplace) kern = batched ? k_fft<INVERSE, true, false, true> : k_fft<INVERSE, false, false, true>;
+    else kern = bigp ? (batched ? k_fft<INVERSE, true, true> : k_fft<INVERSE, false, true>)
                      : (batched ? k_fft<INVERSE, true, false> : k_fft<INVERSE, false, false>);
-    static unsigned long long attr_set[2][2][2] = {};
-    if (fd_first_on_device(attr_set[INVERSE ? 1 : 0][batched ? 1 : 0][bigp ? 1 : 0], ctx->device))
+    static unsigned long long attr_set[2][2][2][2] = {};
+    if (fd_first_on_device(attr_set[INVERSE ? 1 : 0][batched ? 1 : 0][bigp ? 1 : 0][inplace ? 1 : 0], ctx->device))
         FD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // twiddle table of this T (cached on the context; a handful of distinct T per process)
     const float2* tw_dev = nullptr;
@@ -502,6 +656,15 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
     const int elems = T * ((Cc + 1) / 2);
     int block = 128;
     while (block < kMaxBlock && block * 8 < elems) block *= 2;
+    {
+        const int wg_per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / (lds + 256)), 2048 / block));
+        plan.resident = ctx->num_cu * wg_per_cu;
+        const long long nwg = (long long)ngroups * nchunks;
+        plan.vec_ok = (!batched && (C & 1) == 0 && (Cc & 1) == 0 && ((uintptr_t)x & 7) == 0 && ((uintptr_t)y & 7) == 0) ? 1 : 0;
+        const char* e = getenv("FDIFF_FFT_STAGGER");
+        plan.stagger = e ? atoi(e) : 0;
+        if (nwg < 3LL * plan.resident) plan.stagger = 0;           // short launches: the spread would cost more than it hides
+    }
     hipLaunchKernelGGL(kern, dim3(ngroups, nchunks), dim3(block), lds, (hipStream_t)stream, x, y, mean, stdv, tw_dev, B, C,
                        Cc, plan);
     FD_LAUNCH_CHECK(ctx);

@@ -206,3 +206,23 @@ def test_transform_paths_agree_with_golden(golden, mode, monkeypatch):
         x = W.randn("paths", shape, 41)
         np.testing.assert_allclose(host(dft(dev(x))), O.dft(x), atol=ATOL, rtol=0)
         np.testing.assert_allclose(host(idft(dev(x))), O.idft(x), atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("inplace", ["1", "0"])
+def test_inplace_and_autosort_forms_agree_with_the_oracle(inplace, monkeypatch):
+    """Smooth lengths (prime factors 2, 3, 5, 7) run the in-place decimation-in-frequency form (one LDS image + a
+    digit-reversal table: four workgroups per CU where the Stockham ping-pong fits two); FDIFF_FFT_INPLACE=0 forces the
+    autosort form.  Both against the oracle at mixed radices, odd lengths, channel chunks, single-channel (batched) sets, a
+    ragged last group and the fused standardisation."""
+    from fourierdiffusion_amd.utils.fourier import dft, idft
+    monkeypatch.setenv("FDIFF_FFT_INPLACE", inplace)
+    monkeypatch.setenv("FDIFF_DFT", "fft")
+    shapes = [(5, 100, 12), (3, 252, 6), (4, 256, 28), (2, 1024, 16), (3, 360, 5), (2, 2048, 3), (7, 105, 4), (3, 81, 2), (2, 125, 7),
+              (3, 343, 3), (2, 1000, 9), (300, 64, 1), (37, 100, 1), (9, 7, 3), (6, 2, 2), (4, 4096, 2), (3, 256, 70), (2, 1024, 40)]
+    for shape in shapes:
+        x = W.randn(f"inpl_{shape}", shape, 43)
+        np.testing.assert_allclose(host(dft(dev(x))), O.dft(x), atol=ATOL, rtol=0, err_msg=f"dft {shape} inplace={inplace}")
+        np.testing.assert_allclose(host(idft(dev(x))), O.idft(x), atol=ATOL, rtol=0, err_msg=f"idft {shape} inplace={inplace}")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(64, 256, 28, generator=g).to(DEV)
+    assert torch.allclose(idft(dft(x)).to(DEV), x, atol=2e-5)
