@@ -162,6 +162,31 @@ __device__ __forceinline__ void stockham_prime(const float2* __restrict__ in, fl
     }
 }
 
+// 16-point DFT in registers as 4 x 4 (two layers of radix-4 butterflies with the W_16^(q r) twiddles between them):
+// x[r + 4 u] = sum_q ( (sum_s a[q + 4 s] W_4^(r s)) W_16^(q r) ) W_4^(q u).  w4 = W_4 (-i forward, +i inverse), w16[e] = W_16^e for
+// e = 1, 2, 3, 6, 9 (index 0..4), all taken from the twiddle table so that they carry the transform's direction.
+__device__ __forceinline__ void dft4(const float2 a0, const float2 a1, const float2 a2, const float2 a3, const float2 w4, float2& b0,
+                                     float2& b1, float2& b2, float2& b3) {
+    const float2 s02 = {a0.x + a2.x, a0.y + a2.y}, d02 = {a0.x - a2.x, a0.y - a2.y};
+    const float2 s13 = {a1.x + a3.x, a1.y + a3.y}, d13 = {a1.x - a3.x, a1.y - a3.y};
+    const float2 rot = cmul(d13, w4);
+    b0 = float2{s02.x + s13.x, s02.y + s13.y};
+    b1 = float2{d02.x + rot.x, d02.y + rot.y};
+    b2 = float2{s02.x - s13.x, s02.y - s13.y};
+    b3 = float2{d02.x - rot.x, d02.y - rot.y};
+}
+__device__ __forceinline__ void dft16(const float2 (&a)[16], float2 (&x)[16], const float2 w4, const float2 (&w16)[5]) {
+    float2 b[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dft4(a[q], a[q + 4], a[q + 8], a[q + 12], w4, b[q][0], b[q][1], b[q][2], b[q][3]);
+    // W_16^(q r): q = 1: e = r (1, 2, 3); q = 2: e = 2 r (2, 4, 6); q = 3: e = 3 r (3, 6, 9); W_16^4 = W_4
+    b[1][1] = cmul(b[1][1], w16[0]); b[1][2] = cmul(b[1][2], w16[1]); b[1][3] = cmul(b[1][3], w16[2]);
+    b[2][1] = cmul(b[2][1], w16[1]); b[2][2] = cmul(b[2][2], w4);     b[2][3] = cmul(b[2][3], w16[3]);
+    b[3][1] = cmul(b[3][1], w16[2]); b[3][2] = cmul(b[3][2], w16[3]); b[3][3] = cmul(b[3][3], w16[4]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dft4(b[0][r], b[1][r], b[2][r], b[3][r], w4, x[r], x[r + 4], x[r + 8], x[r + 12]);
+}
+
 // One Stockham stage of small radix R with a whole butterfly per thread: R inputs are read once, pre-twiddled by
 // W_T^(k*ktw*t) and combined by the R-point DFT (R = 2, 4: additions only; 3, 5, 7: the R roots of unity from the twiddle
 // table).  Compared with one output per thread this does 1/R of the LDS reads, twiddle fetches and index arithmetic.
@@ -178,6 +203,11 @@ __device__ __forceinline__ void stockham_butterflies(const float2* __restrict__ 
     float2 wr[R];                                   // R-th roots of unity in the transform's direction
 #pragma unroll
     for (int m = 0; m < R; ++m) wr[m] = tw[m * tr];
+    float2 w16[5] = {};
+    if (R == 16) {
+        const int e16 = T / 16;
+        w16[0] = tw[e16]; w16[1] = tw[2 * e16]; w16[2] = tw[3 * e16]; w16[3] = tw[6 * e16]; w16[4] = tw[9 * e16];
+    }
     const int trC = tr * Cp, RNs = R * Ns;          // (wave-uniform products: scalar unit)
     for (int id = threadIdx.x; id < total; id += NT) {
         const int j = fdiv(id, inv_cp), p = id - m24(j, Cp);
@@ -193,7 +223,15 @@ __device__ __forceinline__ void stockham_butterflies(const float2* __restrict__ 
         }
         float2* o = out + m24(m24(blk, RNs) + k, Cp) + p;                    // output u at o[u * Ns * Cp]
         const int os = Ns * Cp;
-        if (R == 2) {
+        if (R == 16) {
+            float2 x16[16];
+            float2 a16[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) a16[t] = a[t % R];
+            dft16(a16, x16, tw[T / 4], w16);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) o[u * os] = x16[u];
+        } else if (R == 2) {
             o[0] = float2{a[0].x + a[1].x, a[0].y + a[1].y};
             o[os] = float2{a[0].x - a[1].x, a[0].y - a[1].y};
         } else if (R == 4) {
@@ -236,6 +274,11 @@ __device__ __forceinline__ void dif_butterflies(float2* __restrict__ X, const fl
     float2 wr[R];                                   // R-th roots of unity in the transform's direction
 #pragma unroll
     for (int q = 0; q < R; ++q) wr[q] = tw[q * tr];
+    float2 w16[5] = {};
+    if (R == 16) {
+        const int e16 = T / 16;
+        w16[0] = tw[e16]; w16[1] = tw[2 * e16]; w16[2] = tw[3 * e16]; w16[3] = tw[6 * e16]; w16[4] = tw[9 * e16];
+    }
     const int ms = m * Cp;
     for (int id = threadIdx.x; id < total; id += NT) {
         const int bj = fdiv(id, inv_cp), p = id - m24(bj, Cp);
@@ -244,7 +287,14 @@ __device__ __forceinline__ void dif_butterflies(float2* __restrict__ X, const fl
         float2 a[R], b[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) a[t] = x0[t * ms];
-        if (R == 2) {
+        if (R == 16) {
+            float2 a16[16], x16[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) a16[t] = a[t % R];
+            dft16(a16, x16, tw[T / 4], w16);
+#pragma unroll
+            for (int u = 0; u < R; ++u) b[u] = x16[u % 16];
+        } else if (R == 2) {
             b[0] = float2{a[0].x + a[1].x, a[0].y + a[1].y};
             b[1] = float2{a[0].x - a[1].x, a[0].y - a[1].y};
         } else if (R == 4) {
@@ -406,6 +456,7 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
                 case 3: dif_butterflies<3>(bufA, tw, T, Cp, Lc); break;
                 case 4: dif_butterflies<4>(bufA, tw, T, Cp, Lc); break;
                 case 5: dif_butterflies<5>(bufA, tw, T, Cp, Lc); break;
+                case 16: dif_butterflies<16>(bufA, tw, T, Cp, Lc); break;
                 default: dif_butterflies<7>(bufA, tw, T, Cp, Lc); break;
             }
             Lc /= r;
@@ -425,6 +476,7 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
             case 4: stockham_butterflies<4>(src, dst, tw, T, Cp, Ns); break;
             case 5: stockham_butterflies<5>(src, dst, tw, T, Cp, Ns); break;
             case 7: stockham_butterflies<7>(src, dst, tw, T, Cp, Ns); break;
+            case 16: stockham_butterflies<16>(src, dst, tw, T, Cp, Ns); break;
             case 11: stockham_prime<11>(src, dst, tw, T, Cp, Ns); break;
             case 13: stockham_prime<13>(src, dst, tw, T, Cp, Ns); break;
             case 17: if (BIGP) { stockham_prime<17>(src, dst, tw, T, Cp, Ns); break; }
@@ -499,6 +551,14 @@ bool make_plan(int T, FftPlan& plan) {
     plan.T = T;
     plan.nstages = 0;
     int n = T;
+    // radix 16 (one 4 x 4 butterfly in registers): half the LDS round trips, barriers and index arithmetic of two radix-4
+    // stages; FDIFF_FFT_RADIX16=0 plans radix-4 stages only (A/B runs, parity tests)
+    static const bool r16 = !(getenv("FDIFF_FFT_RADIX16") && getenv("FDIFF_FFT_RADIX16")[0] == '0');
+    while (r16 && n % 16 == 0) {
+        if (plan.nstages >= kMaxStages) return false;
+        plan.radix[plan.nstages++] = 16;
+        n /= 16;
+    }
     while (n % 4 == 0) {
         if (plan.nstages >= kMaxStages) return false;
         plan.radix[plan.nstages++] = 4;
@@ -596,7 +656,7 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
     // ((512, 1024, 16): two chunks of 8) the single image keeps rows whole: iRFFT 48.2 -> 41.6 us.  So: in place exactly when that
     // saves a channel split.  FDIFF_FFT_INPLACE=0 / 1 forces either form where both exist (the parity tests run both).
     bool smooth = T < 65536;
-    for (int i = 0; i < plan.nstages; ++i) smooth &= (plan.radix[i] <= 5 || plan.radix[i] == 7);
+    for (int i = 0; i < plan.nstages; ++i) smooth &= (plan.radix[i] <= 5 || plan.radix[i] == 7 || plan.radix[i] == 16);
     static const int lds_target_kb0 = getenv("FDIFF_FFT_LDS_KB") ? atoi(getenv("FDIFF_FFT_LDS_KB")) : 72;
     const long long auto_pairs = ((long long)lds_target_kb0 * 1024 - (long long)T * 8) / ((long long)T * 16);
     bool inplace = smooth && C > 1 && auto_pairs >= 4 && (C + 1) / 2 > auto_pairs;
@@ -655,7 +715,8 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
     // threads per workgroup: about 4 complex elements per thread and stage, whole waves, 128..1024
     const int elems = T * ((Cc + 1) / 2);
     int block = 128;
-    while (block < kMaxBlock && block * 8 < elems) block *= 2;
+    static const int ept = getenv("FDIFF_FFT_EPT") ? atoi(getenv("FDIFF_FFT_EPT")) : 8;
+    while (block < kMaxBlock && block * ept < elems) block *= 2;
     {
         const int wg_per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / (lds + 256)), 2048 / block));
         plan.resident = ctx->num_cu * wg_per_cu;

@@ -210,6 +210,10 @@ def test_transform_paths_agree_with_golden(golden, mode, monkeypatch):
 
 @pytest.mark.parametrize("inplace", ["1", "0"])
 def test_inplace_and_autosort_forms_agree_with_the_oracle(inplace, monkeypatch):
+    _forms(inplace, monkeypatch)
+
+
+def _forms(inplace, monkeypatch):
     """Smooth lengths (prime factors 2, 3, 5, 7) run the in-place decimation-in-frequency form (one LDS image + a
     digit-reversal table: four workgroups per CU where the Stockham ping-pong fits two); FDIFF_FFT_INPLACE=0 forces the
     autosort form.  Both against the oracle at mixed radices, odd lengths, channel chunks, single-channel (batched) sets, a
