@@ -99,14 +99,29 @@ __global__ __launch_bounds__(NWW * 64) void k_attention_wide(const float* __rest
     char* const vbf = smem + (size_t)NTOK * 4 * KF::bytes;         // [NJ][RT][4 g][16 dim rows][16 B]: (half, r) -> key (2jj+half)*16 + 4g + r
     const float* base = qkv + (size_t)b * T * 3 * D;
 
-    // ---- stage K (one thread per (token, lane group)) and V^T (one thread per (key block, row tile, lane group, dim row))
+    // ---- stage K (one thread per (token, lane group)) and V^T.  head_dim % 4 == 0 (every common size): 16-byte loads of four
+    //      consecutive dims of one token (the fp32 rows are 16-byte aligned: D % 4 == 0); V^T is then scattered into its
+    //      [key block][row tile][lane group][dim row][8 keys] layout by 2-byte LDS stores.  Otherwise guarded scalar loads.
+    const bool v4 = (hd & 3) == 0;
     for (int i = threadIdx.x; i < NTOK * 4; i += NWW * 64) {
         const int t = i >> 2, gq = i & 3;
         float kv[KF::per_lane];
 #pragma unroll
-        for (int e = 0; e < KF::per_lane; ++e) {
-            const int d = KF::per_lane * gq + e;
-            kv[e] = (t < T && d < hd) ? base[(size_t)t * 3 * D + D + head * hd + d] : 0.f;
+        for (int e = 0; e < KF::per_lane; ++e) kv[e] = 0.f;
+        if (t < T) {
+            const float* kp = base + (size_t)t * 3 * D + D + head * hd + KF::per_lane * gq;
+            if (v4) {
+#pragma unroll
+                for (int e4 = 0; e4 < KF::per_lane / 4; ++e4)
+                    if (KF::per_lane * gq + 4 * e4 < hd) {
+                        const float4 q4 = *reinterpret_cast<const float4*>(kp + 4 * e4);
+                        kv[4 * e4] = q4.x; kv[4 * e4 + 1] = q4.y; kv[4 * e4 + 2] = q4.z; kv[4 * e4 + 3] = q4.w;
+                    }
+            } else {
+#pragma unroll
+                for (int e = 0; e < KF::per_lane; ++e)
+                    if (KF::per_lane * gq + e < hd) kv[e] = kp[e];
+            }
         }
         if constexpr (HDS == 16) {
             *reinterpret_cast<u32x2*>(kbf + (size_t)i * 8) = u32x2{cvt_pk_bf16(kv[0], kv[1]), cvt_pk_bf16(kv[2], kv[3])};
@@ -116,6 +131,18 @@ __global__ __launch_bounds__(NWW * 64) void k_attention_wide(const float* __rest
                                                                    cvt_pk_bf16(kv[6 % KF::per_lane], kv[7 % KF::per_lane])};
         }
     }
+    if (v4) {
+        // one thread per (token slot, group of 4 dims): dims d .. d+3 of key t -> element e = (half, r) of rows d .. d+3
+        // (every slot of every 32-key block is written, also the 16 of a missing odd tile: P is 0 there, V must be finite)
+        for (int i = threadIdx.x; i < NJ * 32 * (HDS / 4); i += NWW * 64) {
+            const int t = i / (HDS / 4), d = 4 * (i - t * (HDS / 4));
+            float4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t < T && d < hd) v = *reinterpret_cast<const float4*>(base + (size_t)t * 3 * D + 2 * D + head * hd + d);
+            const int jj = t >> 5, half = (t >> 4) & 1, gg = (t >> 2) & 3, r = t & 3;
+            __bf16* dst = reinterpret_cast<__bf16*>(vbf + ((size_t)(((jj * RT + (d >> 4)) * 4 + gg) * 16 + (d & 15))) * 16) + (half * 4 + r);
+            dst[0] = (__bf16)v.x; dst[8] = (__bf16)v.y; dst[16] = (__bf16)v.z; dst[24] = (__bf16)v.w;     // next dim row = +16 bytes
+        }
+    } else {
     for (int i = threadIdx.x; i < NJ * RT * 64; i += NWW * 64) {
         const int row = i & 15, gg = (i >> 4) & 3, rt = (i >> 6) % RT, jj = i / (64 * RT);
         const int d = 16 * rt + row;
@@ -127,6 +154,7 @@ __global__ __launch_bounds__(NWW * 64) void k_attention_wide(const float* __rest
         }
         *reinterpret_cast<u32x4*>(vbf + (size_t)i * 16) = u32x4{cvt_pk_bf16(vv[0], vv[1]), cvt_pk_bf16(vv[2], vv[3]),
                                                                cvt_pk_bf16(vv[4], vv[5]), cvt_pk_bf16(vv[6], vv[7])};
+    }
     }
     __syncthreads();
 
