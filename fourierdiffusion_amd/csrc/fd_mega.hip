@@ -72,6 +72,15 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #ifndef FD_XF_REGS
 #define FD_XF_REGS 1     // FFN activation fragments: 1 = registers for the whole phase, 0 = LDS read per use
 #endif
+#ifndef FD_DMA_LIGHT
+#define FD_DMA_LIGHT 1   // FFN weight DMA issued by the waves with the fewest token tiles only (uneven splits)
+#endif
+#ifndef FD_DMA_LATE
+#define FD_DMA_LATE 0    // light-wave DMA issued behind the step's items instead of in front of them
+#endif
+#ifndef FD_DMA_SPREAD
+#define FD_DMA_SPREAD 0  // FFN weight DMA of step st+3: 1 = one instruction per item from every wave, 0 = a burst by one wave set per step
+#endif
 #ifndef FD_FOLD_RES
 #define FD_FOLD_RES 1    // start the owner's FFN accumulators from the residual (no extra live registers in the loop)
 #endif
@@ -1123,8 +1132,34 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     do_h(0);
                     __builtin_amdgcn_sched_barrier(0);
                     for (int st = 0; st < NS; ++st) {
+#if FD_DMA_LIGHT
+                        // Uneven tile split (e.g. 14 tiles = 4,4,3,3 per quarter): the MQ waves that carry one tile less issue the
+                        // whole buffer every step -- they have an item's worth of slack per step, and the waves on the critical
+                        // path never leave the matrix pipe for the texture path.  Even splits alternate the F-half sets as before.
+                        // (exactly MQ such waves with distinct wave % MQ -- issue_ffn_half's block split -- exist when half of the
+                        //  quarters carry the extra tile and the F-half sets are rotated by that half: 14 tiles, rot 2)
+                        const bool light_ok = (2 * trem == MQ) && (SHP(rot) == trem);
+                        const bool my_turn = light_ok ? (ntile < MT) : ((st & 1) == FH);
+#else
                         const bool my_turn = ((st & 1) == FH);
+#endif
+#if FD_DMA_SPREAD
+                        const bool dma_on = st + 3 < NS && FD_DMA_ON;
+                        const char* dsrc = nullptr;
+                        char* ddst = nullptr;
+                        if (dma_on) {
+                            int stn = st + 3 + st_rot;
+                            stn -= (stn >= NS) ? NS : 0;
+                            dsrc = limg + P.off_ffn + (size_t)stn * WB1 + lane * 16;
+                            ddst = ring + ((st + 3 + rb) % NBUF) * WB1;
+                        }
+#else
+#if FD_DMA_LATE
+                        if (my_turn && !light_ok && st + 3 < NS && FD_DMA_ON) issue_ffn_half(st + 3);
+#else
                         if (my_turn && st + 3 < NS && FD_DMA_ON) issue_ffn_half(st + 3);
+#endif
+#endif
                         // NTT == 1: H(0) of this step issued during the previous step, before this step's successor
                         // buffer was visible -- its W1 can only be fetched now
                         if (NTT == 1 && st + 1 < NS) load_w1(st + 1);
@@ -1137,6 +1172,19 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             } else if (st + 1 < NS) {
                                 do_h(0);                              // first item of the next step
                             }
+#if FD_DMA_SPREAD
+                            // one DMA instruction per item, behind the H MFMAs just issued: its issue cycles overlap the matrix
+                            // pipe's work instead of stalling a wave at the head of the step (every wave issues NDMA per step,
+                            // repeats included, so vmcnt(NDMA) below still means "everything but the newest buffer landed")
+                            if (dma_on) {
+#pragma unroll
+                                for (int q = i; q < ((i == NTT - 1) ? NDMA : ((i + 1 < NDMA) ? i + 1 : NDMA)); ++q) {   // the last item takes what is left
+                                    int b = wave + q * NW;
+                                    b -= (b >= 2 * NBF) ? NW : 0;
+                                    __builtin_amdgcn_global_load_lds(GLB_PTR(dsrc + b * 1024), LDS_PTR(ddst + b * 1024), 16, 0, 0);
+                                }
+                            }
+#endif
                             __builtin_amdgcn_sched_barrier(0);
                             const bf16x8 hb = relu_pack(g0, g1);
                             __builtin_amdgcn_sched_barrier(0);
@@ -1145,11 +1193,20 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             if (i == NTT - 1 && st + 1 < NS) load_w2(st + 1);
                             __builtin_amdgcn_sched_barrier(0);
                         }
+#if FD_DMA_LATE && FD_DMA_LIGHT && !FD_DMA_SPREAD
+                        // light waves issue behind their last item: the slack they have before the heavier waves reach the barrier
+                        if (my_turn && light_ok && st + 3 < NS && FD_DMA_ON) issue_ffn_half(st + 3);
+#endif
                         // buffer st+2 must have landed before anyone reads it in step st+1 (own DMA, then barrier)
                         // (this wave's share of buffer st+2 was issued one step ago if it was not its turn now; a wave
                         // whose turn it is has nothing older than the NDH instructions it just issued, except at st = 0)
+#if FD_DMA_SPREAD
+                        if (dma_on) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
                         if (my_turn && st + 3 < NS && FD_DMA_ON) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDH) : "memory");
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                         // bare s_barrier: __syncthreads() carries a workgroup fence that hipcc lowers to
                         // s_waitcnt vmcnt(0) lgkmcnt(0) -- it would drain the DMA issued this very step (3 steps of
                         // slack thrown away, measured) and the fragment prefetch of the next step.  What must be
