@@ -310,3 +310,46 @@ def test_default_model_gradients_vs_reference_fixture(golden, name, B, prec):
         else:
             assert e_sub <= 8e-2 and e_nrm <= 3e-2, (k, e_sub, e_nrm)
     _log(f"[parity] {prec} gradients vs reference fixture ({name}, d_model 72, L 10): worst subset max-rel {worst[0]:.3e} ({worst[1]})")
+
+
+def test_interleaved_models_and_eval_share_the_context_arena():
+    """the dropout-decision buffers live in the context's workspace arena and are written by side-stream kernels.
+    Training steps of two models with different layer counts interleaved with evaluation forwards (which carve the same
+    arena) must give the same gradients as each model trained alone with the same keys -- a mask kernel that started before
+    the other call's kernels had finished with the arena, or a wait on the wrong event, would change them."""
+    from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
+    from fourierdiffusion_amd.utils.losses import get_sde_loss_fn
+    cfgs = [dict(T=40, C=4, D=72, L=2, H=12), dict(T=56, C=3, D=72, L=3, H=12)]
+    data = []
+    for i, cfg in enumerate(cfgs):
+        X = W.randn(f"ilv_x{i}", (6, cfg["T"], cfg["C"]), 3)
+        z = W.randn(f"ilv_z{i}", (6, cfg["T"], cfg["C"]), 3)
+        t = W.uniform(f"ilv_t{i}", (6,), 3, 0.2, 1.0)
+        data.append((X, z, t))
+
+    def step(m, sch, i, seed):
+        fn = get_sde_loss_fn(sch, train=True)
+        X, z, t = data[i]
+        m.zero_grad()
+        torch.manual_seed(seed)
+        loss = fn(m, batch_of(X, t), noise=dev(z), backward=True).item()
+        return loss, m.grads.clone()
+
+    alone = []
+    for i, cfg in enumerate(cfgs):
+        m, sch, _ = make_model(cfg, precision="bf16")
+        alone.append([step(m, sch, i, 31 + k) for k in range(2)])
+    models = [make_model(cfg, precision="bf16") for cfg in cfgs]
+    mixed = [[], []]
+    for k in range(2):
+        for i in (0, 1):
+            m, sch, _ = models[i]
+            mixed[i].append(step(m, sch, i, 31 + k))
+            other = models[1 - i][0]
+            Xo, _, to = data[1 - i]
+            other.eval()
+            _ = other(DiffusableBatch(X=dev(Xo), timesteps=dev(to)))        # carves the arena between the training steps
+    for i in (0, 1):
+        for k in range(2):
+            assert mixed[i][k][0] == alone[i][k][0], (i, k)
+            assert torch.equal(mixed[i][k][1], alone[i][k][1]), (i, k)
