@@ -38,31 +38,6 @@ __global__ __launch_bounds__(kBlock) void k_randn(float* __restrict__ out, size_
     }
 }
 
-// out = scale * G[t] * z
-__global__ __launch_bounds__(kBlock) void k_prior(const float* __restrict__ G, const float* __restrict__ zin,
-                                                    float* __restrict__ out, size_t n, int T, int C,
-                                                    float scale, uint64_t seed, uint64_t offset) {
-    const size_t ngroups = (n + 3) / 4;
-    for (size_t g = blockIdx.x * (size_t)kBlock + threadIdx.x; g < ngroups; g += (size_t)gridDim.x * kBlock) {
-        const size_t e = g * 4;
-        float z[4];
-        if (zin) {
-            const float4 v = ld4(zin, e, n);
-            z[0] = v.x; z[1] = v.y; z[2] = v.z; z[3] = v.w;
-        } else {
-            fd_randn4(offset + g, seed, z);
-        }
-        float o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const size_t ei = e + i;
-            const int t = (int)((ei / (size_t)C) % (size_t)T);
-            o[i] = (ei < n) ? scale * (G[t] * z[i]) : 0.f;
-        }
-        st4(out, e, n, float4{o[0], o[1], o[2], o[3]});
-    }
-}
-
 // Time index t of the four elements of group e .. e+3 of a (B, T, C) tensor: ONE division for the row and one for its remainder
 // by T, then carries (eight runtime divisions per group were ~200 VALU instructions, more than the Philox evaluation).
 __device__ __forceinline__ void group_rows(size_t e, size_t n, int T, int C, int (&t)[4]) {
@@ -86,6 +61,29 @@ __device__ __forceinline__ void group_rows(size_t e, size_t n, int T, int C, int
 // Philox stream.  Two 16-byte groups per thread and iteration, all four loads issued before the first Philox round, so that
 // the ~350 VALU instructions of two counters run under the loads' latency (one group per iteration left the kernel at 3.3 TB/s
 // where the 28-byte-per-parameter AdamW pass streams 5.0).
+// out = scale * G[t] * z
+__global__ __launch_bounds__(kBlock) void k_prior(const float* __restrict__ G, const float* __restrict__ zin,
+                                                    float* __restrict__ out, size_t n, int T, int C,
+                                                    float scale, uint64_t seed, uint64_t offset) {
+    const size_t ngroups = (n + 3) / 4;
+    for (size_t g = blockIdx.x * (size_t)kBlock + threadIdx.x; g < ngroups; g += (size_t)gridDim.x * kBlock) {
+        const size_t e = g * 4;
+        float z[4];
+        if (zin) {
+            const float4 v = ld4(zin, e, n);
+            z[0] = v.x; z[1] = v.y; z[2] = v.z; z[3] = v.w;
+        } else {
+            fd_randn4(offset + g, seed, z);
+        }
+        int t[4];
+        group_rows(e, n, T, C, t);
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (e + i < n) ? scale * (G[t[i]] * z[i]) : 0.f;
+        st4(out, e, n, float4{o[0], o[1], o[2], o[3]});
+    }
+}
+
 typedef __attribute__((ext_vector_type(4))) float f32x4_nt;
 __device__ __forceinline__ float4 ldnt4(const float* p) {
     const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
@@ -167,25 +165,42 @@ __global__ __launch_bounds__(kBlock) void k_perturb(const float* __restrict__ G,
         }
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
         float o[4], tg[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const size_t ei = (e + i < n) ? e + i : n - 1;
-            const int b = (int)(ei / per_b);
-            const int t = (int)((ei / (size_t)C) % (size_t)T);
-            const float tt = tvec[b];
-            float mcoef, s;
+        // (sample, time, channel) of the group's first element by two divisions, the other three by carries; the per-sample
+        // coefficients (two exponentials, or a power) are evaluated once per group and again only where the group crosses into the
+        // next sample -- per element they were ~600 instructions around 12 bytes of traffic
+        const size_t row0 = e / (size_t)C;
+        int c = (int)(e - row0 * (size_t)C);
+        int b = (int)(row0 / (size_t)T);
+        int t = (int)(row0 - (size_t)b * T);
+        auto coef = [&](int bb, float& mcoef, float& sdev) {
+            const float tt = tvec[bb];
             if (kind == 0) {
                 const float lmc = -0.25f * tt * tt * (p1 - p0) - 0.5f * tt * p0;   // sde.py:195-197
                 mcoef = expf(lmc);
-                s = sqrtf(1.0f - expf(2.0f * lmc));                                 // sde.py:203-205
+                sdev = sqrtf(1.0f - expf(2.0f * lmc));                              // sde.py:203-205
             } else {
                 mcoef = 1.0f;
-                s = p0 * powf(p1 / p0, tt);                                         // sde.py:117
+                sdev = p0 * powf(p1 / p0, tt);                                      // sde.py:117
             }
+        };
+        const int Bn = (int)(n / per_b);
+        float mcoef, s;
+        coef(b < Bn ? b : Bn - 1, mcoef, s);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = e + i < n;
             const float sd = s * G[t];
             o[i] = mcoef * xs[i] + sd * z[i];
             tg[i] = z[i] / sd;
-            if (std_out && (ei % (size_t)C) == 0 && e + i < n) std_out[(size_t)b * T + t] = sd;
+            if (std_out && c == 0 && in) std_out[(size_t)b * T + t] = sd;
+            if (++c == C) {
+                c = 0;
+                if (++t == T) {
+                    t = 0;
+                    ++b;
+                    if (i < 3 && e + i + 1 < n) coef(b, mcoef, s);
+                }
+            }
         }
         st4(xn, e, n, float4{o[0], o[1], o[2], o[3]});
         if (target) st4(target, e, n, float4{tg[0], tg[1], tg[2], tg[3]});
