@@ -47,10 +47,21 @@ WORKLOADS = {
     "mimic": dict(T=256, C=28, sde=("ve", 0.01, 2.0), batch=512, n_steps=2000, strong_total=4096,
                   desc="BASELINE.json configs[3]: mimiciii-synth (T=256, C=28), default transformer, VE-SDE(0.01, 2), "
                        "fourier_noise_scaling, 2000 predictor steps"),
+    "nasdaq": dict(T=252, C=6, sde=("vp", 0.1, 20.0), batch=512, n_steps=1000, strong_total=4096,
+                   desc="nasdaq-synth (T=252, C=6; the shape of BASELINE.json configs[2]), default transformer, VP-SDE, "
+                        "fourier_noise_scaling"),
+    "long": dict(T=1024, C=16, sde=("vp", 0.1, 20.0), batch=64, n_steps=1000, strong_total=512,
+                 desc="BASELINE.json configs[4]: synthetic long-horizon (T=1024, C=16), default transformer, VP-SDE, "
+                      "fourier_noise_scaling, two launches per encoder layer (the series does not fit one workgroup)"),
 }
 T, CH = WORKLOADS["ecg"]["T"], WORKLOADS["ecg"]["C"]
 TRAIN = dict(T=252, C=6, batch=64, desc="BASELINE.json configs[2]: nasdaq-synth (T=252, C=6), default transformer (d_model=72, "
              "L=10, H=12, ff=2048), VP-SDE, fourier_noise_scaling, dropout 0.1, AdamW + global-norm clip 1.0")
+TRAIN_WORKLOADS = {
+    "nasdaq": TRAIN,
+    "ecg": dict(T=100, C=12, batch=64, desc="ecg-synth (T=100, C=12; the shape of BASELINE.json configs[1]), default transformer, "
+                "VP-SDE, fourier_noise_scaling, dropout 0.1, AdamW + global-norm clip 1.0"),
+}
 
 
 def flops_per_series_forward(T=T, C=CH, D=D, L=L, F=F):
@@ -93,6 +104,47 @@ def cpu_baseline(batch: int, T: int, CH: int, n_timed: int = 3):
     return cb.time_sampler_steps(batch=batch, T=T, C=CH, d_model=D, num_layers=L, n_head=H, n_timed=n_timed)
 
 
+def secondary_rows():
+    """The rows of the path that are not the headline (the training step, the other BASELINE.json shapes, the
+    HBM-bound transforms), each measured by its own process AFTER the headline's timed region and reported inside the same
+    JSON line, so that the driver's single default run sees them too.  None of this touches `value` / `ms_per_step`.
+    A row that fails reports {"error": ...}; the headline is printed regardless."""
+    import subprocess
+    me = os.path.abspath(__file__)
+    quick = bool(os.environ.get("FDIFF_BENCH_SECONDARY_QUICK"))          # (tests: a few steps per row)
+    nd = ["--diffusion-steps", "20"] if quick else []           # (otherwise each workload's own step count: 1000 / 2000)
+    common = ["--no-cpu-baseline", "--no-secondary", "--gpus", "1"]
+    rows = {
+        "train_nasdaq_T252_B64": [me, "--mode", "train", "--train-workload", "nasdaq", "--steps", "5" if quick else "100"],
+        "train_ecg_T100_B64": [me, "--mode", "train", "--train-workload", "ecg", "--steps", "5" if quick else "100"],
+        "sample_long_T1024_B64": [me, "--workload", "long", "--steps", "2", "--warmup", "1"] + nd,
+        "sample_mimic_T256_B512": [me, "--workload", "mimic", "--steps", "2", "--warmup", "1"] + nd,
+        "sample_nasdaq_T252_B512": [me, "--workload", "nasdaq", "--steps", "2", "--warmup", "1"] + nd,
+    }
+    keep = ("metric", "value", "unit", "steps", "ms_per_step", "score_net_step_ms", "dtype", "achieved_tflops_whole_step")
+    out = {}
+    for name, cmd in rows.items():
+        try:
+            r = subprocess.run([sys.executable] + cmd + common, capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            j = json.loads(line)
+            row = {k: j[k] for k in keep if k in j}
+            row["workload"] = j["config"]["workload"]
+            if j.get("roofline"):
+                row["roofline"] = {k: j["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_kernel_us")
+                                   if k in j["roofline"]}
+            out[name] = row
+        except Exception as e:
+            out[name] = {"error": repr(e)[:300]}
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "hbm_kernels_bench.py"), "--json"] +
+                           (["--quick"] if quick else []), capture_output=True, text=True, timeout=300)
+        out["hbm_kernels"] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as e:
+        out["hbm_kernels"] = {"error": repr(e)[:300]}
+    return out
+
+
 def rank_report(dist, rank, world, dev_index):
     """FDIFF_BENCH_REPORT_RANKS=1 (scripts/scale_check.sh): every rank's device binding and Philox counter base, gathered on
     rank 0 -- one process per GPU and disjoint noise streams are checked on the real node, not assumed."""
@@ -111,8 +163,9 @@ def rank_report(dist, rank, world, dev_index):
 
 def main_train(args, rank, local_rank, world):
     """configs[2]: batch-sharded training.  Every rank holds 64 synthetic series (weak scaling); a step = one optimizer step."""
-    T, CH = TRAIN["T"], TRAIN["C"]
-    B = args.batch or TRAIN["batch"]
+    TR = TRAIN_WORKLOADS[args.train_workload]
+    T, CH = TR["T"], TR["C"]
+    B = args.batch or TR["batch"]
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -185,7 +238,7 @@ def main_train(args, rank, local_rank, world):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if model.train_mode_effective == "bf16" else "f32",
             "data": "synthetic (N(0,1) series per rank, random-init weights seed 42)",
-            "config": {"workload": TRAIN["desc"] + f", batch={B}/GPU, one optimizer step per bench step",
+            "config": {"workload": TR["desc"] + f", batch={B}/GPU, one optimizer step per bench step",
                        "global_batch": world * B, "seq_len": T, "parallelism": f"data parallel x{world}, flat RCCL all-reduce"},
             "achieved_tflops_whole_step": 3 * fwd_flops * world * B * steps / elapsed / 1e12,
         }
@@ -224,6 +277,9 @@ def main():
     ap.add_argument("--diffusion-steps", type=int, default=None)
     ap.add_argument("--precision", default=os.environ.get("FDIFF_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-workload", default="nasdaq", choices=sorted(TRAIN_WORKLOADS))
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the other rows of the path that the default one-GPU run measures after its timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -369,6 +425,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(B, T, CH)
             except Exception as e:   # the GPU result must still be reported
                 out["cpu_baseline"] = {"error": repr(e)}
+        if world == 1 and args.workload == "ecg" and not args.no_secondary:
+            del X
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_rows()
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

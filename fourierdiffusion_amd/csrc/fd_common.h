@@ -51,9 +51,11 @@ struct fd_ctx {
     std::vector<std::pair<int, void*>> fft_tw;
     // measurement hooks (fd_prof_begin / fd_prof_end)
     // several kernels may be bracketed in one window (the training step brackets its forward FFN kernel and the weight-gradient
-    // kernel); fd_prof_end reports the one with the largest TOTAL time
+    // kernel); fd_prof_end reports the one with the largest TOTAL time.  At most 1024 launches per kernel name are bracketed (a
+    // timing event is a barrier packet: bracketing all 20 000 layer launches of a step-by-step sampler run would slow the run
+    // it measures; every bracketed name of a window is launched equally often, so the totals stay comparable)
     bool prof_on = false;
-    struct prof_kernel { std::string name; double flops; };
+    struct prof_kernel { std::string name; double flops; int scopes = 0; };
     std::vector<prof_kernel> prof_kernels;
     struct prof_event { int kernel; hipEvent_t a, b; };
     std::vector<prof_event> prof_events;
@@ -74,11 +76,13 @@ struct fd_prof_scope {
     int kernel = -1;
     fd_prof_scope(fd_ctx* c, hipStream_t st, const char* name, double flops) : ctx(c), s(st) {
         if (!ctx->prof_on || ctx->prof_events.size() >= 8192) { ctx = nullptr; return; }
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { ctx = nullptr; return; }
         for (size_t i = 0; i < ctx->prof_kernels.size(); ++i)
             if (ctx->prof_kernels[i].name == name) kernel = (int)i;
+        if (kernel >= 0 && ctx->prof_kernels[kernel].scopes >= 1024) { ctx = nullptr; return; }
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { ctx = nullptr; return; }
         if (kernel < 0) { ctx->prof_kernels.push_back({name, flops}); kernel = (int)ctx->prof_kernels.size() - 1; }
         ctx->prof_kernels[kernel].flops = flops;
+        ++ctx->prof_kernels[kernel].scopes;
         (void)hipEventRecord(a, s);
     }
     ~fd_prof_scope() {

@@ -983,6 +983,9 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
         if (imq->mega && !getenv("FDIFF_ATTN_F32") && !getenv("FDIFF_ATTN_UNFUSED")) {
             // Q/K/V projections inside the attention kernel (the persistent kernel's per-layer weight images)
             const char* limg = imq->mimg + imq->off_layers + (size_t)i * imq->layer_stride;
+            // measurement hook (bench.py --workload long): in-projection + attention of M tokens
+            fd_prof_scope scope(ctx, s, "k_attention_bf16 (fused Q/K/V projection + softmax attention, one launch per layer)",
+                                (double)M * (6.0 * D * D + 4.0 * T * D));
             arc = fd_attention_bf16(ctx, h0, att, B, T, H, hd, s, limg + imq->off_wk, limg + imq->off_wv, limg + imq->off_wq, imq->ks1);
         }
         if (arc == FD_ERR_UNSUPPORTED) {
@@ -1005,6 +1008,8 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
         if (fuse) {
             // out-proj + residual + LN1 + FFN + LN2 in one kernel (it reads its own output location last: out = h1 is
             // a different buffer from the residual input h0)
+            fd_prof_scope scope(ctx, s, "k_ffn_ln (out-proj + LN1 + FFN + LN2, one launch per layer)",
+                                (double)M * (2.0 * D * D + 4.0 * D * m->d.dim_ff));
             if (int rc = run_ffn(m, nullptr, h1, i, M, s, att, h0)) return rc;
             std::swap(h0, h1);
         } else {

@@ -136,6 +136,35 @@ def test_bench_strong_scaling_rehearsal():
     assert d["metric"] == "sampled series/sec (T=256, C=28)" and d["value"] > 0
 
 
+def test_bench_default_line_carries_the_secondary_rows():
+    """The driver runs `python bench.py` once: the default one-GPU line also reports the training step, the other BASELINE
+    shapes (configs[3], configs[4]) and the HBM-bound transforms, each measured by its own process after the headline's timed
+    region (`secondary`; FDIFF_BENCH_SECONDARY_QUICK shortens the rows for this test)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FDIFF_BENCH_SECONDARY_QUICK="1", PYTHONPATH=root)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--diffusion-steps", "20", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["metric"] == "sampled series/sec (T=100, C=12)" and d["n_gpus"] == 1
+    sec = d["secondary"]
+    for k in ("train_nasdaq_T252_B64", "train_ecg_T100_B64", "sample_long_T1024_B64", "sample_mimic_T256_B512", "sample_nasdaq_T252_B512"):
+        assert "error" not in sec[k], (k, sec[k])
+        assert sec[k]["value"] > 0 and sec[k]["roofline"]["frac"] > 0, (k, sec[k])
+    assert sec["train_nasdaq_T252_B64"]["roofline"]["kernel"].startswith("k_tr_")
+    assert sec["sample_long_T1024_B64"]["roofline"]["kernel"].startswith(("k_attention_bf16", "k_ffn_ln"))
+    assert sec["sample_mimic_T256_B512"]["roofline"]["kernel"].startswith("k_mega")
+    hb = sec["hbm_kernels"]["shapes"]
+    assert set(hb) == {"B4096_T256_C28", "B512_T1024_C16", "B512_T100_C12"} and all(v["dft_TBps"] > 0.1 for v in hb.values())
+
+
 def test_ecg_datamodule_preprocessing_on_the_engine(tmp_path):
     """ECGDatamodule (datamodules.py:165-238): CSV layout of the MIT-BIH files, `subsample_localization` keeps the 1000 most
     time-localised series, `smooth_frequency` convolves the spectrum -- both through the engine's spectral utilities."""
