@@ -79,6 +79,8 @@ _PROTOS = {
     "fd_score_set_train_mode": (C.c_int, [_vp, C.c_int]),
     "fd_score_forward_train": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_float, C.c_uint64, C.c_uint64, _vp]),
     "fd_score_backward": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "fd_score_train_dsm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_float, C.c_int, C.c_float, C.c_uint64, C.c_uint64,
+                                     _vp, _vp, C.c_int, _vp]),
     "fd_sampler_run": (C.c_int, [_vp, C.POINTER(SdeParams), _vp, _vp, C.c_int, C.c_float, _vp, _vp,
                                  C.c_uint64, C.c_uint64, C.c_int, C.c_int, _vp]),
     "fd_langevin_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_float, C.c_float, _vp, C.c_int, C.c_int,

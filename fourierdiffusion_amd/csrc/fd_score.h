@@ -90,6 +90,9 @@ bool fd_train_bf16_supported(const fd_score* m);
 int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, float* out, int B, float p, uint64_t seed,
                                 uint64_t offset, hipStream_t s);
 int fd_score_backward_bf16(fd_score* m, const float* dout, float* grads, int accumulate, hipStream_t s);
+int fd_score_train_dsm_bf16(fd_score* m, const float* x, const float* t, const float* target, const float* stdv, int lw,
+                            float grad_weight, int B, float p, uint64_t seed, uint64_t offset, float* loss_out, float* grads,
+                            int accumulate, hipStream_t s);
 int fd_embed_backward(fd_score* m, const float* dh, const float* emb, float* dtemb, float* grads, int B, float* skp,
                       size_t skp_floats, hipStream_t s);   // fd_score_bwd.hip
 // fd_attn_bf16.hip

@@ -416,6 +416,102 @@ __global__ __launch_bounds__(256) void k_embed_reduce(const float* __restrict__ 
     }
 }
 
+// ---- the embedding-side backward in two launches (fd_embed_backward) ----
+// Per series b: wpart[b][d * C + c] = sum_t dh[b, t, d] * x[b, t, c] (its share of the embedder weight gradient) and
+// dtemb[b, d] = sum_t dh[b, t, d].  grid (ceil((D * C + D) / 16), B): 16 outputs x 16 strands of t per block (a strand is T / 16
+// rows, all of its loads in flight: the kernel is one or two memory round trips long), outputs [0, D * C) are the weight
+// entries, [D * C, D * C + D) the time-embedding gradient; fixed-order combine.
+__global__ __launch_bounds__(256) void k_embed_bwd_series(const float* __restrict__ dh, const float* __restrict__ x,
+                                                           float* __restrict__ wpart, float* __restrict__ dtemb, int T, int C,
+                                                           int D) {
+    __shared__ float red[16][17];
+    const int col = threadIdx.x & 15, sub = threadIdx.x >> 4;
+    const int b = blockIdx.y, o = blockIdx.x * 16 + col, nW = D * C;
+    const float* dhb = dh + (size_t)b * T * D;
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.f;
+    if (o < nW) {
+        const int d = o / C, c = o - d * C;
+        const float* pd = dhb + d;
+        const float* px = x + (size_t)b * T * C + c;
+        int t = sub;
+        for (; t + 16 * 7 < T; t += 16 * 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = fmaf(pd[(size_t)(t + 16 * k) * D], px[(size_t)(t + 16 * k) * C], a[k]);
+        }
+        for (; t < T; t += 16) a[0] = fmaf(pd[(size_t)t * D], px[(size_t)t * C], a[0]);
+    } else if (o < nW + D) {
+        const float* pd = dhb + (o - nW);
+        int t = sub;
+        for (; t + 16 * 7 < T; t += 16 * 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += pd[(size_t)(t + 16 * k) * D];
+        }
+        for (; t < T; t += 16) a[0] += pd[(size_t)t * D];
+    }
+    red[sub][col] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (sub != 0 || o >= nW + D) return;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k][col];
+    if (o < nW) wpart[(size_t)b * nW + o] = v;
+    else dtemb[(size_t)b * D + (o - nW)] = v;
+}
+
+// Everything that sums over the batch: 64 outputs x 4 strands of b per block, fixed-order combine
+//   [0, T*D)                dpos[t, d]   += sum_b dh[b, t, d]
+//   [.., + D*C)             demb_w[d, c] += sum_b wpart[b][d, c]
+//   [.., + D*D)             dtd_w[i, j]  += sum_b dtemb[b, i] * emb[b, j]
+//   [.., + D)               s = sum_b dtemb[b, d];  demb_b[d] += s;  dtd_b[d] += s   (sum_{b,t} dh = sum_b dtemb)
+struct EmbedFinalArgs {
+    const float *dh, *wpart, *dtemb, *emb;
+    float *dpos, *demb_w, *demb_b, *dtd_w, *dtd_b;
+    int B, T, C, D;
+};
+__global__ __launch_bounds__(256) void k_embed_bwd_final(EmbedFinalArgs A) {
+    __shared__ float red[4][64];
+    const int B = A.B, D = A.D;
+    const size_t n0 = (size_t)A.T * D, n1 = n0 + (size_t)D * A.C, n2 = n1 + (size_t)D * D, n3 = n2 + D;
+    const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const size_t id = blockIdx.x * (size_t)64 + col;
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.f;
+    if (id < n3) {
+        const float* p;
+        size_t stride;
+        if (id < n0) { p = A.dh + id; stride = n0; }
+        else if (id < n1) { p = A.wpart + (id - n0); stride = (size_t)D * A.C; }
+        else if (id < n2) { p = A.dtemb + (id - n1) / D; stride = D; }
+        else { p = A.dtemb + (id - n2); stride = D; }
+        int b = sub;
+        if (id >= n1 && id < n2) {
+            const float* q = A.emb + (id - n1) % D;
+            for (; b + 4 * 7 < B; b += 4 * 8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] = fmaf(p[(size_t)(b + 4 * k) * stride], q[(size_t)(b + 4 * k) * D], a[k]);
+            }
+            for (; b < B; b += 4) a[0] = fmaf(p[(size_t)b * stride], q[(size_t)b * D], a[0]);
+        } else {
+            for (; b + 4 * 7 < B; b += 4 * 8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] += p[(size_t)(b + 4 * k) * stride];
+            }
+            for (; b < B; b += 4) a[0] += p[(size_t)b * stride];
+        }
+    }
+    red[sub][col] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (sub != 0 || id >= n3) return;
+    const float v = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    if (id < n0) A.dpos[id] += v;
+    else if (id < n1) A.demb_w[id - n0] += v;
+    else if (id < n2) A.dtd_w[id - n1] += v;
+    else { A.demb_b[id - n2] += v; A.dtd_b[id - n2] += v; }
+}
+
 inline unsigned ew_grid(fd_ctx* ctx, size_t n) {
     size_t b = (n + 255) / 256;
     const size_t cap = (size_t)ctx->num_cu * 8;
@@ -495,6 +591,19 @@ int fd_embed_backward(fd_score* m, const float* dh, const float* emb, float* dte
     fd_ctx* ctx = m->ctx;
     const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model;
     const int M = B * T;
+    static const bool unfused = getenv("FDIFF_EMBED_BWD_UNFUSED") != nullptr;
+    if (!unfused && skp && (size_t)B * D * C <= skp_floats) {
+        // two launches instead of eight (two split-K GEMMs + their reduces, two column sums in two stages each, the batch / time
+        // reduce): everything here is a reduction of the (B*T, D) gradient over t or over b, ~100 us of 5 us kernels before
+        hipLaunchKernelGGL(k_embed_bwd_series, dim3((unsigned)((D * C + D + 15) / 16), B), dim3(256), 0, s, dh, m->saved_x, skp, dtemb, T,
+                           C, D);
+        EmbedFinalArgs A{dh, skp, dtemb, emb, grads + m->pos, grads + m->emb_w, grads + m->emb_b, grads + m->td_w, grads + m->td_b,
+                         B, T, C, D};
+        const size_t n = (size_t)T * D + (size_t)D * C + (size_t)D * D + D;
+        hipLaunchKernelGGL(k_embed_bwd_final, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, A);
+        FD_LAUNCH_CHECK(ctx);
+        return fd_take_deferred(ctx);
+    }
     fdgemm::linear_bwd_weight(dh, m->saved_x, grads + m->emb_w, M, D, C, true, s, skp, skp_floats);
     colsum(ctx, dh, grads + m->emb_b, M, D, s);
     hipLaunchKernelGGL(k_embed_reduce, dim3((unsigned)((T * D + 255) / 256 + (B * D + 63) / 64)), dim3(256), 0, s, dh, grads + m->pos,

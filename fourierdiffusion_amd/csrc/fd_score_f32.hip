@@ -682,6 +682,24 @@ extern "C" int fd_score_forward_train(fd_score* m, const float* x, const float* 
     return rc;
 }
 
+// fd_score_forward_train + fd_dsm_loss + fd_score_backward in one call (include/fdiff_hip.h); only the bf16 transformer path has
+// the fused loss head, every other model answers FD_ERR_UNSUPPORTED and the caller runs the three calls.
+extern "C" int fd_score_train_dsm(fd_score* m, const float* x, const float* t, const float* target, const float* std,
+                                  int likelihood_weighting, float grad_weight, int B, float dropout_p, uint64_t seed, uint64_t offset,
+                                  float* loss_out, float* grads, int accumulate, void* stream) {
+    if (!m) return FD_ERR_ARG;
+    fd_ctx* ctx = m->ctx;
+    FD_REQUIRE(ctx, x && t && target && std && loss_out && grads, "fd_score_train_dsm: null pointer");
+    FD_REQUIRE(ctx, B > 0, "fd_score_train_dsm: B=%d", B);
+    FD_REQUIRE(ctx, dropout_p >= 0.f && dropout_p < 1.f, "fd_score_train_dsm: dropout_p=%f", dropout_p);
+    if (!m->prepared) return fd_fail(ctx, FD_ERR_STATE, "fd_score_train_dsm: call fd_score_prepare first");
+    if (m->train_mode != FD_MODE_BF16 || m->backbone != FD_BACKBONE_TRANSFORMER || !fd_train_bf16_supported(m) ||
+        getenv("FDIFF_TRAIN_DSM_UNFUSED"))
+        return fd_fail(ctx, FD_ERR_UNSUPPORTED, "fd_score_train_dsm: the fused step exists on the bf16 transformer training path only");
+    return fd_score_train_dsm_bf16(m, x, t, target, std, likelihood_weighting, grad_weight, B, dropout_p, seed, offset, loss_out, grads,
+                                   accumulate, (hipStream_t)stream);
+}
+
 // Arithmetic of fd_score_forward_train / fd_score_backward: FD_MODE_F32 = exact-f32 kernels (parity anchor, any model),
 // FD_MODE_BF16 = bf16 MFMA operands with fp32 accumulation (fd_train_bf16.hip).  Returns FD_ERR_UNSUPPORTED (and keeps the
 // previous mode) when the bf16 kernels are not instantiated for the model.

@@ -1694,14 +1694,31 @@ __global__ __launch_bounds__(1024) void k_tr_vecreduce(const VecRedArgs a) {
     }
 }
 
-// out = a + sum of `np` partial tensors (fixed order)
+// out = a + sum of `np` <= 8 partial tensors (fixed order); 16-byte accesses, every partial's load in flight at once
 __global__ __launch_bounds__(256) void k_tr_sum_parts(const float* __restrict__ a0, const float* __restrict__ parts, int np,
                                                        size_t stride, float* __restrict__ out, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
-    float v = a0[i];
-    for (int p = 0; p < np; ++p) v += parts[(size_t)p * stride + i];
-    out[i] = v;
+    if (i + 3 < n) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(a0 + i);
+        f32x4 q[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int pp = p < np ? p : 0;
+            q[p] = *reinterpret_cast<const f32x4*>(parts + (size_t)pp * stride + i);
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            if (p < np) v += q[p];
+        for (int p = 8; p < np; ++p) v += *reinterpret_cast<const f32x4*>(parts + (size_t)p * stride + i);
+        *reinterpret_cast<f32x4*>(out + i) = v;
+    } else {
+        for (size_t j = i; j < n; ++j) {
+            float v = a0[j];
+            for (int p = 0; p < np; ++p) v += parts[(size_t)p * stride + j];
+            out[j] = v;
+        }
+    }
 }
 
 }  // namespace
@@ -1822,6 +1839,178 @@ TrDims make_dims(const fd_score* m, int B, float p, uint64_t seed) {
     return d;
 }
 
+// ---- the loss head: unembedder forward + DSM loss + unembedder backward for the tokens [tiles ts, ts + TS, ...] of series b ----
+// score = hL Wu^T + bu; d = score + target; loss element = coef d^2 with coef = 1 / sum_k std_k^-2 (default) or std_t^2
+// (likelihood weighting) -- losses.py:92-124 as in k_dsm_loss; dscore = 2 coef d / (B T C) * grad_weight;
+// dh = dscore Wu; per-workgroup partials of dWu = dscore^T hL, dbu = sum_t dscore and of the loss.  fp32 on the VALU: the
+// whole head is 6 C D FLOP per token on (B*T, C <= 40) data.
+struct HeadArgs {
+    const float *hL, *Wu, *bu, *target, *stdv;
+    float *dh, *part;      // part[(b * TS + ts)][C*D (dWu, row-major like the parameter) | C (dbu) | 1 (loss)]
+    int T, C, D, TS, lw;
+    float inv_cnt, gw;
+};
+// One 32-token tile per loop trip (the host picks TS = number of tiles whenever the partials fit, so a workgroup normally runs
+// one trip): every global read of the trip -- the tile's hL rows, its targets, the std row, Wu, bu -- is issued before the
+// first use, i.e. ONE memory round trip, three barriers, then the stores.  (The first version walked its tiles with a
+// load -> barrier -> compute chain per phase: 26 us for 64 x 4 workgroups.)
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_tr_head(HeadArgs A) {
+    extern __shared__ float head_lds[];
+    constexpr int HMAX = 10;                   // 32 * D / 256 register slots for the tile's rows: d_model <= 80 (host check)
+    const int T = A.T, C = A.C, D = A.D, D1 = D + 1;
+    float* Wu_s = head_lds;                    // [C][D + 1]
+    float* hs = Wu_s + C * D1;                 // [32][D + 1]
+    float* ds = hs + 32 * D1;                  // [32][C]
+    float* red = ds + 32 * C;                  // [4] + w
+    const int tid = threadIdx.x, ts = blockIdx.x, b = blockIdx.y;
+    const float* sd = A.stdv + (size_t)b * T;
+    const int ntile = (T + 31) / 32;
+    // --- everything the first tile needs, in flight together
+    float wreg[KMAX], hreg[HMAX], sreg[4];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { const int i = tid + 256 * k; wreg[k] = i < C * D ? A.Wu[i] : 0.f; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = tid + 256 * k; sreg[k] = i < T ? sd[i] : 0.f; }
+    int tile = ts;
+    {
+        const size_t row0 = (size_t)b * T + tile * 32;
+        const int nrow = min(32, T - tile * 32);
+#pragma unroll
+        for (int k = 0; k < HMAX; ++k) { const int i = tid + 256 * k; hreg[k] = i < nrow * D ? A.hL[row0 * D + i] : 0.f; }
+    }
+    float acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+    float bacc = 0.f, loss = 0.f;
+    {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tid + 256 * k < T) a += 1.0f / (sreg[k] * sreg[k]);
+        for (int k = tid + 1024; k < T; k += 256) a += 1.0f / (sd[k] * sd[k]);
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
+        if ((tid & 63) == 0) red[tid >> 6] = a;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { const int i = tid + 256 * k; if (i < C * D) Wu_s[(i / D) * D1 + (i % D)] = wreg[k]; }
+    }
+    for (; tile < ntile; tile += A.TS) {
+        const int t0 = tile * 32, nrow = min(32, T - t0);
+        const size_t row0 = (size_t)b * T + t0;
+        // the tile's targets and bias for this thread's (row, channel) items: issued here, consumed after the barrier
+        float treg[KMAX], breg[KMAX];           // 32 * C / 256 <= KMAX items (C * D <= 256 * KMAX, D >= 8)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = tid + 256 * k;
+            const bool ok = i < nrow * C;
+            treg[k] = ok ? A.target[row0 * C + i] : 0.f;
+            breg[k] = ok ? A.bu[i % C] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < HMAX; ++k) { const int i = tid + 256 * k; if (i < 32 * D) hs[(i / D) * D1 + (i % D)] = hreg[k]; }
+        __syncthreads();
+        const float w = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = tid + 256 * k;
+            if (i < 32 * C) {
+                const int r = i / C, c = i - r * C;
+                float dout = 0.f;
+                if (r < nrow) {
+                    float d0 = breg[k], d1 = 0.f;
+                    const float* hr = hs + r * D1;
+                    const float* wr = Wu_s + c * D1;
+                    int d = 0;
+                    for (; d + 1 < D; d += 2) { d0 = fmaf(hr[d], wr[d], d0); d1 = fmaf(hr[d + 1], wr[d + 1], d1); }
+                    if (d < D) d0 = fmaf(hr[d], wr[d], d0);
+                    const float dd = (d0 + d1) + treg[k];
+                    const float sdt = sd[t0 + r];
+                    const float coef = A.lw ? sdt * sdt : w;
+                    loss = fmaf(coef * dd, dd, loss);
+                    dout = 2.0f * coef * dd * A.inv_cnt * A.gw;
+                }
+                ds[i] = dout;
+            }
+        }
+        __syncthreads();
+        // next trip's rows (rare: only when the partials of one tile per workgroup do not fit the scratch)
+        if (tile + A.TS < ntile) {
+            const size_t rown = (size_t)b * T + (tile + A.TS) * 32;
+            const int nn = min(32, T - (tile + A.TS) * 32);
+#pragma unroll
+            for (int k = 0; k < HMAX; ++k) { const int i = tid + 256 * k; hreg[k] = i < nn * D ? A.hL[rown * D + i] : 0.f; }
+        }
+#pragma unroll
+        for (int k = 0; k < HMAX; ++k) {
+            const int i = tid + 256 * k;
+            if (i < nrow * D) {
+                const int r = i / D, d = i - r * D;
+                float v = 0.f;
+                for (int c = 0; c < C; ++c) v = fmaf(ds[r * C + c], Wu_s[c * D1 + d], v);
+                A.dh[row0 * D + i] = v;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int o = tid + 256 * k;
+            if (o < C * D) {
+                const int c = o / D, d = o - c * D;
+                float v0 = acc[k], v1 = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < 32; r += 2) {
+                    v0 = fmaf(ds[r * C + c], hs[r * D1 + d], v0);
+                    v1 = fmaf(ds[(r + 1) * C + c], hs[(r + 1) * D1 + d], v1);
+                }
+                acc[k] = v0 + v1;
+            }
+        }
+        if (tid < C)
+            for (int r = 0; r < 32; ++r) bacc += ds[r * C + tid];
+        __syncthreads();
+    }
+    float* out = A.part + ((size_t)b * A.TS + ts) * ((size_t)C * D + C + 1);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int o = tid + 256 * k;
+        if (o < C * D) out[o] = acc[k];
+    }
+    if (tid < C) out[C * D + tid] = bacc;
+    for (int o = 32; o > 0; o >>= 1) loss += __shfl_down(loss, o);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = loss;
+    __syncthreads();
+    if (tid == 0) out[C * D + C] = ((red[0] + red[1]) + (red[2] + red[3])) * A.inv_cnt;
+}
+// dWu += sum_r part[r][0 .. CD), dbu += sum_r part[r][CD .. CD + C), loss = sum_r part[r][CD + C]: 16 outputs x 16 strands of
+// r per block (a strand is R / 16 rows, eight loads in flight), combined in a fixed order
+__global__ __launch_bounds__(256) void k_tr_head_final(const float* __restrict__ part, int R, int CD, int C, float* __restrict__ dWu,
+                                                        float* __restrict__ dbu, float* __restrict__ loss_out) {
+    __shared__ float red[16][17];
+    const int n = CD + C + 1;
+    const int col = threadIdx.x & 15, sub = threadIdx.x >> 4;
+    const int id = blockIdx.x * 16 + col;
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.f;
+    if (id < n) {
+        int r = sub;
+        for (; r + 16 * 7 < R; r += 16 * 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += part[(size_t)(r + 16 * k) * n + id];
+        }
+        for (; r < R; r += 16) a[0] += part[(size_t)r * n + id];
+    }
+    red[sub][col] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (sub != 0 || id >= n) return;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k][col];
+    if (id < CD) dWu[id] += v;
+    else if (id < CD + C) dbu[id - CD] += v;
+    else *loss_out = v;
+}
+
 template <int KS1, int DT, int KSO>
 int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B, float p, uint64_t seed, uint64_t offset,
                  hipStream_t s, TrBufs& tb, uint64_t gen_in, bool img_forked) {
@@ -1917,7 +2106,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             hipLaunchKernelGGL((k_tr_ffn_fwd<KS1, DT, KSO>), dim3(tb.nwg), dim3(TW * 64), lds_ffn, s, d, fa);
         }
     }
-    fdgemm::linear_fwd(tb.hL, P + m->un_w, P + m->un_b, out, M, C, D, false, s);
+    if (out) fdgemm::linear_fwd(tb.hL, P + m->un_w, P + m->un_b, out, M, C, D, false, s);      // (null: the fused loss head reads hL)
     FD_LAUNCH_CHECK(ctx);
     if (p > 0.f) {      // the dropout-decision buffers may be rewritten once everything enqueued so far has run
         FD_HIP(ctx, hipEventRecord(ctx->tr_readers_event, s));
@@ -1928,7 +2117,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
 }
 
 template <int KS1, int DT, int KSO>
-int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, hipStream_t s, TrBufs& tb) {
+int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, hipStream_t s, TrBufs& tb, bool head_done) {
     fd_ctx* ctx = m->ctx;
     const fd_bf16_images* im = m->bf16;
     const int B = m->saved_B;
@@ -1936,11 +2125,14 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     const int M = B * T;
     const float* P = m->params;
     const TrDims d = make_dims(m, B, m->saved_p, m->saved_seed);
-    if (!accumulate) FD_HIP(ctx, hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(L > 0 ? m->layers[0].in_w : m->nparams), s));
-    // ---- unembedder
-    fdgemm::linear_bwd_weight(dout, tb.hL, grads + m->un_w, M, C, D, true, s, tb.skp, kSkpFloats);
-    if (int rc = fd_colsum_det(ctx, dout, grads + m->un_b, M, C, s)) return rc;
-    fdgemm::linear_bwd_input(dout, P + m->un_w, tb.dh, M, C, D, false, s);
+    if (!accumulate && !head_done)
+        FD_HIP(ctx, hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(L > 0 ? m->layers[0].in_w : m->nparams), s));
+    // ---- unembedder (the fused loss head, fd_score_train_dsm, has already produced tb.dh and these two gradients)
+    if (!head_done) {
+        fdgemm::linear_bwd_weight(dout, tb.hL, grads + m->un_w, M, C, D, true, s, tb.skp, kSkpFloats);
+        if (int rc = fd_colsum_det(ctx, dout, grads + m->un_b, M, C, s)) return rc;
+        fdgemm::linear_bwd_input(dout, P + m->un_w, tb.dh, M, C, D, false, s);
+    }
     const size_t scr = std::max((size_t)TW * KS1 * 1024, (size_t)4 * DT * 1024);
     const size_t NSh = (size_t)m->d.dim_ff / 64;
     const size_t lds_bwd = (size_t)4 * 2 * (2 * KS1 + DT) * 1024 + scr + (size_t)TW * 64 * NSh + (size_t)4 * 5 * 16 * DT * sizeof(float) +
@@ -2039,7 +2231,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     if (L > 0) {
         // gradient of the first layer's input = residual path + the pairs' in_proj contributions
         const size_t nn = (size_t)M * D;
-        hipLaunchKernelGGL(k_tr_sum_parts, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, tb.dres[0], tb.dxp[0], d.NP,
+        hipLaunchKernelGGL(k_tr_sum_parts, dim3((unsigned)((nn / 4 + 256) / 256)), dim3(256), 0, s, tb.dres[0], tb.dxp[0], d.NP,
                            tb.part_stride, tb.dh, nn);
     }
     if (L > 0) {
@@ -2132,7 +2324,56 @@ int fd_score_backward_bf16(fd_score* m, const float* dout, float* grads, int acc
     if (ctx->ws_bytes < need) return fd_fail(ctx, FD_ERR_STATE, "fd_score_backward: workspace was resized since the training forward");
     TrBufs tb;
     tr_carve(m, m->saved_B, (char*)ctx->ws, &tb);
-#define CALL_B(K, T_, O) tr_backward_t<K, T_, O>(m, dout, grads, accumulate, s, tb)
+#define CALL_B(K, T_, O) tr_backward_t<K, T_, O>(m, dout, grads, accumulate, s, tb, false)
+    FD_TR_DISPATCH(CALL_B);
+#undef CALL_B
+}
+
+// ---- forward + denoising score-matching loss + backward as ONE call (fd_score_train_dsm) ----
+// The three-call form (fd_score_forward_train -> fd_dsm_loss -> fd_score_backward) runs the unembedder, the loss and the
+// unembedder's backward as eight launches (three fp32 GEMMs with split-K reduces, a two-stage column sum, the loss and its
+// sum: ~75 us of 5-20 us kernels on (B*T, C <= 40) data).  Here the loss head is one kernel per (series, token split) that
+// keeps the unembedder weight in LDS, plus one fixed-order reduce of its partials.
+int fd_score_train_dsm_bf16(fd_score* m, const float* x, const float* t, const float* target, const float* stdv, int lw,
+                            float grad_weight, int B, float p, uint64_t seed, uint64_t offset, float* loss_out, float* grads,
+                            int accumulate, hipStream_t s) {
+    fd_ctx* ctx = m->ctx;
+    if (!fd_train_bf16_supported(m)) return fd_fail(ctx, FD_ERR_UNSUPPORTED, "bf16 training path unsupported for this model");
+    const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model;
+    const int CD = C * D;
+    // register slots per thread: C * D weight-gradient entries and 32 * C (row, channel) items over 256 threads
+    const int slots = std::max((CD + 255) / 256, (32 * C + 255) / 256);
+    const int kmax = slots <= 2 ? 2 : slots <= 4 ? 4 : slots <= 8 ? 8 : slots <= 16 ? 16 : 0;
+    const size_t lds = sizeof(float) * ((size_t)C * (D + 1) + (size_t)32 * (D + 1) + (size_t)32 * C + 16);
+    const size_t prow = (size_t)CD + C + 1;
+    int TS = (T + 31) / 32;                            // one 32-token tile per workgroup whenever the partials fit
+    while (TS > 1 && (size_t)B * TS * prow > kSkpFloats) --TS;
+    if (!kmax || D > 80 || D < 8 || T > 4096 || lds > 64 * 1024 || (size_t)B * TS * prow > kSkpFloats)
+        return fd_fail(ctx, FD_ERR_UNSUPPORTED, "fd_score_train_dsm: loss head not instantiated for C=%d, d_model=%d, B=%d", C, D, B);
+    if (int rc = fd_score_forward_train_bf16(m, x, t, nullptr, B, p, seed, offset, s)) return rc;
+    m->saved_bf16 = true; m->have_saved = false;       // consumed by the backward below
+    m->saved_B = B; m->saved_p = p; m->saved_seed = seed; m->saved_offset = offset; m->saved_x = x; m->saved_t = t;
+    m->saved_ws_gen = ctx->ws_gen; m->saved_ws = ctx->ws;
+    TrBufs tb;
+    tr_carve(m, B, (char*)ctx->ws, &tb);
+    HeadArgs ha{};
+    ha.hL = tb.hL; ha.Wu = m->params + m->un_w; ha.bu = m->params + m->un_b; ha.target = target; ha.stdv = stdv;
+    ha.dh = tb.dh; ha.part = tb.skp; ha.T = T; ha.C = C; ha.D = D; ha.TS = TS; ha.lw = lw;
+    ha.inv_cnt = 1.0f / ((float)((size_t)T * C) * (float)B); ha.gw = grad_weight;
+    const dim3 grid(TS, B);
+    switch (kmax) {
+        case 2: hipLaunchKernelGGL(k_tr_head<2>, grid, dim3(256), lds, s, ha); break;
+        case 4: hipLaunchKernelGGL(k_tr_head<4>, grid, dim3(256), lds, s, ha); break;
+        case 8: hipLaunchKernelGGL(k_tr_head<8>, grid, dim3(256), lds, s, ha); break;
+        default: hipLaunchKernelGGL(k_tr_head<16>, grid, dim3(256), lds, s, ha); break;
+    }
+    // (tr_backward_t skips its own clear of the non-layer gradients when the head has already added to them)
+    if (!accumulate)
+        FD_HIP(ctx, hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(m->d.num_layers > 0 ? m->layers[0].in_w : m->nparams), s));
+    hipLaunchKernelGGL(k_tr_head_final, dim3((unsigned)((prow + 15) / 16)), dim3(256), 0, s, (const float*)tb.skp, B * TS, CD, C,
+                       grads + m->un_w, grads + m->un_b, loss_out);
+    FD_LAUNCH_CHECK(ctx);
+#define CALL_B(K, T_, O) tr_backward_t<K, T_, O>(m, nullptr, grads, accumulate, s, tb, true)
     FD_TR_DISPATCH(CALL_B);
 #undef CALL_B
 }

@@ -296,6 +296,35 @@ class ScoreModule:
 
     __call__ = forward
 
+    def train_dsm(self, x_noisy: torch.Tensor, timesteps: torch.Tensor, target: torch.Tensor, std: torch.Tensor,
+                  likelihood_weighting: bool = False, grad_weight: float = 1.0) -> Optional[torch.Tensor]:
+        """Training forward + denoising score-matching loss + backward as one engine call (fd_score_train_dsm): the loss
+        tensor, with the gradients ACCUMULATED into ``self.grads`` -- or None when this model has no fused step (exact-f32
+        training, MLP / LSTM backbones, very wide C * d_model), in which case the caller runs forward -> fd_dsm_loss ->
+        backward.  Same Philox stream use as ``forward`` in training mode (one key per call)."""
+        if getattr(self, "_no_fused_dsm", False) or not self.training:
+            return None
+        ctx, h = self._engine()
+        if self.train_mode_effective != "bf16":
+            return None
+        Xd = _C.dev_f32(x_noisy.to(self.device), "x_noisy")
+        td = _C.dev_f32(timesteps.to(self.device), "timesteps")
+        tg = _C.dev_f32(target, "target")
+        sd = _C.dev_f32(std, "std")
+        if self.grads is None or self.grads.device != self.device:
+            self.grads = torch.zeros_like(self._flat)
+        loss = torch.empty(1, device=self.device, dtype=torch.float32)
+        key, off = _rng.stream()
+        rc = _C.lib().fd_score_train_dsm(h, Xd.data_ptr(), td.data_ptr(), tg.data_ptr(), sd.data_ptr(),
+                                         1 if likelihood_weighting else 0, float(grad_weight), Xd.shape[0], float(self.dropout),
+                                         key, off, loss.data_ptr(), self.grads.data_ptr(), 1, _C.stream_of(Xd))
+        if rc == -5:                                   # FD_ERR_UNSUPPORTED for these dimensions: remember, use the three calls
+            self._no_fused_dsm = True
+            return None
+        _C.check(rc, ctx)
+        self._train_inputs = (Xd, td, tg, sd)
+        return loss[0]
+
     def zero_grad(self) -> None:
         if self.grads is not None:
             self.grads.zero_()

@@ -45,9 +45,16 @@ def get_sde_loss_fn(
             # t ~ U[eps, T] per sample, drawn on X's device like the reference (losses.py:59-63: torch.rand(..., device=X.device)).
             # A host-side draw + .to(device) is a blocking copy from pageable memory: it stalled the host behind the previous
             # optimizer step in every iteration, so the GPU idled through the next step's first ~35 launches (~0.2 ms per step).
-            timesteps = torch.rand(X.shape[0], device=dev) * (scheduler.T - scheduler.eps) + scheduler.eps
+            # (uniform_(eps, T) is rand * (T - eps) + eps in one kernel instead of three)
+            timesteps = torch.empty(X.shape[0], device=dev).uniform_(scheduler.eps, scheduler.T)
         timesteps = _C.dev_f32(timesteps.to(dev), "timesteps")
         x_noisy, target, std = scheduler.perturb(X, timesteps, noise=noise)
+        if train and do_bwd and hasattr(model, "train_dsm"):
+            # forward + loss + backward as one engine call where the model has it (bf16 transformer training path)
+            fused = model.train_dsm(x_noisy, timesteps, target, std, likelihood_weighting=likelihood_weighting,
+                                    grad_weight=grad_weight)
+            if fused is not None:
+                return fused
         if train:
             score = model(DiffusableBatch(X=x_noisy, y=batch.y, timesteps=timesteps))
         else:

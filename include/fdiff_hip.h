@@ -221,6 +221,16 @@ int fd_score_forward_train(fd_score* m, const float* x, const float* t, float* o
 /* dout (B,T,C) -> grads (flat, same layout as params; ACCUMULATED into if accumulate != 0) */
 int fd_score_backward(fd_score* m, const float* dout, float* grads, int accumulate, void* stream);
 
+/* One optimisation step's device work in one call: fd_score_forward_train -> fd_dsm_loss -> fd_score_backward
+ * (the body of get_sde_loss_fn's loss_fn + loss.backward(), src/fdiff/utils/losses.py:39-125 and
+ * score_models.py:96-120) with the unembedder, the loss and the unembedder's backward fused into one kernel.
+ * x: the perturbed batch (B,T,C); target, std: fd_perturb's outputs; loss_out: device float[1];
+ * grad_weight scales the gradient (not the loss); grads as in fd_score_backward.
+ * FD_ERR_UNSUPPORTED when the model does not train on the bf16 transformer path: run the three calls. */
+int fd_score_train_dsm(fd_score* m, const float* x, const float* t, const float* target, const float* std,
+                       int likelihood_weighting, float grad_weight, int B, float dropout_p, uint64_t seed,
+                       uint64_t offset, float* loss_out, float* grads, int accumulate, void* stream);
+
 /* ----------------------------------------------------------- a12 sampler
  * replaces the inner loop of DiffusionSampler.sample (src/fdiff/sampling/sampler.py:83-104):
  * for i in range(n_steps): score = model(x, t_i); x = sde.step(score, t_i, x).
