@@ -116,16 +116,25 @@ __device__ __forceinline__ float row_sum16(float v) {      // over the 16 lanes 
     return v;
 }
 
-// 8 dropout decisions from one Philox4x32-10 evaluation: bit e = (16-bit field e >= thr16), i.e. kept with probability
-// 1 - thr16 / 65536 (thr16 = round(p * 65536): p = 0.1 -> 0.100006; the rescale uses the exact keep probability).
-__device__ __forceinline__ unsigned drop8(uint64_t ctr, uint64_t seed, unsigned thr16) {
+// 16 dropout decisions from one Philox4x32-10 evaluation: decision e looks at the 16-bit window at byte offset e of the
+// 128-bit output (wrapping), bit e = (window >= thr16), i.e. kept with probability 1 - thr16 / 65536 exactly as with disjoint
+// 16-bit fields (thr16 = round(p * 65536): p = 0.1 -> 0.100006; the rescale uses the exact keep probability).  Every byte is
+// the HIGH byte of exactly one window, so a decision is settled by its own byte unless that byte equals thr16 >> 8 (1 case in
+// 256), where the neighbouring byte breaks the tie: marginals exact to 2^-16, dependence between neighbours only through
+// those ties.  Half the Philox evaluations of the 8-per-call form (they are the cost of dropout: ~560 issue cycles each,
+// 10 M of them per layer at 16 K tokens).
+__device__ __forceinline__ unsigned drop16(uint64_t ctr, uint64_t seed, unsigned thr16) {
     const fd_u4 r = fd_philox4x32_10(ctr, seed);
-    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+    const unsigned w[5] = {r.x, r.y, r.z, r.w, r.x};
     unsigned m = 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        m |= ((w[i] & 0xffffu) >= thr16 ? 1u : 0u) << (2 * i);
-        m |= ((w[i] >> 16) >= thr16 ? 1u : 0u) << (2 * i + 1);
+        const unsigned v0 = w[i] & 0xffffu, v1 = (w[i] >> 8) & 0xffffu, v2 = w[i] >> 16;
+        const unsigned v3 = __builtin_amdgcn_alignbit(w[i + 1], w[i], 24) & 0xffffu;
+        m |= (v0 >= thr16 ? 1u : 0u) << (4 * i);
+        m |= (v1 >= thr16 ? 1u : 0u) << (4 * i + 1);
+        m |= (v2 >= thr16 ? 1u : 0u) << (4 * i + 2);
+        m |= (v3 >= thr16 ? 1u : 0u) << (4 * i + 3);
     }
     return m;
 }
@@ -340,7 +349,7 @@ __device__ __forceinline__ void row_drop_bits(const TrDims& d, const unsigned ch
     }
 }
 
-// Every dropout decision of one encoder layer (8 per Philox4x32-10 evaluation), generated AHEAD of the kernels that use
+// Every dropout decision of one encoder layer (16 per Philox4x32-10 evaluation), generated AHEAD of the kernels that use
 // them on the context's side stream: the RNG has no data dependency, and inside the latency-bound forward kernels a Philox
 // evaluation (~560 issue cycles) per 32-wide FFN chunk was the longest item of the loop.  Byte layouts:
 //   hkeep (Mpad, 4, F/32)      hidden units of token m, lane group g, chunk: bits 0-3 units 4g+r, bits 4-7 units 16+4g+r
@@ -353,23 +362,17 @@ struct MaskArgs {
     int NS2;                      // chunks per token (F / 32)
 };
 __global__ __launch_bounds__(256) void k_tr_masks(const TrDims d, const MaskArgs a) {
-    const long long total = a.n_h + a.n_p + 2 * a.n_r;
+    // one evaluation = two adjacent bytes of a buffer (every byte count is even: each has a factor 4); counters are per pair
+    const long long h2 = a.n_h / 2, p2 = a.n_p / 2, r2 = a.n_r / 2;
+    const long long total = h2 + p2 + 2 * r2;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        if (i < a.n_h) {
-            // byte index (m*4 + g)*NS2 + chunk  <->  counter (m*NS2 + chunk)*4 + g
-            const long long mg = i / a.NS2, chunk = i - mg * a.NS2;
-            const long long m = mg >> 2, g = mg & 3;
-            a.hkeep[i] = (unsigned char)drop8(a.off2 + ((unsigned long long)m * a.NS2 + chunk) * 4ull + (unsigned)g, d.seed, d.thr16);
-        } else if (i < a.n_h + a.n_p) {
-            const long long k = i - a.n_h;
-            a.pmask[k] = (unsigned char)drop8(a.off0 + (unsigned long long)k, d.seed, d.thr16);
-        } else if (i < a.n_h + a.n_p + a.n_r) {
-            const long long k = i - a.n_h - a.n_p;
-            a.rb1[k] = (unsigned char)drop8(a.off1 + (unsigned long long)k, d.seed, d.thr16);
-        } else {
-            const long long k = i - a.n_h - a.n_p - a.n_r;
-            a.rb3[k] = (unsigned char)drop8(a.off3 + (unsigned long long)k, d.seed, d.thr16);
-        }
+        unsigned short* dst;
+        unsigned long long ctr;
+        if (i < h2) { dst = reinterpret_cast<unsigned short*>(a.hkeep) + i; ctr = a.off2 + (unsigned long long)i; }
+        else if (i < h2 + p2) { dst = reinterpret_cast<unsigned short*>(a.pmask) + (i - h2); ctr = a.off0 + (unsigned long long)(i - h2); }
+        else if (i < h2 + p2 + r2) { dst = reinterpret_cast<unsigned short*>(a.rb1) + (i - h2 - p2); ctr = a.off1 + (unsigned long long)(i - h2 - p2); }
+        else { dst = reinterpret_cast<unsigned short*>(a.rb3) + (i - h2 - p2 - r2); ctr = a.off3 + (unsigned long long)(i - h2 - p2 - r2); }
+        *dst = (unsigned short)drop16(ctr, d.seed, d.thr16);
     }
 }
 
@@ -380,29 +383,52 @@ __global__ __launch_bounds__(256) void k_tr_masks(const TrDims d, const MaskArgs
 // is a side-stream kernel off the critical path.  Same bits, second layout: byte [(b, head)][key][jq][g] = bits of queries
 // 32 jq + 4 g + r (bit r) and 32 jq + 16 + 4 g + r (bit 4 + r).  One workgroup per ((b, head), jq): the 32 queries' rows
 // (32 x NJ x 4 bytes) go through LDS.
+// One workgroup per ((b, head), group of 8 query blocks = 256 queries): their rows (256 x NJ * 4 bytes, contiguous) are staged
+// in LDS.  An item = (query block jq, key block jb, key lane group g, query lane group gq): the 8 x 8 bit block {8 queries of
+// group gq} x {8 keys of group g} is read as eight bytes (one per query), transposed in registers (three masked exchange
+// steps on a 64-bit word) and written as eight bytes (one per key) into the output tile [key][8 jq x 4 gq], which leaves as
+// 32-byte runs.  (The first version gathered every output byte from eight LDS byte reads and stored single bytes 32 B apart:
+// 27 us per layer at T = 252 for 12 MB of traffic.)
 __global__ __launch_bounds__(256) void k_tr_masks_T(const unsigned char* __restrict__ pmask, unsigned char* __restrict__ pmaskT,
                                                      int T, int NJ) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char srow[];      // [32 queries][NJ * 4]
-    const int jq = blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) unsigned char srow[];      // [256 queries][NJ * 4 + 4] | [NJ * 32 keys][36]
+    const int jq0 = 8 * blockIdx.y, njq = min(8, NJ - jq0);
     const size_t bh = blockIdx.x;                 // (series, head) on the x axis: no 65 535 limit
-    const int RB = NJ * 4;
-    for (int i = threadIdx.x * 4; i < 32 * RB; i += 256 * 4) {
-        const int q = 32 * jq + i / RB;
+    const int RB = NJ * 4, RBP = RB + 4;          // padded rows: the eight rows an item reads lie 4 rows apart
+    constexpr int OB = 36;
+    unsigned char* orow = srow + 256 * RBP;
+    for (int i = threadIdx.x * 4; i < 32 * njq * RB; i += 256 * 4) {
+        const int ql = i / RB, c = i - ql * RB, q = 32 * jq0 + ql;
         unsigned w = 0u;
-        if (q < T) w = *reinterpret_cast<const unsigned*>(pmask + (bh * T + q) * RB + (i % RB));
-        *reinterpret_cast<unsigned*>(srow + i) = w;
+        if (q < T) w = *reinterpret_cast<const unsigned*>(pmask + (bh * T + q) * RB + c);
+        *reinterpret_cast<unsigned*>(srow + ql * RBP + c) = w;
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < T * 4; o += 256) {
-        const int key = o >> 2, gq = o & 3;
-        const int col = (key >> 5) * 4 + ((key >> 2) & 3), sh = ((key >> 4) & 1) * 4 + (key & 3);
-        unsigned out = 0u;
+    const int nitem = njq * NJ * 16;
+    for (int it = threadIdx.x; it < nitem; it += 256) {
+        const int jql = it / (NJ * 16), rest = it - jql * NJ * 16;
+        const int jb = rest >> 4, g = (rest >> 2) & 3, gq = rest & 3;
+        const unsigned char* base = srow + (jql * 32 + 4 * gq) * RBP + jb * 4 + g;
+        unsigned lo = 0u, hi = 0u;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ql = (e >> 2) * 16 + 4 * gq + (e & 3);
-            out |= ((srow[ql * RB + col] >> sh) & 1u) << e;
+        for (int e = 0; e < 4; ++e) {
+            lo |= (unsigned)base[e * RBP] << (8 * e);                   // queries 4 gq + e
+            hi |= (unsigned)base[(16 + e) * RBP] << (8 * e);            // queries 16 + 4 gq + e
         }
-        pmaskT[((bh * T + key) * NJ + jq) * 4 + gq] = (unsigned char)out;
+        unsigned long long x = (unsigned long long)lo | ((unsigned long long)hi << 32), t;
+        t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;  x = x ^ t ^ (t << 7);
+        t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x = x ^ t ^ (t << 14);
+        t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x = x ^ t ^ (t << 28);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const int key = 32 * jb + (f >> 2) * 16 + 4 * g + (f & 3);
+            orow[key * OB + jql * 4 + gq] = (unsigned char)(x >> (8 * f));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T * njq; i += 256) {       // one 4-byte word = (key, jq): njq consecutive words per key
+        const int key = i / njq, jql = i - key * njq;
+        *reinterpret_cast<unsigned*>(pmaskT + ((bh * T + key) * NJ + jq0 + jql) * 4) = *reinterpret_cast<const unsigned*>(orow + key * OB + jql * 4);
     }
 }
 
@@ -2038,6 +2064,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_fwd<KS1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_fwd<KS1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_ffn_fwd<KS1, DT, KSO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_masks_T, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     if (p > 0.f) {
         // dropout decisions of every layer on the side stream, layer by layer, ahead of the kernels that read them
@@ -2067,14 +2094,14 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             ma.n_p = (long long)B * m->d.n_head * T * d.NJ * 4;
             ma.n_r = (long long)tb.Mpad * ((DT + 1) / 2) * 4;
             const long long tot = ma.n_h + ma.n_p + 2 * ma.n_r;
-            const unsigned grid = (unsigned)std::min<long long>((tot + 255) / 256, (long long)ctx->num_cu * 16);
+            const unsigned grid = (unsigned)std::min<long long>((tot / 2 + 255) / 256, (long long)ctx->num_cu * 16);
             hipLaunchKernelGGL(k_tr_masks, dim3(grid), dim3(256), 0, ctx->side_stream, d, ma);
             FD_HIP(ctx, hipEventRecord(ctx->side_events[l], ctx->side_stream));
         }
         // key-oriented copies of the attention keep bits: only the backward reads them, so they queue behind the decisions of
         // every layer (the forward never waits for them); last layer first, the order the backward wants them in
         for (int l = L - 1; l >= 0; --l)
-            hipLaunchKernelGGL(k_tr_masks_T, dim3(B * m->d.n_head, d.NJ), dim3(256), (size_t)32 * d.NJ * 4, ctx->side_stream,
+            hipLaunchKernelGGL(k_tr_masks_T, dim3(B * m->d.n_head, (d.NJ + 7) / 8), dim3(256), (size_t)256 * (d.NJ * 4 + 4) + (size_t)d.NJ * 32 * 36, ctx->side_stream,
                                tb.layers[l].pmask, tb.layers[l].pmaskT, T, d.NJ);
         if (!ctx->tr_masksT_event) FD_HIP(ctx, hipEventCreateWithFlags(&ctx->tr_masksT_event, hipEventDisableTiming));
         FD_HIP(ctx, hipEventRecord(ctx->tr_masksT_event, ctx->side_stream));
@@ -2206,6 +2233,11 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         hipStream_t ws = (l & 1) ? ctx->side_stream2 : ctx->side_stream;     // two layers' weight gradients in flight
         if (serial) ws = s;                                                   // measurement: solo kernel times
         wa.part = tb.part + (size_t)(l & 1) * kMaxTS * tb.layer_params;
+        // Layer 0's launch is the step's tail: the input-gradient chain has ended, nothing shares the chip with it and the
+        // optimizer waits for it.  More token splits shorten each workgroup's block chain (experiments: FDIFF_TR_TS_LAST).
+        static const int ts_last_env = getenv("FDIFF_TR_TS_LAST") ? atoi(getenv("FDIFF_TR_TS_LAST")) : 0;
+        const int ts_l = (l == 0 && ts_last_env > 0) ? std::max(1, std::min({kMaxTS, ts_last_env, wa.nblk})) : tb.TS;
+        wa.TS = ra.TS = ts_l;
         FD_HIP(ctx, hipEventRecord(ctx->side_events[l], s));
         FD_HIP(ctx, hipStreamWaitEvent(ws, ctx->side_events[l], 0));
         {
@@ -2213,7 +2245,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
             // linear1 + linear2 2 x 2 M D F (the recomputation of the hidden / d hidden blocks is not algorithmic work)
             fd_prof_scope scope(ctx, ws, "k_tr_wgrad (all weight gradients of one encoder layer, training backward)",
                                 (double)M * (8.0 * D * D + 4.0 * D * F));
-            hipLaunchKernelGGL((k_tr_wgrad<KS1, DT>), dim3(F / 128 + 4, tb.TS), dim3(256), lds_wg, ws, d, w, wa);
+            hipLaunchKernelGGL((k_tr_wgrad<KS1, DT>), dim3(F / 128 + 4, ts_l), dim3(256), lds_wg, ws, d, w, wa);
         }
         ra.part = wa.part;
         ra.grads = grads + lo.in_w;

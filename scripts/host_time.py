@@ -18,6 +18,8 @@ sch.set_noise_scaling(T)
 model = ScoreModule(n_channels=CH, max_len=T, noise_scheduler=sch, fourier_noise_scaling=True, d_model=72, num_layers=10, n_head=12).to(dev)
 model.train_precision = "bf16"
 model.train()
+if os.environ.get("FDIFF_DROPOUT"):          # (0 = no dropout decisions at all: what the mask kernels on the side stream cost)
+    model.dropout = float(os.environ["FDIFF_DROPOUT"])
 opt = FusedAdamW(model, lr=1e-3, max_grad_norm=1.0)
 X = torch.randn(B, T, CH).to(dev)
 

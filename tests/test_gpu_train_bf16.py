@@ -213,8 +213,11 @@ def test_dropout_forward_backward_consistency_bf16():
     l0 = loss_at(11, True)
     grads = m.grads.clone()
     assert m.train_mode_effective == "bf16"
-    assert loss_at(11, False) == l0
-    assert loss_at(12, False) != l0
+    # (the training call with backward runs the fused loss head, the one without it the stand-alone loss kernel: the same
+    # numbers summed in another order; each form is bit-reproducible)
+    l0f = loss_at(11, False)
+    assert l0f == loss_at(11, False) and abs(l0f - l0) <= 1e-6 * abs(l0)
+    assert abs(loss_at(12, False) - l0) > 1e-5 * abs(l0)
     m.dropout = 0.0
     l_nodrop = loss_at(11, False)
     m.dropout = 0.1
