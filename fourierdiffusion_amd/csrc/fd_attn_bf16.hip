@@ -284,12 +284,38 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
 
     const bool lo_grp = (g >> 1) == 0;
     const int myhead = 2 * pair + (g >> 1);
-    f32x4 cmask;                                                     // keys beyond T in the ragged last tile
+    // keys beyond T in the ragged last tile.  Recomputed at its few uses (four compares) from a laundered copy of the lane
+    // group: as a kernel-long f32x4 it was four of the 14 dwords hipcc spilled at the 128-VGPR budget (scripts/scratch_report.py
+    // lists the kernels that touch scratch memory; without it this one went 106.1 -> 104.9 us per layer at T = 1024).
+    auto cmask_now = [&]() {
+        int gl = g;
+        asm volatile("" : "+v"(gl));
+        f32x4 m;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cmask[r] = ((KT - 1) * 16 + 4 * g + r >= T) ? kNegBig : 0.f;
-    auto kfrag = [&](int kt) { return *reinterpret_cast<const s16x4*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8); };
-    auto vfrag = [&](int jb) { return *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(jb * 4 + g) * 16 + tok) * 16); };
+        for (int r = 0; r < 4; ++r) m[r] = ((KT - 1) * 16 + 4 * gl + r >= T) ? kNegBig : 0.f;
+        return m;
+    };
+#define cmask cmask_now()
+    // The same reads for the code off the steady-state pipeline (partial last block, exact path): the lane's address terms
+    // go through an opaque move, so that hipcc builds these addresses where they are used instead of keeping one VGPR per
+    // (call site, loop start) alive across the whole unit loop -- those were the rest of the spilled dwords.
+    auto kfrag_cold = [&](int kt) {
+        int tl = tok, gl = g;
+        asm volatile("" : "+v"(tl), "+v"(gl));
+        return *reinterpret_cast<const s16x4*>(kbf + ((size_t)(kt * 16 + tl) * 4 + gl) * 8);
+    };
+    auto vfrag_cold = [&](int jb) {
+        int tl = tok, gl = g;
+        asm volatile("" : "+v"(tl), "+v"(gl));
+        return *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(jb * 4 + gl) * 16 + tl) * 16);
+    };
     for (int du = du0 + wave; du < du1; du += NW) {
+        // the lane's fragment addresses are rebuilt per unit (a few VALU) from opaque copies of (tok, g): hoisted out of this
+        // loop they were kept alive -- i.e. spilled -- across it, one VGPR per address stream of the key pipeline
+        int tokd = tok, gd = g;
+        asm volatile("" : "+v"(tokd), "+v"(gd));
+        auto kfrag = [&](int kt) { return *reinterpret_cast<const s16x4*>(kbf + ((size_t)(kt * 16 + tokd) * 4 + gd) * 8); };
+        auto vfrag = [&](int jb) { return *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(jb * 4 + gd) * 16 + tokd) * 16); };
         int qt[NQ];
         bool qv[NQ];
 #pragma unroll
@@ -445,8 +471,8 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
             // beyond T need no mask here: their K rows, V rows and ones-row entries are all 0 (exp2(0) * 0).
             for (int jb = NFULL * 4; jb < NJ; ++jb) {
                 const int ka = 2 * jb, kb2 = (2 * jb + 1 < KT) ? 2 * jb + 1 : ka;
-                const s16x4 kfa = kfrag(ka), kfb = kfrag(kb2);
-                const bf16x8 vfj = vfrag(jb);           // (a missing odd tile: its V^T half was staged as zeros)
+                const s16x4 kfa = kfrag_cold(ka), kfb = kfrag_cold(kb2);
+                const bf16x8 vfj = vfrag_cold(jb);      // (a missing odd tile: its V^T half was staged as zeros)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -482,9 +508,9 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
             s16x4 kf[8];
             bf16x8 vf[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) kf[j] = kfrag(kb + j);
+            for (int j = 0; j < 8; ++j) kf[j] = kfrag_cold(kb + j);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) vf[jj] = vfrag((kb >> 1) + jj);
+            for (int jj = 0; jj < 4; ++jj) vf[jj] = vfrag_cold((kb >> 1) + jj);
             constexpr int NKT = 16 * NQ;          // score tiles per block: k = ((hs*4 + jj)*NQ + q)*2 + jl, key tile 2jj+jl
             // pass 1: row maxima of this key block (software-pipelined by hand, see fd_mega.hip)
             float bm[NQ][2];
@@ -561,7 +587,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
 #pragma unroll
             for (int q = 0; q < NQ; ++q) bm[q][0] = bm[q][1] = kNegBig;
             for (int kt = kb; kt < KT; ++kt) {
-                const s16x4 kfa = kfrag(kt);
+                const s16x4 kfa = kfrag_cold(kt);
                 const f32x4 ca = (kt == KT - 1) ? cmask : f4zero();
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
@@ -583,8 +609,8 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
                 }
             for (int jb = kb >> 1; jb < NJ; ++jb) {
                 const int ka = 2 * jb, kb2 = (2 * jb + 1 < KT) ? 2 * jb + 1 : ka;
-                const s16x4 kfa = kfrag(ka), kfb = kfrag(kb2);
-                const bf16x8 vfj = vfrag(jb);
+                const s16x4 kfa = kfrag_cold(ka), kfb = kfrag_cold(kb2);
+                const bf16x8 vfj = vfrag_cold(jb);
                 const f32x4 ma = (ka == KT - 1) ? cmask : f4zero();
                 const f32x4 mb = (2 * jb + 1 >= KT) ? allneg : ((kb2 == KT - 1) ? cmask : f4zero());
 #pragma unroll

@@ -258,6 +258,12 @@ __device__ __forceinline__ void stockham_butterflies(const float2* __restrict__ 
     }
 }
 
+// A workgroup-uniform float that was produced by the VALU or read from LDS sits in a VGPR until it is moved to a scalar
+// register by hand (the in-place instantiations were at their 128-VGPR budget with 2-5 spilled dwords; with the radix-16
+// twiddles and the reciprocals in SGPRs they need 93-107 and no scratch memory).
+__device__ __forceinline__ float uniformf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ float2 uniformf2(float2 v) { return float2{uniformf(v.x), uniformf(v.y)}; }
+
 // In-place decimation-in-frequency stage of small radix R on sub-transforms of length Lc (Gentleman-Sande): the butterfly of
 // (block, j), j < m = Lc / R, reads X[base + j + t m], t < R, and writes  b_u = (sum_t a_t W_R^(u t)) W_Lc^(j u)  back to
 // X[base + j + u m] -- the same R places, so ONE LDS image serves the whole transform (the Stockham form needs two) and four
@@ -270,14 +276,17 @@ __device__ __forceinline__ void dif_butterflies(float2* __restrict__ X, const fl
     const int tr = T / R;
     const int ktw = T / Lc;                         // W_Lc = W_T^ktw
     const int total = tr * Cp;
-    const float inv_cp = 1.0f / (float)Cp, inv_m = 1.0f / (float)m;
+    const float inv_cp = uniformf(1.0f / (float)Cp), inv_m = uniformf(1.0f / (float)m);
     float2 wr[R];                                   // R-th roots of unity in the transform's direction
 #pragma unroll
     for (int q = 0; q < R; ++q) wr[q] = tw[q * tr];
     float2 w16[5] = {};
+    float2 w4 = {};
     if (R == 16) {
         const int e16 = T / 16;
-        w16[0] = tw[e16]; w16[1] = tw[2 * e16]; w16[2] = tw[3 * e16]; w16[3] = tw[6 * e16]; w16[4] = tw[9 * e16];
+        w16[0] = uniformf2(tw[e16]); w16[1] = uniformf2(tw[2 * e16]); w16[2] = uniformf2(tw[3 * e16]);
+        w16[3] = uniformf2(tw[6 * e16]); w16[4] = uniformf2(tw[9 * e16]);
+        w4 = uniformf2(tw[T / 4]);
     }
     const int ms = m * Cp;
     for (int id = threadIdx.x; id < total; id += NT) {
@@ -291,7 +300,7 @@ __device__ __forceinline__ void dif_butterflies(float2* __restrict__ X, const fl
             float2 a16[16], x16[16];
 #pragma unroll
             for (int t = 0; t < 16; ++t) a16[t] = a[t % R];
-            dft16(a16, x16, tw[T / 4], w16);
+            dft16(a16, x16, w4, w16);
 #pragma unroll
             for (int u = 0; u < R; ++u) b[u] = x16[u % 16];
         } else if (R == 2) {
@@ -334,8 +343,10 @@ __device__ __forceinline__ void dif_butterflies(float2* __restrict__ X, const fl
 // -- "channel" j is series blockIdx.x * Cc + j, contiguous along time -- so that a (B, T, 1) set (the reference's ECG
 // data, 87 554 x 187 x 1) still fills complex lanes and workgroups (one series per workgroup ran at 0.6 TB/s).
 // BIGP: the instantiation that carries the register butterflies of the prime radices 17 / 19 / 23 (34-46 complex registers per
-// thread: they spill at the 1024-thread budget, and a kernel with scratch pays for it in every stage -- (4096, 256, 28) lost
-// 9 % when they lived in the common instantiation); lengths without such a factor run the BIGP = false kernel.
+// thread: they spill at the 1024-thread budget, and a kernel with scratch pays for it in every stage --
+// (4096, 256, 28) lost 9 % when they lived in the common instantiation); lengths without such a factor run the BIGP = false
+// kernel.  (Built for 512 threads = 256 VGPRs the BIGP kernel has no scratch but half the waves per CU: (87 554, 187, 1)
+// 58 -> 83 us, so it keeps its spills.)
 template <bool INVERSE, bool BATCHED, bool BIGP, bool INPLACE = false>
 __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, float* __restrict__ y,
                                                     const float* __restrict__ mean, const float* __restrict__ stdv,
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
     float* yb = y + (size_t)b * T * C;
     const int n_real = T / 2 + 1;
     const bool even = (T & 1) == 0;
-    const float scale = rsqrtf((float)T);
+    const float scale = uniformf(rsqrtf((float)T));
     // offset of (row, channel) in xb / yb, and in the (T, C) mean / std tables; BATCHED: channel = series, rows contiguous
     // (32-bit offsets inside one series / series group: T * C * Cc < 2^31 is checked on the host; factors < 2^24 for m24)
     const int cstep = BATCHED ? T : 1, rstep = BATCHED ? 1 : C, mstep = BATCHED ? 0 : 1;
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
     const bool vec2 = !BATCHED && plan.vec_ok != 0;
 
     // ---- load pass: build z[n][p]  (thread order: channel pairs fastest, BATCHED: rows fastest = contiguous in memory)
-    const float inv_cp = 1.0f / (float)Cp, inv_t = 1.0f / (float)T, inv_nr = 1.0f / (float)n_real;
+    const float inv_cp = uniformf(1.0f / (float)Cp), inv_t = uniformf(1.0f / (float)T), inv_nr = uniformf(1.0f / (float)n_real);
     for (int id = threadIdx.x; id < T * Cp; id += NT) {
         int n, p;
         if (BATCHED) { p = fdiv(id, inv_t); n = id - m24(p, T); } else { n = fdiv(id, inv_cp); p = id - m24(n, Cp); }

@@ -12,11 +12,16 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// (tails by predicated scalar accesses: indexing the float4 with a run-time subscript put it in scratch memory, and with a
+// private segment k_sde_step took 18.5 us for 2.4 MB instead of 5.8, 73 us instead of 59 at 117 MB x 3 -- rocprofv3 kernel
+// times, profiles/r03_scratch_sde_step.txt; scripts/scratch_report.py lists every kernel of the library that uses scratch)
 __device__ __forceinline__ float4 ld4(const float* p, size_t e, size_t n) {
     if (e + 4 <= n) return *reinterpret_cast<const float4*>(p + e);
-    float4 v = {0.f, 0.f, 0.f, 0.f};
-    float* f = reinterpret_cast<float*>(&v);
-    for (size_t i = e; i < n; ++i) f[i - e] = p[i];
+    float4 v;
+    v.x = e < n ? p[e] : 0.f;
+    v.y = e + 1 < n ? p[e + 1] : 0.f;
+    v.z = e + 2 < n ? p[e + 2] : 0.f;
+    v.w = 0.f;
     return v;
 }
 __device__ __forceinline__ void st4(float* p, size_t e, size_t n, float4 v) {
@@ -24,8 +29,9 @@ __device__ __forceinline__ void st4(float* p, size_t e, size_t n, float4 v) {
         *reinterpret_cast<float4*>(p + e) = v;
         return;
     }
-    const float* f = reinterpret_cast<const float*>(&v);
-    for (size_t i = e; i < n; ++i) p[i] = f[i - e];
+    if (e < n) p[e] = v.x;
+    if (e + 1 < n) p[e + 1] = v.y;
+    if (e + 2 < n) p[e + 2] = v.z;
 }
 
 __global__ __launch_bounds__(kBlock) void k_randn(float* __restrict__ out, size_t n, uint64_t seed,

@@ -40,6 +40,8 @@ def main():
                     n_head=12).to(dev)
     m.precision = os.environ.get("FDIFF_PRECISION", "bf16")
     m.train_precision = os.environ.get("FDIFF_TRAIN_PRECISION", "bf16")
+    if os.environ.get("FDIFF_DROPOUT"):          # (experiments: 0 = what the dropout decisions cost)
+        m.dropout = float(os.environ["FDIFF_DROPOUT"])
     if what == "sample":
         m.eval()
         sch.set_timesteps(N)
