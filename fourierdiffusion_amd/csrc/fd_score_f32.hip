@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ x, cons
                                                 const float* __restrict__ be, const float* __restrict__ pe,
                                                 const float* __restrict__ temb, float* __restrict__ h, int M, int T,
                                                 int C, int D, int use_lds) {
-    extern __shared__ float wsh[];
+    extern __shared__ __attribute__((aligned(16))) float wsh[];
     if (use_lds) {
         float* const xs = wsh + D * C;
         const int row0 = blockIdx.x * kEmbRows, nrows = min(kEmbRows, M - row0);
@@ -244,6 +244,31 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ x, cons
         }
         for (int i = threadIdx.x; i < nrows * C; i += 256) xs[i] = x[(size_t)row0 * C + i];
         __syncthreads();
+        if (use_lds == 2) {
+            // four consecutive features per thread: one (row, b, t) decomposition, 16-byte LDS / global accesses (one output
+            // per thread spent most of its ~150 instructions on the two integer divisions: 23 us at 65 536 tokens)
+            const int D4 = D >> 2;
+            for (int i = threadIdx.x; i < nrows * D4; i += 256) {
+                const int r = i / D4, d = (i - r * D4) * 4, m = row0 + r;
+                const int b = m / T, tt = m - b * T;
+                const float* xr = xs + r * C;
+                float4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < C; ++c) {
+                    const float xv = xr[c];
+                    const float4 w = *reinterpret_cast<const float4*>(wsh + c * D + d);
+                    acc.x = fmaf(xv, w.x, acc.x); acc.y = fmaf(xv, w.y, acc.y);
+                    acc.z = fmaf(xv, w.z, acc.z); acc.w = fmaf(xv, w.w, acc.w);
+                }
+                const float4 bv = *reinterpret_cast<const float4*>(be + d);
+                const float4 pv = pe ? *reinterpret_cast<const float4*>(pe + (size_t)tt * D + d) : float4{0.f, 0.f, 0.f, 0.f};
+                const float4 tv = *reinterpret_cast<const float4*>(temb + (size_t)b * D + d);
+                float4 o;
+                o.x = ((acc.x + bv.x) + pv.x) + tv.x; o.y = ((acc.y + bv.y) + pv.y) + tv.y;
+                o.z = ((acc.z + bv.z) + pv.z) + tv.z; o.w = ((acc.w + bv.w) + pv.w) + tv.w;
+                *reinterpret_cast<float4*>(h + (size_t)m * D + d) = o;
+            }
+            return;
+        }
         for (int i = threadIdx.x; i < nrows * D; i += 256) {
             const int r = i / D, d = i - r * D, m = row0 + r;
             const int b = m / T, tt = m - b * T;
@@ -464,7 +489,10 @@ void embed(const float* x, const float* We, const float* be, const float* pe, co
            int T, int C, int D, hipStream_t s) {
     const size_t n = (size_t)M * D;
     const size_t lds = ((size_t)D * C + (size_t)kEmbRows * C) * sizeof(float);
-    const int use_lds = (lds <= 48 * 1024) ? 1 : 0;
+    int use_lds = (lds <= 48 * 1024) ? 1 : 0;
+    // 16-byte form: D % 4 == 0 and every vector operand 16-byte aligned (the parameter offsets are not when d_model / 2 is odd)
+    const uintptr_t al = (uintptr_t)be | (uintptr_t)pe | (uintptr_t)temb | (uintptr_t)h;
+    if (use_lds && (D & 3) == 0 && (al & 15) == 0) use_lds = 2;
     const unsigned grid = use_lds ? (unsigned)((M + kEmbRows - 1) / kEmbRows) : (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_embed, dim3(grid), dim3(256), use_lds ? lds : 0, s, x, We, be, pe, temb, h, M, T, C, D, use_lds);
 }
