@@ -309,6 +309,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
         asm volatile("" : "+v"(tl), "+v"(gl));
         return *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(jb * 4 + gl) * 16 + tl) * 16);
     };
+    bool prefer_exact = exact_only != 0;                              // wave-uniform
     for (int du = du0 + wave; du < du1; du += NW) {
         // the lane's fragment addresses are rebuilt per unit (a few VALU) from opaque copies of (tok, g): hoisted out of this
         // loop they were kept alive -- i.e. spilled -- across it, one VGPR per address stream of the key pipeline
@@ -651,7 +652,11 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
             }
             return bad;
         };
-        if (exact_only) {
+        // A unit whose fast pass underflowed has paid for both forms (2.5 x).  Units of one wave belong to one (series, head
+        // pair) and neighbouring query tiles, so after the first failure the wave goes straight to the exact form for its
+        // remaining units (1.5 x): a sampler trajectory that leaves the data scale (random-init weights: |x| grows ~150 x
+        // along the VP reverse SDE) made every layer-0 unit fail from the fifth step on, 186 us instead of 97 at T = 1024.
+        if (prefer_exact) {
             run_exact();
             (void)row_sums();
         } else {
@@ -659,6 +664,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
             if (__builtin_amdgcn_ballot_w64(row_sums()) != 0ull && ABL != 2) {
                 run_exact();
                 (void)row_sums();
+                prefer_exact = true;
             }
         }
         ATTN_STAMP(3, tprev);
