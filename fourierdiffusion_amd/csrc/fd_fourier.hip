@@ -671,6 +671,12 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
     static const int lds_target_kb0 = getenv("FDIFF_FFT_LDS_KB") ? atoi(getenv("FDIFF_FFT_LDS_KB")) : 72;
     const long long auto_pairs = ((long long)lds_target_kb0 * 1024 - (long long)T * 8) / ((long long)T * 16);
     bool inplace = smooth && C > 1 && auto_pairs >= 4 && (C + 1) / 2 > auto_pairs;
+    // Round 3, after the in-place instantiations stopped spilling (93-107 VGPRs, no scratch memory) and with 16 elements per
+    // thread (profiles/r03_fft_forms.txt, rocprofv3 kernel times): lengths whose plan starts with a radix-16 stage are faster
+    // in place -- (4096, 256, 28) 68.9 / 71.6 -> 63.7 / 69.7 us with four 256-thread workgroups per CU, (512, 1024, 16)
+    // 35.7 / 35.6 (two channel chunks) -> 27.9 / 26.1 us, (65 536, 256, 1) 43.2 / 45.2 -> 40.8 / 41.4 us; lengths of small odd
+    // radices are not ((4096, 252, 6) 27.6 -> 32.7 us) and keep the autosort form.
+    if (smooth && plan.nstages > 0 && plan.radix[0] == 16 && (C > 1 || (C == 1 && B >= 4))) inplace = true;
     if (const char* e = getenv("FDIFF_FFT_INPLACE")) inplace = smooth && e[0] != '0';
     // LDS: twiddles (8T) + complex images of T * ceil(Cc/2) float2: two (Stockham ping-pong) or one + 2T bytes (in place)
     const size_t lds_cap = 128 * 1024;
@@ -726,7 +732,8 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
     // threads per workgroup: about 4 complex elements per thread and stage, whole waves, 128..1024
     const int elems = T * ((Cc + 1) / 2);
     int block = 128;
-    static const int ept = getenv("FDIFF_FFT_EPT") ? atoi(getenv("FDIFF_FFT_EPT")) : 8;
+    static const int ept_env = getenv("FDIFF_FFT_EPT") ? atoi(getenv("FDIFF_FFT_EPT")) : 0;
+    const int ept = ept_env > 0 ? ept_env : (inplace ? 16 : 8);
     while (block < kMaxBlock && block * ept < elems) block *= 2;
     {
         const int wg_per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / (lds + 256)), 2048 / block));
