@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hbm -o hbm -- python $GRAFT_REPO_ROOT/scripts/hbm_kernels_bench.py > $OUT/hbm.log 2>&1
 python $GRAFT_REPO_ROOT/scripts/kstats.py $OUT/hbm/hbm_kernel_stats.csv 8 | cut -c1-100,100-140
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_hbm_$c -o p -- python $GRAFT_REPO_ROOT/scripts/hbm_kernels_bench.py > /dev/null 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_hbm_$c -o p -- python $GRAFT_REPO_ROOT/scripts/hbm_kernels_bench.py --json > /dev/null 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/long -o long -- python $GRAFT_REPO_ROOT/scripts/shape_bench.py sample long 64 20 > $OUT/long.log 2>&1
 tail -1 $OUT/long.log
@@ -28,16 +28,16 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             k = r["Kernel_Name"]
             name = "k_fft_fwd" if "k_fft<false" in k else ("k_fft_inv" if "k_fft<true" in k else ("k_sde_step" if "k_sde_step" in k else None))
             if name and r["Counter_Name"] == c:
-                a = acc[(name, r["Grid_Size"], c)]; a[0] += float(r["Counter_Value"]); a[1] += 1
+                a = acc[(name, r["Grid_Size"] + " / wg " + r["Workgroup_Size"], c)]; a[0] += float(r["Counter_Value"]); a[1] += 1
 rows = {}
 for (name, grid, c), (tot, n) in acc.items():
     rows.setdefault((name, grid), {})[c] = tot / n
 with open("$OUT/hbm_traffic.txt", "w") as f:
-    f.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over scripts/hbm_kernels_bench.py; KB per launch, FETCH doubled\n")
+    f.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over scripts/hbm_kernels_bench.py --json (shapes (4096,256,28), (512,1024,16), (512,100,12)); MB per launch, FETCH doubled\n")
     f.write("# per the gfx950 note of MI355X_MICROARCH.md; one row per (kernel, grid size = shape)\n")
     for (name, grid), v in sorted(rows.items()):
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            f.write(f"{name:12s} grid {grid:>10s}: fetch {2*v['FETCH_SIZE']/1024:9.1f} MB  write {v['WRITE_SIZE']/1024:9.1f} MB\n")
+            f.write(f"{name:12s} grid {grid:>20s}: fetch {2*v['FETCH_SIZE']/1024:9.1f} MB  write {v['WRITE_SIZE']/1024:9.1f} MB\n")
 print(open("$OUT/hbm_traffic.txt").read()[:3000])
 tot = collections.defaultdict(float)
 for f in glob.glob("$OUT/pmc_long_*/*counter_collection.csv"):
