@@ -407,20 +407,30 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
 
     // ---- load pass: build z[n][p]  (thread order: channel pairs fastest, BATCHED: rows fastest = contiguous in memory)
     const float inv_cp = uniformf(1.0f / (float)Cp), inv_t = uniformf(1.0f / (float)T), inv_nr = uniformf(1.0f / (float)n_real);
-    for (int id = threadIdx.x; id < T * Cp; id += NT) {
-        int n, p;
-        if (BATCHED) { p = fdiv(id, inv_t); n = id - m24(p, T); } else { n = fdiv(id, inv_cp); p = id - m24(n, Cp); }
-        const int ca = c0 + 2 * p;
-        const bool has_b = (2 * p + 1) < cc;
-        float2 z;
-        if (!INVERSE) {
+    if (!INVERSE) {
+        for (int id = threadIdx.x; id < T * Cp; id += NT) {
+            int n, p;
+            if (BATCHED) { p = fdiv(id, inv_t); n = id - m24(p, T); } else { n = fdiv(id, inv_cp); p = id - m24(n, Cp); }
+            const int ca = c0 + 2 * p;
+            const bool has_b = (2 * p + 1) < cc;
+            float2 z;
             if (vec2) {           // both channels of the pair in one 8-byte access (C even: 8-byte aligned)
                 z = *reinterpret_cast<const float2*>(xb + m24(n, rstep) + ca);
             } else {
                 z.x = ldg(xb + m24(n, rstep) + m24(ca, cstep));
                 z.y = has_b ? ldg(xb + m24(n, rstep) + m24(ca + 1, cstep)) : 0.f;
             }
-        } else {
+            bufA[BATCHED ? m24(n, Cp) + p : id] = z;        // (non-batched: id == n * Cp + p)
+        }
+    } else if (BIGP && !BATCHED) {
+        // (the instantiation with the radix 17 / 19 / 23 register butterflies lives at its VGPR budget with spills: there the
+        // one-item-two-places form below measured 9-13 % slower -- (4096, 187, 12) 38.6 -> 42 us --, so it keeps a thread per
+        // time step)
+        for (int id = threadIdx.x; id < T * Cp; id += NT) {
+            const int n = fdiv(id, inv_cp), p = id - m24(n, Cp);
+            const int ca = c0 + 2 * p;
+            const bool has_b = (2 * p + 1) < cc;
+            float2 z;
             // Hermitian extension of the packed half spectrum (fourier.py:62-77): X[T-k] = conj X[k]
             const int kk = (n <= T / 2) ? n : T - n;
             const bool has_im = (kk != 0) && !(even && kk == T / 2);
@@ -450,8 +460,42 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
             // Z = Xa + i Xb
             z.x = are - bim;
             z.y = aim + bre;
+            bufA[id] = z;
         }
-        bufA[BATCHED ? m24(n, Cp) + p : id] = z;        // (non-batched: id == n * Cp + p)
+    } else {
+        // Hermitian extension of the packed half spectrum (fourier.py:62-77): X[T-k] = conj X[k].  One item = one coefficient
+        // k <= T/2 of a channel pair: it is read once and written to both places k and T - k (a thread per time step n read
+        // every coefficient twice: iRFFT fetched 124 MB for a 112 MB tensor and ran the index arithmetic of the pass twice).
+        for (int id = threadIdx.x; id < n_real * Cp; id += NT) {
+            int kk, p;
+            if (BATCHED) { p = fdiv(id, inv_nr); kk = id - m24(p, n_real); } else { kk = fdiv(id, inv_cp); p = id - m24(kk, Cp); }
+            const int ca = c0 + 2 * p;
+            const bool has_b = (2 * p + 1) < cc;
+            const bool has_im = (kk != 0) && !(even && kk == T / 2);
+            const int ire = m24(kk, rstep), iim = m24(n_real + kk - 1, rstep);
+            const int oa = m24(ca, cstep), ob = m24(ca + 1, cstep);
+            float are, aim, bre, bim;
+            if (vec2) {
+                const float2 re2 = *reinterpret_cast<const float2*>(xb + ire + oa);
+                const float2 im2 = has_im ? *reinterpret_cast<const float2*>(xb + iim + oa) : float2{0.f, 0.f};
+                are = re2.x; bre = re2.y; aim = im2.x; bim = im2.y;
+            } else {
+                are = ldg(xb + ire + oa); aim = has_im ? ldg(xb + iim + oa) : 0.f;
+                bre = has_b ? ldg(xb + ire + ob) : 0.f; bim = (has_b && has_im) ? ldg(xb + iim + ob) : 0.f;
+            }
+            if (mean) {   // de-standardise in the frequency domain (cmd/sample.py:76-78)
+                const int mre = m24(kk, C), mim = m24(n_real + kk - 1, C), ma = ca * mstep, mb = (ca + 1) * mstep;
+                are = are * stdv[mre + ma] + mean[mre + ma];
+                if (has_im) aim = aim * stdv[mim + ma] + mean[mim + ma];
+                if (has_b) {
+                    bre = bre * stdv[mre + mb] + mean[mre + mb];
+                    if (has_im) bim = bim * stdv[mim + mb] + mean[mim + mb];
+                }
+            }
+            // Z = Xa + i Xb at k; at T - k both imaginary parts change sign
+            bufA[m24(kk, Cp) + p] = float2{are - bim, aim + bre};
+            if (has_im) bufA[m24(T - kk, Cp) + p] = float2{are + bim, bre - aim};
+        }
     }
     __syncthreads();
 
