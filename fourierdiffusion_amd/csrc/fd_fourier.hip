@@ -404,10 +404,42 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
     // channel pairs as 8-byte accesses: rows of an even number of channels, chunks start at even channels and the tensor base is
     // 8-byte aligned (the host passes `vec_ok`): half the memory instructions and address arithmetic of the load / store passes
     const bool vec2 = !BATCHED && plan.vec_ok != 0;
+    // two channel pairs as one 16-byte access (vec_ok == 2: C and the chunk multiples of 4, 16-byte aligned tensors): half the
+    // items, address arithmetic and memory instructions of the passes again
+    const bool vec4 = vec2 && plan.vec_ok == 2 && !BIGP;
+    const int Cq = Cp >> 1;
+    const float inv_cq = uniformf(1.0f / (float)max(Cq, 1));
+    auto f4 = [](const float* q) { return *reinterpret_cast<const float4*>(q); };
 
     // ---- load pass: build z[n][p]  (thread order: channel pairs fastest, BATCHED: rows fastest = contiguous in memory)
     const float inv_cp = uniformf(1.0f / (float)Cp), inv_t = uniformf(1.0f / (float)T), inv_nr = uniformf(1.0f / (float)n_real);
-    if (!INVERSE) {
+    if (!INVERSE && vec4) {
+        for (int id = threadIdx.x; id < T * Cq; id += NT) {
+            const int n = fdiv(id, inv_cq), q = id - m24(n, Cq);
+            *reinterpret_cast<float4*>(bufA + m24(n, Cp) + 2 * q) = f4(xb + m24(n, C) + c0 + 4 * q);
+        }
+    } else if (INVERSE && vec4) {
+        for (int id = threadIdx.x; id < n_real * Cq; id += NT) {
+            const int kk = fdiv(id, inv_cq), q = id - m24(kk, Cq);
+            const int ca = c0 + 4 * q;
+            const bool has_im = (kk != 0) && !(even && kk == T / 2);
+            const int ire = m24(kk, C) + ca, iim = m24(n_real + kk - 1, C) + ca;
+            float4 re4 = f4(xb + ire);
+            float4 im4 = has_im ? f4(xb + iim) : float4{0.f, 0.f, 0.f, 0.f};
+            if (mean) {   // de-standardise in the frequency domain (cmd/sample.py:76-78)
+                const float4 s4 = f4(stdv + ire), m4 = f4(mean + ire);
+                re4 = float4{re4.x * s4.x + m4.x, re4.y * s4.y + m4.y, re4.z * s4.z + m4.z, re4.w * s4.w + m4.w};
+                if (has_im) {
+                    const float4 t4 = f4(stdv + iim), n4 = f4(mean + iim);
+                    im4 = float4{im4.x * t4.x + n4.x, im4.y * t4.y + n4.y, im4.z * t4.z + n4.z, im4.w * t4.w + n4.w};
+                }
+            }
+            // (re4, im4) = (Xa, Xb) of two channel pairs; Z = Xa + i Xb at k, both imaginary parts change sign at T - k
+            *reinterpret_cast<float4*>(bufA + m24(kk, Cp) + 2 * q) = float4{re4.x - im4.y, im4.x + re4.y, re4.z - im4.w, im4.z + re4.w};
+            if (has_im)
+                *reinterpret_cast<float4*>(bufA + m24(T - kk, Cp) + 2 * q) = float4{re4.x + im4.y, re4.y - im4.x, re4.z + im4.w, re4.w - im4.z};
+        }
+    } else if (!INVERSE) {
         for (int id = threadIdx.x; id < T * Cp; id += NT) {
             int n, p;
             if (BATCHED) { p = fdiv(id, inv_t); n = id - m24(p, T); } else { n = fdiv(id, inv_cp); p = id - m24(n, Cp); }
@@ -550,7 +582,35 @@ __global__ __launch_bounds__(kMaxBlock) void k_fft(const float* __restrict__ x, 
     auto at = [&](int k) { return INPLACE ? (int)rev[k] : k; };
 
     // ---- store pass
-    if (!INVERSE) {
+    if (!INVERSE && vec4) {
+        for (int id = threadIdx.x; id < n_real * Cq; id += NT) {
+            const int k = fdiv(id, inv_cq), q = id - m24(k, Cq);
+            const int ca = c0 + 4 * q;
+            const float4 zk = *reinterpret_cast<const float4*>(src + m24(at(k), Cp) + 2 * q);
+            const float4 zm = *reinterpret_cast<const float4*>(src + m24(at((k == 0) ? 0 : (T - k)), Cp) + 2 * q);
+            const float h = 0.5f * scale;
+            float4 re4 = {(zk.x + zm.x) * h, (zk.y + zm.y) * h, (zk.z + zm.z) * h, (zk.w + zm.w) * h};      // Xa.re, Xb.re of both pairs
+            float4 im4 = {(zk.y - zm.y) * h, (zm.x - zk.x) * h, (zk.w - zm.w) * h, (zm.z - zk.z) * h};      // Xa.im, Xb.im
+            const bool has_im = (k != 0) && !(even && k == T / 2);   // fourier.py:26-37 drop exact zeros
+            const int ire = m24(k, C) + ca, iim = m24(n_real + k - 1, C) + ca;
+            if (mean) {   // standardise (datamodules.py:61-62)
+                const float4 m4 = f4(mean + ire), s4 = f4(stdv + ire);
+                re4 = float4{(re4.x - m4.x) / s4.x, (re4.y - m4.y) / s4.y, (re4.z - m4.z) / s4.z, (re4.w - m4.w) / s4.w};
+                if (has_im) {
+                    const float4 n4 = f4(mean + iim), t4 = f4(stdv + iim);
+                    im4 = float4{(im4.x - n4.x) / t4.x, (im4.y - n4.y) / t4.y, (im4.z - n4.z) / t4.z, (im4.w - n4.w) / t4.w};
+                }
+            }
+            *reinterpret_cast<float4*>(yb + ire) = re4;
+            if (has_im) *reinterpret_cast<float4*>(yb + iim) = im4;
+        }
+    } else if (INVERSE && vec4) {
+        for (int id = threadIdx.x; id < T * Cq; id += NT) {
+            const int n = fdiv(id, inv_cq), q = id - m24(n, Cq);
+            const float4 z = *reinterpret_cast<const float4*>(src + m24(at(n), Cp) + 2 * q);
+            *reinterpret_cast<float4*>(yb + m24(n, C) + c0 + 4 * q) = float4{z.x * scale, z.y * scale, z.z * scale, z.w * scale};
+        }
+    } else if (!INVERSE) {
         // X_a[k] = (Z[k] + conj Z[T-k]) / 2 ,  X_b[k] = (Z[k] - conj Z[T-k]) / (2i)
         for (int id = threadIdx.x; id < n_real * Cp; id += NT) {
             int k, p;
@@ -784,6 +844,9 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
         plan.resident = ctx->num_cu * wg_per_cu;
         const long long nwg = (long long)ngroups * nchunks;
         plan.vec_ok = (!batched && (C & 1) == 0 && (Cc & 1) == 0 && ((uintptr_t)x & 7) == 0 && ((uintptr_t)y & 7) == 0) ? 1 : 0;
+        const uintptr_t al16 = (uintptr_t)x | (uintptr_t)y | (uintptr_t)mean | (uintptr_t)stdv;
+        static const bool no_vec4 = getenv("FDIFF_FFT_VEC4") && getenv("FDIFF_FFT_VEC4")[0] == '0';
+        if (plan.vec_ok && (C & 3) == 0 && (Cc & 3) == 0 && (al16 & 15) == 0 && !no_vec4) plan.vec_ok = 2;
         const char* e = getenv("FDIFF_FFT_STAGGER");
         plan.stagger = e ? atoi(e) : 0;
         if (nwg < 3LL * plan.resident) plan.stagger = 0;           // short launches: the spread would cost more than it hides
