@@ -795,6 +795,7 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
     const int pairs_2wg = target > fixed ? (int)((target - fixed) / per_pair) : 0;
     // (in place: whole rows in one chunk whenever they fit at all -- that is what this form is selected for)
     if (pairs_2wg >= 4 && pairs_2wg < max_pairs && !(inplace && (C + 1) / 2 <= max_pairs)) max_pairs = pairs_2wg;
+    if (const char* e = getenv("FDIFF_FFT_MAXPAIRS")) max_pairs = std::max(1, std::min(max_pairs, atoi(e)));      // experiments
     int Cc = C;
     if ((C + 1) / 2 > max_pairs) Cc = max_pairs * 2;
     // single-channel sets: Cc consecutive series per workgroup (BATCHED), as many as keep >= 2 workgroups per CU busy,
