@@ -57,6 +57,8 @@ _PROTOS = {
     "fd_localization_metrics": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "fd_frequency_smooth": (C.c_int, [_vp, _vp, C.c_float, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "fd_randn": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vp]),
+    "fd_philox_words": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vp]),
+    "fd_dropout_decisions": (C.c_int, [_vp, _vp, C.c_size_t, C.c_float, C.c_uint64, C.c_uint64, _vp]),
     "fd_prior_sample": (C.c_int, [_vp, C.POINTER(SdeParams), _vp, _vp, C.c_uint64, C.c_uint64, _vp,
                                   C.c_int, C.c_int, C.c_int, _vp]),
     "fd_sde_step": (C.c_int, [_vp, C.POINTER(SdeParams), _vp, _vp, _vp, _vp, C.c_uint64, C.c_uint64,

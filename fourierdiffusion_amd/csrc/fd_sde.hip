@@ -297,6 +297,44 @@ extern "C" int fd_randn(fd_ctx* ctx, float* out, size_t n, uint64_t seed, uint64
     return FD_OK;
 }
 
+// Raw generator output and the dropout decisions derived from it (tests pin both to the oracle's numpy restatement and to the
+// published Philox4x32-10 known-answer vector).
+namespace {
+__global__ __launch_bounds__(kBlock) void k_philox_words(uint32_t* __restrict__ out, size_t n, uint64_t seed, uint64_t offset) {
+    for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const fd_u4 r = fd_philox4x32_10(offset + i, seed);
+        *reinterpret_cast<uint4*>(out + 4 * i) = uint4{r.x, r.y, r.z, r.w};
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_drop16(unsigned short* __restrict__ out, size_t n, uint64_t seed, uint64_t offset,
+                                                    unsigned thr16) {
+    for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+        out[i] = (unsigned short)fd_drop16(offset + i, seed, thr16);
+}
+}  // namespace
+
+extern "C" int fd_philox_words(fd_ctx* ctx, uint32_t* out, size_t n_counters, uint64_t seed, uint64_t offset, void* stream) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, out && n_counters > 0, "fd_philox_words: null output or no counters");
+    hipLaunchKernelGGL(k_philox_words, dim3(grid_for(n_counters, ctx->num_cu)), dim3(kBlock), 0, (hipStream_t)stream, out, n_counters,
+                       seed, offset);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
+extern "C" int fd_dropout_decisions(fd_ctx* ctx, uint16_t* out, size_t n_counters, float p, uint64_t seed, uint64_t offset,
+                                    void* stream) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, out && n_counters > 0, "fd_dropout_decisions: null output or no counters");
+    FD_REQUIRE(ctx, p >= 0.f && p < 1.f, "fd_dropout_decisions: p=%f", p);
+    unsigned thr16 = (unsigned)((double)p * 65536.0 + 0.5);      // (the training path's rounding: fd_train_bf16.hip make_dims)
+    if (p > 0.f && thr16 == 0) thr16 = 1;
+    hipLaunchKernelGGL(k_drop16, dim3(grid_for(n_counters, ctx->num_cu)), dim3(kBlock), 0, (hipStream_t)stream, out, n_counters, seed,
+                       offset, thr16);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
 extern "C" int fd_prior_sample(fd_ctx* ctx, const fd_sde_params* sde, const float* G, const float* z,
                                uint64_t seed, uint64_t offset, float* out, int B, int T, int C, void* stream) {
     if (!ctx) return FD_ERR_ARG;

@@ -116,29 +116,6 @@ __device__ __forceinline__ float row_sum16(float v) {      // over the 16 lanes 
     return v;
 }
 
-// 16 dropout decisions from one Philox4x32-10 evaluation: decision e looks at the 16-bit window at byte offset e of the
-// 128-bit output (wrapping), bit e = (window >= thr16), i.e. kept with probability 1 - thr16 / 65536 exactly as with disjoint
-// 16-bit fields (thr16 = round(p * 65536): p = 0.1 -> 0.100006; the rescale uses the exact keep probability).  Every byte is
-// the HIGH byte of exactly one window, so a decision is settled by its own byte unless that byte equals thr16 >> 8 (1 case in
-// 256), where the neighbouring byte breaks the tie: marginals exact to 2^-16, dependence between neighbours only through
-// those ties.  Half the Philox evaluations of the 8-per-call form (they are the cost of dropout: ~560 issue cycles each,
-// 10 M of them per layer at 16 K tokens).
-__device__ __forceinline__ unsigned drop16(uint64_t ctr, uint64_t seed, unsigned thr16) {
-    const fd_u4 r = fd_philox4x32_10(ctr, seed);
-    const unsigned w[5] = {r.x, r.y, r.z, r.w, r.x};
-    unsigned m = 0u;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned v0 = w[i] & 0xffffu, v1 = (w[i] >> 8) & 0xffffu, v2 = w[i] >> 16;
-        const unsigned v3 = __builtin_amdgcn_alignbit(w[i + 1], w[i], 24) & 0xffffu;
-        m |= (v0 >= thr16 ? 1u : 0u) << (4 * i);
-        m |= (v1 >= thr16 ? 1u : 0u) << (4 * i + 1);
-        m |= (v2 >= thr16 ? 1u : 0u) << (4 * i + 2);
-        m |= (v3 >= thr16 ? 1u : 0u) << (4 * i + 3);
-    }
-    return m;
-}
-
 struct TrDims {
     int B, T, M, D, F, H, hd, NP, KT, NJ, NFT, RBW;   // NFT = 16*DT feature rows of a T-block, RBW = 32*KS1 slots of a row
     float p, keep_scale;
@@ -372,7 +349,7 @@ __global__ __launch_bounds__(256) void k_tr_masks(const TrDims d, const MaskArgs
         else if (i < h2 + p2) { dst = reinterpret_cast<unsigned short*>(a.pmask) + (i - h2); ctr = a.off0 + (unsigned long long)(i - h2); }
         else if (i < h2 + p2 + r2) { dst = reinterpret_cast<unsigned short*>(a.rb1) + (i - h2 - p2); ctr = a.off1 + (unsigned long long)(i - h2 - p2); }
         else { dst = reinterpret_cast<unsigned short*>(a.rb3) + (i - h2 - p2 - r2); ctr = a.off3 + (unsigned long long)(i - h2 - p2 - r2); }
-        *dst = (unsigned short)drop16(ctr, d.seed, d.thr16);
+        *dst = (unsigned short)fd_drop16(ctr, d.seed, d.thr16);
     }
 }
 

@@ -99,6 +99,17 @@ typedef struct fd_sde_params {
 /* Standard normals from the engine's Philox4x32-10 stream: element i of the call uses
  * counter (offset + i/4), key = seed.  Used for the prior, the per-step noise and tests. */
 int fd_randn(fd_ctx* ctx, float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
+/* The generator underneath, for audits and tests: out[4 i .. 4 i + 3] = Philox4x32-10(counter = (offset + i, 0), key = seed)
+ * (Salmon et al., SC'11; the stream torch.randn / nn.Dropout draw from on the reference's CUDA path is the same generator
+ * with another counter layout, so the draws are equal in distribution, not bit for bit: SURVEY 7.2). */
+int fd_philox_words(fd_ctx* ctx, uint32_t* out, size_t n_counters, uint64_t seed, uint64_t offset, void* stream);
+/* The dropout decisions of the bf16 training path (replaces nn.Dropout's masks inside nn.TransformerEncoderLayer,
+ * score_models.py:41-49): out[i] bit e = KEEP decision e of counter offset + i, e = 0..15.  Decision e compares the 16-bit
+ * window at byte offset e of the 128-bit Philox output (little endian, wrapping) with thr16 = round(p * 65536): kept with
+ * probability 1 - thr16 / 65536 exactly; windows overlap in one byte, so neighbours depend on each other only through ties
+ * of the high byte (1 in 256). */
+int fd_dropout_decisions(fd_ctx* ctx, uint16_t* out, size_t n_counters, float p, uint64_t seed, uint64_t offset,
+                         void* stream);
 
 /* replaces SDE.prior_sampling (sde.py:79-87) + VE override (sde.py:125-127):
  *   out = G[t] * z (VE: * sigma_max).  z == NULL -> z drawn on device (seed, offset). */

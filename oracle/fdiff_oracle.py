@@ -546,3 +546,46 @@ def dataset_standardize(X: Array, fourier_transform: bool, X_ref: Optional[Array
     mean = ref.mean(axis=0)                                  # :52
     std = ref.std(axis=0, ddof=1)                            # :53
     return (X - mean) / std, mean, std                       # :61-62
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The engine's counter-based generator (csrc/fd_philox.h) restated for the tests: Philox4x32-10 of Salmon, Moraes, Dror and
+# Shaw, "Parallel random numbers: as easy as 1, 2, 3" (SC'11), constants and round function as published (Random123 v1.14
+# philox.h; the known-answer vectors of its kat_vectors file pin this restatement in tests/test_oracle_golden.py), and the
+# 16-decisions-per-evaluation dropout rule of the bf16 training path (fd_drop16).
+def philox4x32_10(counter: Array, key: Array) -> Array:
+    """counter (..., 4) uint32, key (..., 2) uint32 -> (..., 4) uint32."""
+    c = np.asarray(counter, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    k = np.asarray(key, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (c[..., i].copy() for i in range(4))
+    k0, k1 = k[..., 0].copy(), k[..., 1].copy()
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2                       # 32 x 32 -> 64 bit products (no overflow in uint64)
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & MASK, p1 >> np.uint64(32), p1 & MASK
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+
+
+def engine_philox_words(seed: int, offset: int, n: int) -> Array:
+    """What fd_philox_words writes: counter i = (lo, hi, 0, 0) of the 64-bit value offset + i, key = (lo, hi) of seed."""
+    ctr = (np.uint64(offset) + np.arange(n, dtype=np.uint64))
+    counter = np.stack([ctr & np.uint64(0xFFFFFFFF), ctr >> np.uint64(32), np.zeros(n, np.uint64), np.zeros(n, np.uint64)], axis=-1)
+    key = np.broadcast_to(np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64), (n, 2))
+    return philox4x32_10(counter, key)
+
+
+def dropout_decisions16(words: Array, p: float) -> Array:
+    """fd_drop16: (n, 4) uint32 generator output -> (n,) uint16, bit e = keep decision e: the 16-bit little-endian window at
+    byte offset e of the 128-bit output (wrapping) >= thr16 = round(p * 65536)."""
+    thr16 = int(p * 65536.0 + 0.5)
+    if p > 0 and thr16 == 0:
+        thr16 = 1
+    b = np.ascontiguousarray(words.astype("<u4")).view(np.uint8).reshape(-1, 16).astype(np.uint32)
+    out = np.zeros(b.shape[0], dtype=np.uint32)
+    for e in range(16):
+        window = b[:, e] | (b[:, (e + 1) % 16] << 8)
+        out |= (window >= thr16).astype(np.uint32) << e
+    return out.astype(np.uint16)
+

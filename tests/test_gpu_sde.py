@@ -154,3 +154,32 @@ def test_perturb_and_loss_vs_oracle(lw):
             fd = (O.dsm_loss(score + e, host(target), host(std), lw) -
                   O.dsm_loss(score - e, host(target), host(std), lw)) / 2e-3
             np.testing.assert_allclose(hs[b, k, c], fd, rtol=1e-4, atol=1e-7)
+
+
+def test_generator_and_dropout_decisions_bit_exact_vs_oracle():
+    """Integer work, bit-exact bar: the device Philox4x32-10 (fd_philox_words) equals the oracle's restatement -- which the CPU
+    suite pins to the published known-answer vectors -- for counters that cross the 32-bit boundary, and the 16 dropout
+    decisions per evaluation of the bf16 training path (fd_dropout_decisions) equal the oracle's rule at several p."""
+    import ctypes as C
+
+    import torch
+
+    from fourierdiffusion_amd import _C
+    from oracle import fdiff_oracle as O
+    lib = _C.lib()
+    dev = torch.device("cuda", 0)
+    ctx = _C.ctx(dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    n = 100_003
+    for seed, offset in [(0, 0), (0x1234567890ABCDEF, 0xFFFFFFF0), (0xFFFFFFFFFFFFFFFF, (1 << 40) + 12345)]:
+        words = torch.empty(n, 4, dtype=torch.int32, device=dev)
+        _C.check(lib.fd_philox_words(ctx, words.data_ptr(), n, seed, offset, st), ctx)
+        ref = O.engine_philox_words(seed, offset, n)
+        got = words.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, ref), (seed, offset)
+        for p in (0.1, 0.5, 0.003, 0.9):
+            dec = torch.empty(n, dtype=torch.int16, device=dev)
+            _C.check(lib.fd_dropout_decisions(ctx, dec.data_ptr(), n, C.c_float(p), seed, offset, st), ctx)
+            assert np.array_equal(dec.cpu().numpy().view(np.uint16), O.dropout_decisions16(ref, p)), (seed, offset, p)
+    assert tuple(int(v) for v in O.engine_philox_words(0, 0, 1)[0]) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+

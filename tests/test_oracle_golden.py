@@ -274,3 +274,33 @@ def test_backbone_oracles_match_the_reference_modules(golden):
             X = W.randn(f"bb_x_{kind}_{name}", (B, cfg["T"], cfg["C"]), 5)
             t = W.uniform(f"bb_t_{kind}_{name}", (B,), 5, 0.05, 1.0)
             np.testing.assert_allclose(f(sd, X, t), g[f"fwd_{kind}_{name}"], atol=5e-6, rtol=0)
+
+
+def test_philox4x32_10_known_answers():
+    """The oracle's restatement of the generator against the published known-answer vectors of Philox4x32-10 (Random123
+    kat_vectors: counter, key -> output); the GPU test then holds the engine's device code to this restatement."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = O.philox4x32_10(np.array([ctr], dtype=np.uint64), np.array([key], dtype=np.uint64))[0]
+        assert tuple(int(v) for v in got) == want, (ctr, key, [hex(int(v)) for v in got])
+
+
+def test_dropout_decision_rule_marginals_and_ties():
+    """fd_drop16's rule on the oracle side: 16 decisions per evaluation, keep probability 1 - thr16 / 65536 (p = 0.1: 0.899994),
+    a byte other than thr16 >> 8 settles its decision alone, and neighbouring decisions are uncorrelated to 1e-3."""
+    words = O.engine_philox_words(seed=0x1234567890ABCDEF, offset=7, n=1 << 16)
+    dec = O.dropout_decisions16(words, 0.1)
+    bits = ((dec[:, None].astype(np.uint32) >> np.arange(16)) & 1).astype(np.float64)          # (n, 16)
+    n = bits.size
+    keep = bits.mean()
+    assert abs(keep - (1 - 6554 / 65536)) < 4 * np.sqrt(0.09 / n), keep
+    raw = np.ascontiguousarray(words.astype("<u4")).view(np.uint8).reshape(-1, 16)
+    high = np.roll(raw, -1, axis=1)                                         # window e = byte e | byte e+1 << 8: its high byte
+    clear = high != (6554 >> 8)
+    assert np.array_equal(bits[clear] > 0, high[clear] > (6554 >> 8))       # the high byte alone decides away from the tie value
+    a, b = bits[:, :-1].ravel(), bits[:, 1:].ravel()
+    rho = np.corrcoef(a, b)[0, 1]
+    assert abs(rho) < 5e-3, rho
+
