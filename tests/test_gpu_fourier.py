@@ -177,6 +177,23 @@ def test_single_channel_sets_batched_path(B, T):
     np.testing.assert_allclose(back, x, atol=3e-5, rtol=0)
 
 
+@pytest.mark.parametrize("B,T,C", [(5, 256, 28), (3, 1024, 16), (7, 100, 12), (4, 252, 8), (6, 255, 4), (3, 64, 40)])
+def test_sixteen_byte_passes_with_standardisation(B, T, C):
+    """C % 4 == 0: the load / store passes move two channel pairs per 16-byte access, also through the (T, C) mean / std tables
+    of the fused standardise variants (in place for radix-16 lengths, autosort otherwise): parity with the oracle, both ways."""
+    from fourierdiffusion_amd.utils.fourier import destandardize_idft, dft, dft_standardize, idft
+    x = W.randn("v4_x", (B, T, C), 31)
+    xt = W.randn("v4_xt", (B, T, C), 32)
+    mean = W.randn("v4_m", (T, C), 33)
+    std = np.abs(W.randn("v4_s", (T, C), 34)) + 0.5
+    np.testing.assert_allclose(host(dft(dev(x))), O.dft(x), atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(idft(dev(xt))), O.idft(xt), atol=ATOL, rtol=0)
+    got = host(dft_standardize(dev(x), dev(mean), dev(std)))
+    np.testing.assert_allclose(got, (O.dft(x) - mean) / std, atol=3e-5, rtol=0)
+    back = host(destandardize_idft(dev(xt), dev(mean), dev(std)))
+    np.testing.assert_allclose(back, O.idft(xt * std + mean), atol=3e-5, rtol=0)
+
+
 def test_multichannel_smoothing_across_scratch_chunks():
     """(4096, 255, 28): the mixing runs as transpose -> fp32-MFMA GEMM -> transpose over chunks of series sized by the context's
     GEMM scratch (2 chunks here); series on both sides of the chunk boundary match the oracle."""
