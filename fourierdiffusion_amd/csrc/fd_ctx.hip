@@ -97,7 +97,15 @@ extern "C" int fd_prof_begin(fd_ctx* ctx) {
     }
     ctx->prof_events.clear();
     ctx->prof_kernels.clear();
+    ctx->prof_stride = 1;
     ctx->prof_on = true;
+    return FD_OK;
+}
+
+extern "C" int fd_prof_stride(fd_ctx* ctx, int every) {
+    if (!ctx) return FD_ERR_ARG;
+    FD_REQUIRE(ctx, every >= 1, "fd_prof_stride: every=%d", every);
+    ctx->prof_stride = every;
     return FD_OK;
 }
 

@@ -54,6 +54,9 @@ size_t fd_ctx_workspace_bytes(fd_ctx* ctx);
  * the kernel name, the average launch duration, the launch count and the ALGORITHMIC flops of one launch
  * (SURVEY.md 8d formula x series x diffusion steps in the launch; padding flops are not counted). */
 int fd_prof_begin(fd_ctx* ctx);
+/* after fd_prof_begin: bracket only every `every`-th launch of each kernel (an event pair costs the stream ~5 us; the
+ * training step launches its bracketed kernels 20 times) */
+int fd_prof_stride(fd_ctx* ctx, int every);
 int fd_prof_end(fd_ctx* ctx, char* name_out /* >= 128 bytes */, double* avg_us, int* launches,
                 double* flops_per_launch);
 
