@@ -709,7 +709,9 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         const unsigned char* srcb = a.hkeep + ((size_t)m * 4 + g) * (2 * NS) + fhw * NS;
         for (int c = 0; c < NS; c += 16) *reinterpret_cast<u32x4*>(actB + lane * NS + c) = *reinterpret_cast<const u32x4*>(srcb + c);
     } else {
-        for (int c = 0; c < NS; c += 16) *reinterpret_cast<u32x4*>(actB + lane * NS + c) = u32x4{~0u, ~0u, ~0u, ~0u};
+        // (no dropout: every unit kept; a token beyond M: nothing kept, so the chunk loop needs no validity test)
+        const unsigned fill = valid ? ~0u : 0u;
+        for (int c = 0; c < NS; c += 16) *reinterpret_cast<u32x4*>(actB + lane * NS + c) = u32x4{fill, fill, fill, fill};
     }
     unsigned bits3[DT];
     row_drop_bits<DT>(d, a.rb3, m, valid, g, bits3);
@@ -718,32 +720,53 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f4zero();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // ---- FFN: this wave's F-half, hidden in registers
-    for (int c = 0; c < NS; ++c) {
+    // ---- FFN: this wave's F-half, hidden in registers.  A step's W1 / W2 fragments are read from the ring into registers
+    // during the PREVIOUS step (its buffer became visible one barrier earlier: the wait below leaves only the newest DMA batch
+    // in flight), so no LDS round trip sits between the barrier and the step's MFMAs (five of them per step before: the
+    // wave's time was its stalls, not its instruction count -- 14 % fewer instructions changed nothing).  Two steps per
+    // trip = two register sets, the read for the step after the last one is clamped (no branch, no copies at the back edge).
+    unsigned bits_cur = 0u;
+    auto frags = [&](int c, bf16x8 (&w1)[2 * KS1], bf16x8 (&w2)[DT]) {
+        const int cc = c < NS ? c : NS - 1;
+        const char* wb = ring + (cc % NBUF) * WB + fhw * NB * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 2 * KS1; ++i) w1[i] = *reinterpret_cast<const bf16x8*>(wb + i * 1024);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) w2[dt] = *reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024);
+    };
+    auto step = [&](int c, const bf16x8 (&w1)[2 * KS1], const bf16x8 (&w2)[DT], bf16x8 (&n1)[2 * KS1], bf16x8 (&n2)[DT]) {
         if (c + 3 < NS) issue(c + 3);
-        const char* wb = ring + (c % NBUF) * WB + fhw * NB * 1024 + lane * 16;
+        frags(c + 1, n1, n2);
         f32x4 h0 = f4zero(), h1 = f4zero();
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
-            h0 = MFMA(*reinterpret_cast<const bf16x8*>(wb + ks * 1024), xf[ks], h0);
-            h1 = MFMA(*reinterpret_cast<const bf16x8*>(wb + (KS1 + ks) * 1024), xf[ks], h1);
+            h0 = MFMA(w1[ks], xf[ks], h0);
+            h1 = MFMA(w1[KS1 + ks], xf[ks], h1);
         }
         int ce = c + rot;
         ce -= (ce >= NS) ? NS : 0;
-        const unsigned bits = actB[lane * NS + ce];               // dropout decisions of this chunk (staged before the loop)
+        int cn = ce + 1;                                           // next step's chunk (clamped read after the last step)
+        cn -= (cn >= NS) ? NS : 0;
+        const unsigned bits = bits_cur;                            // dropout decisions of this chunk (staged before the loop),
+        bits_cur = actB[lane * NS + cn];                           // read one step ahead like the fragments
         unsigned act = 0u;
         unsigned long long bal[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool k0 = valid && ((bits >> r) & 1u) && h0[r] > 0.f, k1 = valid && ((bits >> (4 + r)) & 1u) && h1[r] > 0.f;
-            act |= (k0 ? 1u : 0u) << r;
-            act |= (k1 ? 1u : 0u) << (4 + r);
-            h0[r] = k0 ? h0[r] * d.keep_scale : 0.f;
-            h1[r] = k1 ? h1[r] * d.keep_scale : 0.f;
+            // branch-free (bitwise & on the two tests; the staged byte is 0 for tokens beyond M): the `valid && .. && ..` form
+            // made hipcc wrap every register's tests in exec-mask save / restore pairs -- 90 SALU instructions per step in a
+            // loop whose waves are bound by their own instruction count (two per SIMD, 40 % of their cycles waiting)
+            const bool p0 = h0[r] > 0.f, b0 = (bits & (1u << r)) != 0u, p1 = h1[r] > 0.f, b1 = (bits & (16u << r)) != 0u;
+            const bool k0 = p0 & b0, k1 = p1 & b1;
+            act |= k0 ? (1u << r) : 0u;
+            act |= k1 ? (16u << r) : 0u;
+            h0[r] = k0 ? h0[r] : 0.f;                 // (the keep scale is applied once to the accumulators after the loop)
+            h1[r] = k1 ? h1[r] : 0.f;
             // the same decisions with the 16 tokens of the tile as the bits of one word per hidden unit (weight-gradient
             // kernel): ballot bit 16 g + tok of register r <-> hidden unit 4 g + r (+16 for the second tile)
-            bal[r] = __builtin_amdgcn_ballot_w64(k0);
-            bal[4 + r] = __builtin_amdgcn_ballot_w64(k1);
+            // (ballot of each test, combined on the scalar unit: the ballot of the combined bool goes through a 0 / 1 VGPR)
+            bal[r] = __builtin_amdgcn_ballot_w64(p0) & __builtin_amdgcn_ballot_w64(b0);
+            bal[4 + r] = __builtin_amdgcn_ballot_w64(p1) & __builtin_amdgcn_ballot_w64(b1);
         }
         if (lane == 0) {
 #pragma unroll
@@ -752,11 +775,20 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         actB[lane * NS + ce] = (unsigned char)act;
         const bf16x8 hb = pack8(h0, h1);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(*reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024), hb, acc[dt]);
-        if (c + 3 < NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(w2[dt], hb, acc[dt]);
+        if (c + 3 < NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this step's LDS reads are done before the buffer may be refilled
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the prefetch reads and this step's LDS writes are done
         __builtin_amdgcn_s_barrier();
+    };
+    {
+        bf16x8 wa1[2 * KS1], wa2[DT], wb1[2 * KS1], wb2[DT];
+        frags(0, wa1, wa2);
+        bits_cur = actB[lane * NS + rot];
+        for (int c = 0; c < NS; c += 2) {        // (NS = F / 64 is even: F % 1024 == 0)
+            step(c, wa1, wa2, wb1, wb2);
+            step(c + 1, wb1, wb2, wa1, wa2);
+        }
     }
     if (owner) {
         const int m0w = (blockIdx.x * 4 + tile) * 16;
@@ -788,7 +820,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     __syncthreads();
     if (!owner) return;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) acc[dt] += xch[(tile * DT + dt) * 64 + lane];
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = (acc[dt] + xch[(tile * DT + dt) * 64 + lane]) * d.keep_scale;      // hidden-unit keep scale
     {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
