@@ -1014,35 +1014,59 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f4zero();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // ---- d x1 += W1^T (active . W2^T d f) over this wave's F-half: d hidden lives in registers only
-    for (int c = 0; c < NS; ++c) {
+    // ---- d x1 += W1^T (active . W2^T d f) over this wave's F-half: d hidden lives in registers only.  As in k_tr_ffn_fwd the
+    // fragments and the activity byte of a chunk are read one step ahead (two register sets, two steps per trip); the keep
+    // scale of the hidden units is applied once to the accumulators behind the loop.
+    unsigned act_cur = 0u;
+    auto frags = [&](int c, bf16x8 (&w1)[2 * KS1], bf16x8 (&w2)[DT]) {
+        const int cc = c < NS ? c : NS - 1;
+        const char* wb = ring + (cc % NBUF) * WB + fhw * NB * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 2 * KS1; ++i) w1[i] = *reinterpret_cast<const bf16x8*>(wb + i * 1024);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) w2[dt] = *reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024);
+    };
+    auto step = [&](int c, const bf16x8 (&w1)[2 * KS1], const bf16x8 (&w2)[DT], bf16x8 (&n1)[2 * KS1], bf16x8 (&n2)[DT]) {
 #ifndef FD_TR_ABL_NODMA
         if (c + 3 < NS) issue(c + 3);
 #endif
-        const char* wb = ring + (c % NBUF) * WB + fhw * NB * 1024 + lane * 16;
+        frags(c + 1, n1, n2);
         f32x4 h0 = f4zero(), h1 = f4zero();
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
-            h0 = MFMA(*reinterpret_cast<const bf16x8*>(wb + ks * 1024), dfr[ks], h0);
-            h1 = MFMA(*reinterpret_cast<const bf16x8*>(wb + (KS1 + ks) * 1024), dfr[ks], h1);
+            h0 = MFMA(w1[ks], dfr[ks], h0);
+            h1 = MFMA(w1[KS1 + ks], dfr[ks], h1);
         }
-        int ce = c + rot;
-        ce -= (ce >= NS) ? NS : 0;
-        const unsigned act = actB[lane * NS + ce];
+        int cn = c + 1 + rot;
+        cn -= (cn >= NS) ? NS : 0;
+        cn -= (cn >= NS) ? NS : 0;                    // (c + 1 == NS: the clamped read of the step after the last)
+        const unsigned act = act_cur;
+        act_cur = actB[lane * NS + cn];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            h0[r] = ((act >> r) & 1u) ? h0[r] * d.keep_scale : 0.f;
-            h1[r] = ((act >> (4 + r)) & 1u) ? h1[r] * d.keep_scale : 0.f;
+            h0[r] = (act & (1u << r)) ? h0[r] : 0.f;
+            h1[r] = (act & (16u << r)) ? h1[r] : 0.f;
         }
         const bf16x8 hb = pack8(h0, h1);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(*reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024), hb, acc[dt]);
-        if (c + 3 < NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(w2[dt], hb, acc[dt]);
+        if (c + 3 < NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xc07f);
 #ifndef FD_TR_ABL_NOBAR
         __builtin_amdgcn_s_barrier();
 #endif
+    };
+    {
+        bf16x8 wa1[2 * KS1], wa2[DT], wb1[2 * KS1], wb2[DT];
+        frags(0, wa1, wa2);
+        act_cur = actB[lane * NS + rot];
+        for (int c = 0; c < NS; c += 2) {        // (NS = F / 64 is even: F % 1024 == 0)
+            step(c, wa1, wa2, wb1, wb2);
+            step(c + 1, wb1, wb2, wa1, wa2);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[dt] *= d.keep_scale;
     }
     __syncthreads();
     if (!owner) {
