@@ -34,6 +34,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte access at a dword-aligned address
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -635,8 +636,15 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
 #pragma unroll
         for (int ks = 0; ks < KSO; ++ks) {
             const int head = 4 * ks + g, hc = head < d.H ? head : d.H - 1;
+            // the head's 8 dim slots as two dword-aligned 16-byte loads (eight scalar loads per (token, head): every one of the 24
+            // instructions walked 64 different cache lines -- issuing them took 6.7 K clocks of a 29 K-clock prologue); slots
+            // >= head_dim belong to the next head / row (16 bytes of slack behind the buffer) and are zeroed below
+            {
+                const f32x4_a4* p8 = reinterpret_cast<const f32x4_a4*>(a.att + (size_t)mc * D + hc * d.hd);
+                const f32x4_a4 lo = p8[0], hi = p8[1];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) e8[ks][e] = a.att[(size_t)mc * D + hc * d.hd + (e < d.hd ? e : 0)];
+                for (int e = 0; e < 4; ++e) { e8[ks][e] = lo[e]; e8[ks][4 + e] = hi[e]; }
+            }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
                 wof[dt][ks] = *reinterpret_cast<const bf16x8*>(a.wo_img + ((size_t)(dt * KSO + ks) * 64 + lane) * 16);
@@ -1837,7 +1845,7 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
     for (size_t l = 0; l < L; ++l) {
         TrLayerBufs& b = tb.layers[l];
         b.x0 = (float*)take(sizeof(float) * M * D);
-        b.att = (float*)take(sizeof(float) * M * D);
+        b.att = (float*)take(sizeof(float) * M * D + 16);      // (+16: k_tr_ffn_fwd reads whole 8-slot head groups)
         b.s1 = (float*)take(sizeof(float) * M * D);
         b.s2 = (float*)take(sizeof(float) * M * D);
         b.lse2 = (float*)take(sizeof(float) * B * H * T);
