@@ -348,10 +348,22 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
 #pragma unroll
             for (int ks = 0; ks < KSO; ++ks) {
                 const int head = 4 * ks + g;               // k-slot group g of k-step ks = the 8 (padded) dims of one head
+                // the head's 8 dim slots as two dword-aligned 16-byte loads from a clamped address, selected afterwards (eight
+                // conditional scalar loads per (token, head) were eight divergent branches and eight instructions that each walk
+                // 64 cache lines; slots >= head_dim read the next head / row: the buffer is followed by `tmp` in the arena)
                 float v[8];
+                {
+                    typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                    const int mc = valid ? m : m_wg, hc = head < pre.H ? head : pre.H - 1;
+                    const f32x4_a4* p8 = reinterpret_cast<const f32x4_a4*>(pre.att + (size_t)mc * D + hc * pre.hd);
+                    const f32x4_a4 lo = p8[0], hi = p8[1];
+                    const bool ok = valid && head < pre.H;
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    v[e] = (valid && head < pre.H && e < pre.hd) ? pre.att[(size_t)m * D + head * pre.hd + e] : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (ok && e < pre.hd) ? lo[e] : 0.f;
+                        v[4 + e] = (ok && 4 + e < pre.hd) ? hi[e] : 0.f;
+                    }
+                }
                 u32x4 pk;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pk[e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);

@@ -35,6 +35,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte access at a dword-aligned address
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -548,14 +549,20 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
         const float inv = d.keep_scale * __builtin_amdgcn_rcpf(lmine);     // (v_rcp_f32, 1 ulp; the product is rounded to bf16)
         const int m = b * T + t;
         if (t < T && myhead < H) {
+            float ov[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (lo_grp ? o2[0][r] : o2[1][r]) * inv;
+            // row form: the lane's dims as one 16- or 8-byte store where head_dim allows (four scalar stores otherwise)
+            float* orow = a.att + (size_t)m * D + myhead * hd + 4 * (g & 1);
+            const int nv = min(4, max(0, hd - 4 * (g & 1)));
+            if (nv == 4) *reinterpret_cast<f32x4_a4*>(orow) = f32x4_a4{ov[0], ov[1], ov[2], ov[3]};
+            else if (nv == 2) *reinterpret_cast<f32x2_a4*>(orow) = f32x2_a4{ov[0], ov[1]};
+            else
+                for (int r = 0; r < nv; ++r) orow[r] = ov[r];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int dd = 4 * (g & 1) + r;
-                if (dd < hd) {
-                    const float o = (lo_grp ? o2[0][r] : o2[1][r]) * inv;
-                    a.att[(size_t)m * D + myhead * hd + dd] = o;
-                    a.attT[((size_t)(m >> 5) * d.NFT + myhead * hd + dd) * 32 + (m & 31)] = (__bf16)o;
-                }
+                if (dd < hd) a.attT[((size_t)(m >> 5) * d.NFT + myhead * hd + dd) * 32 + (m & 31)] = (__bf16)ov[r];
             }
             if ((g & 1) == 0) a.lse2[((size_t)b * H + myhead) * T + t] = mmine + __builtin_amdgcn_logf(lmine);
         }
@@ -1216,14 +1223,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
             const int t = kt * 16 + tok, mm = b * T + t;
             f32x4 dor = f4zero();
             float part = 0.f;
-            if (t < T && myhead < H) {
+            {
+                // the lane's four dims as one dword-aligned 16-byte load per tensor from a clamped address, selected afterwards
+                // (conditional scalar loads: a divergent branch and eight instructions that each walk 64 cache lines); dims >=
+                // head_dim read the next head / row (the buffers are followed by others in the arena)
+                const bool ok = t < T && myhead < H;
+                const size_t off = (size_t)(ok ? mm : b * T) * D + (ok ? myhead : 0) * hd + 4 * (g & 1);
+                const f32x4_a4 dv = *reinterpret_cast<const f32x4_a4*>(a.datt + off);
+                const f32x4_a4 av = *reinterpret_cast<const f32x4_a4*>(a.att + off);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int dd = 4 * (g & 1) + r;
-                    if (dd < hd) {
-                        dor[r] = a.datt[(size_t)mm * D + myhead * hd + dd];
-                        part += dor[r] * a.att[(size_t)mm * D + myhead * hd + dd];
-                    }
+                    const bool use = ok && 4 * (g & 1) + r < hd;
+                    dor[r] = use ? dv[r] : 0.f;
+                    part += use ? dv[r] * av[r] : 0.f;
                 }
             }
             *reinterpret_cast<s16x4*>(oR + ro) = pack4(dor);
