@@ -1829,7 +1829,9 @@ constexpr size_t kSkpFloats = (size_t)1 << 20;
 // least 6 blocks per split so that the per-workgroup prologue (64 KiB of weight fragments) stays amortised.
 int tr_TS(const fd_score* m, int B) {
     const long long nblk = ((long long)B * m->d.max_len + 31) / 32;
-    int ts = (int)std::min<long long>(16, std::max<long long>(1, nblk / 6));
+    // (20 splits = 400 workgroups since the chain kernels got faster: 2.67 -> 2.61 ms per step at 16 128 tokens against 16;
+    // 18 / 22 / 24: 2.62 / 2.62 / 2.64)
+    int ts = (int)std::min<long long>(20, std::max<long long>(1, nblk / 6));
     if (const char* e = getenv("FDIFF_TR_TS")) ts = std::max(1, std::min(kMaxTS, atoi(e)));     // experiments
     return ts;
 }
