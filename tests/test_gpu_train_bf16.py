@@ -192,6 +192,41 @@ def test_fused_training_call_equals_forward_loss_backward(shape, lw):
     _log(f"[parity] fused train call vs three calls {shape} lw={lw}: loss rel {abs(lf - lt) / abs(lt):.2e}, worst tensor max-err/max {worst:.2e}")
 
 
+def test_fused_training_call_overwrite_mode_through_the_c_abi():
+    """fd_score_train_dsm with accumulate = 0 (a C-ABI caller that does not zero its gradient buffer): bit-identical to
+    accumulate = 1 on a zeroed buffer, whatever the buffer held before; same Philox key."""
+    import ctypes as C
+
+    from fourierdiffusion_amd import _C
+    cfg = dict(T=100, C=12, D=72, L=2, H=12)
+    B = 6
+    m, sch, _ = make_model(cfg, precision="bf16")
+    m.train()
+    ctx, h = m._engine()
+    assert m.train_mode_effective == "bf16"
+    lib = _C.lib()
+    X = dev(W.randn("ow_x", (B, cfg["T"], cfg["C"]), 9))
+    t = dev(W.uniform("ow_t", (B,), 9, 0.05, 1.0))
+    z = dev(W.randn("ow_z", (B, cfg["T"], cfg["C"]), 9))
+    xn, target, std = sch.perturb(X, t, noise=z)
+    out = []
+    for acc, fill in ((1, 0.0), (0, 123.0)):
+        grads = torch.full_like(m.flat_parameters, fill)
+        loss = torch.empty(1, device=DEV)
+        rc = lib.fd_score_train_dsm(h, xn.data_ptr(), t.data_ptr(), target.data_ptr(), std.data_ptr(), 0, C.c_float(1.0), B,
+                                    C.c_float(0.1), 4242, 17, loss.data_ptr(), grads.data_ptr(), acc,
+                                    torch.cuda.current_stream(DEV).cuda_stream)
+        _C.check(rc, ctx)
+        out.append((loss.item(), grads.clone()))
+    assert out[0][0] == out[1][0]
+    frozen = [(off, numel) for name, off, numel, shp, _ in m._layout if name.startswith("time_encoder.W")]
+    g1 = out[1][1].clone()
+    for off, numel in frozen:                       # (requires_grad = False: its slot is cleared, not computed)
+        assert float(g1[off:off + numel].abs().max()) == 0.0
+    assert torch.equal(out[0][1], g1)
+    assert float(g1.abs().max()) > 0
+
+
 def test_dropout_forward_backward_consistency_bf16():
     """dropout p=0.1 in the bf16 path: the stored keep bits are what the backward uses.  grad . v against a central
     difference of the (bf16) loss along a random direction, same Philox key: 10 % tolerance (bf16 forward noise)."""
