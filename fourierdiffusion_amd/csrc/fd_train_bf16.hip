@@ -1180,7 +1180,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
     const int PMH = T * NJ * 4;                                  // bytes per head
     const size_t pstride = (size_t)KS1 * 1024;
     auto wfrag = [&](const char* img, int ks) { return *reinterpret_cast<const bf16x8*>(img + pair * pstride + ((size_t)ks * 64 + lane) * 16); };
-    auto xfrag = [&](int tile, int ks) { const int t = tile * 16 + tok; return row_frag(a.x0rb, b * T + t, t < T, d.RBW, ks, g); };
     const bool lo_grp = (g >> 1) == 0;
     const int myhead = 2 * pair + (g >> 1);
     if (d.p > 0.f) {
@@ -1197,11 +1196,41 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
         bf16x8 wqf[KS1], wkf[KS1], wvf[KS1];
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) { wqf[ks] = wfrag(a.wq, ks); wkf[ks] = wfrag(a.wk, ks); wvf[ks] = wfrag(a.wv, ks); }
+        // Every global operand of a tile (x rows, dO / O rows, lse, the dO column values) is requested one tile ahead, from clamped
+        // addresses without branches: a tile was load -> wait -> 15 MFMAs -> load -> wait ..., 8 K clocks each with two tiles
+        // per wave (in-kernel clocks: staging 16 K of a 70 K-clock workgroup).
+        auto fetch = [&](int kt, bf16x8 (&xf)[KS1], f32x4_a4& dv, f32x4_a4& av, float& ls, f32x4& doc) {
+            const int t = kt * 16 + tok, tc = t < T ? t : T - 1;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks)
+                xf[ks] = *reinterpret_cast<const bf16x8*>(a.x0rb + (size_t)(b * T + tc) * d.RBW + 32 * ks + 8 * g);
+            const int hc = myhead < H ? myhead : H - 1;
+            const size_t off = (size_t)(b * T + tc) * D + hc * hd + 4 * (g & 1);
+            dv = *reinterpret_cast<const f32x4_a4*>(a.datt + off);
+            av = *reinterpret_cast<const f32x4_a4*>(a.att + off);
+            ls = a.lse2[((size_t)b * H + hc) * T + tc];
+            const int hs = tok >> 3, dd = tok & 7, head = min(2 * pair + hs, H - 1), ddc = dd < hd ? dd : hd - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tt = min(kt * 16 + 4 * g + r, T - 1);
+                doc[r] = a.datt[((size_t)b * T + tt) * D + head * hd + ddc];
+            }
+        };
+        bf16x8 cxf[KS1], nxf[KS1];
+        f32x4_a4 cdv, cav, ndv, nav;
+        float cls = 0.f, nls = 0.f;
+        f32x4 cdoc = f4zero(), ndoc = f4zero();
+        if (wave < KT) fetch(wave, cxf, cdv, cav, cls, cdoc);
         for (int kt = wave; kt < KT; kt += NW) {
+            fetch(kt + NW < KT ? kt + NW : kt, nxf, ndv, nav, nls, ndoc);
             f32x4 qr = f4zero(), kr = f4zero(), vr = f4zero(), qc = f4zero(), kc = f4zero();
+            const int t = kt * 16 + tok, mm = b * T + t;
+            (void)mm;
+            const bool tv = t < T;
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
-                const bf16x8 xf = xfrag(kt, ks);
+                const u32x4 raw = __builtin_bit_cast(u32x4, cxf[ks]);
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, u32x4{tv ? raw[0] : 0u, tv ? raw[1] : 0u, tv ? raw[2] : 0u, tv ? raw[3] : 0u});
                 qr = MFMA(wqf[ks], xf, qr);       // [dim rows][token col] -> row form
                 kr = MFMA(wkf[ks], xf, kr);
                 vr = MFMA(wvf[ks], xf, vr);
@@ -1219,24 +1248,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
                 *reinterpret_cast<u32x2*>(qC + co + 8) = u32x2{0u, 0u};
                 *reinterpret_cast<u32x2*>(kC + co + 8) = u32x2{0u, 0u};
             }
-            // dO rows and rowsum(dO . O) of this lane's head (4 of its dims per lane, the lane pair g, g^1 holds all 8)
-            const int t = kt * 16 + tok, mm = b * T + t;
+            // dO rows and rowsum(dO . O) of this lane's head (4 of its dims per lane, the lane pair g, g^1 holds all 8); dims >=
+            // head_dim were read from the next head / row (the buffers are followed by others in the arena) and are dropped
             f32x4 dor = f4zero();
             float part = 0.f;
-            {
-                // the lane's four dims as one dword-aligned 16-byte load per tensor from a clamped address, selected afterwards
-                // (conditional scalar loads: a divergent branch and eight instructions that each walk 64 cache lines); dims >=
-                // head_dim read the next head / row (the buffers are followed by others in the arena)
-                const bool ok = t < T && myhead < H;
-                const size_t off = (size_t)(ok ? mm : b * T) * D + (ok ? myhead : 0) * hd + 4 * (g & 1);
-                const f32x4_a4 dv = *reinterpret_cast<const f32x4_a4*>(a.datt + off);
-                const f32x4_a4 av = *reinterpret_cast<const f32x4_a4*>(a.att + off);
+            const bool ok = tv && myhead < H;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool use = ok && 4 * (g & 1) + r < hd;
-                    dor[r] = use ? dv[r] : 0.f;
-                    part += use ? dv[r] * av[r] : 0.f;
-                }
+            for (int r = 0; r < 4; ++r) {
+                const bool use = ok && 4 * (g & 1) + r < hd;
+                dor[r] = use ? cdv[r] : 0.f;
+                part += use ? cdv[r] * cav[r] : 0.f;
             }
             *reinterpret_cast<s16x4*>(oR + ro) = pack4(dor);
             float ea, eb;
@@ -1245,7 +1266,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
                 drow[(g >> 1) * NTOK + kt * 16 + tok] = ea + eb;
                 // padded queries / a missing odd head: lse = +1e30 makes every P = exp2(s - lse) of that row exactly 0, so the
                 // sweeps need no validity selects (padded KEYS have all-zero K / V / dO operands instead)
-                lse[(g >> 1) * NTOK + kt * 16 + tok] = (t < T && myhead < H) ? a.lse2[((size_t)b * H + myhead) * T + t] : 1.0e30f;
+                lse[(g >> 1) * NTOK + kt * 16 + tok] = ok ? cls : 1.0e30f;
             }
             // dO column form: lane (dim row = tok, g) holds tokens 4g+r of this tile
             {
@@ -1254,11 +1275,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int tt = kt * 16 + 4 * g + r;
-                    if (tt < T && head < H && dd < hd) doc[r] = a.datt[((size_t)b * T + tt) * D + head * hd + dd];
+                    doc[r] = (tt < T && head < H && dd < hd) ? cdoc[r] : 0.f;
                 }
                 *reinterpret_cast<s16x4*>(oC + co) = pack4(doc);
                 if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(oC + co + 8) = u32x2{0u, 0u};
             }
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) cxf[ks] = nxf[ks];
+            cdv = ndv; cav = nav; cls = nls; cdoc = ndoc;
         }
     }
     __syncthreads();
