@@ -1187,8 +1187,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
             const int head = 2 * pair + hs;
             if (head >= H) continue;
             const unsigned char* src = a.pmask + ((size_t)b * H + head) * PMH;        // contiguous per (series, head)
-            for (int i = threadIdx.x * 4; i < PMH; i += NW * 64 * 4)                       // PMH is a multiple of 4
-                *reinterpret_cast<unsigned*>(pm + hs * PMH + i) = *reinterpret_cast<const unsigned*>(src + i);
+            if ((PMH & 1023) == 0 || (PMH & 15) == 0) {
+                // straight into the LDS (1 KiB per wave and instruction, no registers, nothing waits here: the copy runs under
+                // the staging below and is awaited in front of its barrier; it was 3.5 K clocks of a 70 K-clock workgroup)
+                const int nkib = PMH >> 10;
+                for (int c = wave; c < nkib; c += NW)
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(src + (size_t)c * 1024 + lane * 16), LDS_PTR(pm + hs * PMH + c * 1024), 16, 0, 0);
+                for (int i = nkib * 1024 + threadIdx.x * 16; i < PMH; i += NW * 64 * 16)      // the last partial KiB
+                    *reinterpret_cast<u32x4*>(pm + hs * PMH + i) = *reinterpret_cast<const u32x4*>(src + i);
+            } else {
+                for (int i = threadIdx.x * 4; i < PMH; i += NW * 64 * 4)                   // PMH is a multiple of 4
+                    *reinterpret_cast<unsigned*>(pm + hs * PMH + i) = *reinterpret_cast<const unsigned*>(src + i);
+            }
         }
     }
     // ---- stage q, k, v (recomputed), dO, rowsum(dO.O), lse
@@ -1285,6 +1295,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
             cdv = ndv; cav = nav; cls = nls; cdoc = ndoc;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the keep-bit DMA)
     __syncthreads();
     auto rfrag = [&](const char* base, int tile) { return *reinterpret_cast<const s16x4*>(base + ((size_t)(tile * 16 + tok) * 4 + g) * 8); };
     auto cfrag = [&](const char* base, int jb) { return *reinterpret_cast<const bf16x8*>(base + ((size_t)(jb * 4 + g) * 16 + tok) * 16); };
