@@ -12,6 +12,32 @@ __global__ __launch_bounds__(256) void k_fill(float* __restrict__ p, int n, floa
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
 }
+// t vectors of ALL steps in one launch: p[i*B + b] = ts[i]  (one k_fill launch per diffusion step was 4.5 us of a 1.5 ms step
+// at T = 1024, and one more launch boundary between the SDE step and the next time embedding)
+__global__ __launch_bounds__(256) void k_fill_steps(float* __restrict__ p, const float* __restrict__ ts, int B, size_t n) {
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i < n) p[i] = ts[i / B];
+}
+constexpr size_t kMaxStepTable = (size_t)16 << 20;     // floats: beyond this (n_steps * B) the t vector is refilled every step
+
+// reserves `fwd + own` (+ the step table) and returns the t vector of step 0 and its stride between steps (0: refill per step)
+int step_table(fd_ctx* ctx, size_t fwd, size_t own, const float* timesteps, int n_steps, int B, hipStream_t s, float** tvec,
+               size_t* stride) {
+    const size_t nt = (size_t)n_steps * B;
+    const bool table = nt <= kMaxStepTable && !getenv("FDIFF_SAMPLER_FILL_PER_STEP");
+    const size_t extra = table ? fd_ws::padded(nt * sizeof(float)) + fd_ws::padded((size_t)n_steps * sizeof(float))
+                               : fd_ws::padded((size_t)B * sizeof(float));
+    if (int rc = fd_ws_reserve(ctx, fwd + own + extra)) return rc;
+    *tvec = (float*)((char*)ctx->ws + fwd + own);
+    *stride = table ? (size_t)B : 0;
+    if (table) {
+        float* ts = (float*)((char*)*tvec + fd_ws::padded(nt * sizeof(float)));
+        // pageable source: the runtime stages the copy before returning
+        FD_HIP(ctx, hipMemcpyAsync(ts, timesteps, (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_fill_steps, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, *tvec, ts, B, nt);
+    }
+    return FD_OK;
+}
 }  // namespace
 
 int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, const float* timesteps, int n_steps,
@@ -38,13 +64,15 @@ extern "C" int fd_sampler_run(fd_score* m, const fd_sde_params* sde, const float
     const int T = m->d.max_len, C = m->d.n_channels;
     const size_t n = (size_t)B * T * C;
     const size_t fwd = (m->backbone != FD_BACKBONE_TRANSFORMER) ? fd_bb_workspace(m, B, false) : fd_score_f32_workspace(m, B, false);
-    const size_t own = fd_ws::padded(n * sizeof(float)) + fd_ws::padded((size_t)B * sizeof(float));
-    if (int rc = fd_ws_reserve(ctx, fwd + own)) return rc;
+    const size_t own = fd_ws::padded(n * sizeof(float));
+    float* tvec0 = nullptr;
+    size_t tstride = 0;
+    if (int rc = step_table(ctx, fwd, own, timesteps, n_steps, B, s, &tvec0, &tstride)) return rc;
     float* score = (float*)((char*)ctx->ws + fwd);
-    float* tvec = (float*)((char*)score + fd_ws::padded(n * sizeof(float)));
     const uint64_t per_step = (uint64_t)((n + 3) / 4);
     for (int i = 0; i < n_steps; ++i) {
-        hipLaunchKernelGGL(k_fill, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, timesteps[i]);
+        float* tvec = tvec0 + (size_t)i * tstride;
+        if (!tstride) hipLaunchKernelGGL(k_fill, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, timesteps[i]);
         const int rc_f = fd_score_forward_any(m, x, tvec, score, B, mode, s);
         if (rc_f) return rc_f;
         const float* z = z_steps ? z_steps + (size_t)i * n : nullptr;
@@ -73,15 +101,17 @@ extern "C" int fd_sampler_run_pc(fd_score* m, const fd_sde_params* sde, const fl
     const int T = m->d.max_len, C = m->d.n_channels;
     const size_t n = (size_t)B * T * C;
     const size_t fwd = (m->backbone != FD_BACKBONE_TRANSFORMER) ? fd_bb_workspace(m, B, false) : fd_score_f32_workspace(m, B, false);
-    const size_t own = fd_ws::padded(n * sizeof(float)) + fd_ws::padded((size_t)B * sizeof(float));
-    if (int rc = fd_ws_reserve(ctx, fwd + own)) return rc;
+    const size_t own = fd_ws::padded(n * sizeof(float));
+    float* tvec0 = nullptr;
+    size_t tstride = 0;
+    if (int rc = step_table(ctx, fwd, own, timesteps, n_steps, B, s, &tvec0, &tstride)) return rc;
     float* score = (float*)((char*)ctx->ws + fwd);
-    float* tvec = (float*)((char*)score + fd_ws::padded(n * sizeof(float)));
     const uint64_t per_step = (uint64_t)((n + 3) / 4);
     // Philox counters: predictor noise of step i at offset + i*per_step (as fd_sampler_run); corrector noise behind them
     const uint64_t corr_base = offset + (uint64_t)n_steps * per_step;
     for (int i = 0; i < n_steps; ++i) {
-        hipLaunchKernelGGL(k_fill, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, timesteps[i]);
+        float* tvec = tvec0 + (size_t)i * tstride;
+        if (!tstride) hipLaunchKernelGGL(k_fill, dim3((B + 255) / 256), dim3(256), 0, s, tvec, B, timesteps[i]);
         for (int k = 0; k < n_corr; ++k) {
             if (int rc = fd_score_forward_any(m, x, tvec, score, B, mode, s)) return rc;
             // alpha_t of Song et al.: 1 - beta(t) dt for the VP-SDE, 1 for the VE-SDE

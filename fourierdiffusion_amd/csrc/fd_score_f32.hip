@@ -290,6 +290,51 @@ __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ x, cons
     h[id] = ((acc + be[d]) + (pe ? pe[(size_t)tt * D + d] : 0.f)) + temb[(size_t)b * D + d];
 }
 
+// The same sum with the weights in registers: a thread owns four consecutive features (its 4 x C slice of We, read once from
+// global memory as it lies: no transpose, no LDS) and walks rows; the 16-byte loads of a row's x are shared by the D / 4 threads of
+// the row.  fma order over c as in k_embed.  (The LDS form waits for an LDS round trip per channel: 21 us at 65 536 tokens, C = 16;
+// this one streams: C % 4 == 0, D % 4 == 0, 16-byte aligned operands.)
+template <int CQ>
+__global__ __launch_bounds__(256) void k_embed_rows(const float* __restrict__ x, const float* __restrict__ We,
+                                                     const float* __restrict__ be, const float* __restrict__ pe,
+                                                     const float* __restrict__ temb, float* __restrict__ h, int M, int T, int D) {
+    constexpr int C = 4 * CQ;
+    const int D4 = D >> 2, RP = 256 / D4;                  // rows per pass of the block
+    const int fg = threadIdx.x % D4, rl = threadIdx.x / D4;
+    if (rl >= RP) return;
+    const int d = 4 * fg;
+    float4 w[4][CQ];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) w[j][q] = *reinterpret_cast<const float4*>(We + (size_t)(d + j) * C + 4 * q);
+    const float4 bv = *reinterpret_cast<const float4*>(be + d);
+    for (int m = blockIdx.x * RP + rl; m < M; m += gridDim.x * RP) {
+        const int b = m / T, tt = m - b * T;
+        float4 xv[CQ];
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) xv[q] = *reinterpret_cast<const float4*>(x + (size_t)m * C + 4 * q);
+        const float4 pv = pe ? *reinterpret_cast<const float4*>(pe + (size_t)tt * D + d) : float4{0.f, 0.f, 0.f, 0.f};
+        const float4 tv = *reinterpret_cast<const float4*>(temb + (size_t)b * D + d);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = fmaf(xv[q].x, w[j][q].x, acc[j]);
+                acc[j] = fmaf(xv[q].y, w[j][q].y, acc[j]);
+                acc[j] = fmaf(xv[q].z, w[j][q].z, acc[j]);
+                acc[j] = fmaf(xv[q].w, w[j][q].w, acc[j]);
+            }
+        }
+        float4 o;
+        o.x = ((acc[0] + bv.x) + pv.x) + tv.x; o.y = ((acc[1] + bv.y) + pv.y) + tv.y;
+        o.z = ((acc[2] + bv.z) + pv.z) + tv.z; o.w = ((acc[3] + bv.w) + pv.w) + tv.w;
+        *reinterpret_cast<float4*>(h + (size_t)m * D + d) = o;       // (cached: layer 0 reads it next; nontemporal 14.9 vs 17.8 us here,
+                                                                      //  but the same store in k_ffn_ln cost the next attention kernel 3 us)
+    }
+}
+
 // Multi-head attention core for one (b, h, 64-query block): lane per query, online softmax over 32-key tiles in LDS.
 // The key tiles are dealt round-robin to the NWV waves of the workgroup and the per-wave (max, sum, output) states are
 // merged through LDS at the end: at the training batch (B=64, T=100) one wave per block left each SIMD with 1-2 waves
@@ -493,6 +538,24 @@ void embed(const float* x, const float* We, const float* be, const float* pe, co
     // 16-byte form: D % 4 == 0 and every vector operand 16-byte aligned (the parameter offsets are not when d_model / 2 is odd)
     const uintptr_t al = (uintptr_t)be | (uintptr_t)pe | (uintptr_t)temb | (uintptr_t)h;
     if (use_lds && (D & 3) == 0 && (al & 15) == 0) use_lds = 2;
+    // weights-in-registers form: C % 4 == 0 (<= 40), D % 4 == 0 (<= 256), every vector operand 16-byte aligned
+    const uintptr_t al2 = al | (uintptr_t)x | (uintptr_t)We;
+    if ((C & 3) == 0 && C <= 40 && (D & 3) == 0 && D <= 256 && (al2 & 15) == 0 && !getenv("FDIFF_EMBED_LDS")) {
+        const int RP = 256 / (D >> 2);
+        static int ncu = 0;                          // (one chip type per process)
+        if (!ncu) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+            else ncu = 256;
+        }
+        const long long want = ((long long)M + RP - 1) / RP, cap = (long long)ncu * 4;   // four co-resident blocks per CU walk the rows
+        const unsigned g = (unsigned)(want < cap ? want : cap);
+#define FD_EMB(CQ_) case CQ_: hipLaunchKernelGGL(k_embed_rows<CQ_>, dim3(g), dim3(256), 0, s, x, We, be, pe, temb, h, M, T, D); return;
+        switch (C >> 2) {
+            FD_EMB(1) FD_EMB(2) FD_EMB(3) FD_EMB(4) FD_EMB(5) FD_EMB(6) FD_EMB(7) FD_EMB(8) FD_EMB(9) FD_EMB(10)
+        }
+#undef FD_EMB
+    }
     const unsigned grid = use_lds ? (unsigned)((M + kEmbRows - 1) / kEmbRows) : (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_embed, dim3(grid), dim3(256), use_lds ? lds : 0, s, x, We, be, pe, temb, h, M, T, C, D, use_lds);
 }

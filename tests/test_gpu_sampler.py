@@ -162,3 +162,36 @@ def test_precomputed_time_embedding_table_is_bit_identical():
                     os.environ["FDIFF_MEGA_NO_TEMB_TABLE"] = old
         assert np.isfinite(outs[0]).all()
         assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_stepwise_loop_step_table_and_register_embed_are_bit_identical(precision):
+    """The step-by-step loop fills the t vectors of all steps in one launch (FDIFF_SAMPLER_FILL_PER_STEP: one k_fill per step as
+    before) and embeds with the weights-in-registers kernel when C % 4 == 0 (FDIFF_EMBED_LDS: the LDS form).  Same values, same
+    fma order: the samples must be bit-identical."""
+    import os
+    from fourierdiffusion_amd.sampling.sampler import DiffusionSampler
+    cfg = dict(T=48, C=8, D=24, L=2, H=4)
+    outs = []
+    keys = ("FDIFF_SAMPLER_STEPWISE", "FDIFF_SAMPLER_FILL_PER_STEP", "FDIFF_EMBED_LDS")
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        for legacy in (False, True):
+            os.environ["FDIFF_SAMPLER_STEPWISE"] = "1"
+            for k in keys[1:]:
+                if legacy:
+                    os.environ[k] = "1"
+                else:
+                    os.environ.pop(k, None)
+            m, _, _ = make_model(cfg, precision=precision)
+            sampler = DiffusionSampler(score_model=m, sample_batch_size=5)
+            torch.manual_seed(11)
+            outs.append(sampler.sample(num_samples=5, num_diffusion_steps=9).numpy())
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0], outs[1])
