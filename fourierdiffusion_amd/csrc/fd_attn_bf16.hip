@@ -656,7 +656,13 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
         // pair) and neighbouring query tiles, so after the first failure the wave goes straight to the exact form for its
         // remaining units (1.5 x): a sampler trajectory that leaves the data scale (random-init weights: |x| grows ~150 x
         // along the VP reverse SDE) made every layer-0 unit fail from the fifth step on, 186 us instead of 97 at T = 1024.
-        if (prefer_exact) {
+        // ... and a unit whose bound is beyond 2048 octaves does not try the fast pass at all: it succeeds only if EVERY row's true
+        // maximum lies within ~100 octaves = 5 % of its bound, and such rows are softmaxes over scores of thousands (layer 0 of
+        // the same trajectories: with two units per wave at T = 1024 the wave-sticky switch alone still paid 2.5 x + 1.5 x).
+        bool huge = false;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) huge |= (bq[q][0] > 2048.f) | (bq[q][1] > 2048.f);
+        if (prefer_exact || (__builtin_amdgcn_ballot_w64(huge) != 0ull && ABL != 2)) {
             run_exact();
             (void)row_sums();
         } else {
