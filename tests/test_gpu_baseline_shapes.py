@@ -186,6 +186,41 @@ def test_softmax_shift_fallback_equals_exact_path():
     assert np.abs(outs[40.0][1] - outs[1.0][1]).max() > 1e-2, "scaled projection must change the output"
 
 
+def test_softmax_shift_failure_memory_in_the_sampler_loop():
+    """Sampler mode: a wave that saw a layer's bound fail sends that layer's units straight to the exact form until the next
+    retry step (every 16th).  20 steps with the scaled projection (every step fails) must agree with the always-exact loop
+    (FDIFF_MEGA_DBG=32) to the rounding of the shift, across the retry boundary, and stay seed-reproducible."""
+    from fourierdiffusion_amd.sampling.sampler import DiffusionSampler
+    from oracle.make_golden import CFG_DEFAULT
+    cfg = dict(CFG_DEFAULT, L=2)
+    old = os.environ.get("FDIFF_MEGA_DBG")
+    outs = []
+    try:
+        for dbg in (None, None, "32"):
+            m, _, sd = make_model(cfg, precision="bf16")
+            st = m.state_dict()
+            for k in list(st):
+                if k.endswith("self_attn.in_proj_weight"):
+                    st[k] = st[k] * 40.0
+            m.load_state_dict(st)
+            m.eval()
+            if dbg is None:
+                os.environ.pop("FDIFF_MEGA_DBG", None)
+            else:
+                os.environ["FDIFF_MEGA_DBG"] = dbg
+            sampler = DiffusionSampler(score_model=m, sample_batch_size=6)
+            torch.manual_seed(3)
+            outs.append(sampler.sample(num_samples=6, num_diffusion_steps=20).numpy())
+    finally:
+        if old is None:
+            os.environ.pop("FDIFF_MEGA_DBG", None)
+        else:
+            os.environ["FDIFF_MEGA_DBG"] = old
+    assert np.isfinite(outs[0]).all() and np.isfinite(outs[2]).all()
+    assert np.array_equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0], outs[2], atol=2e-3 * max(1.0, np.abs(outs[2]).max()), rtol=0)
+
+
 ATTN_SHAPES = {
     # long-series attention kernel (fd_attn_bf16.hip): full 128-key blocks + ragged tail (T=365: 23 key tiles), odd tile count,
     # head_dim 5 and 7 (7: the ones row sits in V^T's last slot, max|k|^2 words move out of it), d_model 56 = two k-steps
