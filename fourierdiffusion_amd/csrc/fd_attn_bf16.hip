@@ -682,10 +682,17 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
             const float inv = 1.0f / lrow[q];
             const int t = qt[q] * 16 + tok;
             if (qv[q] && t < T && myhead < H) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int d = 4 * (g & 1) + r;
-                    if (d < hd) out[((size_t)b * T + t) * D + myhead * hd + d] = o_sel[r] * inv;
+                // row form: the lane's dims as one 16- or 8-byte store at a dword-aligned address where head_dim allows
+                typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+                float* orow = out + ((size_t)b * T + t) * D + myhead * hd + 4 * (g & 1);
+                const int nv = min(4, max(0, hd - 4 * (g & 1)));
+                if (nv == 4) *reinterpret_cast<f32x4_a4*>(orow) = f32x4_a4{o_sel[0] * inv, o_sel[1] * inv, o_sel[2] * inv, o_sel[3] * inv};
+                else if (nv == 2) *reinterpret_cast<f32x2_a4*>(orow) = f32x2_a4{o_sel[0] * inv, o_sel[1] * inv};
+                else {
+                    if (nv > 0) orow[0] = o_sel[0] * inv;
+                    if (nv > 1) orow[1] = o_sel[1] * inv;
+                    if (nv > 2) orow[2] = o_sel[2] * inv;
                 }
             }
         }
