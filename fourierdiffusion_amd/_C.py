@@ -82,6 +82,8 @@ _PROTOS = {
     "fd_score_set_train_mode": (C.c_int, [_vp, C.c_int]),
     "fd_score_forward_train": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_float, C.c_uint64, C.c_uint64, _vp]),
     "fd_score_backward": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "fd_score_train_plan": (C.c_int, [_vp, C.c_int, C.c_char_p, C.POINTER(C.c_int)]),
+    "fd_score_train_dsm_supported": (C.c_int, [_vp, C.c_int]),
     "fd_score_train_dsm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_float, C.c_int, C.c_float, C.c_uint64, C.c_uint64,
                                      _vp, _vp, C.c_int, _vp]),
     "fd_sampler_run": (C.c_int, [_vp, C.POINTER(SdeParams), _vp, _vp, C.c_int, C.c_float, _vp, _vp,
@@ -97,6 +99,7 @@ _PROTOS = {
     "fd_comm_unique_id": (C.c_int, [_vp]),
     "fd_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "fd_comm_destroy": (C.c_int, [_vp]),
+    "fd_comm_rccl_path": (C.c_int, [C.c_char_p, C.c_int]),
     "fd_allreduce_grads": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, _vp]),
     "fd_project_rows": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "fd_transpose_rows": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),

@@ -21,11 +21,18 @@ RcclApi g_rccl;
 
 bool load_rccl() {
     if (g_rccl.lib) return true;
+    // One RCCL image per process: the Python host has torch loaded, and torch ships its own librccl.so (SONAME librccl.so.1).
+    // An image that is already mapped is taken as it is (RTLD_NOLOAD matches by SONAME); only a process without one loads
+    // the system library.  fd_comm_rccl_path() reports which file the bound ncclAllReduce lives in.
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
     for (const char* n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         if (h) break;
+    }
+    for (const char* n : names) {
+        if (h) break;
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!h) return false;
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
@@ -54,6 +61,15 @@ extern "C" int fd_comm_unique_id(void* id_out) {
     return FD_OK;
 }
 
+extern "C" int fd_comm_rccl_path(char* buf, int n) {
+    if (!buf || n < 2) return FD_ERR_ARG;
+    if (!load_rccl()) return FD_ERR_COMM;
+    Dl_info info;
+    if (!dladdr((void*)g_rccl.AllReduce, &info) || !info.dli_fname) return FD_ERR_COMM;
+    snprintf(buf, (size_t)n, "%s", info.dli_fname);
+    return FD_OK;
+}
+
 extern "C" int fd_comm_init(fd_ctx* ctx, int rank, int nranks, const void* unique_id) {
     if (!ctx) return FD_ERR_ARG;
     FD_REQUIRE(ctx, unique_id && nranks >= 1 && rank >= 0 && rank < nranks, "fd_comm_init: bad rank %d / %d", rank,
@@ -67,20 +83,21 @@ extern "C" int fd_comm_init(fd_ctx* ctx, int rank, int nranks, const void* uniqu
     // without HSA_ENABLE_IPC_MODE_LEGACY=0 in EVERY rank's environment RCCL's buffer exchange fails with
     // "hipIpcGetMemHandle: invalid argument"; (2) a rank bound to a device another rank already holds, or to one the
     // launcher's *_VISIBLE_DEVICES hid (one process per GPU: device = LOCAL_RANK).  Both are named in the message.
+    // (No pre-emptive check of nranks against the visible device count: nranks is the GLOBAL world size -- multi-node jobs and
+    //  launchers that expose one GPU per process (ROCR_VISIBLE_DEVICES=$LOCAL_RANK) legitimately have nranks > visible GPUs.
+    //  The device count only annotates the message of a real failure.)
     int ndev = 0;
     (void)hipGetDeviceCount(&ndev);
-    if (nranks > 1 && ndev > 0 && nranks > ndev && !getenv("FDIFF_ALLOW_SHARED_GPU"))
-        return fd_fail(ctx, FD_ERR_COMM, "fd_comm_init: %d ranks but only %d visible GPU(s) in this process (rank %d on device %d); "
-                       "check HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES -- RCCL needs one GPU per rank",
-                       nranks, ndev, rank, ctx->device);
     ncclResult_t r = g_rccl.CommInitRank(&comm, nranks, id, rank);
     if (r != ncclSuccess) {
         const char* ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
         const char* hv = getenv("HIP_VISIBLE_DEVICES");
         const char* rv = getenv("ROCR_VISIBLE_DEVICES");
-        return fd_fail(ctx, FD_ERR_COMM, "ncclCommInitRank failed: %s (rank %d / %d on device %d of %d visible; "
+        return fd_fail(ctx, FD_ERR_COMM, "ncclCommInitRank failed: %s (rank %d / %d on device %d of %d visible%s; "
                        "HSA_ENABLE_IPC_MODE_LEGACY=%s%s, HIP_VISIBLE_DEVICES=%s, ROCR_VISIBLE_DEVICES=%s)",
                        g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?", rank, nranks, ctx->device, ndev,
+                       (nranks > ndev && ndev > 0) ? " -- if all ranks run on this node, two ranks may share a GPU: RCCL needs one GPU per rank"
+                                                   : "",
                        ipc ? ipc : "<unset>", (ipc && ipc[0] == '0') ? "" : " -- must be 0 on this host (dmabuf IPC only)",
                        hv ? hv : "<unset>", rv ? rv : "<unset>");
     }

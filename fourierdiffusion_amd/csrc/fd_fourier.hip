@@ -847,7 +847,9 @@ int launch(fd_ctx* ctx, const float* x, float* y, const float* mean, const float
         plan.vec_ok = (!batched && (C & 1) == 0 && (Cc & 1) == 0 && ((uintptr_t)x & 7) == 0 && ((uintptr_t)y & 7) == 0) ? 1 : 0;
         const uintptr_t al16 = (uintptr_t)x | (uintptr_t)y | (uintptr_t)mean | (uintptr_t)stdv;
         static const bool no_vec4 = getenv("FDIFF_FFT_VEC4") && getenv("FDIFF_FFT_VEC4")[0] == '0';
-        if (plan.vec_ok && (C & 3) == 0 && (Cc & 3) == 0 && (al16 & 15) == 0 && !no_vec4) plan.vec_ok = 2;
+        // (even T only: the row buffer follows T float2 twiddles in LDS, so an odd T leaves it 8-byte aligned and every
+        //  float4 LDS access of the vec4 passes would be a misaligned ds_*_b128)
+        if (plan.vec_ok && (C & 3) == 0 && (Cc & 3) == 0 && (al16 & 15) == 0 && (T & 1) == 0 && !no_vec4) plan.vec_ok = 2;
         const char* e = getenv("FDIFF_FFT_STAGGER");
         plan.stagger = e ? atoi(e) : 0;
         if (nwg < 3LL * plan.resident) plan.stagger = 0;           // short launches: the spread would cost more than it hides

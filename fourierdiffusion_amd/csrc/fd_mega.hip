@@ -397,7 +397,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
     // Layers whose softmax bound failed for this wave (bit l): their units go straight to the exact two-pass form until the
     // next retry step.  With random-init weights x leaves the data scale along the reverse SDE, layer 0 sees it un-normalised,
     // and from then on EVERY one of its units ran the fast pass, failed, and ran the exact passes (2.5 x; 2.6 % of the step).
-    unsigned exact_layers = 0u;                                  // wave-uniform
+    unsigned exact_layers = 0u;                                  // wave-uniform; layers >= 32 are not remembered (they retry the
+                                                                 // fast pass every unit: slower, same results)
     for (int step = 0; step < nsteps; ++step) {
         if ((step & 15) == 0) exact_layers = 0u;                 // retry the fast pass every 16th step
         mark(0, step);
@@ -898,13 +899,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         return bad;
                     };
                     // (dbg bit 64 suppresses the fallback: lets the tests prove that it is what rescues such rows; bit 32: exact only)
-                    bool need_exact = (P.dbg & 32) != 0 || (((exact_layers >> l) & 1u) != 0u && !(P.dbg & 64));
+                    bool need_exact = (P.dbg & 32) != 0 || (l < 32 && ((exact_layers >> l) & 1u) != 0u && !(P.dbg & 64));
                     if (!need_exact) {
                         run_unit(std::false_type{});
                         const bool bad = row_sums();
                         if (__builtin_amdgcn_ballot_w64(bad) != 0ull && !(P.dbg & 64)) {   // wave-uniform: redo with the exact maximum
                             need_exact = true;
-                            exact_layers |= 1u << l;
+                            if (l < 32) exact_layers |= 1u << l;
                         }
                     }
                     if (need_exact) {

@@ -87,6 +87,8 @@ size_t fd_bb_workspace(const fd_score* m, int B, bool train);
 int fd_score_forward_any(fd_score* m, const float* x, const float* t, float* out, int B, int mode, hipStream_t s);
 // fd_train_bf16.hip: bf16 MFMA training path (forward with dropout, backward)
 bool fd_train_bf16_supported(const fd_score* m);
+bool fd_score_train_dsm_bf16_supported(const fd_score* m, int B);
+int fd_train_bf16_token_splits(const fd_score* m, int B, int* nblk);
 int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, float* out, int B, float p, uint64_t seed,
                                 uint64_t offset, hipStream_t s);
 int fd_score_backward_bf16(fd_score* m, const float* dout, float* grads, int accumulate, hipStream_t s);

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
                 const int head = 4 * ks + g;               // k-slot group g of k-step ks = the 8 (padded) dims of one head
                 // the head's 8 dim slots as two dword-aligned 16-byte loads from a clamped address, selected afterwards (eight
                 // conditional scalar loads per (token, head) were eight divergent branches and eight instructions that each walk
-                // 64 cache lines; slots >= head_dim read the next head / row: the buffer is followed by `tmp` in the arena)
+                // 64 cache lines; slots >= head_dim read the next head / row: `att` is carved with 8 floats of slack for the last one)
                 float v[8];
                 {
                     typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -984,7 +984,9 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
     float* h0 = ws.take<float>((size_t)M * D);
     float* h1 = ws.take<float>((size_t)M * D);
     float* qkv = ws.take<float>((size_t)M * 3 * D);
-    float* att = ws.take<float>((size_t)M * D);
+    // + 8 floats: k_ffn_ln's fused prologue reads a head's 8 (padded) dim slots as two 16-byte loads, i.e. up to 2 floats past the
+    // last row's last head when head_dim < 8 (values discarded by the select that follows) -- the slack is part of the contract
+    float* att = ws.take<float>((size_t)M * D + 8);
     float* tmp = ws.take<float>((size_t)M * D);
     fdf32::time_embed(t, P + m->tW, P + m->td_w, P + m->td_b, temb, B, D, s);
     fdf32::embed(x, P + m->emb_w, P + m->emb_b, P + m->pos, temb, h0, M, T, C, D, s);

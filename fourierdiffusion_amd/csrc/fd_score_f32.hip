@@ -791,6 +791,33 @@ extern "C" int fd_score_train_dsm(fd_score* m, const float* x, const float* t, c
                                    accumulate, (hipStream_t)stream);
 }
 
+// 1 when fd_score_train_dsm has a fused step for this (model, train mode, B), 0 when it would answer FD_ERR_UNSUPPORTED; no side
+// effects (the host asks BEFORE drawing the step's Philox key, so an unsupported batch consumes no key).
+extern "C" int fd_score_train_dsm_supported(fd_score* m, int B) {
+    if (!m || B <= 0 || !m->prepared) return 0;
+    if (m->train_mode != FD_MODE_BF16 || m->backbone != FD_BACKBONE_TRANSFORMER || getenv("FDIFF_TRAIN_DSM_UNFUSED")) return 0;
+    return fd_score_train_dsm_bf16_supported(m, B) ? 1 : 0;
+}
+
+// The training launch plan of a batch of B series (no launch): which arithmetic runs and, on the bf16 path, the token splits of
+// the weight-gradient kernel and whether the fused loss head exists -- the parity tests assert the plan they exercised.
+extern "C" int fd_score_train_plan(fd_score* m, int B, char* out, int* token_splits) {
+    if (!m) return FD_ERR_ARG;
+    fd_ctx* ctx = m->ctx;
+    FD_REQUIRE(ctx, out && B > 0, "fd_score_train_plan: null buffer or B=%d", B);
+    if (token_splits) *token_splits = 0;
+    if (m->train_mode != FD_MODE_BF16 || m->backbone != FD_BACKBONE_TRANSFORMER || !fd_train_bf16_supported(m)) {
+        snprintf(out, 192, "exact-f32 training kernels (fd_score_bwd.hip)");
+        return FD_OK;
+    }
+    int nblk = 0;
+    const int ts = fd_train_bf16_token_splits(m, B, &nblk);
+    if (token_splits) *token_splits = ts;
+    snprintf(out, 192, "bf16 training: 5 kernels per layer, k_tr_wgrad token splits TS=%d over %d 32-token blocks, fused loss head %s",
+             ts, nblk, (m->prepared && fd_score_train_dsm_bf16_supported(m, B) && !getenv("FDIFF_TRAIN_DSM_UNFUSED")) ? "yes" : "no");
+    return FD_OK;
+}
+
 // Arithmetic of fd_score_forward_train / fd_score_backward: FD_MODE_F32 = exact-f32 kernels (parity anchor, any model),
 // FD_MODE_BF16 = bf16 MFMA operands with fp32 accumulation (fd_train_bf16.hip).  Returns FD_ERR_UNSUPPORTED (and keeps the
 // previous mode) when the bf16 kernels are not instantiated for the model.

@@ -2456,11 +2456,9 @@ int fd_score_backward_bf16(fd_score* m, const float* dout, float* grads, int acc
 // unembedder's backward as eight launches (three fp32 GEMMs with split-K reduces, a two-stage column sum, the loss and its
 // sum: ~75 us of 5-20 us kernels on (B*T, C <= 40) data).  Here the loss head is one kernel per (series, token split) that
 // keeps the unembedder weight in LDS, plus one fixed-order reduce of its partials.
-int fd_score_train_dsm_bf16(fd_score* m, const float* x, const float* t, const float* target, const float* stdv, int lw,
-                            float grad_weight, int B, float p, uint64_t seed, uint64_t offset, float* loss_out, float* grads,
-                            int accumulate, hipStream_t s) {
-    fd_ctx* ctx = m->ctx;
-    if (!fd_train_bf16_supported(m)) return fd_fail(ctx, FD_ERR_UNSUPPORTED, "bf16 training path unsupported for this model");
+// The fused loss head's launch plan for a batch of B series; false = not instantiated for this (model, B) (the caller then runs
+// forward -> fd_dsm_loss -> backward).  No side effects: fd_score_train_dsm_supported answers from it before any Philox key is drawn.
+static bool tr_head_plan(const fd_score* m, int B, int* TS_out, int* kmax_out, size_t* lds_out) {
     const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model;
     const int CD = C * D;
     // register slots per thread: C * D weight-gradient entries and 32 * C (row, channel) items over 256 threads
@@ -2470,7 +2468,31 @@ int fd_score_train_dsm_bf16(fd_score* m, const float* x, const float* t, const f
     const size_t prow = (size_t)CD + C + 1;
     int TS = (T + 31) / 32;                            // one 32-token tile per workgroup whenever the partials fit
     while (TS > 1 && (size_t)B * TS * prow > kSkpFloats) --TS;
-    if (!kmax || D > 80 || D < 8 || T > 4096 || lds > 64 * 1024 || (size_t)B * TS * prow > kSkpFloats)
+    if (!kmax || D > 80 || D < 8 || T > 4096 || lds > 64 * 1024 || (size_t)B * TS * prow > kSkpFloats) return false;
+    *TS_out = TS; *kmax_out = kmax; *lds_out = lds;
+    return true;
+}
+int fd_train_bf16_token_splits(const fd_score* m, int B, int* nblk) {
+    if (nblk) *nblk = (int)(((long long)B * m->d.max_len + 31) / 32);
+    return tr_TS(m, B);
+}
+bool fd_score_train_dsm_bf16_supported(const fd_score* m, int B) {
+    int TS, kmax;
+    size_t lds;
+    return fd_train_bf16_supported(m) && tr_head_plan(m, B, &TS, &kmax, &lds);
+}
+
+int fd_score_train_dsm_bf16(fd_score* m, const float* x, const float* t, const float* target, const float* stdv, int lw,
+                            float grad_weight, int B, float p, uint64_t seed, uint64_t offset, float* loss_out, float* grads,
+                            int accumulate, hipStream_t s) {
+    fd_ctx* ctx = m->ctx;
+    if (!fd_train_bf16_supported(m)) return fd_fail(ctx, FD_ERR_UNSUPPORTED, "bf16 training path unsupported for this model");
+    const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model;
+    const int CD = C * D;
+    const size_t prow = (size_t)CD + C + 1;
+    int TS = 0, kmax = 0;
+    size_t lds = 0;
+    if (!tr_head_plan(m, B, &TS, &kmax, &lds))
         return fd_fail(ctx, FD_ERR_UNSUPPORTED, "fd_score_train_dsm: loss head not instantiated for C=%d, d_model=%d, B=%d", C, D, B);
     if (int rc = fd_score_forward_train_bf16(m, x, t, nullptr, B, p, seed, offset, s)) return rc;
     m->saved_bf16 = true; m->have_saved = false;       // consumed by the backward below

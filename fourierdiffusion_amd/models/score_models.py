@@ -269,6 +269,15 @@ class ScoreModule:
         _C.check(rc, ctx)
         return buf.value.decode(), spw.value
 
+    def train_plan(self, batch_size: int) -> Tuple[str, int]:
+        """(description of the training launch plan of a batch of this size, token splits of the weight-gradient kernel; 0 on
+        the exact-f32 path) -- fd_score_train_plan."""
+        ctx, h = self._engine()
+        buf = C.create_string_buffer(192)
+        ts = C.c_int(0)
+        _C.check(_C.lib().fd_score_train_plan(h, int(batch_size), buf, C.byref(ts)), ctx)
+        return buf.value.decode(), ts.value
+
     # ------------------------------------------------------------------ forward / backward
     def forward(self, batch: DiffusableBatch) -> torch.Tensor:
         X = batch.X
@@ -302,10 +311,20 @@ class ScoreModule:
         tensor, with the gradients ACCUMULATED into ``self.grads`` -- or None when this model has no fused step (exact-f32
         training, MLP / LSTM backbones, very wide C * d_model), in which case the caller runs forward -> fd_dsm_loss ->
         backward.  Same Philox stream use as ``forward`` in training mode (one key per call)."""
-        if getattr(self, "_no_fused_dsm", False) or not self.training:
+        if not self.training or getattr(self, "_no_fused_dsm", False):     # (_no_fused_dsm: a manual switch, never latched here)
             return None
         ctx, h = self._engine()
         if self.train_mode_effective != "bf16":
+            return None
+        # capability per batch size, asked BEFORE a Philox key is drawn (an unsupported batch must not consume one: the trainer
+        # counts keys per step to keep empty-slice ranks in step) and cached per B -- one oversized batch does not switch the
+        # fused step off for later, smaller ones
+        Bn = int(x_noisy.shape[0])
+        cache = self.__dict__.setdefault("_fused_dsm_ok", {})
+        ok = cache.get(Bn)
+        if ok is None:
+            ok = cache[Bn] = bool(_C.lib().fd_score_train_dsm_supported(h, Bn))
+        if not ok:
             return None
         Xd = _C.dev_f32(x_noisy.to(self.device), "x_noisy")
         td = _C.dev_f32(timesteps.to(self.device), "timesteps")
@@ -318,9 +337,6 @@ class ScoreModule:
         rc = _C.lib().fd_score_train_dsm(h, Xd.data_ptr(), td.data_ptr(), tg.data_ptr(), sd.data_ptr(),
                                          1 if likelihood_weighting else 0, float(grad_weight), Xd.shape[0], float(self.dropout),
                                          key, off, loss.data_ptr(), self.grads.data_ptr(), 1, _C.stream_of(Xd))
-        if rc == -5:                                   # FD_ERR_UNSUPPORTED for these dimensions: remember, use the three calls
-            self._no_fused_dsm = True
-            return None
         _C.check(rc, ctx)
         self._train_inputs = (Xd, td, tg, sd)
         return loss[0]

@@ -35,48 +35,77 @@ def _as_tensor(x) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x
 
 
+class _View:
+    """One representation of the samples a collection evaluates in: a key prefix, the map from time-domain samples into the
+    representation, and the metrics bound to the ORIGINAL samples in that representation."""
+
+    def __init__(self, prefix: str, transform, metrics: list) -> None:
+        self.prefix, self.transform, self.metrics = prefix, transform, metrics
+
+    def _prefixed(self, results) -> dict[str, Any]:
+        return {f"{self.prefix}_{key}": val for res in results for key, val in res.items()}
+
+    def evaluate(self, samples: torch.Tensor) -> dict[str, Any]:
+        if not self.metrics:
+            return {}
+        mapped = self.transform(samples)
+        return self._prefixed(m(mapped) for m in self.metrics)
+
+    def baselines(self) -> dict[str, Any]:
+        return self._prefixed(m.baseline_metrics for m in self.metrics)
+
+
 class MetricCollection:
-    """metrics.py:28-99: every metric is evaluated on the samples (time_*) and on their dft (freq_*), optionally a marginal
-    Wasserstein on the spectral densities (spectral_*), plus the metrics' baselines."""
+    """Same surface and result keys as the reference's collection (metrics.py:28-99): every partially instantiated metric is bound
+    to the original samples once per view -- `time` (the samples as they are) and `freq` (their dft) -- and, on request, a marginal
+    Wasserstein on the spectral densities forms a third view (`spectral`, seed 42, all distances kept, no baselines).  A call
+    returns the union of the views' results (+ the time / freq baselines) sorted by key."""
 
     def __init__(self, metrics: list, original_samples: Optional[np.ndarray | torch.Tensor] = None,
                  include_baselines: bool = True, include_spectral_density: bool = False) -> None:
-        metrics_time: list[Metric] = []
-        metrics_freq: list[Metric] = []
-        if original_samples is not None:
-            original_samples = _as_tensor(original_samples)
-        original_samples_freq = dft(original_samples) if original_samples is not None else None
-        for metric in metrics:
-            if isinstance(metric, partial):                   # partially instantiated: bind the original samples
-                assert original_samples is not None, "Original samples must be provided for the metrics to be instantiated."
-                metrics_time.append(metric(original_samples=original_samples))
-                metrics_freq.append(metric(original_samples=original_samples_freq))
-        self.metrics_time = metrics_time
-        self.metrics_freq = metrics_freq
+        factories = [m for m in metrics if isinstance(m, partial)]      # (like the reference, only partials are taken up)
+        if factories and original_samples is None:
+            raise AssertionError("Original samples must be provided for the metrics to be instantiated.")
+        original = _as_tensor(original_samples) if original_samples is not None else None
+        self._views = [_View("time", lambda x: x, []), _View("freq", dft, [])]
+        for view in self._views:
+            if factories:
+                bound_to = view.transform(original)
+                view.metrics = [make(original_samples=bound_to) for make in factories]
         self.include_baselines = include_baselines
-        self.metric_spectral = (MarginalWasserstein(original_samples=spectral_density(original_samples), random_seed=42,
-                                                    save_all_distances=True) if include_spectral_density else None)
+        self.metric_spectral = None
+        self._spectral_view = None
+        if include_spectral_density:
+            self.metric_spectral = MarginalWasserstein(original_samples=spectral_density(original), random_seed=42,
+                                                       save_all_distances=True)
+            self._spectral_view = _View("spectral", spectral_density, [self.metric_spectral])
+
+    # the reference's attribute names for the two bound lists
+    @property
+    def metrics_time(self) -> list:
+        return self._views[0].metrics
+
+    @property
+    def metrics_freq(self) -> list:
+        return self._views[1].metrics
 
     def __call__(self, other_samples: np.ndarray | torch.Tensor) -> dict[str, Any]:
-        other_samples = _as_tensor(other_samples)
-        metric_dict: dict[str, Any] = {}
-        other_samples_freq = dft(other_samples)
-        for metric_time, metric_freq in zip(self.metrics_time, self.metrics_freq):
-            metric_dict.update({f"time_{k}": v for k, v in metric_time(other_samples).items()})
-            metric_dict.update({f"freq_{k}": v for k, v in metric_freq(other_samples_freq).items()})
+        samples = _as_tensor(other_samples)
+        merged: dict[str, Any] = {}
+        for view in self._views:
+            merged.update(view.evaluate(samples))
         if self.include_baselines:
-            metric_dict.update(self.baseline_metrics)
-        if self.metric_spectral is not None:
-            metric_dict.update({f"spectral_{k}": v for k, v in self.metric_spectral(spectral_density(other_samples)).items()})
-        return dict(sorted(metric_dict.items(), key=lambda item: item[0]))
+            merged.update(self.baseline_metrics)
+        if self._spectral_view is not None:
+            merged.update(self._spectral_view.evaluate(samples))
+        return {key: merged[key] for key in sorted(merged)}
 
     @property
     def baseline_metrics(self) -> dict[str, float]:
-        metric_dict: dict[str, float] = {}
-        for metric_time, metric_freq in zip(self.metrics_time, self.metrics_freq):
-            metric_dict.update({f"time_{k}": v for k, v in metric_time.baseline_metrics.items()})
-            metric_dict.update({f"freq_{k}": v for k, v in metric_freq.baseline_metrics.items()})
-        return metric_dict
+        merged: dict[str, float] = {}
+        for view in self._views:
+            merged.update(view.baselines())
+        return merged
 
 
 class _WassersteinMetric(Metric):

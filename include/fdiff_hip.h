@@ -226,6 +226,9 @@ int fd_score_plan(fd_score* m, int B, int mode, char* out /* >= 192 bytes */, in
  * gradients reduced in a fixed order: bit-reproducible).  FD_ERR_UNSUPPORTED when the bf16 kernels are not instantiated
  * for the model's dims (the mode then stays unchanged).  Replaces nothing in the reference (torch autograd is fp32). */
 int fd_score_set_train_mode(fd_score* m, int mode);
+/* The training launch plan of a batch of B series, nothing launched: out (>= 192 bytes) names the arithmetic and, on the bf16
+ * path, the token splits of the weight-gradient kernel (also in *token_splits, nullable; 0 on the exact-f32 path). */
+int fd_score_train_plan(fd_score* m, int B, char* out, int* token_splits);
 
 /* Training forward: keeps activations in the ctx workspace for fd_score_backward.
  * dropout_p > 0 applies the four dropout sites of nn.TransformerEncoderLayer with masks
@@ -244,6 +247,9 @@ int fd_score_backward(fd_score* m, const float* dout, float* grads, int accumula
 int fd_score_train_dsm(fd_score* m, const float* x, const float* t, const float* target, const float* std,
                        int likelihood_weighting, float grad_weight, int B, float dropout_p, uint64_t seed,
                        uint64_t offset, float* loss_out, float* grads, int accumulate, void* stream);
+/* 1 when fd_score_train_dsm has a fused step for this (model, train mode, B), else 0 (it would return FD_ERR_UNSUPPORTED).
+ * No side effects: the host asks before it draws the step's Philox key. */
+int fd_score_train_dsm_supported(fd_score* m, int B);
 
 /* ----------------------------------------------------------- a12 sampler
  * replaces the inner loop of DiffusionSampler.sample (src/fdiff/sampling/sampler.py:83-104):
@@ -287,6 +293,9 @@ int fd_adamw_step(fd_ctx* ctx, float* params, const float* grads, float* exp_avg
 int fd_comm_unique_id(void* id_out /* host, FD_COMM_ID_BYTES */);
 int fd_comm_init(fd_ctx* ctx, int rank, int nranks, const void* unique_id);
 int fd_comm_destroy(fd_ctx* ctx);
+/* path of the shared object the bound ncclAllReduce lives in (one RCCL image per process: an already mapped librccl --
+ * torch's bundled one under the Python host -- is reused, never a second copy).  buf: host, n bytes. */
+int fd_comm_rccl_path(char* buf, int n);
 /* buf = sum over ranks (buf) * scale, in place */
 int fd_allreduce_grads(fd_ctx* ctx, float* buf, int64_t n, float scale, void* stream);
 

@@ -8,6 +8,9 @@ set -u
 cd "$(dirname "$0")/.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 MAXG=${1:-8}
+# SCALE_CHECK_FAST=1 (tests/test_gpu_scale_script.py): a few steps per run, same checks
+if [ -n "${SCALE_CHECK_FAST:-}" ]; then FAST_S="--steps 2 --warmup 1 --diffusion-steps 30"; FAST_M="--diffusion-steps 30"; FAST_T="--steps 5 --warmup 2"; else FAST_S=""; FAST_M="--diffusion-steps 200"; FAST_T=""; fi
+FAILED=0
 NDEV=$(python - <<'PY'
 import torch
 print(torch.cuda.device_count())
@@ -40,7 +43,8 @@ PY
 for N in 1 2 4 8; do
   [ $N -gt $MAXG ] && break
   [ $N -gt $NDEV ] && { echo "stopping at N=$N: only $NDEV GPU(s)"; break; }
-  FDIFF_BENCH_REPORT_RANKS=1 python bench.py --gpus $N --no-cpu-baseline > gpurun_out/scale/sample_weak_$N.log 2>&1; check gpurun_out/scale/sample_weak_$N.log $N weak "T=100, C=12" || tail -5 gpurun_out/scale/sample_weak_$N.log
-  FDIFF_BENCH_REPORT_RANKS=1 python bench.py --gpus $N --workload mimic --scaling strong --steps 1 --warmup 0 --diffusion-steps 200 --no-cpu-baseline > gpurun_out/scale/mimic_strong_$N.log 2>&1; check gpurun_out/scale/mimic_strong_$N.log $N strong "T=256, C=28" || tail -5 gpurun_out/scale/mimic_strong_$N.log
-  FDIFF_BENCH_REPORT_RANKS=1 python bench.py --gpus $N --mode train --no-cpu-baseline > gpurun_out/scale/train_$N.log 2>&1; check gpurun_out/scale/train_$N.log $N weak "training series/sec" || tail -5 gpurun_out/scale/train_$N.log
+  FDIFF_BENCH_REPORT_RANKS=1 python bench.py --gpus $N --no-cpu-baseline --no-secondary $FAST_S > gpurun_out/scale/sample_weak_$N.log 2>&1; check gpurun_out/scale/sample_weak_$N.log $N weak "T=100, C=12" || { FAILED=1; tail -5 gpurun_out/scale/sample_weak_$N.log; }
+  FDIFF_BENCH_REPORT_RANKS=1 python bench.py --gpus $N --workload mimic --scaling strong --steps 1 --warmup 0 $FAST_M --no-cpu-baseline --no-secondary > gpurun_out/scale/mimic_strong_$N.log 2>&1; check gpurun_out/scale/mimic_strong_$N.log $N strong "T=256, C=28" || { FAILED=1; tail -5 gpurun_out/scale/mimic_strong_$N.log; }
+  FDIFF_BENCH_REPORT_RANKS=1 python bench.py --gpus $N --mode train --no-cpu-baseline --no-secondary $FAST_T > gpurun_out/scale/train_$N.log 2>&1; check gpurun_out/scale/train_$N.log $N weak "training series/sec" || { FAILED=1; tail -5 gpurun_out/scale/train_$N.log; }
 done
+exit $FAILED
