@@ -219,8 +219,9 @@ def main_train(args, rank, local_rank, world):
         one_step(i)
     barrier()
     _C.check(lib.fd_prof_begin(ctx), ctx)
-    # every 7th launch of the two bracketed kernels (10 launches each per step: all layers get sampled): with every launch
-    # bracketed the 40 event records per step cost the step 0.07-0.12 ms of its 1.7-2.9 ms
+    # every 7th launch of each of the five bracketed per-layer kernels (10 launches each per step: all layers get sampled;
+    # fd_prof_end names the one with the largest TOTAL time): with every launch bracketed the 100 event records per step
+    # cost the step 0.2-0.3 ms of its 1.5-2.6 ms
     _C.check(lib.fd_prof_stride(ctx, 7), ctx)
     t0 = time.perf_counter()
     for i in range(steps):

@@ -84,6 +84,17 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #ifndef FD_FOLD_RES
 #define FD_FOLD_RES 1    // start the owner's FFN accumulators from the residual (no extra live registers in the loop)
 #endif
+#ifndef FD_FFN_ILV
+#define FD_FFN_ILV 1     // FFN items: relu VALU pinned into the shadows of the next H's MFMAs, the next step's fragment reads and the
+#endif                   // weight DMA into the shadows of the W2 MFMAs (sched_group_barrier pipelines; scripts/ubench/ffn32_proto.hip)
+#ifndef FD_FFN_PRIO
+#define FD_FFN_PRIO 1    // the waves that carry one tile less (and issue the weight DMA) run the FFN loop at s_setprio 1
+#endif
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+#define SG_VALU 0x2
+#define SG_MFMA 0x8
+#define SG_VMEM 0x10
+#define SG_DSR 0x100
 
 namespace {
 
@@ -1139,6 +1150,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     load_w2(0);
                     do_h(0);
                     __builtin_amdgcn_sched_barrier(0);
+                    const bool light_ok = FD_DMA_LIGHT && (2 * trem == MQ) && (SHP(rot) == trem);
+#if FD_FFN_PRIO
+                    // Two waves share a SIMD and a step ends with a barrier: the older wave wins every arbitration, finishes its items
+                    // first and leaves the younger one to run the rest of the step alone, every stall exposed.  With the lighter wave
+                    // (one item less + the DMA issue) preferred, the heavy wave fills its gaps and the tail of the step is the wave
+                    // with the most MFMAs per stall (prototype: 1443 -> 1392 cycles per step on top of the interleaved schedule).
+                    if (light_ok && ntile < MT) __builtin_amdgcn_s_setprio(1);
+#endif
                     for (int st = 0; st < NS; ++st) {
 #if FD_DMA_LIGHT
                         // Uneven tile split (e.g. 14 tiles = 4,4,3,3 per quarter): the MQ waves that carry one tile less issue the
@@ -1146,7 +1165,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         // path never leave the matrix pipe for the texture path.  Even splits alternate the F-half sets as before.
                         // (exactly MQ such waves with distinct wave % MQ -- issue_ffn_half's block split -- exist when half of the
                         //  quarters carry the extra tile and the F-half sets are rotated by that half: 14 tiles, rot 2)
-                        const bool light_ok = (2 * trem == MQ) && (SHP(rot) == trem);
                         const bool my_turn = light_ok ? (ntile < MT) : ((st & 1) == FH);
 #else
                         const bool my_turn = ((st & 1) == FH);
@@ -1164,10 +1182,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
 #else
 #if FD_DMA_LATE
                         if (my_turn && !light_ok && st + 3 < NS && FD_DMA_ON) issue_ffn_half(st + 3);
-#else
+#elif !FD_FFN_ILV
                         if (my_turn && st + 3 < NS && FD_DMA_ON) issue_ffn_half(st + 3);
 #endif
 #endif
+                        const bool dma_now = FD_FFN_ILV && !FD_DMA_SPREAD && !FD_DMA_LATE && my_turn && st + 3 < NS && FD_DMA_ON;
                         // NTT == 1: H(0) of this step issued during the previous step, before this step's successor
                         // buffer was visible -- its W1 can only be fetched now
                         if (NTT == 1 && st + 1 < NS) load_w1(st + 1);
@@ -1176,7 +1195,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             const f32x4 g0 = h0, g1 = h1;             // H(st, i): complete by the time the next H issued
                             if (i + 1 < NTT) {
                                 do_h(i + 1);
-                                if (i + 1 == NTT - 1 && st + 1 < NS) load_w1(st + 1);   // last reader of W1(st) issued
+                                if (!FD_FFN_ILV && i + 1 == NTT - 1 && st + 1 < NS) load_w1(st + 1);   // last reader of W1(st) issued
                             } else if (st + 1 < NS) {
                                 do_h(0);                              // first item of the next step
                             }
@@ -1193,6 +1212,49 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                                 }
                             }
 #endif
+#if FD_FFN_ILV
+                            // relu(item) = 8 VALU, two behind each of the next H's first MFMAs (the H MFMAs are 2 KS1 long: the
+                            // pipeline names 2 KS1 - 2 pairs, the rest of the MFMAs close the group)
+                            const bf16x8 hb = relu_pack(g0, g1);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                SGB(SG_MFMA, 1);
+                                SGB(SG_VALU, 2);
+                            }
+                            SGB(SG_MFMA, 2 * KS1);
+                            __builtin_amdgcn_sched_barrier(0);
+                            // the W2 MFMAs shadow the next step's W1 fragment reads (item NTT - 2: the last reader of W1(st), H of
+                            // item NTT - 1, has issued), the weight DMA of step st + 3 (item 0 of the issuing waves) and the next
+                            // step's W2 reads (last item: they trail the MFMAs that read the current ones)
+                            const bool rd_w1 = (NTT == 1 ? false : i + 1 == NTT - 1) && st + 1 < NS;
+                            if (rd_w1) load_w1(st + 1);
+                            if (i == 0 && dma_now) {
+                                issue_ffn_half(st + 3);
+#pragma unroll
+                                for (int dt = 0; dt < DT; ++dt) acc[dt][i] = MFMA(w2[dt], hb, acc[dt][i]);
+                                if (!rd_w1) {
+#pragma unroll
+                                    for (int q = 0; q < DT - 1; ++q) {
+                                        SGB(SG_MFMA, 1);
+                                        SGB(SG_VMEM, 2);
+                                    }
+                                    SGB(SG_MFMA, 1);
+                                }
+                            } else {
+#pragma unroll
+                                for (int dt = 0; dt < DT; ++dt) acc[dt][i] = MFMA(w2[dt], hb, acc[dt][i]);
+                                if (rd_w1) {
+#pragma unroll
+                                    for (int q = 0; q < DT - 1; ++q) {
+                                        SGB(SG_MFMA, 1);
+                                        SGB(SG_DSR, 2);
+                                    }
+                                    SGB(SG_MFMA, 1);
+                                }
+                            }
+                            if (i == NTT - 1 && st + 1 < NS) load_w2(st + 1);
+                            __builtin_amdgcn_sched_barrier(0);
+#else
                             __builtin_amdgcn_sched_barrier(0);
                             const bf16x8 hb = relu_pack(g0, g1);
                             __builtin_amdgcn_sched_barrier(0);
@@ -1200,6 +1262,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             for (int dt = 0; dt < DT; ++dt) acc[dt][i] = MFMA(w2[dt], hb, acc[dt][i]);
                             if (i == NTT - 1 && st + 1 < NS) load_w2(st + 1);
                             __builtin_amdgcn_sched_barrier(0);
+#endif
                         }
 #if FD_DMA_LATE && FD_DMA_LIGHT && !FD_DMA_SPREAD
                         // light waves issue behind their last item: the slack they have before the heavier waves reach the barrier
@@ -1226,6 +1289,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         __syncthreads();
 #endif
                     }
+#if FD_FFN_PRIO
+                    if (light_ok && ntile < MT) __builtin_amdgcn_s_setprio(0);
+#endif
                 };
                 if (ntile == MT) ffn_loop(std::integral_constant<int, MT>{});
                 else if (MT > 1 && ntile == MT - 1) ffn_loop(std::integral_constant<int, (MT > 1 ? MT - 1 : 1)>{});

@@ -2204,8 +2204,13 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         aa.x0rb = b.x0rb; aa.att = b.att; aa.attT = b.attT; aa.lse2 = b.lse2; aa.pmask = b.pmask;
         aa.wk = limg + im->off_wk; aa.wv = limg + im->off_wv; aa.wq = limg + im->off_wq;
         if (p > 0.f) FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[l], 0));      // this layer's dropout decisions are ready
-        if (attn_nw == 8) hipLaunchKernelGGL((k_tr_attn_fwd<KS1, 8>), dim3(d.NP, B), dim3(512), lds_attn, s, d, aa);
-        else hipLaunchKernelGGL((k_tr_attn_fwd<KS1, 4>), dim3(d.NP, B), dim3(256), lds_attn, s, d, aa);
+        {
+            // measurement hook: Q / K / V projections + scores + P V of M tokens (the softmax itself is not matrix work)
+            fd_prof_scope scope(ctx, s, "k_tr_attn_fwd (Q/K/V projections + softmax attention, training forward)",
+                                (double)M * (6.0 * D * D + 4.0 * (double)T * D));
+            if (attn_nw == 8) hipLaunchKernelGGL((k_tr_attn_fwd<KS1, 8>), dim3(d.NP, B), dim3(512), lds_attn, s, d, aa);
+            else hipLaunchKernelGGL((k_tr_attn_fwd<KS1, 4>), dim3(d.NP, B), dim3(256), lds_attn, s, d, aa);
+        }
         FfnFwdArgs fa{};
         fa.x0 = b.x0; fa.att = b.att; fa.s1 = b.s1; fa.s2 = b.s2;
         fa.out = (l + 1 < L) ? tb.layers[l + 1].x0 : tb.hL;
@@ -2305,14 +2310,26 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         fa.bffn = bl + im->boff_ffn; fa.wot = bl + im->boff_wot;
         fa.g1 = P + lo.n1_w; fa.be1 = P + lo.n1_b; fa.g2 = P + lo.n2_w;
         fa.rb1 = b.rb1; fa.rb3 = b.rb3;
-        hipLaunchKernelGGL((k_tr_ffn_bwd<KS1, DT>), dim3(tb.nwg), dim3(TW * 64), lds_bwd, s, d, fa);
+        {
+            // measurement hook: the input-gradient GEMMs W2^T, W1^T and out-proj^T of M tokens (the recomputed hidden chunk is
+            // not algorithmic work)
+            fd_prof_scope scope(ctx, s, "k_tr_ffn_bwd (LN2 bwd + FFN input gradient + LN1 bwd + out-proj^T, training backward)",
+                                (double)M * (4.0 * D * F + 2.0 * D * D));
+            hipLaunchKernelGGL((k_tr_ffn_bwd<KS1, DT>), dim3(tb.nwg), dim3(TW * 64), lds_bwd, s, d, fa);
+        }
         AttnBwdArgs ab{};
         ab.x0rb = b.x0rb; ab.att = b.att; ab.datt = tb.datt; ab.lse2 = b.lse2; ab.pmask = b.pmask; ab.pmaskT = b.pmaskT;
         ab.dxp = tb.dxp[par]; ab.dqkvT = b.dqkvT;
         ab.wk = limg + im->off_wk; ab.wv = limg + im->off_wv; ab.wq = limg + im->off_wq;
         ab.winT = bl + im->boff_win; ab.part_stride = tb.part_stride;
-        if (attn_nw == 8) hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 8>), dim3(d.NP, B), dim3(512), lds_ab, s, d, ab);
-        else hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 4>), dim3(d.NP, B), dim3(256), lds_ab, s, d, ab);
+        {
+            // measurement hook: dP = dO V^T, dV = P^T dO, dQ = dS K, dK = dS^T Q (2 T D each per token) + the in-proj^T GEMM; the
+            // recomputed scores are not algorithmic work
+            fd_prof_scope scope(ctx, s, "k_tr_attn_bwd (attention backward + in-proj^T, training backward)",
+                                (double)M * (8.0 * (double)T * D + 6.0 * D * D));
+            if (attn_nw == 8) hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 8>), dim3(d.NP, B), dim3(512), lds_ab, s, d, ab);
+            else hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 4>), dim3(d.NP, B), dim3(256), lds_ab, s, d, ab);
+        }
         WgLayer w{};
         w.x0T = b.x0T; w.attT = b.attT; w.doT = b.doT; w.dqkvT = b.dqkvT;
         w.stage = b.stage; w.activeT = b.activeT;
