@@ -17,6 +17,8 @@ struct fd_bf16_images {
     size_t off_wk = 0, off_wv = 0, off_wq = 0, off_wo = 0, off_ffn = 0;
     size_t off_lpar = 0;        // fp32 [6][D] out_b, l2_b, n1_w, n1_b, n2_w, n2_b of the layer, zero-padded to nlp KiB
     int nlp = 0;
+    bool ffn32_stale = false;                      // skipped by the last (training-step) rebuild
+    size_t off_ffn32 = 0, ffn32_layer_bytes = 0;   // pair-form FFN image of the layer (32x32x16 H; 0 bytes: not built)
     // ---- training (fd_train_bf16.hip): transposed-weight images of the backward pass, built lazily with the others
     bool train = false;         // bf16 training kernels instantiated for this model
     char* bimg = nullptr;       // per layer: FFN backward blocks (chunk-major, same block count as the forward image),

@@ -37,6 +37,7 @@ struct fd_mega_params {
     const char* img_layers;
     size_t layer_stride;
     size_t off_wk, off_wv, off_wq, off_wo, off_ffn;
+    size_t off_ffn32;                    // pair-form FFN image (32x32x16 H) of the layer, 0 when the model has none
     size_t off_lpar;                     // fp32 block [6][D] (bo, b2, g1, b1, g2, b2) of the layer, nlp KiB: fetched by DMA
     int nlp;
     // sampler

@@ -29,6 +29,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -36,6 +37,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #ifdef FD_ABL_NOEXP   // ablation build: a full-rate VALU op in place of the half-rate transcendental (wrong results)
 #define FD_EXP2(x) ((x) * 1.0001f)
 #else
@@ -125,6 +127,28 @@ __device__ __forceinline__ bf16x8 relu_pack(f32x4 a, f32x4 b) {
     const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     return __builtin_bit_cast(bf16x8, __builtin_elementwise_max(v, z));
 }
+// 32x32 C tile (hidden x tokens; this lane: token L % 32, rows 8 j + 4 (L / 32) + i in register 4 j + i) -> relu -> the two 16x16x32 B
+// fragments of token tiles 0 / 1 of the pair.  lo = rows j in {0, 1}, hi = j in {2, 3}; v_permlane16_swap exchanges the odd 16-lane
+// rows of `lo` with the even rows of `hi`: afterwards `lo` holds token tile 0 in all four lane rows and `hi` token tile 1, lane row q
+// carrying hidden rows 16 (q & 1) + 8 (e >> 2) + 4 (q >> 1) + (e & 3) in k-slot e (the pair-form W2 image is k-permuted to match).
+__device__ __forceinline__ void relu_split32(const f32x16& h, bf16x8& t0, bf16x8& t1) {
+    typedef __attribute__((ext_vector_type(2))) short s16x2;
+    const s16x2 z = {0, 0};
+    unsigned lo[4], hi[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        lo[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, cvt_pk_bf16(h[2 * d], h[2 * d + 1])), z));
+        hi[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, cvt_pk_bf16(h[8 + 2 * d], h[8 + 2 * d + 1])), z));
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const u32x2 r = __builtin_amdgcn_permlane16_swap(lo[d], hi[d], false, false);
+        lo[d] = r.x;
+        hi[d] = r.y;
+    }
+    t0 = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], lo[2], lo[3]});
+    t1 = __builtin_bit_cast(bf16x8, u32x4{hi[0], hi[1], hi[2], hi[3]});
+}
 __device__ __forceinline__ bf16x8 frag_zero() {
     u32x4 z = {0u, 0u, 0u, 0u};
     return __builtin_bit_cast(bf16x8, z);
@@ -179,9 +203,14 @@ __device__ __forceinline__ float group_max(float v) {
 // A dimension is compile-time when the policy gives it a non-zero value (every real dimension is >= 1).
 struct ShapeDyn {
     static constexpr int T = 0, KT = 0, D = 0, C = 0, H = 0, hd = 0, S = 0, NPG = 0, KSE = 0, CT = 0, rot = 0, L = 0, F = 0;
+    static constexpr int FFN32 = 0;
 };
-template <int T_, int D_, int C_, int H_, int S_, int NPG_, int ROT_, int L_, int F_>
+// FFN32_ = 1: the FFN's H GEMM runs on PAIRS of token tiles by v_mfma_f32_32x32x16_bf16 (K = D + 1 padded to 16 DT = 80 instead of
+// 32 KS1 = 96: 5 x 32 cycles per 32 tokens and 32 hidden units instead of 12 x 16); its B fragments are gathered from the tiles' 16x16x32
+// fragments in LDS by a per-lane address map once per FFN phase (the layout every other phase reads stays), W2 stays in the 16x16x32 form.
+template <int T_, int D_, int C_, int H_, int S_, int NPG_, int ROT_, int L_, int F_, int FFN32_ = 0>
 struct ShapeStatic {
+    static constexpr int FFN32 = FFN32_;
     static constexpr int T = T_, KT = (T_ + 15) / 16, D = D_, C = C_, H = H_, hd = D_ / H_, S = S_, NPG = NPG_;
     static constexpr int KSE = (C_ + 1 + 31) / 32, CT = (C_ + 15) / 16, rot = ROT_, L = L_, F = F_;
 };
@@ -191,6 +220,7 @@ struct ShapeStatic {
 template <int D_, int H_, int L_, int F_>
 struct ShapeModel {
     static constexpr int T = 0, KT = 0, D = D_, C = 0, H = H_, hd = D_ / H_, S = 0, NPG = 0, KSE = 0, CT = 0, rot = 0, L = L_, F = F_;
+    static constexpr int FFN32 = 0;
 };
 #define SHP(name) (SH::name != 0 ? SH::name : P.name)
 
@@ -225,8 +255,12 @@ __global__ __launch_bounds__(64) void k_temb_table(const float* __restrict__ par
 // finishes 25 % later than the older one, 0.65 vs 0.565 ms per diffusion step -- only NW = 8 is instantiated.
 template <int KS1, int DT, int KSO, int MT, class SH, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
-    constexpr int KSX = KS1;                     // x-fragment blocks per token tile
-    constexpr int NBF = 2 * KS1 + DT;            // FFN blocks per (F-half, 32-wide chunk)
+    constexpr int KSX = KS1;                     // x-fragment blocks per token tile (the host's LDS plan; the pair form needs less)
+    constexpr bool F32 = SH::FFN32 != 0;         // pair form of the FFN (see ShapeStatic)
+    constexpr int KS32 = DT;                     // pair form: k-steps of 16 (D + 1 <= 16 DT)
+    static_assert(!F32 || (NW == 8 && MT == 4 && DT == 2 * KS1 - 1 && SH::S * SH::KT >= 12 && ((SH::S * SH::KT) & 1) == 0),
+                  "pair-form FFN: 8 waves, 3 or 4 token tiles per wave, an even tile count, K = 16 DT");
+    constexpr int NBF = F32 ? KS32 + DT : 2 * KS1 + DT;   // FFN blocks per (F-half, 32-wide chunk)
     constexpr int NBUF = 4;                      // FFN weight ring: 4 buffers of one 32-wide chunk per F-half
     constexpr int WB1 = 2 * NBF * 1024;          // bytes per ring buffer ([F-half][block])
     constexpr int NDMA = (2 * NBF + NW - 1) / NW;   // DMA instructions per wave per buffer (padded: uniform vmcnt)
@@ -999,7 +1033,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                 // the image is chunk-major ([32-wide chunk][F-half][block]) and so is a ring buffer: one linear copy.
                 // Every wave issues exactly NDMA instructions (the last ones repeat a block) so that
                 // `s_waitcnt vmcnt(NDMA)` means "everything but the newest buffer has landed" for all waves.
-                const char* src = limg + P.off_ffn + (size_t)st * WB1 + lane * 16;
+                const char* src = limg + (F32 ? P.off_ffn32 : P.off_ffn) + (size_t)st * WB1 + lane * 16;
                 char* dst = ring + ((st_seq + rb) % NBUF) * WB1;
 #pragma unroll
                 for (int i = 0; i < NDMA; ++i) {
@@ -1015,7 +1049,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
             auto issue_ffn_half = [&](int st_seq) {
                 int st = st_seq + st_rot;
                 st -= (st >= NS) ? NS : 0;
-                const char* src = limg + P.off_ffn + (size_t)st * WB1 + lane * 16;
+                const char* src = limg + (F32 ? P.off_ffn32 : P.off_ffn) + (size_t)st * WB1 + lane * 16;
                 char* dst = ring + ((st_seq + rb) % NBUF) * WB1;
                 const int w4 = wave % MQ;
 #pragma unroll
@@ -1176,7 +1210,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         if (dma_on) {
                             int stn = st + 3 + st_rot;
                             stn -= (stn >= NS) ? NS : 0;
-                            dsrc = limg + P.off_ffn + (size_t)stn * WB1 + lane * 16;
+                            dsrc = limg + (F32 ? P.off_ffn32 : P.off_ffn) + (size_t)stn * WB1 + lane * 16;
                             ddst = ring + ((st + 3 + rb) % NBUF) * WB1;
                         }
 #else
@@ -1293,10 +1327,247 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     if (light_ok && ntile < MT) __builtin_amdgcn_s_setprio(0);
 #endif
                 };
+                // ---- pair form (ShapeStatic<..., FFN32 = 1>): item = a PAIR of token tiles.  H^T (32 hidden x 32 tokens) = KS32
+                // v_mfma_f32_32x32x16_bf16 (160 cycles against 2 x 96 in the 16x16x32 form), relu + pack + four v_permlane16_swap turn
+                // the C tile into the pair's two 16x16x32 B fragments, W2 = 2 x DT 16x16x32 MFMAs.  A wave with three tiles runs its odd
+                // one in the 16x16x32 form from the SAME weight image through a per-lane address map (row a of hidden tile ft <-> image
+                // row 16 (a>>2 & 1) + 4 (a>>3) + (a&3) + 8 ft: pack8(h0, h1) then has the pair-form W2 image's k-slot order).
+                // SHAPE 0: two pairs (tile0 even, 4 tiles); 1: pair then single (tile0 even, 3 tiles); 2: single then pair (tile0 odd).
+                // Prototype and measurements: scripts/ubench/ffn32_proto.hip, profiles/r04_ffn_proto_matrix*.txt.
+                auto ffn_loop32 = [&](auto shc) {
+                    constexpr int SHAPE = decltype(shc)::value;
+                    constexpr int NPAIR = SHAPE == 0 ? 2 : 1;
+                    constexpr bool SINGLE = SHAPE != 0;
+                    constexpr int acc_p0 = SHAPE == 2 ? 1 : 0;     // accumulator (tile) index of the first pair's first tile
+                    constexpr int acc_s = SHAPE == 1 ? 2 : 0;      // ... of the single tile
+                    const int a16 = lane & 15;
+                    const int hr = 16 * ((a16 >> 2) & 1) + 4 * (a16 >> 3) + (a16 & 3);
+                    const int pair0 = (SHAPE == 2 ? tile0 + 1 : tile0) >> 1;
+                    const int stile = SHAPE == 1 ? tile0 + 2 : tile0;
+                    // 32x32x16 B fragments of a pair, gathered from the tiles' 16x16x32 fragments as they lie in LDS: lane L supplies token
+                    // L % 32 (tile 2 pair + (L >> 4 & 1), row L & 15) and k-slots 16 ks + 8 (L >> 5) .. + 7 = k-step ks >> 1, lane group
+                    // 2 (ks & 1) + (L >> 5) of that tile (once per FFN phase: every other reader of the fragments keeps its linear address)
+                    bf16x8 xp[NPAIR][KS32];
+                    {
+                        const char* xl = xfr + (2 * pair0 + ((lane >> 4) & 1)) * (KSX * 1024) + (16 * (lane >> 5) + tok) * 16;
+#pragma unroll
+                        for (int pp = 0; pp < NPAIR; ++pp)
+#pragma unroll
+                            for (int ks = 0; ks < KS32; ++ks)
+                                xp[pp][ks] = *reinterpret_cast<const bf16x8*>(xl + pp * (2 * KSX * 1024) + (ks >> 1) * 1024 + (ks & 1) * 512);
+                    }
+                    bf16x8 xs[SINGLE ? KS1 : 1];
+                    if (SINGLE) {
+#pragma unroll
+                        for (int kk = 0; kk < KS1; ++kk) xs[kk] = xfrag(stile, kk);
+                    }
+                    // 16x16x32 A fragments of W1 inside the pair image: k-step kk < KS1 - 1 reads block 2 kk + (g >> 1), the last k-step
+                    // block KS32 - 1 in every lane (its upper k-slot groups meet the zeros of xfrag)
+                    const int o16a = (g >> 1) * 1024 + (32 * (g & 1) + hr) * 16, o16b = (KS32 - 1) * 1024 + (32 * (g & 1) + hr) * 16;
+                    bf16x8 w1[KS32], w2[DT], w1s[SINGLE ? 2 : 1][SINGLE ? KS1 : 1];
+                    f32x16 hp;                                       // pair item in flight
+                    f32x4 h0, h1;                                    // single item in flight
+                    auto ringbuf = [&](int s_) -> const char* { return ring + ((s_ + rb) % NBUF) * WB1 + FH * NBF * 1024; };
+                    auto load_w1 = [&](int s_) {
+                        const char* wb = ringbuf(s_) + lane * 16;
+#pragma unroll
+                        for (int ks = 0; ks < KS32; ++ks) w1[ks] = *reinterpret_cast<const bf16x8*>(wb + ks * 1024);
+                    };
+                    auto load_w1s = [&](int s_) {
+                        if constexpr (SINGLE) {
+                            const char* wb = ringbuf(s_);
+#pragma unroll
+                            for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                                for (int kk = 0; kk < KS1; ++kk)
+                                    w1s[ft][kk] = *reinterpret_cast<const bf16x8*>(wb + (kk < KS1 - 1 ? o16a + kk * 2048 : o16b) + ft * 128);
+                        }
+                    };
+                    auto load_w2 = [&](int s_) {
+                        const char* wb = ringbuf(s_) + lane * 16;
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) w2[dt] = *reinterpret_cast<const bf16x8*>(wb + (KS32 + dt) * 1024);
+                    };
+                    auto h_pair = [&](int pp) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        hp = z;
+#pragma unroll
+                        for (int ks = 0; ks < KS32; ++ks) hp = MFMA32(w1[ks], xp[pp][ks], hp);
+                    };
+                    auto h_single = [&]() {
+                        h0 = f4zero();
+                        h1 = f4zero();
+                        if constexpr (SINGLE) {
+#pragma unroll
+                            for (int kk = 0; kk < KS1; ++kk) {
+                                h0 = MFMA(w1s[0][kk], xs[kk], h0);
+                                h1 = MFMA(w1s[1][kk], xs[kk], h1);
+                            }
+                        }
+                    };
+                    auto w2_pair = [&](const bf16x8& t0, const bf16x8& t1, auto a0c) {
+                        constexpr int a0 = decltype(a0c)::value;
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) {
+                            acc[dt][a0] = MFMA(w2[dt], t0, acc[dt][a0]);
+                            acc[dt][a0 + 1] = MFMA(w2[dt], t1, acc[dt][a0 + 1]);
+                        }
+                    };
+                    load_w1(0);
+                    load_w1s(0);
+                    load_w2(0);
+                    h_pair(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    constexpr int TREM = (SH::S * SH::KT) % MQ;
+                    constexpr bool LIGHT_OK = FD_DMA_LIGHT && (2 * TREM == MQ) && (SH::rot == TREM);
+#if FD_FFN_PRIO
+                    if (LIGHT_OK && SINGLE) __builtin_amdgcn_s_setprio(1);
+#endif
+                    // One step, instantiated per (issues the weight DMA of step st + 3, a next step exists): every condition inside a
+                    // step is a compile-time fact, so a step is ONE basic block (a run-time `st + 1 < NS` / `my turn` test splits it
+                    // and the sched_group_barrier pipelines below stop at the block boundaries: measured 1514 instead of 1390 cycles)
+                    auto step32 = [&](int st, auto dmac, auto nextc) {
+                        constexpr bool dma_now = decltype(dmac)::value && FD_DMA_ON;
+                        constexpr bool NEXT = decltype(nextc)::value;
+                        if constexpr (!SINGLE) {
+                            {   // item 0 = pair 0 (H in flight); H of pair 1 shadows its relu, the next step's W1 reads trail its W2
+                                const f32x16 gp = hp;
+                                bf16x8 t0, t1;
+                                h_pair(1);
+                                relu_split32(gp, t0, t1);
+#pragma unroll
+                                for (int q = 0; q < KS32; ++q) {
+                                    SGB(SG_MFMA, 1);
+                                    SGB(SG_VALU, 4);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (NEXT) load_w1(st + 1);
+                                w2_pair(t0, t1, std::integral_constant<int, 0>{});
+#pragma unroll
+                                for (int q = 0; q < KS32; ++q) {
+                                    SGB(SG_MFMA, 1);
+                                    SGB(SG_DSR, 1);
+                                }
+                                SGB(SG_MFMA, 2 * DT - KS32);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            {   // item 1 = pair 1; H of the next step's pair 0 shadows its relu
+                                const f32x16 gp = hp;
+                                bf16x8 t0, t1;
+                                if (NEXT) h_pair(0);
+                                relu_split32(gp, t0, t1);
+#pragma unroll
+                                for (int q = 0; q < KS32; ++q) {
+                                    SGB(SG_MFMA, 1);
+                                    SGB(SG_VALU, 4);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (dma_now) issue_ffn_half(st + 3);         // (even tile splits: the F-half wave sets take turns)
+                                w2_pair(t0, t1, std::integral_constant<int, 2>{});
+                                if (NEXT) load_w2(st + 1);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        } else {
+                            {   // item 0 = the pair (H in flight); the single tile's H shadows its relu
+                                const f32x16 gp = hp;
+                                bf16x8 t0, t1;
+                                h_single();
+                                relu_split32(gp, t0, t1);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    SGB(SG_MFMA, 1);
+                                    SGB(SG_VALU, 3);
+                                }
+#pragma unroll
+                                for (int q = 4; q < 2 * KS1; ++q) {
+                                    SGB(SG_MFMA, 1);
+                                    SGB(SG_VALU, 4);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (NEXT) {
+                                    load_w1(st + 1);
+                                    load_w1s(st + 1);
+                                }
+                                w2_pair(t0, t1, std::integral_constant<int, acc_p0>{});
+#pragma unroll
+                                for (int q = 0; q < 2 * DT - 2; ++q) {
+                                    SGB(SG_MFMA, 1);
+                                    SGB(SG_DSR, 1);
+                                }
+                                SGB(SG_MFMA, 1);
+                                SGB(SG_DSR, 2);
+                                SGB(SG_MFMA, 1);
+                                SGB(SG_DSR, 1);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            {   // item 1 = the single tile; H of the next step's pair shadows its relu, the weight DMA trails its W2
+                                const f32x4 g0 = h0, g1 = h1;
+                                if (NEXT) h_pair(0);
+                                const bf16x8 hb = relu_pack(g0, g1);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    SGB(SG_MFMA, 1);
+                                    SGB(SG_VALU, 2);
+                                }
+                                SGB(SG_MFMA, KS32 - 4);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (dma_now) {
+                                    issue_ffn_half(st + 3);
+#pragma unroll
+                                    for (int dt = 0; dt < DT; ++dt) acc[dt][acc_s] = MFMA(w2[dt], hb, acc[dt][acc_s]);
+#pragma unroll
+                                    for (int q = 0; q < DT; ++q) {
+                                        SGB(SG_MFMA, 1);
+                                        SGB(SG_VMEM, 1);
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int dt = 0; dt < DT; ++dt) acc[dt][acc_s] = MFMA(w2[dt], hb, acc[dt][acc_s]);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (NEXT) load_w2(st + 1);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                        if (dma_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDH) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                    };
+                    {
+                        using Tc = std::true_type;
+                        using Fc = std::false_type;
+                        int st = 0;
+                        if constexpr (LIGHT_OK) {               // the three-tile waves issue every step's DMA
+                            for (; st < NS - 3; ++st) step32(st, std::integral_constant<bool, SINGLE>{}, Tc{});
+                        } else {                                // the F-half wave sets take turns: even steps FH 0, odd steps FH 1
+                            for (; st + 1 < NS - 3; st += 2) {
+                                step32(st, std::integral_constant<bool, FH == 0>{}, Tc{});
+                                step32(st + 1, std::integral_constant<bool, FH == 1>{}, Tc{});
+                            }
+                            if (st < NS - 3) {
+                                step32(st, std::integral_constant<bool, FH == 0>{}, Tc{});
+                                ++st;
+                            }
+                        }
+                        for (; st < NS - 1; ++st) step32(st, Fc{}, Tc{});
+                        step32(st, Fc{}, Fc{});
+                    }
+#if FD_FFN_PRIO
+                    if (LIGHT_OK && SINGLE) __builtin_amdgcn_s_setprio(0);
+#endif
+                };
+                if constexpr (F32) {
+                    if (ntile == MT) ffn_loop32(std::integral_constant<int, 0>{});
+                    else if constexpr (((SH::S * SH::KT) % MQ) != 0) {
+                        if ((tile0 & 1) == 0) ffn_loop32(std::integral_constant<int, 1>{});
+                        else ffn_loop32(std::integral_constant<int, 2>{});
+                    }
+                } else {
                 if (ntile == MT) ffn_loop(std::integral_constant<int, MT>{});
                 else if (MT > 1 && ntile == MT - 1) ffn_loop(std::integral_constant<int, (MT > 1 ? MT - 1 : 1)>{});
                 else {   // fewer tiles only happens for tiny workgroups: run the full width (extra tiles are zeros)
                     ffn_loop(std::integral_constant<int, MT>{});
+                }
                 }
                 mark(6, step);
                 refresh_lane();
@@ -1447,14 +1718,18 @@ static int launch_mega_t(fd_ctx* ctx, const fd_mega_params& P, int grid, size_t 
 // Static-shape instantiations for the BASELINE.json workloads (default transformer: D=72, H=12, L=10, F=2048):
 // configs[1] ecg (T=100, C=12): 2 series per workgroup, 2 head groups of 3 pairs;
 // configs[2] nasdaq (T=252, C=6) and configs[3] mimiciii (T=256, C=28): 1 series (16 token tiles), 3 groups of 2 pairs.
-using ShapeEcg = ShapeStatic<100, 72, 12, 12, 2, 3, 2, 10, 2048>;
-using ShapeNasdaq = ShapeStatic<252, 72, 6, 12, 1, 2, 1, 10, 2048>;
-using ShapeMimic = ShapeStatic<256, 72, 28, 12, 1, 2, 1, 10, 2048>;
+#ifndef FD_MEGA_FFN32
+#define FD_MEGA_FFN32 1      // pair-form FFN (32x32x16 H) in the static-shape instantiations; 0 = the 16x16x32 form (A/B builds)
+#endif
+using ShapeEcg = ShapeStatic<100, 72, 12, 12, 2, 3, 2, 10, 2048, FD_MEGA_FFN32>;
+using ShapeNasdaq = ShapeStatic<252, 72, 6, 12, 1, 2, 1, 10, 2048, FD_MEGA_FFN32>;
+using ShapeMimic = ShapeStatic<256, 72, 28, 12, 1, 2, 1, 10, 2048, FD_MEGA_FFN32>;
 
 template <class SH>
 static bool shape_matches(const fd_mega_params& P, int ks1, int dt, int kso, int mt) {
     return ks1 == 3 && dt == 5 && kso == 3 && mt == 4 && P.T == SH::T && P.D == SH::D && P.C == SH::C && P.H == SH::H &&
-           P.S == SH::S && P.NPG == SH::NPG && P.rot == SH::rot && P.L == SH::L && P.F == SH::F;
+           P.S == SH::S && P.NPG == SH::NPG && P.rot == SH::rot && P.L == SH::L && P.F == SH::F &&
+           (SH::FFN32 == 0 || P.off_ffn32 != 0);
 }
 
 // `describe` (>= 192 bytes, nullable): when given, the instantiation that WOULD run is written there and nothing is
@@ -1462,8 +1737,8 @@ static bool shape_matches(const fd_mega_params& P, int ks1, int dt, int kso, int
 #define FD_MEGA_GO(K, T_, O, M_, SH, NAME)                                                             \
     do {                                                                                               \
         if (describe) {                                                                                \
-            snprintf(describe, 192, "k_mega<%d,%d,%d,%d,%s> S=%d NPG=%d rot=%d grid=%d lds=%zu", K, T_, O, M_, NAME, P.S, \
-                     P.NPG, P.rot, grid, lds);                                                         \
+            snprintf(describe, 192, "k_mega<%d,%d,%d,%d,%s> S=%d NPG=%d rot=%d grid=%d lds=%zu%s", K, T_, O, M_, NAME, P.S, \
+                     P.NPG, P.rot, grid, lds, SH::FFN32 ? " ffn32 (H by 32x32x16 MFMAs on token-tile pairs)" : ""); \
             return FD_OK;                                                                              \
         }                                                                                              \
         return launch_mega_t<K, T_, O, M_, SH>(ctx, P, grid, lds, s);                                  \

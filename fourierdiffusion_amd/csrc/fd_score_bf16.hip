@@ -78,6 +78,37 @@ __device__ void build_ffn_block(const float* __restrict__ W1, const float* __res
     }
 }
 
+// FFN image of the persistent kernel's PAIR form (fd_mega.hip, FFN32): H of a pair of token tiles by v_mfma_f32_32x32x16_bf16
+// (M = 32 hidden units, N = 32 tokens, K = D + 1 bias slot padded to 16 DT instead of 32 KS1), W2 by the 16x16x32 form.
+// Chunk-major: block ((c*2 + fh)*NB + j), NB = 2 DT, of chunk c (hidden units fbase = fh*F/2 + 32c .. +31):
+//   j <  DT (ks)  : 32x32x16 A fragment: lane l holds hidden unit fbase + (l & 31), k = 16 ks + 8 (l >> 5) + e (k == D -> b1, > D -> 0)
+//   j >= DT (dt)  : 16x16x32 A fragment of W2 rows d = 16 dt + (l & 15); k-slot e of lane row q = l >> 4 is hidden unit
+//                   fbase + 16 (q & 1) + 8 (e >> 2) + 4 (q >> 1) + (e & 3): the order in which four v_permlane16_swap leave a
+//                   relu'd 32x32 C tile in the two 16x16x32 B fragments of the pair (relu_split32 in fd_mega.hip)
+__device__ void build_ffn32_block(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+                                  __bf16* __restrict__ img, int D, int F, int DT, int blk, int lane) {
+    const int NB = 2 * DT;
+    const int j = blk % NB, fh = (blk / NB) & 1, c = blk / (2 * NB);
+    const int fbase = fh * (F / 2) + c * 32;
+    __bf16* dst = img + ((size_t)blk * 64 + lane) * 8;
+    if (j < DT) {
+        const int f = fbase + (lane & 31);
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * j + 8 * (lane >> 5) + e;
+            float v = 0.f;
+            if (k < D) v = W1[(size_t)f * D + k];
+            else if (k == D) v = b1[f];
+            dst[e] = (__bf16)v;
+        }
+    } else {
+        const int d = 16 * (j - DT) + (lane & 15), q = lane >> 4;
+        for (int e = 0; e < 8; ++e) {
+            const int f = fbase + 16 * (q & 1) + 8 * (e >> 2) + 4 * (q >> 1) + (e & 3);
+            dst[e] = (__bf16)((d < D) ? W2[(size_t)d * F + f] : 0.f);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ persistent-kernel weight images
 // One 64-lane block = one 1 KiB MFMA fragment: lane (row = l&15, g = l>>4) holds 8 bf16 = k-slots 8g..8g+7 of
 // k-step ks for matrix row `row` of row tile rt.  kind selects how (rt, row, k) maps onto the fp32 weights.
@@ -178,7 +209,8 @@ __device__ void build_win_block(const float* __restrict__ Win, __bf16* __restric
 struct fd_img_build {
     const float* P;
     const long long* lofs;     // [L][12] fd_layer_off
-    char* mimg; size_t off_layers, layer_stride, off_wk, off_wv, off_wq, off_wo, off_ffn, off_lpar;
+    char* mimg; size_t off_layers, layer_stride, off_wk, off_wv, off_wq, off_wo, off_ffn, off_lpar, off_ffn32;
+    int n_ffn32;               // blocks of the pair-form FFN image per layer (0: not built)
     char* ffn; size_t ffn_layer_bytes;
     char* bimg; size_t b_layer_stride, boff_ffn, boff_wot, boff_win;
     int D, F, H, hd, KS1, DT, KSO, NP;
@@ -221,6 +253,8 @@ __global__ __launch_bounds__(64) void k_build_layer_images(const fd_img_build B)
         return;
     }
     blk -= B.n_lp;
+    if (blk < B.n_ffn32) { build_ffn32_block(P + lo[4], P + lo[5], P + lo[6], (__bf16*)(limg + B.off_ffn32), B.D, B.F, B.DT, blk, lane); return; }
+    blk -= B.n_ffn32;
     if (!B.train) return;
     char* bl = B.bimg + (size_t)l * B.b_layer_stride;
     if (blk < B.n_ffn) { build_ffn_bwd_block(P + lo[4], P + lo[6], (__bf16*)(bl + B.boff_ffn), B.D, B.F, B.KS1, B.DT, blk, lane); return; }
@@ -729,7 +763,11 @@ int fd_bf16_create(fd_score* m) {
         im->off_ffn = im->off_wo + (size_t)im->dt * im->kso * KB;
         im->off_lpar = im->off_ffn + im->ffn_layer_bytes;
         im->nlp = (24 * D + 1023) / 1024;
-        im->layer_stride = im->off_lpar + (size_t)im->nlp * KB;
+        // pair-form FFN image (32x32x16 H): built for the hydra default width class, the only one with static-shape
+        // instantiations of the persistent kernel that use it
+        im->off_ffn32 = im->off_lpar + (size_t)im->nlp * KB;
+        im->ffn32_layer_bytes = (im->ks1 == 3 && im->dt == 5) ? (size_t)2 * (F / 64) * 2 * im->dt * KB : 0;
+        im->layer_stride = im->off_ffn32 + im->ffn32_layer_bytes;
         const size_t total = im->off_layers + im->layer_stride * L;
         if (hipMalloc((void**)&im->mimg, total) != hipSuccess) {
             fd_bf16_destroy(m);
@@ -785,9 +823,12 @@ void fd_bf16_destroy(fd_score* m) {
     m->bf16 = nullptr;
 }
 
-int fd_bf16_prepare(fd_score* m, hipStream_t s) {
+int fd_bf16_prepare(fd_score* m, hipStream_t s, bool training_only) {
     fd_bf16_images* im = m->bf16;
     if (!im || !im->supported) return FD_OK;
+    // the pair-form FFN image is read by the persistent sampler kernel only: a training step's rebuild skips it (a quarter of the
+    // rebuild's blocks) and leaves it marked stale for the next inference call
+    if (im->ffn32_layer_bytes) im->ffn32_stale = training_only;
     const int D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, C = m->d.n_channels, hd = D / H, L = m->d.num_layers;
     const int NB = 2 * im->ks1 + im->dt;
     const float* P = m->params;
@@ -796,6 +837,7 @@ int fd_bf16_prepare(fd_score* m, hipStream_t s) {
     B.mimg = im->mimg; B.off_layers = im->off_layers; B.layer_stride = im->layer_stride;
     B.off_wk = im->off_wk; B.off_wv = im->off_wv; B.off_wq = im->off_wq; B.off_wo = im->off_wo; B.off_ffn = im->off_ffn;
     B.off_lpar = im->off_lpar; B.n_lp = im->mega ? im->nlp : 0;
+    B.off_ffn32 = im->off_ffn32; B.n_ffn32 = (im->mega && !training_only) ? (int)(im->ffn32_layer_bytes / 1024) : 0;
     B.ffn = im->ffn; B.ffn_layer_bytes = im->ffn_layer_bytes;
     B.bimg = im->bimg; B.b_layer_stride = im->b_layer_stride; B.boff_ffn = im->boff_ffn; B.boff_wot = im->boff_wot; B.boff_win = im->boff_win;
     B.D = D; B.F = F; B.H = H; B.hd = hd; B.KS1 = im->ks1; B.DT = im->dt; B.KSO = im->kso; B.NP = im->np;
@@ -804,7 +846,7 @@ int fd_bf16_prepare(fd_score* m, hipStream_t s) {
     // softmax scale and log2(e) folded into W_q / b_q: the kernels' softmax is exp2(s - max)
     B.qscale = (float)(1.4426950408889634 / std::sqrt((double)hd));
     int per_layer = B.n_ffn;
-    if (B.mega) per_layer += 3 * B.n_qkv + B.n_wo + B.n_ffn + B.n_lp;
+    if (B.mega) per_layer += 3 * B.n_qkv + B.n_wo + B.n_ffn + B.n_lp + B.n_ffn32;
     if (B.mega && B.train) per_layer += B.n_ffn + B.n_wot + B.n_win;
     if (L > 0) hipLaunchKernelGGL(k_build_layer_images, dim3(per_layer, L), dim3(64), 0, s, B);
     if (im->pimg) {
@@ -917,6 +959,7 @@ static int fill_mega_params(const fd_score* m, const MegaPlan& pl, int B, fd_meg
     P.layer_stride = im->layer_stride;
     P.off_wk = im->off_wk; P.off_wv = im->off_wv; P.off_wq = im->off_wq; P.off_wo = im->off_wo; P.off_ffn = im->off_ffn;
     P.off_lpar = im->off_lpar; P.nlp = im->nlp;
+    P.off_ffn32 = im->ffn32_layer_bytes ? im->off_ffn32 : 0;
     return FD_OK;
 }
 
@@ -930,9 +973,9 @@ void add_layernorm(const float* a, const float* r, const float* gamma, const flo
                    hipStream_t s);
 }  // namespace fdf32
 
-int fd_bf16_refresh(fd_score* m, hipStream_t s) {
-    if (!m->bf16_stale) return FD_OK;
-    if (int rc = fd_bf16_prepare(m, s)) return rc;
+int fd_bf16_refresh(fd_score* m, hipStream_t s, bool training_only) {
+    if (!m->bf16_stale && (training_only || !m->bf16 || !m->bf16->ffn32_stale)) return FD_OK;
+    if (int rc = fd_bf16_prepare(m, s, training_only)) return rc;
     m->bf16_stale = false;
     return FD_OK;
 }

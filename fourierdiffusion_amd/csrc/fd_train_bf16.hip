@@ -2436,10 +2436,10 @@ int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, flo
         }
         FD_HIP(ctx, hipEventRecord(ctx->side_events[m->d.num_layers], s));
         FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream2, ctx->side_events[m->d.num_layers], 0));
-        if (int rc = fd_bf16_refresh(m, ctx->side_stream2)) return rc;
+        if (int rc = fd_bf16_refresh(m, ctx->side_stream2, true)) return rc;
         FD_HIP(ctx, hipEventRecord(ctx->side_events[m->d.num_layers + 2], ctx->side_stream2));
         img_forked = true;
-    } else if (int rc = fd_bf16_refresh(m, s)) {
+    } else if (int rc = fd_bf16_refresh(m, s, true)) {
         return rc;
     }
     const size_t need = fd_train_bf16_workspace(m, B);
