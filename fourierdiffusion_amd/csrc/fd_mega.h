@@ -2,6 +2,9 @@
 #pragma once
 #include "fd_common.h"
 
+#ifndef FD_W1_SWAP34
+#define FD_W1_SWAP34 1      // pair-form W1 image rows stored with index bits 3 <-> 4 swapped (LDS bank slots; 0 = natural order, A/B builds)
+#endif
 #define FD_MEGA_FORWARD 0   // one score-network forward: x, tvec -> score_out
 #define FD_MEGA_SAMPLE 1    // nsteps x {forward, reverse-SDE step}, x updated in place
 

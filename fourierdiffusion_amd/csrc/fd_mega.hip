@@ -68,27 +68,12 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #ifndef FD_ROLLED_ATTN
 #define FD_ROLLED_ATTN 0
 #endif
-#ifndef FD_FFN_BARE_BARRIER
-#define FD_FFN_BARE_BARRIER 1
-#endif
 #ifndef FD_XF_REGS
 #define FD_XF_REGS 1     // FFN activation fragments: 1 = registers for the whole phase, 0 = LDS read per use
 #endif
 #ifndef FD_DMA_LIGHT
 #define FD_DMA_LIGHT 1   // FFN weight DMA issued by the waves with the fewest token tiles only (uneven splits)
 #endif
-#ifndef FD_DMA_LATE
-#define FD_DMA_LATE 0    // light-wave DMA issued behind the step's items instead of in front of them
-#endif
-#ifndef FD_DMA_SPREAD
-#define FD_DMA_SPREAD 0  // FFN weight DMA of step st+3: 1 = one instruction per item from every wave, 0 = a burst by one wave set per step
-#endif
-#ifndef FD_FOLD_RES
-#define FD_FOLD_RES 1    // start the owner's FFN accumulators from the residual (no extra live registers in the loop)
-#endif
-#ifndef FD_FFN_ILV
-#define FD_FFN_ILV 1     // FFN items: relu VALU pinned into the shadows of the next H's MFMAs, the next step's fragment reads and the
-#endif                   // weight DMA into the shadows of the W2 MFMAs (sched_group_barrier pipelines; scripts/ubench/ffn32_proto.hip)
 #ifndef FD_FFN_PRIO
 #define FD_FFN_PRIO 1    // the waves that carry one tile less (and issue the weight DMA) run the FFN loop at s_setprio 1
 #endif
@@ -976,6 +961,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                 {
                     const int DF = KT >> 1;                            // two-tile units per (pair, series)
                     const int ND = npg * S * DF, NU = ND + ((KT & 1) ? npg * S : 0);
+                    // (s_setprio 1 for the younger wave of every SIMD, or for the waves whose last unit is a single tile, during the
+                    //  units: -0.7 % / -0.9 % per diffusion step, same box -- unlike the FFN loop the units are VALU-issue bound)
 #if FD_STATIC_UNITS
                     // Static hand-out: wave w runs units w, w + NW, ...  (The dynamic LDS counter balanced the per-wave times
                     // but never changed the phase time -- a wave left alone on its SIMD runs at nearly the throughput of two --
@@ -1184,13 +1171,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     load_w2(0);
                     do_h(0);
                     __builtin_amdgcn_sched_barrier(0);
-                    const bool light_ok = FD_DMA_LIGHT && (2 * trem == MQ) && (SHP(rot) == trem);
 #if FD_FFN_PRIO
                     // Two waves share a SIMD and a step ends with a barrier: the older wave wins every arbitration, finishes its items
                     // first and leaves the younger one to run the rest of the step alone, every stall exposed.  With the lighter wave
-                    // (one item less + the DMA issue) preferred, the heavy wave fills its gaps and the tail of the step is the wave
-                    // with the most MFMAs per stall (prototype: 1443 -> 1392 cycles per step on top of the interleaved schedule).
-                    if (light_ok && ntile < MT) __builtin_amdgcn_s_setprio(1);
+                    // (one item less + the DMA issue) preferred, the heavy wave fills its gaps (same-box A/B on the ecg shape: +2.1 %).
+                    if (FD_DMA_LIGHT && (2 * trem == MQ) && (SHP(rot) == trem) && ntile < MT) __builtin_amdgcn_s_setprio(1);
 #endif
                     for (int st = 0; st < NS; ++st) {
 #if FD_DMA_LIGHT
@@ -1199,28 +1184,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         // path never leave the matrix pipe for the texture path.  Even splits alternate the F-half sets as before.
                         // (exactly MQ such waves with distinct wave % MQ -- issue_ffn_half's block split -- exist when half of the
                         //  quarters carry the extra tile and the F-half sets are rotated by that half: 14 tiles, rot 2)
+                        const bool light_ok = (2 * trem == MQ) && (SHP(rot) == trem);
                         const bool my_turn = light_ok ? (ntile < MT) : ((st & 1) == FH);
 #else
                         const bool my_turn = ((st & 1) == FH);
 #endif
-#if FD_DMA_SPREAD
-                        const bool dma_on = st + 3 < NS && FD_DMA_ON;
-                        const char* dsrc = nullptr;
-                        char* ddst = nullptr;
-                        if (dma_on) {
-                            int stn = st + 3 + st_rot;
-                            stn -= (stn >= NS) ? NS : 0;
-                            dsrc = limg + (F32 ? P.off_ffn32 : P.off_ffn) + (size_t)stn * WB1 + lane * 16;
-                            ddst = ring + ((st + 3 + rb) % NBUF) * WB1;
-                        }
-#else
-#if FD_DMA_LATE
-                        if (my_turn && !light_ok && st + 3 < NS && FD_DMA_ON) issue_ffn_half(st + 3);
-#elif !FD_FFN_ILV
                         if (my_turn && st + 3 < NS && FD_DMA_ON) issue_ffn_half(st + 3);
-#endif
-#endif
-                        const bool dma_now = FD_FFN_ILV && !FD_DMA_SPREAD && !FD_DMA_LATE && my_turn && st + 3 < NS && FD_DMA_ON;
                         // NTT == 1: H(0) of this step issued during the previous step, before this step's successor
                         // buffer was visible -- its W1 can only be fetched now
                         if (NTT == 1 && st + 1 < NS) load_w1(st + 1);
@@ -1229,66 +1198,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             const f32x4 g0 = h0, g1 = h1;             // H(st, i): complete by the time the next H issued
                             if (i + 1 < NTT) {
                                 do_h(i + 1);
-                                if (!FD_FFN_ILV && i + 1 == NTT - 1 && st + 1 < NS) load_w1(st + 1);   // last reader of W1(st) issued
+                                if (i + 1 == NTT - 1 && st + 1 < NS) load_w1(st + 1);   // last reader of W1(st) issued
                             } else if (st + 1 < NS) {
                                 do_h(0);                              // first item of the next step
                             }
-#if FD_DMA_SPREAD
-                            // one DMA instruction per item, behind the H MFMAs just issued: its issue cycles overlap the matrix
-                            // pipe's work instead of stalling a wave at the head of the step (every wave issues NDMA per step,
-                            // repeats included, so vmcnt(NDMA) below still means "everything but the newest buffer landed")
-                            if (dma_on) {
-#pragma unroll
-                                for (int q = i; q < ((i == NTT - 1) ? NDMA : ((i + 1 < NDMA) ? i + 1 : NDMA)); ++q) {   // the last item takes what is left
-                                    int b = wave + q * NW;
-                                    b -= (b >= 2 * NBF) ? NW : 0;
-                                    __builtin_amdgcn_global_load_lds(GLB_PTR(dsrc + b * 1024), LDS_PTR(ddst + b * 1024), 16, 0, 0);
-                                }
-                            }
-#endif
-#if FD_FFN_ILV
-                            // relu(item) = 8 VALU, two behind each of the next H's first MFMAs (the H MFMAs are 2 KS1 long: the
-                            // pipeline names 2 KS1 - 2 pairs, the rest of the MFMAs close the group)
-                            const bf16x8 hb = relu_pack(g0, g1);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                SGB(SG_MFMA, 1);
-                                SGB(SG_VALU, 2);
-                            }
-                            SGB(SG_MFMA, 2 * KS1);
-                            __builtin_amdgcn_sched_barrier(0);
-                            // the W2 MFMAs shadow the next step's W1 fragment reads (item NTT - 2: the last reader of W1(st), H of
-                            // item NTT - 1, has issued), the weight DMA of step st + 3 (item 0 of the issuing waves) and the next
-                            // step's W2 reads (last item: they trail the MFMAs that read the current ones)
-                            const bool rd_w1 = (NTT == 1 ? false : i + 1 == NTT - 1) && st + 1 < NS;
-                            if (rd_w1) load_w1(st + 1);
-                            if (i == 0 && dma_now) {
-                                issue_ffn_half(st + 3);
-#pragma unroll
-                                for (int dt = 0; dt < DT; ++dt) acc[dt][i] = MFMA(w2[dt], hb, acc[dt][i]);
-                                if (!rd_w1) {
-#pragma unroll
-                                    for (int q = 0; q < DT - 1; ++q) {
-                                        SGB(SG_MFMA, 1);
-                                        SGB(SG_VMEM, 2);
-                                    }
-                                    SGB(SG_MFMA, 1);
-                                }
-                            } else {
-#pragma unroll
-                                for (int dt = 0; dt < DT; ++dt) acc[dt][i] = MFMA(w2[dt], hb, acc[dt][i]);
-                                if (rd_w1) {
-#pragma unroll
-                                    for (int q = 0; q < DT - 1; ++q) {
-                                        SGB(SG_MFMA, 1);
-                                        SGB(SG_DSR, 2);
-                                    }
-                                    SGB(SG_MFMA, 1);
-                                }
-                            }
-                            if (i == NTT - 1 && st + 1 < NS) load_w2(st + 1);
-                            __builtin_amdgcn_sched_barrier(0);
-#else
                             __builtin_amdgcn_sched_barrier(0);
                             const bf16x8 hb = relu_pack(g0, g1);
                             __builtin_amdgcn_sched_barrier(0);
@@ -1296,35 +1209,21 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             for (int dt = 0; dt < DT; ++dt) acc[dt][i] = MFMA(w2[dt], hb, acc[dt][i]);
                             if (i == NTT - 1 && st + 1 < NS) load_w2(st + 1);
                             __builtin_amdgcn_sched_barrier(0);
-#endif
                         }
-#if FD_DMA_LATE && FD_DMA_LIGHT && !FD_DMA_SPREAD
-                        // light waves issue behind their last item: the slack they have before the heavier waves reach the barrier
-                        if (my_turn && light_ok && st + 3 < NS && FD_DMA_ON) issue_ffn_half(st + 3);
-#endif
                         // buffer st+2 must have landed before anyone reads it in step st+1 (own DMA, then barrier)
                         // (this wave's share of buffer st+2 was issued one step ago if it was not its turn now; a wave
                         // whose turn it is has nothing older than the NDH instructions it just issued, except at st = 0)
-#if FD_DMA_SPREAD
-                        if (dma_on) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
                         if (my_turn && st + 3 < NS && FD_DMA_ON) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDH) : "memory");
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
                         // bare s_barrier: __syncthreads() carries a workgroup fence that hipcc lowers to
                         // s_waitcnt vmcnt(0) lgkmcnt(0) -- it would drain the DMA issued this very step (3 steps of
                         // slack thrown away, measured) and the fragment prefetch of the next step.  What must be
                         // ordered is ordered by hand: this wave's share of buffer st+2 has landed (vmcnt above); LDS
                         // reads of a buffer are consumed (waited on) a full step before that buffer is refilled.
-#if FD_FFN_BARE_BARRIER
                         __builtin_amdgcn_s_barrier();
-#else
-                        __syncthreads();
-#endif
                     }
 #if FD_FFN_PRIO
-                    if (light_ok && ntile < MT) __builtin_amdgcn_s_setprio(0);
+                    if (FD_DMA_LIGHT && (2 * trem == MQ) && (SHP(rot) == trem) && ntile < MT) __builtin_amdgcn_s_setprio(0);
 #endif
                 };
                 // ---- pair form (ShapeStatic<..., FFN32 = 1>): item = a PAIR of token tiles.  H^T (32 hidden x 32 tokens) = KS32
@@ -1340,8 +1239,19 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     constexpr bool SINGLE = SHAPE != 0;
                     constexpr int acc_p0 = SHAPE == 2 ? 1 : 0;     // accumulator (tile) index of the first pair's first tile
                     constexpr int acc_s = SHAPE == 1 ? 2 : 0;      // ... of the single tile
+                    // (the image stores hidden row h of a chunk in lane slot h with bits 3 and 4 swapped: ds_read_b128 serves 16 lanes
+                    //  per cycle -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... -- and both this reader's rows and the pair reader's
+                    //  then fall on 16 distinct 16-byte bank slots per lane group; natural order: 2-way conflicts on all six reads)
                     const int a16 = lane & 15;
+#if FD_W1_SWAP34
+                    const int hr = 8 * ((a16 >> 2) & 1) + 4 * (a16 >> 3) + (a16 & 3);   // row 16 (a>>2 & 1) + 4 (a>>3) + (a&3), bits 3 <-> 4
+                    const int lperm = (lane & 39) | ((lane & 8) << 1) | ((lane & 16) >> 1);   // lane with bits 3 <-> 4 (row L & 31 of the pair form)
+                    constexpr int FTB = 256;
+#else
                     const int hr = 16 * ((a16 >> 2) & 1) + 4 * (a16 >> 3) + (a16 & 3);
+                    const int lperm = lane;
+                    constexpr int FTB = 128;
+#endif
                     const int pair0 = (SHAPE == 2 ? tile0 + 1 : tile0) >> 1;
                     const int stile = SHAPE == 1 ? tile0 + 2 : tile0;
                     // 32x32x16 B fragments of a pair, gathered from the tiles' 16x16x32 fragments as they lie in LDS: lane L supplies token
@@ -1369,7 +1279,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     f32x4 h0, h1;                                    // single item in flight
                     auto ringbuf = [&](int s_) -> const char* { return ring + ((s_ + rb) % NBUF) * WB1 + FH * NBF * 1024; };
                     auto load_w1 = [&](int s_) {
-                        const char* wb = ringbuf(s_) + lane * 16;
+                        const char* wb = ringbuf(s_) + lperm * 16;
 #pragma unroll
                         for (int ks = 0; ks < KS32; ++ks) w1[ks] = *reinterpret_cast<const bf16x8*>(wb + ks * 1024);
                     };
@@ -1380,7 +1290,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
                                 for (int kk = 0; kk < KS1; ++kk)
-                                    w1s[ft][kk] = *reinterpret_cast<const bf16x8*>(wb + (kk < KS1 - 1 ? o16a + kk * 2048 : o16b) + ft * 128);
+                                    w1s[ft][kk] = *reinterpret_cast<const bf16x8*>(wb + (kk < KS1 - 1 ? o16a + kk * 2048 : o16b) + ft * FTB);
                         }
                     };
                     auto load_w2 = [&](int s_) {

@@ -81,7 +81,8 @@ __device__ void build_ffn_block(const float* __restrict__ W1, const float* __res
 // FFN image of the persistent kernel's PAIR form (fd_mega.hip, FFN32): H of a pair of token tiles by v_mfma_f32_32x32x16_bf16
 // (M = 32 hidden units, N = 32 tokens, K = D + 1 bias slot padded to 16 DT instead of 32 KS1), W2 by the 16x16x32 form.
 // Chunk-major: block ((c*2 + fh)*NB + j), NB = 2 DT, of chunk c (hidden units fbase = fh*F/2 + 32c .. +31):
-//   j <  DT (ks)  : 32x32x16 A fragment: lane l holds hidden unit fbase + (l & 31), k = 16 ks + 8 (l >> 5) + e (k == D -> b1, > D -> 0)
+//   j <  DT (ks)  : 32x32x16 A fragment rows, stored with row bits 3 and 4 swapped (LDS bank slots of the kernel's two readers): lane
+//                   slot l holds hidden unit fbase + swap34(l & 31), k = 16 ks + 8 (l >> 5) + e (k == D -> b1, > D -> 0)
 //   j >= DT (dt)  : 16x16x32 A fragment of W2 rows d = 16 dt + (l & 15); k-slot e of lane row q = l >> 4 is hidden unit
 //                   fbase + 16 (q & 1) + 8 (e >> 2) + 4 (q >> 1) + (e & 3): the order in which four v_permlane16_swap leave a
 //                   relu'd 32x32 C tile in the two 16x16x32 B fragments of the pair (relu_split32 in fd_mega.hip)
@@ -92,7 +93,8 @@ __device__ void build_ffn32_block(const float* __restrict__ W1, const float* __r
     const int fbase = fh * (F / 2) + c * 32;
     __bf16* dst = img + ((size_t)blk * 64 + lane) * 8;
     if (j < DT) {
-        const int f = fbase + (lane & 31);
+        const int row = lane & 31;
+        const int f = fbase + (FD_W1_SWAP34 ? ((row & 7) | ((row & 8) << 1) | ((row & 16) >> 1)) : row);
         for (int e = 0; e < 8; ++e) {
             const int k = 16 * j + 8 * (lane >> 5) + e;
             float v = 0.f;
@@ -980,6 +982,25 @@ int fd_bf16_refresh(fd_score* m, hipStream_t s, bool training_only) {
     return FD_OK;
 }
 
+// activation buffers of the step-by-step path, carved from the context arena (fd_score_f32_workspace covers them)
+struct LayerBufs {
+    float *temb, *h0, *h1, *qkv, *att, *tmp;
+};
+static LayerBufs carve_layer_bufs(const fd_score* m, int B, fd_ws& ws) {
+    const size_t M = (size_t)B * m->d.max_len, D = m->d.d_model;
+    LayerBufs lb;
+    lb.temb = ws.take<float>((size_t)B * D);
+    lb.h0 = ws.take<float>(M * D);
+    lb.h1 = ws.take<float>(M * D);
+    lb.qkv = ws.take<float>(M * 3 * D);
+    // + 8 floats: k_ffn_ln's fused prologue reads a head's 8 (padded) dim slots as two 16-byte loads, i.e. up to 2 floats past the
+    // last row's last head when head_dim < 8 (values discarded by the select that follows) -- the slack is part of the contract
+    lb.att = ws.take<float>(M * D + 8);
+    lb.tmp = ws.take<float>(M * D);
+    return lb;
+}
+static int bf16_layer_stack(fd_score* m, int B, LayerBufs& lb, hipStream_t s);
+
 int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* out, int B, hipStream_t s) {
     fd_ctx* ctx = m->ctx;
     if (!m->bf16 || !m->bf16->supported)
@@ -1017,22 +1038,32 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
             return fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.nw, pl.grid, pl.lds, s);
         }
     }
-    const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model, H = m->d.n_head;
-    const int L = m->d.num_layers, hd = D / H;
+    const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model;
     const int M = B * T;
     const float* P = m->params;
     if (int rc = fd_ws_reserve(ctx, fd_score_f32_workspace(m, B, false))) return rc;
     fd_ws ws(ctx);
-    float* temb = ws.take<float>((size_t)B * D);
-    float* h0 = ws.take<float>((size_t)M * D);
-    float* h1 = ws.take<float>((size_t)M * D);
-    float* qkv = ws.take<float>((size_t)M * 3 * D);
-    // + 8 floats: k_ffn_ln's fused prologue reads a head's 8 (padded) dim slots as two 16-byte loads, i.e. up to 2 floats past the
-    // last row's last head when head_dim < 8 (values discarded by the select that follows) -- the slack is part of the contract
-    float* att = ws.take<float>((size_t)M * D + 8);
-    float* tmp = ws.take<float>((size_t)M * D);
-    fdf32::time_embed(t, P + m->tW, P + m->td_w, P + m->td_b, temb, B, D, s);
-    fdf32::embed(x, P + m->emb_w, P + m->emb_b, P + m->pos, temb, h0, M, T, C, D, s);
+    LayerBufs lb = carve_layer_bufs(m, B, ws);
+    fdf32::time_embed(t, P + m->tW, P + m->td_w, P + m->td_b, lb.temb, B, D, s);
+    fdf32::embed(x, P + m->emb_w, P + m->emb_b, P + m->pos, lb.temb, lb.h0, M, T, C, D, s);
+    if (int rc = bf16_layer_stack(m, B, lb, s)) return rc;
+    fdgemm::linear_fwd(lb.h0, P + m->un_w, P + m->un_b, out, M, C, D, false, s);
+    FD_LAUNCH_CHECK(ctx);
+    return FD_OK;
+}
+
+// the encoder layers of the step-by-step path: lb.h0 = layer input on entry, the last layer's output on return
+static int bf16_layer_stack(fd_score* m, int B, LayerBufs& lb, hipStream_t s) {
+    fd_ctx* ctx = m->ctx;
+    const int T = m->d.max_len, D = m->d.d_model, H = m->d.n_head;
+    const int L = m->d.num_layers, hd = D / H;
+    const int M = B * T;
+    const float* P = m->params;
+    float*& h0 = lb.h0;
+    float*& h1 = lb.h1;
+    float* const qkv = lb.qkv;
+    float* const att = lb.att;
+    float* const tmp = lb.tmp;
     for (int i = 0; i < L; ++i) {
         const fd_layer_off& lo = m->layers[i];
         const fd_bf16_images* imq = m->bf16;
@@ -1083,8 +1114,6 @@ int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* ou
             if (int rc = run_ffn(m, h1, h0, i, M, s)) return rc;
         }
     }
-    fdgemm::linear_fwd(h0, P + m->un_w, P + m->un_b, out, M, C, D, false, s);
-    FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }
 

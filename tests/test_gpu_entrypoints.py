@@ -126,7 +126,9 @@ def test_bench_train_mode_two_rank_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
     assert d["metric"] == "training series/sec (T=252, C=6)" and d["value"] > 0 and d["dtype"] == "bf16"
     # the roofline names the bracketed training kernel with the largest TOTAL time in the window (fd_prof_end)
-    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel"].split(" ")[0] in ("k_tr_wgrad", "k_tr_ffn_fwd")
+    # (all five per-layer kernels are bracketed since round 4)
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel"].split(" ")[0] in (
+        "k_tr_wgrad", "k_tr_ffn_fwd", "k_tr_ffn_bwd", "k_tr_attn_fwd", "k_tr_attn_bwd")
 
 
 def test_bench_strong_scaling_rehearsal():
