@@ -43,6 +43,8 @@ int step_table(fd_ctx* ctx, size_t fwd, size_t own, const float* timesteps, int 
 int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, const float* timesteps, int n_steps,
                         float dt, float* x, const float* z_steps, uint64_t seed, uint64_t offset, int B,
                         hipStream_t s);
+int fd_sampler_run_layers(fd_score* m, const fd_sde_params* sde, const float* G, const float* timesteps, int n_steps, float dt,
+                          float* x, const float* z_steps, uint64_t seed, uint64_t offset, int B, hipStream_t s);
 
 extern "C" int fd_sampler_run(fd_score* m, const fd_sde_params* sde, const float* G, const float* timesteps,
                               int n_steps, float dt, float* x, const float* z_steps, uint64_t seed, uint64_t offset,
@@ -59,6 +61,11 @@ extern "C" int fd_sampler_run(fd_score* m, const fd_sde_params* sde, const float
     if (mode == FD_MODE_BF16 && m->backbone == FD_BACKBONE_TRANSFORMER && !getenv("FDIFF_SAMPLER_STEPWISE")) {   // (switch: per-step launches; tests compare the two)
         const int rc = fd_sampler_run_mega(m, sde, G, timesteps, n_steps, dt, x, z_steps, seed, offset, B, s);
         if (rc != FD_ERR_UNSUPPORTED) return rc;     // ran (or failed loudly); else: step-by-step fallback below
+    }
+    if (mode == FD_MODE_BF16 && m->backbone == FD_BACKBONE_TRANSFORMER && !getenv("FDIFF_SAMPLER_STEPWISE")) {
+        // same model family beyond the persistent kernel's length limit: layer launches + one fused launch per step
+        const int rc = fd_sampler_run_layers(m, sde, G, timesteps, n_steps, dt, x, z_steps, seed, offset, B, s);
+        if (rc != FD_ERR_UNSUPPORTED) return rc;
     }
 
     const int T = m->d.max_len, C = m->d.n_channels;

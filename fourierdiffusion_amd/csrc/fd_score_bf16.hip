@@ -22,6 +22,7 @@
 #include "fd_gemm_f32.h"
 #include "fd_bf16_images.h"
 #include "fd_mega.h"
+#include "fd_philox.h"
 #include "fd_score.h"
 #include "fd_sde.h"
 
@@ -1114,6 +1115,219 @@ static int bf16_layer_stack(fd_score* m, int B, LayerBufs& lb, hipStream_t s) {
             if (int rc = run_ffn(m, h1, h0, i, M, s)) return rc;
         }
     }
+    return FD_OK;
+}
+
+// ------------------------------------------------------------------ step-by-step sampler, T > 256 (one series no longer fits a workgroup)
+// Between the last encoder layer of diffusion step i and the first of step i + 1 the step-by-step loop ran four launches: the
+// unembedding GEMM, fd_sde_step, the time embedding and the embedding (45 us of a 1.49 ms step at T = 1024, B = 64, all of them
+// walking the same 65 536 token rows).  k_unembed_step_embed is those four as ONE launch with the persistent kernel's arithmetic
+// (score_models.py:78-90, sde.py:129-165, 215-246): a wave owns 16 token rows; score^T = W_u h^T by MFMA from the rows' bf16
+// fragments, the Euler-Maruyama step on the lane's four channels with the standalone kernel's Philox stream (counter q = the
+// normals of elements 4q .. 4q+3 of the flattened (B,T,C) array), x written back, the new x through LDS into the embedding GEMM's
+// B fragment, + positional row + the NEXT step's time embedding (every series of a sampler step shares t: one table row, computed
+// for all steps before the loop), next step's layer-0 input written.  h == nullptr: embedding only (first step).
+struct StepFuseArgs {
+    const float* h;        // (M, D) last layer's output, or null
+    float* x;              // (B, T, C) state, updated in place
+    float* hn;             // (M, D) next step's layer-0 input, or null (last step)
+    const float* G;        // (T) noise scaling
+    const float* z;        // (B, T, C) injected noise of this step, or null (Philox)
+    const float* pos;      // (max_len, D) positional table
+    const float* temb;     // (D) time embedding of the next step's t
+    const char* img_unemb;
+    const char* img_emb;
+    fd_sde_step_coef cf;
+    unsigned long long seed, ctr0;
+    int M, T, C, D, KSE, CT;
+};
+template <int KS1, int DT>
+__global__ __launch_bounds__(256) void k_unembed_step_embed(const StepFuseArgs A) {
+    constexpr int XS = 41;                                  // floats per token row of the x stash (C <= 40; odd: conflict-free columns)
+    __shared__ float xs_all[4][16 * XS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tok = lane & 15, g = lane >> 4;
+    float* const xs = xs_all[wave];
+    const int m = (blockIdx.x * 4 + wave) * 16 + tok;
+    const bool valid = m < A.M;
+    const int mc = valid ? m : A.M - 1;
+    const int t = mc % A.T;
+    const int C = A.C, D = A.D;
+    float* const xrow = A.x + (size_t)mc * C;
+    auto gfrag = [&](const char* img, int blk) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(img + ((size_t)blk * 64 + lane) * 16);
+    };
+    if (A.h) {
+        // ---- the rows' B fragments: k-slots 32 ks + 8 g .. + 7 of token row m (slot D carries 1.0: the bias row of the image)
+        bf16x8 hf[KS1];
+        const float* hrow = A.h + (size_t)mc * D;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = 32 * ks + 8 * g + 4 * q;          // D % 4 == 0: a group of four lies inside the row, is the bias group, or beyond
+                const float4 w = *reinterpret_cast<const float4*>(hrow + (k < D ? k : D - 4));
+                v[4 * q + 0] = k < D ? w.x : (k == D ? 1.0f : 0.f);
+                v[4 * q + 1] = k < D ? w.y : 0.f;
+                v[4 * q + 2] = k < D ? w.z : 0.f;
+                v[4 * q + 3] = k < D ? w.w : 0.f;
+            }
+            u32x4 pk = {cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
+            hf[ks] = __builtin_bit_cast(bf16x8, pk);
+        }
+        const float Gk = A.G[t];
+        const float gk = A.cf.g * Gk;
+        for (int ct = 0; ct < A.CT; ++ct) {
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfrag(A.img_unemb, ct * KS1 + ks), hf[ks], sc, 0, 0, 0);
+            const int c0 = 16 * ct + 4 * g;
+            if (c0 < C) {
+                const size_t e0 = (size_t)mc * C + c0;
+                float o[4] = {0.f, 0.f, 0.f, 0.f};
+                if ((C & 3) == 0) {
+                    const float4 xv = *reinterpret_cast<const float4*>(A.x + e0);
+                    float z[4];
+                    if (A.z) {
+                        const float4 zz = *reinterpret_cast<const float4*>(A.z + e0);
+                        z[0] = zz.x; z[1] = zz.y; z[2] = zz.z; z[3] = zz.w;
+                    } else {
+                        fd_randn4(A.ctr0 + (e0 >> 2), A.seed, z);
+                    }
+                    o[0] = xv.x - (-A.cf.a_x * xv.x - (gk * gk) * sc[0]) * A.cf.dt + A.cf.sqrt_dt * (gk * z[0]);
+                    o[1] = xv.y - (-A.cf.a_x * xv.y - (gk * gk) * sc[1]) * A.cf.dt + A.cf.sqrt_dt * (gk * z[1]);
+                    o[2] = xv.z - (-A.cf.a_x * xv.z - (gk * gk) * sc[2]) * A.cf.dt + A.cf.sqrt_dt * (gk * z[2]);
+                    o[3] = xv.w - (-A.cf.a_x * xv.w - (gk * gk) * sc[3]) * A.cf.dt + A.cf.sqrt_dt * (gk * z[3]);
+                    if (valid) *reinterpret_cast<float4*>(A.x + e0) = float4{o[0], o[1], o[2], o[3]};
+                } else {
+                    float za[4] = {0.f, 0.f, 0.f, 0.f}, zb[4] = {0.f, 0.f, 0.f, 0.f};
+                    const int sh = (int)(e0 & 3);
+                    if (!A.z) {
+                        const unsigned long long q0 = A.ctr0 + (e0 >> 2);
+                        fd_randn4(q0, A.seed, za);
+                        fd_randn4(q0 + 1, A.seed, zb);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (c0 + r < C) {
+                            float z;
+                            if (A.z) z = A.z[e0 + r];
+                            else z = (sh + r < 4) ? za[(sh + r) & 3] : zb[(sh + r) & 3];
+                            const float xv = A.x[e0 + r];
+                            o[r] = xv - (-A.cf.a_x * xv - (gk * gk) * sc[r]) * A.cf.dt + A.cf.sqrt_dt * (gk * z);
+                            if (valid) A.x[e0 + r] = o[r];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + r < C) xs[tok * XS + c0 + r] = o[r];
+            }
+        }
+    } else {
+        for (int c = g; c < C; c += 4) xs[tok * XS + c] = xrow[c];
+    }
+    if (!A.hn) return;
+    // the stash was written by other lanes of this wave (LDS operations of a wave execute in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- embedding of the new x (score_models.py:78-84): h = x We^T + be + pe[t] + temb
+    f32x4 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < A.KSE; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 32 * ks + 8 * g + e;
+            v[e] = (k < C) ? xs[tok * XS + k] : (k == C ? 1.0f : 0.f);
+        }
+        u32x4 pk = {cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
+        const bf16x8 xb = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfrag(A.img_emb, dt * A.KSE + ks), xb, acc[dt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int d0 = 16 * dt + 4 * g;
+        if (d0 < D && valid) {
+            const float4 pe = *reinterpret_cast<const float4*>(A.pos + (size_t)t * D + d0);
+            const float4 te = *reinterpret_cast<const float4*>(A.temb + d0);
+            float4 o;
+            o.x = acc[dt][0] + (pe.x + te.x);
+            o.y = acc[dt][1] + (pe.y + te.y);
+            o.z = acc[dt][2] + (pe.z + te.z);
+            o.w = acc[dt][3] + (pe.w + te.w);
+            *reinterpret_cast<float4*>(A.hn + (size_t)m * D + d0) = o;
+        }
+    }
+}
+
+// fd_sampler_run's loop for the persistent kernel's model family when the persistent kernel itself does not fit (T > 256):
+// per diffusion step the 2 L layer launches + ONE launch for unembed / reverse-SDE step / next embedding.  Returns
+// FD_ERR_UNSUPPORTED (x untouched) when this model has no such path.
+int fd_sampler_run_layers(fd_score* m, const fd_sde_params* sde, const float* G, const float* timesteps, int n_steps, float dt,
+                          float* x, const float* z_steps, uint64_t seed, uint64_t offset, int B, hipStream_t s) {
+    fd_ctx* ctx = m->ctx;
+    const fd_bf16_images* im = m->bf16;
+    if (!im || !im->supported || !im->mega || getenv("FDIFF_SAMPLER_UNFUSED_STEP")) return FD_ERR_UNSUPPORTED;
+    const bool k35 = im->ks1 == 3 && im->dt == 5, k24 = im->ks1 == 2 && im->dt == 4, k12 = im->ks1 == 1 && im->dt == 2,
+               k11 = im->ks1 == 1 && im->dt == 1;
+    if (!(k35 || k24 || k12 || k11) || m->d.n_channels > 40 || m->d.d_model % 4 != 0) return FD_ERR_UNSUPPORTED;
+    if (int rc = fd_bf16_refresh(m, s)) return rc;
+    const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model;
+    const int M = B * T;
+    const size_t n = (size_t)M * C;
+    const size_t fwd = fd_score_f32_workspace(m, B, false);
+    const size_t tab_bytes = fd_ws::padded(sizeof(fd_sde_step_coef) * (size_t)n_steps);
+    const size_t temb_bytes = fd_ws::padded(sizeof(float) * (size_t)n_steps * D);
+    if (int rc = fd_ws_reserve(ctx, fwd + tab_bytes + temb_bytes)) return rc;
+    fd_ws ws(ctx);
+    LayerBufs lb = carve_layer_bufs(m, B, ws);
+    fd_sde_step_coef* tabd = reinterpret_cast<fd_sde_step_coef*>((char*)ctx->ws + fwd);
+    float* temb_table = reinterpret_cast<float*>((char*)ctx->ws + fwd + tab_bytes);
+    std::vector<fd_sde_step_coef> tab(n_steps);
+    for (int i = 0; i < n_steps; ++i) {
+        const SdeCoef c = fd_sde_coef(*sde, (double)timesteps[i], dt);
+        tab[i] = fd_sde_step_coef{c.a_x, c.g, c.dt, c.sqrt_dt, timesteps[i]};
+    }
+    // pageable source: the runtime stages the copy before returning
+    FD_HIP(ctx, hipMemcpyAsync(tabd, tab.data(), sizeof(fd_sde_step_coef) * (size_t)n_steps, hipMemcpyHostToDevice, s));
+    {
+        fd_mega_params MP;
+        memset(&MP, 0, sizeof MP);
+        MP.params = m->params; MP.tW = m->tW; MP.td_w = m->td_w; MP.td_b = m->td_b; MP.D = D;
+        MP.steps = tabd; MP.nsteps = n_steps;
+        fd_mega_temb_table(MP, temb_table, s);
+    }
+    StepFuseArgs A{};
+    A.x = x; A.G = G; A.pos = m->params + m->pos;
+    A.img_unemb = im->mimg + im->off_unemb; A.img_emb = im->mimg + im->off_emb;
+    A.seed = seed; A.M = M; A.T = T; A.C = C; A.D = D; A.KSE = im->kse; A.CT = im->ct;
+    const unsigned long long per_step = (unsigned long long)((n + 3) / 4);
+    auto launch = [&](const StepFuseArgs& a) {
+        const dim3 grid((unsigned)((M + 63) / 64)), block(256);
+        if (k35) hipLaunchKernelGGL((k_unembed_step_embed<3, 5>), grid, block, 0, s, a);
+        else if (k24) hipLaunchKernelGGL((k_unembed_step_embed<2, 4>), grid, block, 0, s, a);
+        else if (k12) hipLaunchKernelGGL((k_unembed_step_embed<1, 2>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_unembed_step_embed<1, 1>), grid, block, 0, s, a);
+    };
+    // first step's embedding
+    A.h = nullptr; A.hn = lb.h0; A.temb = temb_table; A.cf = tab[0];
+    launch(A);
+    for (int i = 0; i < n_steps; ++i) {
+        if (int rc = bf16_layer_stack(m, B, lb, s)) return rc;
+        A.h = lb.h0;
+        A.hn = (i + 1 < n_steps) ? lb.h1 : nullptr;
+        A.temb = temb_table + (size_t)(i + 1 < n_steps ? i + 1 : i) * D;
+        A.z = z_steps ? z_steps + (size_t)i * n : nullptr;
+        A.cf = tab[i];
+        A.ctr0 = offset + (unsigned long long)i * per_step;
+        launch(A);
+        std::swap(lb.h0, lb.h1);
+    }
+    FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }
 

@@ -136,6 +136,43 @@ def test_persistent_sampler_equals_stepwise_launches_bf16(C):
     np.testing.assert_allclose(outs[0], outs[1], atol=2e-3 * max(1.0, np.abs(outs[1]).max()), rtol=0)
 
 
+@pytest.mark.parametrize("cfg", [dict(T=300, C=12, D=72, L=2, H=12), dict(T=272, C=3, D=72, L=2, H=12), dict(T=260, C=6, D=24, L=2, H=4),
+                                 dict(T=290, C=28, D=72, L=1, H=12)],
+                         ids=lambda c: f"T{c['T']}_C{c['C']}_D{c['D']}")
+def test_long_series_fused_step_equals_separate_launches_bf16(cfg):
+    """T > 256 (the persistent kernel does not fit): per diffusion step the loop runs the layer launches and ONE launch for
+    unembed + reverse-SDE step + the next step's embedding (k_unembed_step_embed, the persistent kernel's arithmetic) against
+    the separate unembedding GEMM / fd_sde_step / time embedding / embedding launches (FDIFF_SAMPLER_UNFUSED_STEP), same seed.
+    C = 3 and 6: lanes whose four channels straddle two Philox counters; C = 28: two channel tiles; ragged last token tile.
+    sampler.py:83-104, sde.py:129-165, score_models.py:78-90."""
+    import os
+    from fourierdiffusion_amd.sampling.sampler import DiffusionSampler
+    outs = []
+    old = os.environ.get("FDIFF_SAMPLER_UNFUSED_STEP")
+    try:
+        for unfused in (False, True):
+            m, _, _ = make_model(cfg, precision="bf16")
+            sampler = DiffusionSampler(score_model=m, sample_batch_size=3)
+            if unfused:
+                os.environ["FDIFF_SAMPLER_UNFUSED_STEP"] = "1"
+            else:
+                os.environ.pop("FDIFF_SAMPLER_UNFUSED_STEP", None)
+            torch.manual_seed(31)
+            outs.append(sampler.sample(num_samples=3, num_diffusion_steps=8).numpy())
+    finally:
+        if old is None:
+            os.environ.pop("FDIFF_SAMPLER_UNFUSED_STEP", None)
+        else:
+            os.environ["FDIFF_SAMPLER_UNFUSED_STEP"] = old
+    assert np.isfinite(outs[0]).all() and np.isfinite(outs[1]).all()
+    # same layer kernels and noise stream; the fused launch embeds / unembeds with bf16 MFMA operands where the separate launches
+    # use fp32 GEMMs: bf16 noise (2^-9 relative per operand), not fp32 rounding -- a wrong lane -> counter map gives O(1)
+    scale = max(1.0, np.abs(outs[1]).max())
+    err = np.abs(outs[0] - outs[1]).max() / scale
+    print(f"[parity] fused long-series step vs separate launches T={cfg['T']} C={cfg['C']} D={cfg['D']}: max err / scale = {err:.3e}")
+    assert err <= 5e-3, err
+
+
 def test_precomputed_time_embedding_table_is_bit_identical():
     """Sampler mode reads the time embedding of every step from a table filled before the launch (fd_mega_temb_table: all
     series share the step's t); FDIFF_MEGA_NO_TEMB_TABLE computes it inside the kernel every step as forward mode does.
