@@ -125,6 +125,11 @@ extern "C" int fd_prof_end(fd_ctx* ctx, char* name_out, double* avg_us, int* lau
         (void)hipEventDestroy(e.b);
     }
     ctx->prof_events.clear();
+    if (getenv("FDIFF_PROF_VERBOSE"))     // every bracketed kernel of the window, not only the dominant one
+        for (size_t k = 0; k < total_ms.size(); ++k)
+            if (n[k] > 0)
+                fprintf(stderr, "[fdiff prof] %-28.28s %4d brackets, avg %8.1f us, %8.2f TFLOP/s\n", ctx->prof_kernels[k].name.c_str(), n[k],
+                        1e3 * total_ms[k] / n[k], ctx->prof_kernels[k].flops / (1e-3 * total_ms[k] / n[k]) / 1e12);
     int best = -1;                        // the bracketed kernel with the largest total time in the window
     for (size_t k = 0; k < total_ms.size(); ++k)
         if (n[k] > 0 && (best < 0 || total_ms[k] > total_ms[best])) best = (int)k;
