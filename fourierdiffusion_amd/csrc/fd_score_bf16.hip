@@ -745,6 +745,11 @@ int fd_bf16_create(fd_score* m) {
     const bool inst_mega = (im->ks1 == 3 && im->dt == 5 && im->kso == 3) || (im->ks1 == 2 && im->dt == 4 && im->kso == 3) ||
                            (im->ks1 == 1 && im->dt == 2 && im->kso == 1) || (im->ks1 == 1 && im->dt == 1 && im->kso == 1);
     im->mega = im->supported && inst_mega && hd <= 7 && D < 16 * im->dt && C <= 40;   // hd <= 7: a free V slot holds the ones row
+    // bf16 training kernels (fd_train_bf16.hip): the persistent kernel's classes, plus head_dim 8 (two heads still share the 16
+    // k-slots of one score MFMA; the training kernels sum their softmax rows on the VALU and need no free slot) in the
+    // d_model 64..79 class with 8 heads (kso = 2) and the d_model 32..47 class with 4 heads (kso = 1)
+    const bool inst_train = inst_mega || (im->ks1 == 3 && im->dt == 5 && im->kso == 2) || (im->ks1 == 2 && im->dt == 3 && im->kso == 1);
+    im->train = im->supported && inst_train && hd <= 8 && D < 16 * im->dt;
     m->bf16 = im;
     if (!im->supported) return FD_OK;
     const int NB = 2 * im->ks1 + im->dt;
@@ -754,7 +759,7 @@ int fd_bf16_create(fd_score* m) {
         m->bf16 = nullptr;
         return fd_fail(m->ctx, FD_ERR_HIP, "fd_bf16_create: hipMalloc of the FFN weight images failed");
     }
-    if (im->mega) {
+    if (im->mega || im->train) {          // (the training kernels read the per-layer W_k | W_v | W_q | W_o | FFN images too)
         const size_t KB = 1024;
         im->off_emb = 0;
         im->off_unemb = im->off_emb + (size_t)im->dt * im->kse * KB;
@@ -769,7 +774,7 @@ int fd_bf16_create(fd_score* m) {
         // pair-form FFN image (32x32x16 H): built for the hydra default width class, the only one with static-shape
         // instantiations of the persistent kernel that use it
         im->off_ffn32 = im->off_lpar + (size_t)im->nlp * KB;
-        im->ffn32_layer_bytes = (im->ks1 == 3 && im->dt == 5) ? (size_t)2 * (F / 64) * 2 * im->dt * KB : 0;
+        im->ffn32_layer_bytes = (im->mega && im->ks1 == 3 && im->dt == 5) ? (size_t)2 * (F / 64) * 2 * im->dt * KB : 0;
         im->layer_stride = im->off_ffn32 + im->ffn32_layer_bytes;
         const size_t total = im->off_layers + im->layer_stride * L;
         if (hipMalloc((void**)&im->mimg, total) != hipSuccess) {
@@ -801,7 +806,6 @@ int fd_bf16_create(fd_score* m) {
     }
     // bf16 training kernels (fd_train_bf16.hip) exist for the persistent kernel's model family; their transposed-weight
     // images: FFN backward (same block count as the forward image) | W_o^T (dt x ks1) | in_proj^T half-blocks (np x 3 x dt)
-    im->train = im->mega;
     if (im->train) {
         im->boff_ffn = 0;
         im->boff_wot = im->ffn_layer_bytes;
@@ -839,13 +843,13 @@ int fd_bf16_prepare(fd_score* m, hipStream_t s, bool training_only) {
     B.P = P; B.lofs = im->layer_off_tab;
     B.mimg = im->mimg; B.off_layers = im->off_layers; B.layer_stride = im->layer_stride;
     B.off_wk = im->off_wk; B.off_wv = im->off_wv; B.off_wq = im->off_wq; B.off_wo = im->off_wo; B.off_ffn = im->off_ffn;
-    B.off_lpar = im->off_lpar; B.n_lp = im->mega ? im->nlp : 0;
+    B.off_lpar = im->off_lpar; B.n_lp = im->mimg ? im->nlp : 0;
     B.off_ffn32 = im->off_ffn32; B.n_ffn32 = (im->mega && !training_only) ? (int)(im->ffn32_layer_bytes / 1024) : 0;
     B.ffn = im->ffn; B.ffn_layer_bytes = im->ffn_layer_bytes;
     B.bimg = im->bimg; B.b_layer_stride = im->b_layer_stride; B.boff_ffn = im->boff_ffn; B.boff_wot = im->boff_wot; B.boff_win = im->boff_win;
     B.D = D; B.F = F; B.H = H; B.hd = hd; B.KS1 = im->ks1; B.DT = im->dt; B.KSO = im->kso; B.NP = im->np;
     B.n_qkv = im->np * im->ks1; B.n_wo = im->dt * im->kso; B.n_ffn = 2 * (F / 64) * NB; B.n_wot = im->dt * im->ks1; B.n_win = im->np * 3 * im->dt;
-    B.mega = im->mega ? 1 : 0; B.train = (im->train && im->bimg) ? 1 : 0;
+    B.mega = im->mimg ? 1 : 0; B.train = (im->train && im->bimg) ? 1 : 0;
     // softmax scale and log2(e) folded into W_q / b_q: the kernels' softmax is exp2(s - max)
     B.qscale = (float)(1.4426950408889634 / std::sqrt((double)hd));
     int per_layer = B.n_ffn;
@@ -862,7 +866,7 @@ int fd_bf16_prepare(fd_score* m, hipStream_t s, bool training_only) {
                                (__bf16*)(pl + im->poff_wo), im->ks1, D, D, H, hd, D, 1.f);
         }
     }
-    if (im->mega) {
+    if (im->mimg) {
         hipLaunchKernelGGL(k_build_image, dim3(im->dt * im->kse), dim3(64), 0, s, IMG_EMB, P + m->emb_w, P + m->emb_b,
                            (__bf16*)(im->mimg + im->off_emb), im->kse, D, C, H, hd, D, 1.f);
         hipLaunchKernelGGL(k_build_image, dim3(im->ct * im->ks1), dim3(64), 0, s, IMG_UNEMB, P + m->un_w, P + m->un_b,

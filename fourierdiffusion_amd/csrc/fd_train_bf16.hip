@@ -2413,6 +2413,8 @@ size_t fd_train_bf16_workspace(const fd_score* m, int B) { return tr_carve(m, B,
     do {                                                                                             \
         const fd_bf16_images* im_ = m->bf16;                                                         \
         if (im_->ks1 == 3 && im_->dt == 5 && im_->kso == 3) return CALL(3, 5, 3);                    \
+        if (im_->ks1 == 3 && im_->dt == 5 && im_->kso == 2) return CALL(3, 5, 2);                    \
+        if (im_->ks1 == 2 && im_->dt == 3 && im_->kso == 1) return CALL(2, 3, 1);                    \
         if (im_->ks1 == 2 && im_->dt == 4 && im_->kso == 3) return CALL(2, 4, 3);                    \
         if (im_->ks1 == 1 && im_->dt == 2 && im_->kso == 1) return CALL(1, 2, 1);                    \
         if (im_->ks1 == 1 && im_->dt == 1 && im_->kso == 1) return CALL(1, 1, 1);                    \

@@ -84,11 +84,54 @@ def test_sampler_default_precision_at_other_widths(name):
     assert err <= (1e-2 if eff == "bf16" else 1e-4) and np.isfinite(got).all(), (err, rms)
 
 
+@pytest.mark.parametrize("cfg", [dict(T=100, C=12, D=64, L=3, H=8), dict(T=48, C=3, D=32, L=2, H=4)], ids=["d64_h8", "d32_h4"])
+def test_bf16_training_at_head_dim_8(cfg):
+    """d_model 64 with 8 heads and d_model 32 with 4 heads (head_dim 8: no free k-slot beside a head's dims) train on the fused
+    bf16 MFMA kernels since round 4 (classes <3,5,2> and <2,3,1>).  Same injected t and z, dropout off: bf16 gradients per tensor against the
+    exact-f32 engine (which test_gpu_train_bf16.py anchors to the reference's autograd fixture), at that file's tolerances;
+    bit-reproducible; with dropout on a finite loss and an optimizer step.  score_models.py:96-130, losses.py:39-125."""
+    from fourierdiffusion_amd.optim import FusedAdamW
+    from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
+    from fourierdiffusion_amd.utils.losses import get_sde_loss_fn
+    from .test_gpu_train_bf16 import _compare_grads, _grads_of, batch_of
+    B = 9
+    X = W.randn("wd_h8_x", (B, cfg["T"], cfg["C"]), 5)
+    z = W.randn("wd_h8_z", (B, cfg["T"], cfg["C"]), 5)
+    t = W.uniform("wd_h8_t", (B,), 5, 0.05, 1.0)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        m, sch, _ = make_model(cfg, precision=prec)
+        m.dropout = 0.0
+        fn = get_sde_loss_fn(sch, train=True)
+        runs = []
+        for rep in range(2 if prec == "bf16" else 1):
+            m.zero_grad()
+            loss = fn(m, batch_of(X, t), noise=dev(z)).item()
+            runs.append((loss, m.grads.clone()))
+        assert m.train_mode_effective == prec, (prec, m.train_mode_effective)
+        if prec == "bf16":
+            assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]), "bf16 step not bit-reproducible"
+        res[prec] = (runs[0][0], _grads_of(m))
+    lf, lb = res["fp32"][0], res["bf16"][0]
+    assert abs(lb - lf) <= 1e-2 * abs(lf), (lb, lf)
+    _compare_grads(f"d_model {cfg['D']} / {cfg['H']} heads (head_dim 8), bf16 vs exact-f32 engine, dropout off", res["bf16"][1], res["fp32"][1],
+                   **(dict(max_tol=0.5, l2_tol=8e-2) if cfg["D"] < 64 else {}))      # (toy-width tolerances of test_gpu_train_bf16.py: tensors of a few hundred elements)
+    # dropout on: one optimizer step through the fused training call
+    m, _, _ = make_model(cfg, precision="bf16")
+    m.train()
+    opt = FusedAdamW(m, lr=1e-3, max_grad_norm=1.0)
+    torch.manual_seed(3)
+    m.zero_grad()
+    loss = m.training_step(DiffusableBatch(X=dev(X)), 0)
+    opt.step()
+    assert m.train_mode_effective == "bf16" and torch.isfinite(loss) and torch.isfinite(m.flat_parameters).all()
+
+
 def test_training_falls_back_and_says_so_at_other_widths():
     """Training at a width without bf16 training kernels runs the exact-f32 path (train_mode_effective), one optimizer step."""
     from fourierdiffusion_amd.optim import FusedAdamW
     from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
-    cfg = WIDTHS["d64_h8"][0]
+    cfg = WIDTHS["d128_h8"][0]
     m, _, _ = make_model(cfg, precision="bf16")
     m.train_precision = "bf16"
     m.train()
