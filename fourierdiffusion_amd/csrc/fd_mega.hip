@@ -241,6 +241,11 @@ __global__ __launch_bounds__(64) void k_temb_table(const float* __restrict__ par
 template <int KS1, int DT, int KSO, int MT, class SH, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
     constexpr int KSX = KS1;                     // x-fragment blocks per token tile (the host's LDS plan; the pair form needs less)
+    // head_dim 8 (the d_model 64 / 8 heads class, KSO = 2): a head's dims fill its 8 k-slots, so there is no free slot for the softmax
+    // shift / the row of ones -- its units always run the exact two-pass form (the shift rides in the score MFMA's C operand) and
+    // take the softmax denominators from one more P V-shaped MFMA per key block whose A operand is all ones (the matrix pipe has
+    // slack in the units, the VALU has none)
+    constexpr bool HD8 = (KSO == 2);
     constexpr bool F32 = SH::FFN32 != 0;         // pair form of the FFN (see ShapeStatic)
     constexpr int KS32 = DT;                     // pair form: k-steps of 16 (D + 1 <= 16 DT)
     static_assert(!F32 || (NW == 8 && MT == 4 && DT == 2 * KS1 - 1 && SH::S * SH::KT >= 12 && ((SH::S * SH::KT) & 1) == 0),
@@ -723,6 +728,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                     }
                     float m2[NQ][2];
                     f32x4 o2[NQ][2];
+                    f32x4 l2[HD8 ? NQ : 1][2];      // head_dim 8: row sums of P (every row of the tile carries the sum)
+                    const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
                     auto run_unit = [&](auto exact_c) {
                     constexpr bool EXACT = decltype(exact_c)::value;
                     s16x4 qb[NQ][2];         // unpatched operands: exact path only
@@ -733,6 +740,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                             if (EXACT) qb[q][hs] = qmasked(q, hs);
                             m2[q][hs] = kNegBig;
                             o2[q][hs] = f4zero();
+                            if (HD8) l2[HD8 ? q : 0][hs] = f4zero();
                         }
                     if (SH::KT == 0 || FD_ROLLED_ATTN) {
                         // Run-time series length: the hand-unrolled pipeline below would need a guard around every MFMA
@@ -796,7 +804,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                                         pa[r] = FD_EXP2(pa[r]);
                                         pb[r] = FD_EXP2(pb[r]);
                                     }
-                                    o2[q][hs] = MFMA(vfj, pack8(pa, pb), o2[q][hs]);
+                                    const bf16x8 pkj = pack8(pa, pb);
+                                    o2[q][hs] = MFMA(vfj, pkj, o2[q][hs]);
+                                    if (HD8) l2[HD8 ? q : 0][hs] = MFMA(ones8, pkj, l2[HD8 ? q : 0][hs]);
                                 }
                         }
                     } else
@@ -855,6 +865,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                                     const float mnew = fmaxf(m2[q][hs], group_max(bm[q][hs]));
                                     const float alpha = __builtin_amdgcn_exp2f(m2[q][hs] - mnew);
                                     o2[q][hs] = o2[q][hs] * alpha;
+                                    if (HD8) l2[HD8 ? q : 0][hs] = l2[HD8 ? q : 0][hs] * alpha;
                                     m2[q][hs] = mnew;
                                 }
                         }
@@ -904,7 +915,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                                 if (k >= 2 * LAG && ((k - 2 * LAG) & 1)) {
                                     const int e = k - 2 * LAG;
                                     const int q = (e >> 1) % NQ, jj = ((e >> 1) / NQ) & 3, hs = (e >> 1) / NQ >> 2;
-                                    if (2 * jj < nk) o2[q][hs] = MFMA(vf[jj], pk[e >> 1], o2[q][hs]);
+                                    if (2 * jj < nk) {
+                                        o2[q][hs] = MFMA(vf[jj], pk[e >> 1], o2[q][hs]);
+                                        if (HD8) l2[HD8 ? q : 0][hs] = MFMA(ones8, pk[e >> 1], l2[HD8 ? q : 0][hs]);
+                                    }
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
                             }
@@ -918,6 +932,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         bool bad = false;
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) {
+                            if (HD8) {
+                                lrow[q] = lo_grp ? l2[HD8 ? q : 0][0][0] : l2[HD8 ? q : 0][1][0];
+                                bad |= !(lrow[q] > 7.8e-31f);
+                                continue;
+                            }
                             float cand = lo_grp ? o2[q][0][0] : o2[q][1][0];
 #pragma unroll
                             for (int r = 1; r < 4; ++r) cand = ((hd & 3) == r) ? (lo_grp ? o2[q][0][r] : o2[q][1][r]) : cand;
@@ -929,8 +948,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
                         return bad;
                     };
                     // (dbg bit 64 suppresses the fallback: lets the tests prove that it is what rescues such rows; bit 32: exact only)
-                    bool need_exact = (P.dbg & 32) != 0 || (l < 32 && ((exact_layers >> l) & 1u) != 0u && !(P.dbg & 64));
-                    if (!need_exact) {
+                    bool need_exact = HD8 || (P.dbg & 32) != 0 || (l < 32 && ((exact_layers >> l) & 1u) != 0u && !(P.dbg & 64));
+                    if (!HD8 && !need_exact) {
                         run_unit(std::false_type{});
                         const bool bad = row_sums();
                         if (__builtin_amdgcn_ballot_w64(bad) != 0ull && !(P.dbg & 64)) {   // wave-uniform: redo with the exact maximum
@@ -1690,6 +1709,7 @@ int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int ks
     if (ks1 == K && dt == T_ && kso == O && mt == M_) FD_MEGA_GO(K, T_, O, M_, ShapeDyn, "ShapeDyn");
 #define FD_MEGA_MT(K, T_, O) FD_MEGA_CASE(K, T_, O, 1) FD_MEGA_CASE(K, T_, O, 2) FD_MEGA_CASE(K, T_, O, 3) FD_MEGA_CASE(K, T_, O, 4)
     FD_MEGA_MT(3, 5, 3)   // d_model 72, 12 heads (hydra default)
+    FD_MEGA_MT(3, 5, 2)   // d_model 64, 8 heads: head_dim 8 (exact two-pass softmax, denominators from an all-ones MFMA)
     FD_MEGA_MT(2, 4, 3)   // d_model 60, 12 heads (class default)
     FD_MEGA_MT(1, 2, 1)   // d_model 24, 4 heads
     FD_MEGA_MT(1, 1, 1)   // d_model 8, 4 heads

@@ -744,7 +744,10 @@ int fd_bf16_create(fd_score* m) {
     im->supported = inst && (D % 4 == 0) && (F % 128 == 0) && L > 0;
     const bool inst_mega = (im->ks1 == 3 && im->dt == 5 && im->kso == 3) || (im->ks1 == 2 && im->dt == 4 && im->kso == 3) ||
                            (im->ks1 == 1 && im->dt == 2 && im->kso == 1) || (im->ks1 == 1 && im->dt == 1 && im->kso == 1);
-    im->mega = im->supported && inst_mega && hd <= 7 && D < 16 * im->dt && C <= 40;   // hd <= 7: a free V slot holds the ones row
+    // hd <= 7: a free slot per head carries the softmax shift / the row of ones; hd == 8 in the class <3,5,2> (d_model 64, 8 heads):
+    // the persistent kernel's exact two-pass form with the denominators from an all-ones MFMA (fd_mega.hip HD8)
+    const bool mega_hd8 = im->ks1 == 3 && im->dt == 5 && im->kso == 2 && hd == 8;
+    im->mega = im->supported && ((inst_mega && hd <= 7) || mega_hd8) && D < 16 * im->dt && C <= 40;
     // bf16 training kernels (fd_train_bf16.hip): the persistent kernel's classes, plus head_dim 8 (two heads still share the 16
     // k-slots of one score MFMA; the training kernels sum their softmax rows on the VALU and need no free slot) in the
     // d_model 64..79 class with 8 heads (kso = 2) and the d_model 32..47 class with 4 heads (kso = 1)
@@ -795,7 +798,7 @@ int fd_bf16_create(fd_score* m) {
             return fd_fail(m->ctx, FD_ERR_HIP, "fd_bf16_create: upload of the layer offset table failed");
         }
     }
-    if (!im->mega) {
+    if (!im->mega || hd > 7) {      // (head_dim 8 beyond the persistent kernel's length limit runs the projection kernels)
         im->nrt_in = (3 * D + 15) / 16;
         im->poff_wo = (size_t)im->nrt_in * im->ks1 * 1024;
         im->p_layer_stride = im->poff_wo + (size_t)im->dt * im->ks1 * 1024;
@@ -1073,7 +1076,7 @@ static int bf16_layer_stack(fd_score* m, int B, LayerBufs& lb, hipStream_t s) {
         const fd_layer_off& lo = m->layers[i];
         const fd_bf16_images* imq = m->bf16;
         int arc = FD_ERR_UNSUPPORTED;
-        if (imq->mega && !getenv("FDIFF_ATTN_F32") && !getenv("FDIFF_ATTN_UNFUSED")) {
+        if (imq->mega && hd <= 7 && !getenv("FDIFF_ATTN_F32") && !getenv("FDIFF_ATTN_UNFUSED")) {
             // Q/K/V projections inside the attention kernel (the persistent kernel's per-layer weight images)
             const char* limg = imq->mimg + imq->off_layers + (size_t)i * imq->layer_stride;
             // measurement hook (bench.py --workload long): in-projection + attention of M tokens

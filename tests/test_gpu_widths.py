@@ -21,7 +21,8 @@ pytestmark = pytest.mark.gpu
 
 WIDTHS = {
     # name: (cfg, expected effective eval precision, substring of the plan)
-    "d64_h8": (dict(T=100, C=12, D=64, L=3, H=8), "bf16", "per-layer"),          # head_dim 8: f32 attention + bf16 FFN <3,5>
+    "d64_h8": (dict(T=100, C=12, D=64, L=3, H=8), "bf16", "k_mega<3,5,2"),       # head_dim 8 inside the persistent kernel since round 4 (exact two-pass units)
+    "d64_h8_long": (dict(T=300, C=4, D=64, L=2, H=8), "bf16", "per-layer"),      # the same width beyond the persistent kernel's length limit
     "d128_h8": (dict(T=60, C=5, D=128, L=2, H=8), "bf16", "per-layer"),          # head_dim 16, FFN <5,9>
     "d96_h12": (dict(T=100, C=7, D=96, L=2, H=12), "bf16", "per-layer"),         # head_dim 8, FFN <4,7>
     "d32_h4": (dict(T=48, C=3, D=32, L=2, H=4), "bf16", "per-layer"),            # FFN <2,3>
@@ -64,7 +65,7 @@ def test_forward_both_modes_vs_oracle(name):
         np.testing.assert_allclose(out, ref, atol=2e-5, rtol=0)
 
 
-@pytest.mark.parametrize("name", ["d64_h8", "d128_h8", "d160_h8"])
+@pytest.mark.parametrize("name", ["d64_h8", "d64_h8_long", "d128_h8", "d160_h8"])
 def test_sampler_default_precision_at_other_widths(name):
     """DiffusionSampler.sample with ``precision`` left at its default ("bf16"), as test_sampler.py of the reference drives it
     (tests/test_sampler.py: any model the config builds must sample): 10 reverse-diffusion steps with injected normals
