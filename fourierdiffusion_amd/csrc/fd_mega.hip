@@ -245,7 +245,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
     // shift / the row of ones -- its units always run the exact two-pass form (the shift rides in the score MFMA's C operand) and
     // take the softmax denominators from one more P V-shaped MFMA per key block whose A operand is all ones (the matrix pipe has
     // slack in the units, the VALU has none)
-    constexpr bool HD8 = (KSO == 2);
+    constexpr bool HD8 = (KS1 == 3 && DT == 5 && KSO == 2) || (KS1 == 2 && DT == 3 && KSO == 1);   // (d_model 64 / 8 heads, 32 / 4 heads)
     constexpr bool F32 = SH::FFN32 != 0;         // pair form of the FFN (see ShapeStatic)
     constexpr int KS32 = DT;                     // pair form: k-steps of 16 (D + 1 <= 16 DT)
     static_assert(!F32 || (NW == 8 && MT == 4 && DT == 2 * KS1 - 1 && SH::S * SH::KT >= 12 && ((SH::S * SH::KT) & 1) == 0),
@@ -1710,6 +1710,7 @@ int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int ks
 #define FD_MEGA_MT(K, T_, O) FD_MEGA_CASE(K, T_, O, 1) FD_MEGA_CASE(K, T_, O, 2) FD_MEGA_CASE(K, T_, O, 3) FD_MEGA_CASE(K, T_, O, 4)
     FD_MEGA_MT(3, 5, 3)   // d_model 72, 12 heads (hydra default)
     FD_MEGA_MT(3, 5, 2)   // d_model 64, 8 heads: head_dim 8 (exact two-pass softmax, denominators from an all-ones MFMA)
+    FD_MEGA_MT(2, 3, 1)   // d_model 32, 4 heads: head_dim 8
     FD_MEGA_MT(2, 4, 3)   // d_model 60, 12 heads (class default)
     FD_MEGA_MT(1, 2, 1)   // d_model 24, 4 heads
     FD_MEGA_MT(1, 1, 1)   // d_model 8, 4 heads

@@ -746,7 +746,7 @@ int fd_bf16_create(fd_score* m) {
                            (im->ks1 == 1 && im->dt == 2 && im->kso == 1) || (im->ks1 == 1 && im->dt == 1 && im->kso == 1);
     // hd <= 7: a free slot per head carries the softmax shift / the row of ones; hd == 8 in the class <3,5,2> (d_model 64, 8 heads):
     // the persistent kernel's exact two-pass form with the denominators from an all-ones MFMA (fd_mega.hip HD8)
-    const bool mega_hd8 = im->ks1 == 3 && im->dt == 5 && im->kso == 2 && hd == 8;
+    const bool mega_hd8 = hd == 8 && ((im->ks1 == 3 && im->dt == 5 && im->kso == 2) || (im->ks1 == 2 && im->dt == 3 && im->kso == 1));
     im->mega = im->supported && ((inst_mega && hd <= 7) || mega_hd8) && D < 16 * im->dt && C <= 40;
     // bf16 training kernels (fd_train_bf16.hip): the persistent kernel's classes, plus head_dim 8 (two heads still share the 16
     // k-slots of one score MFMA; the training kernels sum their softmax rows on the VALU and need no free slot) in the

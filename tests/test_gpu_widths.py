@@ -25,7 +25,7 @@ WIDTHS = {
     "d64_h8_long": (dict(T=300, C=4, D=64, L=2, H=8), "bf16", "per-layer"),      # the same width beyond the persistent kernel's length limit
     "d128_h8": (dict(T=60, C=5, D=128, L=2, H=8), "bf16", "per-layer"),          # head_dim 16, FFN <5,9>
     "d96_h12": (dict(T=100, C=7, D=96, L=2, H=12), "bf16", "per-layer"),         # head_dim 8, FFN <4,7>
-    "d32_h4": (dict(T=48, C=3, D=32, L=2, H=4), "bf16", "per-layer"),            # FFN <2,3>
+    "d32_h4": (dict(T=48, C=3, D=32, L=2, H=4), "bf16", "k_mega<2,3,1"),         # head_dim 8 inside the persistent kernel (round 4)
     "d112_h16": (dict(T=40, C=4, D=112, L=2, H=16), "bf16", "per-layer"),        # head_dim 7: bf16 attention, FFN <4,8>
     "d80_h16": (dict(T=300, C=4, D=80, L=2, H=16), "bf16", "per-layer"),         # head_dim 5, FFN <3,6>, T > 256
     "d48_h8": (dict(T=64, C=6, D=48, L=2, H=8), "bf16", "per-layer"),            # head_dim 6, class <2,4> without its W_o image
