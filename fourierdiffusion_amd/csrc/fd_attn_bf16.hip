@@ -121,7 +121,7 @@ struct fd_attn_w {
 template <int KS1>
 __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const float* __restrict__ in, float* __restrict__ out, int T,
                                                            int H, int hd, int D, float qscale, int du_per_block, int exact_only,
-                                                           fd_attn_w wimg, size_t pair_stride, int slices, int B) {
+                                                           fd_attn_w wimg, size_t pair_stride, int slices, int B, int out_bf16) {
     constexpr bool PROJ = KS1 > 0;
     constexpr int KSN = PROJ ? KS1 : 1;
     // Workgroup -> (series, head pair, query slice).  Hardware workgroup ids go round-robin over the 8 XCDs; all
@@ -681,7 +681,18 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
             for (int r = 0; r < 4; ++r) o_sel[r] = lo_grp ? o2[q][0][r] : o2[q][1][r];
             const float inv = 1.0f / lrow[q];
             const int t = qt[q] * 16 + tok;
-            if (qv[q] && t < T && myhead < H) {
+            if (out_bf16) {
+                // bf16 rows (M, D) for k_ffn_ln's fused out-projection prologue, which rounds the attention output to bf16 MFMA
+                // operands anyway: the same round-to-nearest-even here, half the bytes there (head_dim even: dword-aligned words)
+                typedef unsigned u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+                if (qv[q] && t < T && myhead < H) {
+                    __bf16* orow = reinterpret_cast<__bf16*>(out) + ((size_t)b * T + t) * D + myhead * hd + 4 * (g & 1);
+                    const int nv = min(4, max(0, hd - 4 * (g & 1)));
+                    const unsigned w0 = cvt_pk_bf16(o_sel[0] * inv, o_sel[1] * inv), w1 = cvt_pk_bf16(o_sel[2] * inv, o_sel[3] * inv);
+                    if (nv == 4) *reinterpret_cast<u32x2_a4*>(orow) = u32x2_a4{w0, w1};
+                    else if (nv == 2) *reinterpret_cast<unsigned*>(orow) = w0;
+                }
+            } else if (qv[q] && t < T && myhead < H) {
                 // row form: the lane's dims as one 16- or 8-byte store at a dword-aligned address where head_dim allows
                 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
                 typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
@@ -706,11 +717,13 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
 // input (B*T, D) and the images are the persistent kernel's per-layer W_k / W_v / W_q fragment blocks (ks1 blocks per
 // head pair).  Returns FD_ERR_UNSUPPORTED when the shape does not fit (head_dim > 7, K/V^T of one series exceed the
 // LDS, or no instantiation for ks1): the caller then runs the unfused / exact-f32 path.
+// out_bf16: `out` receives bf16 rows (M, D) instead of fp32 ones (even head_dim only; the consumer is k_ffn_ln's fused prologue).
 int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, int H, int hd, hipStream_t s, const char* wk,
-                      const char* wv, const char* wq, int ks1) {
+                      const char* wv, const char* wq, int ks1, int out_bf16) {
     const int KT = (T + 15) / 16, NJ = (KT + 1) / 2, D = H * hd;
     const size_t lds_kv = (size_t)KT * 16 * 32 + (size_t)NJ * 1024 + (hd == 7 ? 16 : 0);
     if (hd > 7 || lds_kv + NQ * 512 > 160 * 1024) return FD_ERR_UNSUPPORTED;
+    if (out_bf16 && (hd & 1)) return FD_ERR_UNSUPPORTED;
     const bool proj = wk != nullptr;
     if (proj && ((ks1 != 3 && ks1 != 2) || (D & 3))) return FD_ERR_UNSUPPORTED;   // (raw x rows are read as float4)
     const void* kern = proj ? (ks1 == 3 ? (const void*)k_attention_bf16<3> : (const void*)k_attention_bf16<2>)
@@ -746,9 +759,9 @@ int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, in
     const fd_attn_w w{wk, wv, wq};
     const size_t pair_stride = (size_t)ks1 * 1024;
     const dim3 grid((unsigned)(((B + 7) / 8) * 8 * NP * slices)), block(NTH);
-    if (!proj) hipLaunchKernelGGL(k_attention_bf16<0>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B);
-    else if (ks1 == 3) hipLaunchKernelGGL(k_attention_bf16<3>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B);
-    else hipLaunchKernelGGL(k_attention_bf16<2>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B);
+    if (!proj) hipLaunchKernelGGL(k_attention_bf16<0>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B, out_bf16);
+    else if (ks1 == 3) hipLaunchKernelGGL(k_attention_bf16<3>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B, out_bf16);
+    else hipLaunchKernelGGL(k_attention_bf16<2>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B, out_bf16);
     FD_LAUNCH_CHECK(ctx);
 #if defined(FD_ATTN_ABL) && FD_ATTN_ABL == 3
     {

@@ -310,7 +310,8 @@ __device__ __forceinline__ bf16x8 relu_pack(f32x4 a, f32x4 b) {
 // from the attention output `att` (M, D) and the layer input `h0`: one launch and two (M, D) fp32 round trips less per
 // layer on the step-by-step path.  The tile's fp32 x then never leaves the CU: it seeds the owner wave's accumulators.
 struct fd_ffn_pre {
-    const float* att;     // (M, D) concatenated head outputs
+    const float* att;     // (M, D) concatenated head outputs, fp32 rows -- or bf16 rows when att_bf16 (k_attention_bf16 out_bf16)
+    int att_bf16;
     const float* h0;      // (M, D) layer input (residual)
     const char* wo_img;   // [DT][KSO] 1 KiB fragment blocks of W_o (IMG_WO)
     const float* bo;
@@ -388,22 +389,29 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
                 // the head's 8 dim slots as two dword-aligned 16-byte loads from a clamped address, selected afterwards (eight
                 // conditional scalar loads per (token, head) were eight divergent branches and eight instructions that each walk
                 // 64 cache lines; slots >= head_dim read the next head / row: `att` is carved with 8 floats of slack for the last one)
-                float v[8];
-                {
+                u32x4 pk;
+                const int mc = valid ? m : m_wg, hc = head < pre.H ? head : pre.H - 1;
+                const bool ok = valid && head < pre.H;
+                if (pre.att_bf16) {
+                    // bf16 rows written by k_attention_bf16 (the rounding this prologue would do, done at the producer): ONE 16-byte
+                    // load per (token, head) at a dword-aligned address (head_dim even), slot pairs >= head_dim cleared
+                    typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                    const u32x4_a4 raw = *reinterpret_cast<const u32x4_a4*>(reinterpret_cast<const __bf16*>(pre.att) + (size_t)mc * D + hc * pre.hd);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (ok && 2 * e < pre.hd) ? raw[e] : 0u;
+                } else {
+                    float v[8];
                     typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-                    const int mc = valid ? m : m_wg, hc = head < pre.H ? head : pre.H - 1;
                     const f32x4_a4* p8 = reinterpret_cast<const f32x4_a4*>(pre.att + (size_t)mc * D + hc * pre.hd);
                     const f32x4_a4 lo = p8[0], hi = p8[1];
-                    const bool ok = valid && head < pre.H;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = (ok && e < pre.hd) ? lo[e] : 0.f;
                         v[4 + e] = (ok && 4 + e < pre.hd) ? hi[e] : 0.f;
                     }
-                }
-                u32x4 pk;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
+                    for (int e = 0; e < 4; ++e) pk[e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
+                }
                 const bf16x8 af = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo[dt][ks], af, o[dt], 0, 0, 0);
@@ -683,7 +691,7 @@ int dispatch_ffn(fd_ctx* ctx, const float* x, float* out, const char* wimg, cons
 // x != nullptr: out = LN2(x + FFN(x)).  x == nullptr: x = LN1(h0 + att Wo^T + bo) is computed in the kernel (fused
 // prologue; needs the persistent kernel's W_o image), then the same.
 int run_ffn(fd_score* m, const float* x, float* out, int layer, int M, hipStream_t s, const float* att = nullptr,
-            const float* h0 = nullptr) {
+            const float* h0 = nullptr, int att_bf16 = 0) {
     fd_ctx* ctx = m->ctx;
     const fd_bf16_images* im = m->bf16;
     const fd_layer_off& lo = m->layers[layer];
@@ -692,7 +700,7 @@ int run_ffn(fd_score* m, const float* x, float* out, int layer, int M, hipStream
     const int D = m->d.d_model, F = m->d.dim_ff;
     fd_ffn_pre pre{};
     if (!x) {
-        pre.att = att; pre.h0 = h0;
+        pre.att = att; pre.h0 = h0; pre.att_bf16 = att_bf16;
         pre.wo_img = im->mimg + im->off_layers + (size_t)layer * im->layer_stride + im->off_wo;
         pre.bo = P + lo.out_b; pre.g1 = P + lo.n1_w; pre.b1 = P + lo.n1_b;
         pre.H = m->d.n_head; pre.hd = D / m->d.n_head;
@@ -1076,14 +1084,20 @@ static int bf16_layer_stack(fd_score* m, int B, LayerBufs& lb, hipStream_t s) {
         const fd_layer_off& lo = m->layers[i];
         const fd_bf16_images* imq = m->bf16;
         int arc = FD_ERR_UNSUPPORTED;
+        const bool fuse = imq->mega && imq->kso == 3 && (imq->ks1 == 3 || imq->ks1 == 2) && !getenv("FDIFF_FFN_UNFUSED");
+        // attention output handed to k_ffn_ln's fused prologue as bf16 rows (bit-identical results: the prologue rounds the rows
+        // to bf16 MFMA operands either way; FDIFF_ATT_F32ROWS=1 keeps the fp32 rows for A/B runs)
+        static const bool att_f32rows = getenv("FDIFF_ATT_F32ROWS") != nullptr;
+        int att_bf16 = (fuse && !(hd & 1) && !att_f32rows) ? 1 : 0;
         if (imq->mega && hd <= 7 && !getenv("FDIFF_ATTN_F32") && !getenv("FDIFF_ATTN_UNFUSED")) {
             // Q/K/V projections inside the attention kernel (the persistent kernel's per-layer weight images)
             const char* limg = imq->mimg + imq->off_layers + (size_t)i * imq->layer_stride;
             // measurement hook (bench.py --workload long): in-projection + attention of M tokens
             fd_prof_scope scope(ctx, s, "k_attention_bf16 (fused Q/K/V projection + softmax attention, one launch per layer)",
                                 (double)M * (6.0 * D * D + 4.0 * T * D));
-            arc = fd_attention_bf16(ctx, h0, att, B, T, H, hd, s, limg + imq->off_wk, limg + imq->off_wv, limg + imq->off_wq, imq->ks1);
+            arc = fd_attention_bf16(ctx, h0, att, B, T, H, hd, s, limg + imq->off_wk, limg + imq->off_wv, limg + imq->off_wq, imq->ks1, att_bf16);
         }
+        if (arc == FD_ERR_UNSUPPORTED) att_bf16 = 0;
         if (arc == FD_ERR_UNSUPPORTED) {
             const bool pbf = imq->pimg && !getenv("FDIFF_PROJ_F32");       // bf16 MFMA projections (fd_linear_bf16.hip)
             int prc = FD_ERR_UNSUPPORTED;
@@ -1100,13 +1114,12 @@ static int bf16_layer_stack(fd_score* m, int B, LayerBufs& lb, hipStream_t s) {
         }
         if (arc != FD_OK) return arc;
         const fd_bf16_images* im = m->bf16;
-        const bool fuse = im->mega && im->kso == 3 && (im->ks1 == 3 || im->ks1 == 2) && !getenv("FDIFF_FFN_UNFUSED");
         if (fuse) {
             // out-proj + residual + LN1 + FFN + LN2 in one kernel (it reads its own output location last: out = h1 is
             // a different buffer from the residual input h0)
             fd_prof_scope scope(ctx, s, "k_ffn_ln (out-proj + LN1 + FFN + LN2, one launch per layer)",
                                 (double)M * (2.0 * D * D + 4.0 * D * m->d.dim_ff));
-            if (int rc = run_ffn(m, nullptr, h1, i, M, s, att, h0)) return rc;
+            if (int rc = run_ffn(m, nullptr, h1, i, M, s, att, h0, att_bf16)) return rc;
             std::swap(h0, h1);
         } else {
             int orc = FD_ERR_UNSUPPORTED;

@@ -152,6 +152,24 @@ __device__ __forceinline__ void store_ctile(float* __restrict__ base, int m, boo
         if (valid && d0 < D) *reinterpret_cast<float4*>(base + (size_t)m * D + d0) = float4{v[dt][0], v[dt][1], v[dt][2], v[dt][3]};
     }
 }
+// the same tile from a bf16 (M, D) tensor (the per-head partial tensors of d x, k_tr_attn_bwd OH form): 8-byte loads
+template <int DT>
+__device__ __forceinline__ void load_ctile_bf16(const __bf16* __restrict__ base, int m, bool valid, int D, int g, f32x4 (&v)[DT]) {
+    const int mc = valid ? m : 0;
+    u32x2 raw[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int d0 = 16 * dt + 4 * g;
+        raw[dt] = *reinterpret_cast<const u32x2*>(base + (size_t)mc * D + (d0 < D ? d0 : D - 4));
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const bool ok = valid && (16 * dt + 4 * g < D);
+        const unsigned lo = ok ? raw[dt][0] : 0u, hi = ok ? raw[dt][1] : 0u;
+        v[dt] = f32x4{__builtin_bit_cast(float, lo << 16), __builtin_bit_cast(float, lo & 0xffff0000u),
+                      __builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+    }
+}
 // T-block store: feature rows 16dt+4g+r, column m&31; `ones` puts 1.0 into row D (bias column of the weight gradients).
 // Every row of the 16*DT block rows is written for this token (pads as 0), invalid tokens write zeros.
 template <int DT>
@@ -376,11 +394,26 @@ __global__ __launch_bounds__(256) void k_tr_masks_T(const unsigned char* __restr
     const int RB = NJ * 4, RBP = RB + 4;          // padded rows: the eight rows an item reads lie 4 rows apart
     constexpr int OB = 36;
     unsigned char* orow = srow + 256 * RBP;
-    for (int i = threadIdx.x * 4; i < 32 * njq * RB; i += 256 * 4) {
-        const int ql = i / RB, c = i - ql * RB, q = 32 * jq0 + ql;
-        unsigned w = 0u;
-        if (q < T) w = *reinterpret_cast<const unsigned*>(pmask + (bh * T + q) * RB + c);
-        *reinterpret_cast<unsigned*>(srow + ql * RBP + c) = w;
+    // The group's rows are one contiguous run of global memory; eight words per thread and trip, every load of the trip in
+    // flight before the first LDS store, from clamped addresses (a load inside the `q < T` branch made hipcc wait for each one:
+    // eight serial L2 round trips per workgroup were most of this kernel's 29 us at T = 252).
+    {
+        const int nword = 32 * njq * NJ, nvalid = (min(T, 32 * jq0 + 32 * njq) - 32 * jq0) * NJ;     // words to fill / that exist
+        const unsigned* src = reinterpret_cast<const unsigned*>(pmask + (bh * T + 32 * jq0) * RB);
+        for (int base = 0; base < nword; base += 256 * 8) {
+            unsigned w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + (int)threadIdx.x;
+                w[u] = src[idx < nvalid ? idx : nvalid - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + (int)threadIdx.x;
+                const int ql = idx / NJ, c = idx - ql * NJ;
+                if (idx < nword) *reinterpret_cast<unsigned*>(srow + ql * RBP + 4 * c) = idx < nvalid ? w[u] : 0u;
+            }
+        }
     }
     __syncthreads();
     const int nitem = njq * NJ * 16;
@@ -444,6 +477,9 @@ struct AttnFwdArgs {
 // per SIMD that hide each other's LDS / MFMA / exp latencies at T = 252)
 #ifndef FD_TR_ATTN_MINW
 #define FD_TR_ATTN_MINW 2
+#endif
+#ifndef FD_TR_ATTN_OH_MINW
+#define FD_TR_ATTN_OH_MINW 3          // one-head attention backward: three 4-wave workgroups per CU
 #endif
 template <int KS1, int NW>
 __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const AttnFwdArgs a) {
@@ -879,6 +915,7 @@ struct FfnBwdArgs {
     const float* dy0;         // (M, D) gradient of the layer output: residual-path part ...
     const float* dyp;         // ... plus `npart` partial tensors (the next layer's attention backward, one per head pair)
     int npart; size_t part_stride;
+    int part_bf16;            // the partial tensors are bf16 (one per head), part_stride in elements either way
     const float* s1; const float* s2;
     const unsigned char* active;
     float* datt;              // (M, D) gradient of the attention output
@@ -978,11 +1015,22 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     // ---- gradient of the layer output
     f32x4 dy[DT];
     load_ctile<DT>(a.dy0, m, valid, D, g, dy);
-    for (int pi = 0; pi < a.npart; ++pi) {
-        f32x4 t[DT];
-        load_ctile<DT>(a.dyp + (size_t)pi * a.part_stride, m, valid, D, g, t);
+    // (four partial tensors per trip, every load of the trip in flight at once: one exposed round trip per four parts; the order
+    // of the additions is the part order either way)
+    for (int pi = 0; pi < a.npart; pi += 4) {
+        f32x4 t[4][DT];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) dy[dt] += t[dt];
+        for (int q = 0; q < 4; ++q) {
+            const int pq = pi + q < a.npart ? pi + q : a.npart - 1;
+            if (a.part_bf16) load_ctile_bf16<DT>(reinterpret_cast<const __bf16*>(a.dyp) + (size_t)pq * a.part_stride, m, valid, D, g, t[q]);
+            else load_ctile<DT>(a.dyp + (size_t)pq * a.part_stride, m, valid, D, g, t[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (pi + q < a.npart) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) dy[dt] += t[q][dt];
+            }
     }
     // ---- LayerNorm2 backward
     f32x4 xh[DT];
@@ -1153,38 +1201,49 @@ struct AttnBwdArgs {
     const float* lse2;
     const unsigned char* pmask;
     const unsigned char* pmaskT;   // key-oriented copy (k_tr_masks_T)
-    float* dxp;               // [NP][M, D]: this pair's contribution to the layer-input gradient
+    float* dxp;               // [NP][M, D]: this pair's contribution to the layer-input gradient (OH: [2 NP][M, D], fp32 or bf16)
+    int part_bf16;
     __bf16* dqkvT;            // T-block with 3*NP*16 rows: row which*(NP*16) + pair*16 + (8 hs + dim)
     const char* wk; const char* wv; const char* wq;
     const char* winT;         // [pair][which][DT] half blocks
     size_t part_stride;
 };
 
-template <int KS1, int DT, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_attn_bwd(const TrDims d, const AttnBwdArgs a) {
+// OH = 0: one workgroup per (head pair, series), both heads of the pair in every sweep iteration.
+// OH = 1: one workgroup per (head, series): H x B workgroups of NW waves with the LDS images of ONE head (row forms 16 B per
+//         token, column forms 8 dim rows), so that three or four workgroups share a CU and the grid is a whole number of rounds
+//         (H = 12, B = 64: 768 workgroups = 3 per CU; the pair form is 384 workgroups of 8 waves at one per CU: 1.5 rounds).
+//         A lane whose k-slots (row forms) / dim row (column forms) belong to the pair's other head supplies zeros without
+//         reading the LDS; d x parts are per head (a.dxp holds H of them).
+template <int KS1, int DT, int NW, int OH>
+__global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR_ATTN_MINW : 1)) void k_tr_attn_bwd(const TrDims d, const AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NHS = OH ? 1 : 2;                              // heads swept by this workgroup
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = blockIdx.x, b = blockIdx.y;
+    const int pair = OH ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, b = blockIdx.y;
+    const int hs0 = OH ? (int)(blockIdx.x & 1) : 0;              // OH: the head of the pair this workgroup owns
     const int T = d.T, KT = d.KT, NJ = d.NJ, NTOK = KT * 16, hd = d.hd, H = d.H, D = d.D;
-    // "row" form [token][4 g][8 B] (16x16x16 operand with the pair's 16 dim slots as k) and "column" form
-    // [32-token block][4 g][16 dim rows][16 B] (16x16x32 A operand with 32 tokens as k) of q, k, v, dO
-    const size_t RSZ = (size_t)NTOK * 32, CSZ = (size_t)NJ * 1024;
+    // "row" form [token][4 g][8 B] (16x16x16 operand with the pair's 16 dim slots as k; OH: [token][2][8 B]) and "column" form
+    // [32-token block][4 g][16 dim rows][16 B] (16x16x32 A operand with 32 tokens as k; OH: 8 dim rows) of q, k, v, dO
+    const size_t RSZ = (size_t)NTOK * (OH ? 16 : 32), CSZ = (size_t)NJ * (OH ? 512 : 1024);
     char* const qR = smem;            char* const kR = qR + RSZ;  char* const vR = kR + RSZ;  char* const oR = vR + RSZ;
     char* const qC = oR + RSZ;        char* const kC = qC + CSZ;  char* const oC = kC + CSZ;
-    float* const drow = reinterpret_cast<float*>(oC + CSZ);      // [2][NTOK]  rowsum(dO . O) per (head of the pair, query)
-    float* const lse = drow + 2 * NTOK;                          // [2][NTOK]
-    // keep bits of the pair's two heads, [2][T][NJ][4] bytes, staged once: the key-owner sweep reads 8 scattered bytes per
+    float* const drow = reinterpret_cast<float*>(oC + CSZ);      // [NHS][NTOK]  rowsum(dO . O) per (head, query)
+    float* const lse = drow + NHS * NTOK;                        // [NHS][NTOK]
+    // keep bits of the swept heads, [NHS][T][NJ][4] bytes, staged once: the key-owner sweep reads 8 scattered bytes per
     // (query pair, head) and a global gather there was a dependent L2 round trip per iteration
-    unsigned char* const pm = reinterpret_cast<unsigned char*>(lse + 2 * NTOK);
+    unsigned char* const pm = reinterpret_cast<unsigned char*>(lse + NHS * NTOK);
     const int PMH = T * NJ * 4;                                  // bytes per head
     const size_t pstride = (size_t)KS1 * 1024;
     auto wfrag = [&](const char* img, int ks) { return *reinterpret_cast<const bf16x8*>(img + pair * pstride + ((size_t)ks * 64 + lane) * 16); };
     const bool lo_grp = (g >> 1) == 0;
     const int myhead = 2 * pair + (g >> 1);
+    const bool mineR = !OH || (g >> 1) == hs0;                   // this lane's k-slots / C rows belong to a swept head
+    const bool mineC = !OH || (tok >> 3) == hs0;                 // this lane's dim row / column belongs to a swept head
     if (d.p > 0.f) {
-        for (int hs = 0; hs < 2; ++hs) {
-            const int head = 2 * pair + hs;
+        for (int hi = 0; hi < NHS; ++hi) {
+            const int head = 2 * pair + (OH ? hs0 : hi);
             if (head >= H) continue;
             const unsigned char* src = a.pmask + ((size_t)b * H + head) * PMH;        // contiguous per (series, head)
             if ((PMH & 1023) == 0 || (PMH & 15) == 0) {
@@ -1192,15 +1251,23 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
                 // the staging below and is awaited in front of its barrier; it was 3.5 K clocks of a 70 K-clock workgroup)
                 const int nkib = PMH >> 10;
                 for (int c = wave; c < nkib; c += NW)
-                    __builtin_amdgcn_global_load_lds(GLB_PTR(src + (size_t)c * 1024 + lane * 16), LDS_PTR(pm + hs * PMH + c * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(src + (size_t)c * 1024 + lane * 16), LDS_PTR(pm + hi * PMH + c * 1024), 16, 0, 0);
                 for (int i = nkib * 1024 + threadIdx.x * 16; i < PMH; i += NW * 64 * 16)      // the last partial KiB
-                    *reinterpret_cast<u32x4*>(pm + hs * PMH + i) = *reinterpret_cast<const u32x4*>(src + i);
+                    *reinterpret_cast<u32x4*>(pm + hi * PMH + i) = *reinterpret_cast<const u32x4*>(src + i);
             } else {
                 for (int i = threadIdx.x * 4; i < PMH; i += NW * 64 * 4)                   // PMH is a multiple of 4
-                    *reinterpret_cast<unsigned*>(pm + hs * PMH + i) = *reinterpret_cast<const unsigned*>(src + i);
+                    *reinterpret_cast<unsigned*>(pm + hi * PMH + i) = *reinterpret_cast<const unsigned*>(src + i);
             }
         }
     }
+    // LDS offsets of this lane's row-form / column-form words of a token tile (writers; the readers are rfrag / cfrag)
+    auto row_off = [&](int tile) -> size_t {
+        return OH ? ((size_t)(tile * 16 + tok) * 2 + (g & 1)) * 8 : ((size_t)(tile * 16 + tok) * 4 + g) * 8;
+    };
+    auto col_off = [&](int tile) -> size_t {
+        return OH ? ((size_t)((tile >> 1) * 4 + g) * 8 + (tok & 7)) * 16 + 8 * (tile & 1)
+                  : ((size_t)((tile >> 1) * 4 + g) * 16 + tok) * 16 + 8 * (tile & 1);
+    };
     // ---- stage q, k, v (recomputed), dO, rowsum(dO.O), lse
     {
         bf16x8 wqf[KS1], wkf[KS1], wvf[KS1];
@@ -1234,8 +1301,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
         for (int kt = wave; kt < KT; kt += NW) {
             fetch(kt + NW < KT ? kt + NW : kt, nxf, ndv, nav, nls, ndoc);
             f32x4 qr = f4zero(), kr = f4zero(), vr = f4zero(), qc = f4zero(), kc = f4zero();
-            const int t = kt * 16 + tok, mm = b * T + t;
-            (void)mm;
+            const int t = kt * 16 + tok;
             const bool tv = t < T;
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
@@ -1247,16 +1313,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
                 qc = MFMA(xf, wqf[ks], qc);       // [token rows][dim col] -> column form
                 kc = MFMA(xf, wkf[ks], kc);
             }
-            const size_t ro = ((size_t)(kt * 16 + tok) * 4 + g) * 8;
-            *reinterpret_cast<s16x4*>(qR + ro) = pack4(qr);
-            *reinterpret_cast<s16x4*>(kR + ro) = pack4(kr);
-            *reinterpret_cast<s16x4*>(vR + ro) = pack4(vr);
-            const size_t co = ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16 + 8 * (kt & 1);
-            *reinterpret_cast<s16x4*>(qC + co) = pack4(qc);
-            *reinterpret_cast<s16x4*>(kC + co) = pack4(kc);
-            if ((KT & 1) && kt == KT - 1) {
-                *reinterpret_cast<u32x2*>(qC + co + 8) = u32x2{0u, 0u};
-                *reinterpret_cast<u32x2*>(kC + co + 8) = u32x2{0u, 0u};
+            const size_t ro = row_off(kt);
+            if (mineR) {
+                *reinterpret_cast<s16x4*>(qR + ro) = pack4(qr);
+                *reinterpret_cast<s16x4*>(kR + ro) = pack4(kr);
+                *reinterpret_cast<s16x4*>(vR + ro) = pack4(vr);
+            }
+            const size_t co = col_off(kt);
+            const bool odd_tail = (KT & 1) && kt == KT - 1;
+            if (mineC) {
+                *reinterpret_cast<s16x4*>(qC + co) = pack4(qc);
+                *reinterpret_cast<s16x4*>(kC + co) = pack4(kc);
+                if (odd_tail) {
+                    *reinterpret_cast<u32x2*>(qC + co + 8) = u32x2{0u, 0u};
+                    *reinterpret_cast<u32x2*>(kC + co + 8) = u32x2{0u, 0u};
+                }
             }
             // dO rows and rowsum(dO . O) of this lane's head (4 of its dims per lane, the lane pair g, g^1 holds all 8); dims >=
             // head_dim were read from the next head / row (the buffers are followed by others in the arena) and are dropped
@@ -1269,17 +1340,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
                 dor[r] = use ? cdv[r] : 0.f;
                 part += use ? cdv[r] * cav[r] : 0.f;
             }
-            *reinterpret_cast<s16x4*>(oR + ro) = pack4(dor);
+            if (mineR) *reinterpret_cast<s16x4*>(oR + ro) = pack4(dor);
             float ea, eb;
             swap16(part, ea, eb);
-            if ((g & 1) == 0) {
-                drow[(g >> 1) * NTOK + kt * 16 + tok] = ea + eb;
+            if ((g & 1) == 0 && mineR) {
+                const int hi = OH ? 0 : (g >> 1);
+                drow[hi * NTOK + kt * 16 + tok] = ea + eb;
                 // padded queries / a missing odd head: lse = +1e30 makes every P = exp2(s - lse) of that row exactly 0, so the
                 // sweeps need no validity selects (padded KEYS have all-zero K / V / dO operands instead)
-                lse[(g >> 1) * NTOK + kt * 16 + tok] = ok ? cls : 1.0e30f;
+                lse[hi * NTOK + kt * 16 + tok] = ok ? cls : 1.0e30f;
             }
             // dO column form: lane (dim row = tok, g) holds tokens 4g+r of this tile
-            {
+            if (mineC) {
                 const int hs = tok >> 3, dd = tok & 7, head = 2 * pair + hs;
                 f32x4 doc = f4zero();
 #pragma unroll
@@ -1288,7 +1360,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
                     doc[r] = (tt < T && head < H && dd < hd) ? cdoc[r] : 0.f;
                 }
                 *reinterpret_cast<s16x4*>(oC + co) = pack4(doc);
-                if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(oC + co + 8) = u32x2{0u, 0u};
+                if (odd_tail) *reinterpret_cast<u32x2*>(oC + co + 8) = u32x2{0u, 0u};
             }
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) cxf[ks] = nxf[ks];
@@ -1297,32 +1369,49 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the keep-bit DMA)
     __syncthreads();
-    auto rfrag = [&](const char* base, int tile) { return *reinterpret_cast<const s16x4*>(base + ((size_t)(tile * 16 + tok) * 4 + g) * 8); };
-    auto cfrag = [&](const char* base, int jb) { return *reinterpret_cast<const bf16x8*>(base + ((size_t)(jb * 4 + g) * 16 + tok) * 16); };
-    auto headmask = [&](s16x4 v, int hs) {        // keep only the k-slots of head hs of the pair
+    auto rfrag = [&](const char* base, int tile) {
+        if constexpr (OH) {
+            const u32x2 v = *reinterpret_cast<const u32x2*>(base + ((size_t)(tile * 16 + tok) * 2 + (g & 1)) * 8);
+            return __builtin_bit_cast(s16x4, u32x2{mineR ? v[0] : 0u, mineR ? v[1] : 0u});
+        } else {
+            return *reinterpret_cast<const s16x4*>(base + ((size_t)(tile * 16 + tok) * 4 + g) * 8);
+        }
+    };
+    auto cfrag = [&](const char* base, int jb) {
+        if constexpr (OH) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(base + ((size_t)(jb * 4 + g) * 8 + (tok & 7)) * 16);
+            return __builtin_bit_cast(bf16x8, u32x4{mineC ? v[0] : 0u, mineC ? v[1] : 0u, mineC ? v[2] : 0u, mineC ? v[3] : 0u});
+        } else {
+            return *reinterpret_cast<const bf16x8*>(base + ((size_t)(jb * 4 + g) * 16 + tok) * 16);
+        }
+    };
+    auto headmask = [&](s16x4 v, int hs) {        // keep only the k-slots of head hs of the pair (OH: rfrag has done it)
+        if constexpr (OH) return v;
         const u32x2 u = __builtin_bit_cast(u32x2, v);
         const bool mine = (g >> 1) == hs;
         return __builtin_bit_cast(s16x4, u32x2{mine ? u[0] : 0u, mine ? u[1] : 0u});
     };
     const float ln2 = 0.6931471805599453f;
     const float inv_sqrt_hd = __builtin_amdgcn_rsqf((float)hd);
-    // each wave owns token tiles tt = wave, wave+4, ...: as QUERY tile (d q), then as KEY tile (d k, d v), then the
+    // each wave owns token tiles tt = wave, wave+NW, ...: as QUERY tile (d q), then as KEY tile (d k, d v), then the
     // input gradient of in_proj for those 16 tokens
     for (int tt = wave; tt < KT; tt += NW) {
-        f32x4 dq[2] = {f4zero(), f4zero()}, dk[2] = {f4zero(), f4zero()}, dv[2] = {f4zero(), f4zero()};
+        f32x4 dq[NHS], dk[NHS], dv[NHS];
+#pragma unroll
+        for (int hi = 0; hi < NHS; ++hi) { dq[hi] = f4zero(); dk[hi] = f4zero(); dv[hi] = f4zero(); }
         // ---------------- as query tile: S^T tiles [key rows 4g+r][query col]
         {
             const int t = tt * 16 + tok;
-            s16x4 qb[2], ob[2];
-            float lq[2], dr[2];
+            s16x4 qb[NHS], ob[NHS];
+            float lq[NHS], dr[NHS];
             {
                 const s16x4 qf = rfrag(qR, tt), of = rfrag(oR, tt);
 #pragma unroll
-                for (int hs = 0; hs < 2; ++hs) {
-                    qb[hs] = headmask(qf, hs);
-                    ob[hs] = headmask(of, hs);
-                    lq[hs] = lse[hs * NTOK + tt * 16 + tok];
-                    dr[hs] = drow[hs * NTOK + tt * 16 + tok];
+                for (int hi = 0; hi < NHS; ++hi) {
+                    qb[hi] = headmask(qf, hi);
+                    ob[hi] = headmask(of, hi);
+                    lq[hi] = lse[hi * NTOK + tt * 16 + tok];
+                    dr[hi] = drow[hi * NTOK + tt * 16 + tok];
                 }
             }
             const int tcl = t < T ? t : T - 1;                       // (padded query columns are discarded at the end)
@@ -1333,21 +1422,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
                 const s16x4 kfa = rfrag(kR, ka), kfb = rfrag(kR, kb), vfa = rfrag(vR, ka), vfb = rfrag(vR, kb);
                 const bf16x8 kcf = cfrag(kC, jb);
 #pragma unroll
-                for (int hs = 0; hs < 2; ++hs) {
-                    f32x4 sa = MFMA16(kfa, qb[hs], f4zero()), sb = MFMA16(kfb, qb[hs], f4zero());
-                    f32x4 pa = MFMA16(vfa, ob[hs], f4zero()), pb = MFMA16(vfb, ob[hs], f4zero());    // dP (dropped P's gradient)
+                for (int hi = 0; hi < NHS; ++hi) {
+                    f32x4 sa = MFMA16(kfa, qb[hi], f4zero()), sb = MFMA16(kfb, qb[hi], f4zero());
+                    f32x4 pa = MFMA16(vfa, ob[hi], f4zero()), pb = MFMA16(vfb, ob[hi], f4zero());    // dP (dropped P's gradient)
                     unsigned bits = 0xffu;
-                    if (d.p > 0.f) bits = pm[hs * PMH + (tcl * NJ + jb) * 4 + g];
+                    if (d.p > 0.f) bits = pm[hi * PMH + (tcl * NJ + jb) * 4 + g];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float Pa = __builtin_amdgcn_exp2f(sa[r] - lq[hs]);
-                        const float Pb = __builtin_amdgcn_exp2f(sb[r] - lq[hs]);
+                        const float Pa = __builtin_amdgcn_exp2f(sa[r] - lq[hi]);
+                        const float Pb = __builtin_amdgcn_exp2f(sb[r] - lq[hi]);
                         const float ma = ((bits >> r) & 1u) ? d.keep_scale : 0.f;          // keep multiplier of this score
                         const float mb = ((bits >> (4 + r)) & 1u) ? d.keep_scale : 0.f;
-                        sa[r] = Pa * __builtin_fmaf(pa[r], ma, -dr[hs]);
-                        sb[r] = Pb * __builtin_fmaf(pb[r], mb, -dr[hs]);
+                        sa[r] = Pa * __builtin_fmaf(pa[r], ma, -dr[hi]);
+                        sb[r] = Pb * __builtin_fmaf(pb[r], mb, -dr[hi]);
                     }
-                    dq[hs] = MFMA(kcf, pack8(sa, sb), dq[hs]);       // [dim rows][query col] += K^T dS^T
+                    dq[hi] = MFMA(kcf, pack8(sa, sb), dq[hi]);       // [dim rows][query col] += K^T dS^T
                 }
             }
         }
@@ -1355,43 +1444,45 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
         {
             const int kt = tt;
             // the head's k-slots are selected on the key side once per tile (masking either operand of the contraction does)
-            s16x4 kfh[2], vfh[2];
+            s16x4 kfh[NHS], vfh[NHS];
             {
                 const s16x4 kf = rfrag(kR, kt), vf = rfrag(vR, kt);
 #pragma unroll
-                for (int hs = 0; hs < 2; ++hs) { kfh[hs] = headmask(kf, hs); vfh[hs] = headmask(vf, hs); }
+                for (int hi = 0; hi < NHS; ++hi) { kfh[hi] = headmask(kf, hi); vfh[hi] = headmask(vf, hi); }
             }
             const int key = kt * 16 + tok, keycl = key < T ? key : T - 1;       // (padded key columns are discarded at the end)
             // keep bits in the key-oriented layout: one 32-bit word per (key, query block) and head holds the four lane groups'
             // bytes; the next block's words are in flight during the current one
-            const unsigned char* pt[2];
+            const unsigned char* pt[NHS];
+            unsigned wn[NHS];
 #pragma unroll
-            for (int hs = 0; hs < 2; ++hs) {
-                const int head = min(2 * pair + hs, H - 1);
-                pt[hs] = a.pmaskT + (((size_t)b * H + head) * T + keycl) * NJ * 4;
+            for (int hi = 0; hi < NHS; ++hi) {
+                const int head = min(2 * pair + (OH ? hs0 : hi), H - 1);
+                pt[hi] = a.pmaskT + (((size_t)b * H + head) * T + keycl) * NJ * 4;
+                wn[hi] = 0xffffffffu;
+                if (d.p > 0.f) wn[hi] = *reinterpret_cast<const unsigned*>(pt[hi]);
             }
-            unsigned wn[2] = {0xffffffffu, 0xffffffffu};
-            if (d.p > 0.f) { wn[0] = *reinterpret_cast<const unsigned*>(pt[0]); wn[1] = *reinterpret_cast<const unsigned*>(pt[1]); }
             for (int jq = 0; jq < NJ; ++jq) {
                 const int qa_t = 2 * jq, qb_t = (2 * jq + 1 < KT) ? 2 * jq + 1 : qa_t;
-                const unsigned wc[2] = {wn[0], wn[1]};
-                if (d.p > 0.f && jq + 1 < NJ) {
-                    wn[0] = *reinterpret_cast<const unsigned*>(pt[0] + (jq + 1) * 4);
-                    wn[1] = *reinterpret_cast<const unsigned*>(pt[1] + (jq + 1) * 4);
+                unsigned wc[NHS];
+#pragma unroll
+                for (int hi = 0; hi < NHS; ++hi) {
+                    wc[hi] = wn[hi];
+                    if (d.p > 0.f && jq + 1 < NJ) wn[hi] = *reinterpret_cast<const unsigned*>(pt[hi] + (jq + 1) * 4);
                 }
                 const s16x4 qfa = rfrag(qR, qa_t), qfb = rfrag(qR, qb_t), ofa = rfrag(oR, qa_t), ofb = rfrag(oR, qb_t);
                 const bf16x8 qcf = cfrag(qC, jq), ocf = cfrag(oC, jq);
 #pragma unroll
-                for (int hs = 0; hs < 2; ++hs) {
-                    f32x4 sa = MFMA16(qfa, kfh[hs], f4zero()), sb = MFMA16(qfb, kfh[hs], f4zero());
-                    f32x4 pa = MFMA16(ofa, vfh[hs], f4zero()), pb = MFMA16(ofb, vfh[hs], f4zero());
+                for (int hi = 0; hi < NHS; ++hi) {
+                    f32x4 sa = MFMA16(qfa, kfh[hi], f4zero()), sb = MFMA16(qfb, kfh[hi], f4zero());
+                    f32x4 pa = MFMA16(ofa, vfh[hi], f4zero()), pb = MFMA16(ofb, vfh[hi], f4zero());
                     // padded query rows carry lse = 1e30 (P = 0); a missing odd query tile re-reads tile qa_t against zero halves
                     // of the Q / dO column blocks
-                    const f32x4 la = *reinterpret_cast<const f32x4*>(lse + hs * NTOK + qa_t * 16 + 4 * g);
-                    const f32x4 lb = *reinterpret_cast<const f32x4*>(lse + hs * NTOK + qb_t * 16 + 4 * g);
-                    const f32x4 da = *reinterpret_cast<const f32x4*>(drow + hs * NTOK + qa_t * 16 + 4 * g);
-                    const f32x4 db = *reinterpret_cast<const f32x4*>(drow + hs * NTOK + qb_t * 16 + 4 * g);
-                    const unsigned bits = (wc[hs] >> (8 * g)) & 0xffu;
+                    const f32x4 la = *reinterpret_cast<const f32x4*>(lse + hi * NTOK + qa_t * 16 + 4 * g);
+                    const f32x4 lb = *reinterpret_cast<const f32x4*>(lse + hi * NTOK + qb_t * 16 + 4 * g);
+                    const f32x4 da = *reinterpret_cast<const f32x4*>(drow + hi * NTOK + qa_t * 16 + 4 * g);
+                    const f32x4 db = *reinterpret_cast<const f32x4*>(drow + hi * NTOK + qb_t * 16 + 4 * g);
+                    const unsigned bits = (wc[hi] >> (8 * g)) & 0xffu;
                     f32x4 pda, pdb;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -1404,8 +1495,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
                         sa[r] = Pa * __builtin_fmaf(pa[r], ma, -da[r]);
                         sb[r] = Pb * __builtin_fmaf(pb[r], mb, -db[r]);
                     }
-                    dv[hs] = MFMA(ocf, pack8(pda, pdb), dv[hs]);     // [dim rows][key col] += dO^T P_drop
-                    dk[hs] = MFMA(qcf, pack8(sa, sb), dk[hs]);       // += Q^T dS
+                    dv[hi] = MFMA(ocf, pack8(pda, pdb), dv[hi]);     // [dim rows][key col] += dO^T P_drop
+                    dk[hi] = MFMA(qcf, pack8(sa, sb), dk[hi]);       // += Q^T dS
                 }
             }
         }
@@ -1416,11 +1507,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
             f32x4 gq, gk, gv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool dv_ok = (4 * (g & 1) + r < hd) && myhead < H && tv;
+                const bool dv_ok = (4 * (g & 1) + r < hd) && myhead < H && tv && mineR;
                 // s_nat = q_raw . k / sqrt(hd);  q_img = q_raw log2(e)/sqrt(hd)
-                gq[r] = dv_ok ? (lo_grp ? dq[0][r] : dq[1][r]) * inv_sqrt_hd : 0.f;      // d q_raw
-                gk[r] = dv_ok ? (lo_grp ? dk[0][r] : dk[1][r]) * ln2 : 0.f;              // d k = sum dS q_img ln2
-                gv[r] = dv_ok ? (lo_grp ? dv[0][r] : dv[1][r]) : 0.f;
+                gq[r] = dv_ok ? (lo_grp || OH ? dq[0][r] : dq[NHS - 1][r]) * inv_sqrt_hd : 0.f;      // d q_raw
+                gk[r] = dv_ok ? (lo_grp || OH ? dk[0][r] : dk[NHS - 1][r]) * ln2 : 0.f;              // d k = sum dS q_img ln2
+                gv[r] = dv_ok ? (lo_grp || OH ? dv[0][r] : dv[NHS - 1][r]) : 0.f;
             }
             const s16x4 bq = pack4(gq), bk = pack4(gk), bv = pack4(gv);
             const int rows = d.NP * 16;
@@ -1429,7 +1520,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = pair * 16 + 4 * g + r;
-                    if (tv) {
+                    if (tv && mineR) {
                         tcol[(size_t)(0 * rows + j) * 32] = (__bf16)gq[r];
                         tcol[(size_t)(1 * rows + j) * 32] = (__bf16)gk[r];
                         tcol[(size_t)(2 * rows + j) * 32] = (__bf16)gv[r];
@@ -1437,6 +1528,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
                 }
             }
             const char* wbase = a.winT + (size_t)pair * 3 * DT * 512;
+            const size_t pidx = OH ? (size_t)blockIdx.x : (size_t)pair;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 f32x4 o = f4zero();
@@ -1444,8 +1536,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? FD_TR_ATTN_MINW : 1) void k_tr_a
                 o = MFMA16(*reinterpret_cast<const s16x4*>(wbase + ((size_t)(1 * DT + dt) * 64 + lane) * 8), bk, o);
                 o = MFMA16(*reinterpret_cast<const s16x4*>(wbase + ((size_t)(2 * DT + dt) * 64 + lane) * 8), bv, o);
                 const int d0 = 16 * dt + 4 * g;
-                if (tv && d0 < D)
-                    *reinterpret_cast<float4*>(a.dxp + (size_t)pair * a.part_stride + (size_t)mm * D + d0) = float4{o[0], o[1], o[2], o[3]};
+                if (tv && d0 < D) {
+                    if (OH && a.part_bf16)
+                        *reinterpret_cast<s16x4*>(reinterpret_cast<__bf16*>(a.dxp) + pidx * a.part_stride + (size_t)mm * D + d0) = pack4(o);
+                    else
+                        *reinterpret_cast<float4*>(a.dxp + pidx * a.part_stride + (size_t)mm * D + d0) = float4{o[0], o[1], o[2], o[3]};
+                }
             }
         }
     }
@@ -1835,6 +1931,33 @@ __global__ __launch_bounds__(256) void k_tr_sum_parts(const float* __restrict__ 
     }
 }
 
+// the same with bf16 partial tensors (k_tr_attn_bwd OH form)
+__global__ __launch_bounds__(256) void k_tr_sum_parts_bf16(const float* __restrict__ a0, const __bf16* __restrict__ parts, int np,
+                                                            size_t stride, float* __restrict__ out, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(a0 + i);
+        for (int p0 = 0; p0 < np; p0 += 4) {
+            u32x2 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const u32x2*>(parts + (size_t)(p0 + u < np ? p0 + u : np - 1) * stride + i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (p0 + u < np)
+                    v += f32x4{__builtin_bit_cast(float, q[u][0] << 16), __builtin_bit_cast(float, q[u][0] & 0xffff0000u),
+                               __builtin_bit_cast(float, q[u][1] << 16), __builtin_bit_cast(float, q[u][1] & 0xffff0000u)};
+        }
+        *reinterpret_cast<f32x4*>(out + i) = v;
+    } else {
+        for (size_t j = i; j < n; ++j) {
+            float v = a0[j];
+            for (int p = 0; p < np; ++p) v += (float)parts[(size_t)p * stride + j];
+            out[j] = v;
+        }
+    }
+}
+
 }  // namespace
 
 // ================================================================================================ host side
@@ -1916,7 +2039,7 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
     tb.datt = (float*)take(sizeof(float) * M * D);
     for (int i = 0; i < 2; ++i) {
         tb.dres[i] = (float*)take(sizeof(float) * M * D);
-        tb.dxp[i] = (float*)take(sizeof(float) * NP * M * D);
+        tb.dxp[i] = (float*)take(sizeof(float) * 2 * NP * M * D);     // per head pair, or per head (tr_attn_one_head)
     }
     tb.dtemb = (float*)take(sizeof(float) * B * D);
     tb.skp = (float*)take(sizeof(float) * kSkpFloats);
@@ -1940,6 +2063,17 @@ hipError_t side_stream_create(hipStream_t* st) {
 int tr_attn_waves(int KT) {
     if (const char* e = getenv("FDIFF_TR_ATTN_NW")) return atoi(e) == 8 ? 8 : 4;     // experiments
     return KT > 4 ? 8 : 4;
+}
+
+// Attention backward per (head, series) instead of per (head pair, series): see k_tr_attn_bwd.  FDIFF_TR_ATTN_OH=0 keeps the
+// pair form (A/B measurements).
+// 0: pair form; 1: one head per workgroup, fp32 parts; 2: one head per workgroup, bf16 parts.  Measured at B = 64 (same box,
+// alternating runs, profiles/r04_train_attn_bwd_forms.txt): T = 252 (16 tiles) 2.65 / 2.63 / 2.61 ms per optimizer step, T = 100
+// (7 tiles) 1.49 / 1.55 / 1.53 -- with few tiles the duplicated staging of the one-head form outweighs its even rounds.
+int tr_attn_oh_mode(int KT) {
+    const char* e = getenv("FDIFF_TR_ATTN_OH");               // (read per call: the tests switch forms inside one process)
+    const int v = e ? atoi(e) : -1;
+    return v >= 0 ? v : (KT >= 12 ? 2 : 0);
 }
 
 TrDims make_dims(const fd_score* m, int B, float p, uint64_t seed) {
@@ -2260,13 +2394,19 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     const size_t lds_bwd = (size_t)4 * 2 * (2 * KS1 + DT) * 1024 + scr + (size_t)TW * 64 * NSh + (size_t)4 * 5 * 16 * DT * sizeof(float) +
                            (size_t)TW * KS1 * 1024;
     const int attn_nw = tr_attn_waves(d.KT);
-    const size_t lds_ab = (size_t)4 * d.KT * 16 * 32 + (size_t)3 * d.NJ * 1024 + (size_t)4 * d.KT * 16 * sizeof(float) +
-                          (size_t)2 * d.T * d.NJ * 4;
+    const bool attn_oh = tr_attn_oh_mode(d.KT) != 0;
+    const int attn_parts = attn_oh ? 2 * d.NP : d.NP;             // partial tensors of d x written by k_tr_attn_bwd
+    const int part_bf16 = tr_attn_oh_mode(d.KT) == 2 ? 1 : 0;
+    const size_t lds_ab = attn_oh ? (size_t)4 * d.KT * 16 * 16 + (size_t)3 * d.NJ * 512 + (size_t)2 * d.KT * 16 * sizeof(float) +
+                                        (size_t)d.T * d.NJ * 4
+                                  : (size_t)4 * d.KT * 16 * 32 + (size_t)3 * d.NJ * 1024 + (size_t)4 * d.KT * 16 * sizeof(float) +
+                                        (size_t)2 * d.T * d.NJ * 4;
     static unsigned long long attr = 0;
     if (fd_first_on_device(attr, ctx->device)) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_ffn_bwd<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_bwd<KS1, DT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_bwd<KS1, DT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_bwd<KS1, DT, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_bwd<KS1, DT, 8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_bwd<KS1, DT, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_wgrad<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     // side stream: the weight gradients of layer l only need that layer's k_tr_ffn_bwd / k_tr_attn_bwd outputs, so they run
@@ -2278,7 +2418,10 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         FD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->side_events.push_back(e);
     }
-    const size_t lds_wg = (size_t)3 * StageL<KS1, DT>::bytes;
+    // FDIFF_TR_WG_LDS_KB pads the request (experiments: above 80 KiB only one weight-gradient workgroup fits a CU, which
+    // leaves registers and LDS for the chain's attention-backward workgroups beside it)
+    static const size_t wg_pad = getenv("FDIFF_TR_WG_LDS_KB") ? (size_t)atoi(getenv("FDIFF_TR_WG_LDS_KB")) * 1024 : 0;
+    const size_t lds_wg = std::max((size_t)3 * StageL<KS1, DT>::bytes, wg_pad);
     static const bool serial = getenv("FDIFF_TR_SERIAL") != nullptr;
     WgArgs wa{};
     wa.nparams = (long long)tb.layer_params; wa.TS = tb.TS; wa.nblk = (M + 31) / 32;
@@ -2301,8 +2444,8 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         const int par = l & 1;
         FfnBwdArgs fa{};
         if (l == L - 1) { fa.dy0 = tb.dh; fa.dyp = nullptr; fa.npart = 0; }
-        else { fa.dy0 = tb.dres[par ^ 1]; fa.dyp = tb.dxp[par ^ 1]; fa.npart = d.NP; }
-        fa.part_stride = tb.part_stride;
+        else { fa.dy0 = tb.dres[par ^ 1]; fa.dyp = tb.dxp[par ^ 1]; fa.npart = attn_parts; }
+        fa.part_stride = tb.part_stride; fa.part_bf16 = part_bf16;
         fa.s1 = b.s1; fa.s2 = b.s2; fa.active = b.active;
         fa.datt = tb.datt; fa.dres = tb.dres[par];
         fa.stage = b.stage; fa.doT = b.doT;
@@ -2321,14 +2464,15 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         ab.x0rb = b.x0rb; ab.att = b.att; ab.datt = tb.datt; ab.lse2 = b.lse2; ab.pmask = b.pmask; ab.pmaskT = b.pmaskT;
         ab.dxp = tb.dxp[par]; ab.dqkvT = b.dqkvT;
         ab.wk = limg + im->off_wk; ab.wv = limg + im->off_wv; ab.wq = limg + im->off_wq;
-        ab.winT = bl + im->boff_win; ab.part_stride = tb.part_stride;
+        ab.winT = bl + im->boff_win; ab.part_stride = tb.part_stride; ab.part_bf16 = part_bf16;
         {
             // measurement hook: dP = dO V^T, dV = P^T dO, dQ = dS K, dK = dS^T Q (2 T D each per token) + the in-proj^T GEMM; the
             // recomputed scores are not algorithmic work
             fd_prof_scope scope(ctx, s, "k_tr_attn_bwd (attention backward + in-proj^T, training backward)",
                                 (double)M * (8.0 * (double)T * D + 6.0 * D * D));
-            if (attn_nw == 8) hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 8>), dim3(d.NP, B), dim3(512), lds_ab, s, d, ab);
-            else hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 4>), dim3(d.NP, B), dim3(256), lds_ab, s, d, ab);
+            if (attn_oh) hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 4, 1>), dim3(2 * d.NP, B), dim3(256), lds_ab, s, d, ab);
+            else if (attn_nw == 8) hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 8, 0>), dim3(d.NP, B), dim3(512), lds_ab, s, d, ab);
+            else hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 4, 0>), dim3(d.NP, B), dim3(256), lds_ab, s, d, ab);
         }
         WgLayer w{};
         w.x0T = b.x0T; w.attT = b.attT; w.doT = b.doT; w.dqkvT = b.dqkvT;
@@ -2370,7 +2514,11 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     if (L > 0) {
         // gradient of the first layer's input = residual path + the pairs' in_proj contributions
         const size_t nn = (size_t)M * D;
-        hipLaunchKernelGGL(k_tr_sum_parts, dim3((unsigned)((nn / 4 + 256) / 256)), dim3(256), 0, s, tb.dres[0], tb.dxp[0], d.NP,
+        if (part_bf16)
+            hipLaunchKernelGGL(k_tr_sum_parts_bf16, dim3((unsigned)((nn / 4 + 256) / 256)), dim3(256), 0, s, tb.dres[0],
+                               reinterpret_cast<const __bf16*>(tb.dxp[0]), attn_parts, tb.part_stride, tb.dh, nn);
+        else
+            hipLaunchKernelGGL(k_tr_sum_parts, dim3((unsigned)((nn / 4 + 256) / 256)), dim3(256), 0, s, tb.dres[0], tb.dxp[0], attn_parts,
                            tb.part_stride, tb.dh, nn);
     }
     if (L > 0) {

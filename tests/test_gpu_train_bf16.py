@@ -125,6 +125,42 @@ def test_gradients_vs_exact_f32_engine(name):
     _compare_grads(name, res["bf16"][1], res["fp32"][1])
 
 
+@pytest.mark.parametrize("cfg,B,p", [(dict(T=37, C=5, D=72, L=2, H=12), 7, 0.0), (dict(T=200, C=4, D=72, L=2, H=12), 3, 0.1),
+                                      (dict(T=50, C=3, D=60, L=3, H=12), 5, 0.1), (dict(T=100, C=2, D=24, L=2, H=3), 4, 0.1)])
+def test_attention_backward_forms_agree(monkeypatch, cfg, B, p):
+    """k_tr_attn_bwd per (head pair, series) (FDIFF_TR_ATTN_OH=0), per (head, series) with fp32 partial tensors of d x (=1) and
+    with bf16 ones (=2; the default from 12 token tiles on): same Philox key, dropout on / off, ragged T, an odd head count.
+    Form 1 computes every gradient with the pair form's arithmetic except that a pair's two heads enter d x as two fp32 terms
+    instead of one MFMA accumulation: a last-bit difference in d x that flips single bf16 operand roundings downstream
+    (measured: <= 3.1e-4 of the tensor maximum; bound 2e-3); form 2 rounds the per-head d x contributions to bf16 (measured
+    <= 2.4e-3, bound 5e-3; the comparison against the exact-f32 engine at the benched shapes is tests/test_gpu_benched_shapes.py); all three
+    are bit-reproducible."""
+    from fourierdiffusion_amd.utils.losses import get_sde_loss_fn
+    tag = f"T{cfg['T']}_D{cfg['D']}_H{cfg['H']}_p{p}"
+    X = W.randn(f"oh_x_{tag}", (B, cfg["T"], cfg["C"]), 3)
+    z = W.randn(f"oh_z_{tag}", (B, cfg["T"], cfg["C"]), 3)
+    t = W.uniform(f"oh_t_{tag}", (B,), 3, 0.05, 1.0)
+    m, sch, _ = make_model(cfg, precision="bf16")
+    m.dropout = p
+    fn = get_sde_loss_fn(sch, train=True)
+    res = {}
+    for form in ("0", "1", "2", "2"):
+        monkeypatch.setenv("FDIFF_TR_ATTN_OH", form)
+        m.zero_grad()
+        torch.manual_seed(77)
+        loss = fn(m, batch_of(X, t), noise=dev(z)).item()
+        assert m.train_mode_effective == "bf16"
+        g = m.grads.clone()
+        if form in res:
+            assert loss == res[form][0] and torch.equal(g, res[form][1]), "one-head form is not bit-reproducible"
+        res[form] = (loss, g, _grads_of(m))
+    assert res["0"][0] == res["1"][0] == res["2"][0]               # the forward does not depend on the backward form
+    for form, tol in (("1", 2e-3), ("2", 5e-3)):
+        worst = max(np.abs(res[form][2][k] - r).max() / max(np.abs(r).max(), 1e-20) for k, r in res["0"][2].items())
+        _log(f"[parity] attention backward form {form} vs pair form ({tag}): worst max-rel over the tensors {worst:.3e}")
+        assert worst <= tol, (form, worst)
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
 def test_training_gradients_are_bit_reproducible(prec):
     """No float atomics on either training path: two identical forward+backward runs (dropout on, same Philox key) give
