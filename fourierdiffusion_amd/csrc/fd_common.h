@@ -44,7 +44,6 @@ struct fd_ctx {
     // tr_readers_gen = ws_gen at that moment: a different ws_gen at the next training forward means some other call carved the
     // arena in between and may still be running on the caller's stream, so the side stream must wait for a FRESH event
     hipEvent_t tr_readers_event = nullptr;
-    hipEvent_t tr_masksT_event = nullptr;      // behind the key-oriented copies of the attention keep bits (read by the backward only)
     bool tr_readers_event_valid = false;
     uint64_t tr_readers_gen = 0;
     // FFT twiddle tables (T, device pointer), built on first use of a length

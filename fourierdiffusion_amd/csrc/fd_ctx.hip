@@ -29,7 +29,6 @@ extern "C" int fd_ctx_destroy(fd_ctx* ctx) {
     if (ctx->red_scratch) (void)hipFree(ctx->red_scratch);
     for (hipEvent_t e : ctx->side_events) (void)hipEventDestroy(e);
     if (ctx->tr_readers_event) (void)hipEventDestroy(ctx->tr_readers_event);
-    if (ctx->tr_masksT_event) (void)hipEventDestroy(ctx->tr_masksT_event);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->side_stream2) (void)hipStreamDestroy(ctx->side_stream2);
     for (auto& e : ctx->fft_tw) (void)hipFree(e.second);

@@ -373,77 +373,6 @@ __global__ __launch_bounds__(256) void k_tr_masks(const TrDims d, const MaskArgs
     }
 }
 
-// Key-oriented copy of the attention keep bits for the backward's key-owner sweep (d K, d V): the forward and the query-owner
-// sweep read byte [(b, head)][query][jb][g] = bits of keys 32 jb + 4 g + r (bit r) and 32 jb + 16 + 4 g + r (bit 4 + r); the
-// key-owner sweep needs, per key, the bits of eight QUERIES.  Gathering them there cost eight LDS byte reads with their
-// address arithmetic per (query block, head) in a VALU-bound loop (280 VALU against 153 in the query-owner loop); here it
-// is a side-stream kernel off the critical path.  Same bits, second layout: byte [(b, head)][key][jq][g] = bits of queries
-// 32 jq + 4 g + r (bit r) and 32 jq + 16 + 4 g + r (bit 4 + r).  One workgroup per ((b, head), jq): the 32 queries' rows
-// (32 x NJ x 4 bytes) go through LDS.
-// One workgroup per ((b, head), group of 8 query blocks = 256 queries): their rows (256 x NJ * 4 bytes, contiguous) are staged
-// in LDS.  An item = (query block jq, key block jb, key lane group g, query lane group gq): the 8 x 8 bit block {8 queries of
-// group gq} x {8 keys of group g} is read as eight bytes (one per query), transposed in registers (three masked exchange
-// steps on a 64-bit word) and written as eight bytes (one per key) into the output tile [key][8 jq x 4 gq], which leaves as
-// 32-byte runs.  (The first version gathered every output byte from eight LDS byte reads and stored single bytes 32 B apart:
-// 27 us per layer at T = 252 for 12 MB of traffic.)
-__global__ __launch_bounds__(256) void k_tr_masks_T(const unsigned char* __restrict__ pmask, unsigned char* __restrict__ pmaskT,
-                                                     int T, int NJ) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char srow[];      // [256 queries][NJ * 4 + 4] | [NJ * 32 keys][36]
-    const int jq0 = 8 * blockIdx.y, njq = min(8, NJ - jq0);
-    const size_t bh = blockIdx.x;                 // (series, head) on the x axis: no 65 535 limit
-    const int RB = NJ * 4, RBP = RB + 4;          // padded rows: the eight rows an item reads lie 4 rows apart
-    constexpr int OB = 36;
-    unsigned char* orow = srow + 256 * RBP;
-    // The group's rows are one contiguous run of global memory; eight words per thread and trip, every load of the trip in
-    // flight before the first LDS store, from clamped addresses (a load inside the `q < T` branch made hipcc wait for each one:
-    // eight serial L2 round trips per workgroup were most of this kernel's 29 us at T = 252).
-    {
-        const int nword = 32 * njq * NJ, nvalid = (min(T, 32 * jq0 + 32 * njq) - 32 * jq0) * NJ;     // words to fill / that exist
-        const unsigned* src = reinterpret_cast<const unsigned*>(pmask + (bh * T + 32 * jq0) * RB);
-        for (int base = 0; base < nword; base += 256 * 8) {
-            unsigned w[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * 256 + (int)threadIdx.x;
-                w[u] = src[idx < nvalid ? idx : nvalid - 1];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * 256 + (int)threadIdx.x;
-                const int ql = idx / NJ, c = idx - ql * NJ;
-                if (idx < nword) *reinterpret_cast<unsigned*>(srow + ql * RBP + 4 * c) = idx < nvalid ? w[u] : 0u;
-            }
-        }
-    }
-    __syncthreads();
-    const int nitem = njq * NJ * 16;
-    for (int it = threadIdx.x; it < nitem; it += 256) {
-        const int jql = it / (NJ * 16), rest = it - jql * NJ * 16;
-        const int jb = rest >> 4, g = (rest >> 2) & 3, gq = rest & 3;
-        const unsigned char* base = srow + (jql * 32 + 4 * gq) * RBP + jb * 4 + g;
-        unsigned lo = 0u, hi = 0u;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            lo |= (unsigned)base[e * RBP] << (8 * e);                   // queries 4 gq + e
-            hi |= (unsigned)base[(16 + e) * RBP] << (8 * e);            // queries 16 + 4 gq + e
-        }
-        unsigned long long x = (unsigned long long)lo | ((unsigned long long)hi << 32), t;
-        t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;  x = x ^ t ^ (t << 7);
-        t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x = x ^ t ^ (t << 14);
-        t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x = x ^ t ^ (t << 28);
-#pragma unroll
-        for (int f = 0; f < 8; ++f) {
-            const int key = 32 * jb + (f >> 2) * 16 + 4 * g + (f & 3);
-            orow[key * OB + jql * 4 + gq] = (unsigned char)(x >> (8 * f));
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < T * njq; i += 256) {       // one 4-byte word = (key, jq): njq consecutive words per key
-        const int key = i / njq, jql = i - key * njq;
-        *reinterpret_cast<unsigned*>(pmaskT + ((bh * T + key) * NJ + jq0 + jql) * 4) = *reinterpret_cast<const unsigned*>(orow + key * OB + jql * 4);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ layer-input preparation
 // fp32 (M, D) -> bf16 rows (ones in slot D) + T-block (ones row), for the first layer's input (the embedding kernel is the
 // exact-f32 one).  One wave per 16-token tile.
@@ -490,6 +419,14 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
     const int T = d.T, KT = d.KT, NJ = d.NJ, NTOK = KT * 16, hd = d.hd, H = d.H, D = d.D;
     char* const kbf = smem;                          // [NTOK][4][8 B]
     char* const vbf = smem + (size_t)NTOK * 32;      // [NJ][4][16][16 B]
+    // keep masks of four packed probabilities by nibble of keep bits: klut[n] = two dwords of bf16 lane masks (bit r of n keeps the
+    // r-th of the four).  The dropped P is cleared AFTER packing: one 8-byte LDS read + two ANDs per four scores instead of and +
+    // compare + select per score (24 of ~60 VALU instructions per (key block, head) iteration of pass 2)
+    unsigned* const klut = reinterpret_cast<unsigned*>(vbf + (size_t)NJ * 1024);
+    if (threadIdx.x < 32) {
+        const unsigned n = threadIdx.x >> 1, hi = threadIdx.x & 1;
+        klut[threadIdx.x] = ((n >> (2 * hi)) & 1u ? 0x0000ffffu : 0u) | ((n >> (2 * hi + 1)) & 1u ? 0xffff0000u : 0u);
+    }
     const size_t pstride = (size_t)KS1 * 1024;
     auto wfrag = [&](const char* img, int ks) { return *reinterpret_cast<const bf16x8*>(img + pair * pstride + ((size_t)ks * 64 + lane) * 16); };
     auto xfrag = [&](int tile, int ks) { const int t = tile * 16 + tok; return row_frag(a.x0rb, b * T + t, t < T, d.RBW, ks, g); };
@@ -571,12 +508,9 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
                 const size_t bidx = ((((size_t)b * H + head) * T + (t < T ? t : 0)) * NJ + jb) * 4 + g;
                 unsigned bits = 0xffu;
                 if (d.p > 0.f && t < T && head < H) bits = a.pmask[bidx];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pa[r] = (bits >> r) & 1u ? pa[r] : 0.f;
-                    pb[r] = (bits >> (4 + r)) & 1u ? pb[r] : 0.f;
-                }
-                o2[hs] = MFMA(vf, pack8(pa, pb), o2[hs]);
+                const u32x2 ka2 = *reinterpret_cast<const u32x2*>(klut + 2 * (bits & 15u)), kb2 = *reinterpret_cast<const u32x2*>(klut + 2 * (bits >> 4));
+                const u32x4 pk = __builtin_bit_cast(u32x4, pack8(pa, pb));
+                o2[hs] = MFMA(vf, __builtin_bit_cast(bf16x8, u32x4{pk[0] & ka2[0], pk[1] & ka2[1], pk[2] & kb2[0], pk[3] & kb2[1]}), o2[hs]);
             }
         }
 #pragma unroll
@@ -1200,7 +1134,6 @@ struct AttnBwdArgs {
     const float* datt;        // (M, D)
     const float* lse2;
     const unsigned char* pmask;
-    const unsigned char* pmaskT;   // key-oriented copy (k_tr_masks_T)
     float* dxp;               // [NP][M, D]: this pair's contribution to the layer-input gradient (OH: [2 NP][M, D], fp32 or bf16)
     int part_bf16;
     __bf16* dqkvT;            // T-block with 3*NP*16 rows: row which*(NP*16) + pair*16 + (8 hs + dim)
@@ -1235,6 +1168,14 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
     // (query pair, head) and a global gather there was a dependent L2 round trip per iteration
     unsigned char* const pm = reinterpret_cast<unsigned char*>(lse + NHS * NTOK);
     const int PMH = T * NJ * 4;                                  // bytes per head
+    // keep multipliers of four scores by nibble of keep bits: lut[n] = {bit r of n ? keep_scale : 0}.  One 16-byte LDS read per
+    // four scores instead of and + compare + select per score (24 of the 94 VALU instructions of a key-sweep iteration)
+    float* const lut = reinterpret_cast<float*>(pm + (((size_t)NHS * PMH + 15) & ~(size_t)15));
+    if (threadIdx.x < 64) lut[threadIdx.x] = ((threadIdx.x >> 2) >> (threadIdx.x & 3)) & 1u ? d.keep_scale : 0.f;
+    // key-oriented copy of the same bits for the key-owner sweep, [NHS][NTOK keys][NJ][4]: byte (key, jq, gq) = bits of queries
+    // 32 jq + 4 gq + r (bit r) and 32 jq + 16 + 4 gq + r (bit 4 + r); built from `pm` by the workgroup itself once it has landed
+    unsigned char* const pmT = reinterpret_cast<unsigned char*>(lut + 64);
+    const int PTH = NTOK * NJ * 4;                               // bytes per head
     const size_t pstride = (size_t)KS1 * 1024;
     auto wfrag = [&](const char* img, int ks) { return *reinterpret_cast<const bf16x8*>(img + pair * pstride + ((size_t)ks * 64 + lane) * 16); };
     const bool lo_grp = (g >> 1) == 0;
@@ -1345,10 +1286,12 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
             swap16(part, ea, eb);
             if ((g & 1) == 0 && mineR) {
                 const int hi = OH ? 0 : (g >> 1);
-                drow[hi * NTOK + kt * 16 + tok] = ea + eb;
+                // both stored NEGATED: -lse is the C operand of the score MFMAs (S - lse leaves the matrix pipe, no subtraction per
+                // score), -rowsum(dO . O) the addend of d S = P (d P keep - D)
+                drow[hi * NTOK + kt * 16 + tok] = -(ea + eb);
                 // padded queries / a missing odd head: lse = +1e30 makes every P = exp2(s - lse) of that row exactly 0, so the
                 // sweeps need no validity selects (padded KEYS have all-zero K / V / dO operands instead)
-                lse[hi * NTOK + kt * 16 + tok] = ok ? cls : 1.0e30f;
+                lse[hi * NTOK + kt * 16 + tok] = ok ? -cls : -1.0e30f;
             }
             // dO column form: lane (dim row = tok, g) holds tokens 4g+r of this tile
             if (mineC) {
@@ -1369,6 +1312,40 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the keep-bit DMA)
     __syncthreads();
+    // The key-owner sweep needs, per key, the keep bits of eight QUERIES (gathering them from the query-oriented bytes inside the
+    // sweep cost eight LDS byte reads with their address arithmetic per iteration).  Rounds 2-4 had a side-stream kernel write a
+    // key-oriented copy to global memory (k_tr_masks_T: 25 us per layer at T = 252 beside the forward chain, and a global load
+    // per sweep iteration); the workgroup now transposes its own head's bits in LDS: an item = the 8 x 8 bit block {8 queries
+    // of lane group gq} x {8 keys of lane group gk} of (query block jq, key block jb), read as eight bytes (one per query),
+    // transposed in registers (three masked exchange steps on a 64-bit word), written as eight bytes (one per key).
+    if (d.p > 0.f) {
+        const int RB = NJ * 4, nitem = NJ * NJ * 16;
+        for (int hi = 0; hi < NHS; ++hi) {
+            const unsigned char* src = pm + hi * PMH;
+            unsigned char* dst = pmT + hi * PTH;
+            for (int it = threadIdx.x; it < nitem; it += NW * 64) {
+                const int jq = it / (NJ * 16), rest = it - jq * NJ * 16;
+                const int jb = rest >> 4, gk = (rest >> 2) & 3, gq = rest & 3;
+                unsigned lo = 0u, hi32 = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q0 = min(32 * jq + 4 * gq + e, T - 1), q1 = min(32 * jq + 16 + 4 * gq + e, T - 1);
+                    lo |= (unsigned)src[q0 * RB + jb * 4 + gk] << (8 * e);
+                    hi32 |= (unsigned)src[q1 * RB + jb * 4 + gk] << (8 * e);
+                }
+                unsigned long long x = (unsigned long long)lo | ((unsigned long long)hi32 << 32), t;
+                t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;  x = x ^ t ^ (t << 7);
+                t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x = x ^ t ^ (t << 14);
+                t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x = x ^ t ^ (t << 28);
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    const int key = 32 * jb + (f >> 2) * 16 + 4 * gk + (f & 3);
+                    if (key < NTOK) dst[(key * NJ + jq) * 4 + gq] = (unsigned char)(x >> (8 * f));
+                }
+            }
+        }
+        __syncthreads();
+    }
     auto rfrag = [&](const char* base, int tile) {
         if constexpr (OH) {
             const u32x2 v = *reinterpret_cast<const u32x2*>(base + ((size_t)(tile * 16 + tok) * 2 + (g & 1)) * 8);
@@ -1377,13 +1354,16 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
             return *reinterpret_cast<const s16x4*>(base + ((size_t)(tile * 16 + tok) * 4 + g) * 8);
         }
     };
+    // OH, operands read inside the sweeps: no zero fill.  A lane of the other head's k-slots meets the zeros of the per-tile operand
+    // (q / dO rows in the query sweep, k / v rows in the key sweep: rfrag); a lane of the other head's dim ROW of a column form
+    // produces a C row that the epilogue drops.  What such a lane reads is its own head's (finite) data at the same g & 1 / tok & 7.
+    auto rfrag_loop = [&](const char* base, int tile) {
+        if constexpr (OH) return *reinterpret_cast<const s16x4*>(base + ((size_t)(tile * 16 + tok) * 2 + (g & 1)) * 8);
+        else return *reinterpret_cast<const s16x4*>(base + ((size_t)(tile * 16 + tok) * 4 + g) * 8);
+    };
     auto cfrag = [&](const char* base, int jb) {
-        if constexpr (OH) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(base + ((size_t)(jb * 4 + g) * 8 + (tok & 7)) * 16);
-            return __builtin_bit_cast(bf16x8, u32x4{mineC ? v[0] : 0u, mineC ? v[1] : 0u, mineC ? v[2] : 0u, mineC ? v[3] : 0u});
-        } else {
-            return *reinterpret_cast<const bf16x8*>(base + ((size_t)(jb * 4 + g) * 16 + tok) * 16);
-        }
+        if constexpr (OH) return *reinterpret_cast<const bf16x8*>(base + ((size_t)(jb * 4 + g) * 8 + (tok & 7)) * 16);
+        else return *reinterpret_cast<const bf16x8*>(base + ((size_t)(jb * 4 + g) * 16 + tok) * 16);
     };
     auto headmask = [&](s16x4 v, int hs) {        // keep only the k-slots of head hs of the pair (OH: rfrag has done it)
         if constexpr (OH) return v;
@@ -1403,14 +1383,16 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
         {
             const int t = tt * 16 + tok;
             s16x4 qb[NHS], ob[NHS];
-            float lq[NHS], dr[NHS];
+            f32x4 lq[NHS];           // -lse of this lane's query in all four C rows
+            float dr[NHS];           // -rowsum(dO . O)
             {
                 const s16x4 qf = rfrag(qR, tt), of = rfrag(oR, tt);
 #pragma unroll
                 for (int hi = 0; hi < NHS; ++hi) {
                     qb[hi] = headmask(qf, hi);
                     ob[hi] = headmask(of, hi);
-                    lq[hi] = lse[hi * NTOK + tt * 16 + tok];
+                    const float nl = lse[hi * NTOK + tt * 16 + tok];
+                    lq[hi] = f32x4{nl, nl, nl, nl};
                     dr[hi] = drow[hi * NTOK + tt * 16 + tok];
                 }
             }
@@ -1419,22 +1401,22 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
                 // a missing odd key tile re-reads tile ka: its half of the K column block is zero, so it adds nothing to d q;
                 // padded keys likewise (zero K columns); no per-score validity selects
                 const int ka = 2 * jb, kb = (2 * jb + 1 < KT) ? 2 * jb + 1 : ka;
-                const s16x4 kfa = rfrag(kR, ka), kfb = rfrag(kR, kb), vfa = rfrag(vR, ka), vfb = rfrag(vR, kb);
+                const s16x4 kfa = rfrag_loop(kR, ka), kfb = rfrag_loop(kR, kb), vfa = rfrag_loop(vR, ka), vfb = rfrag_loop(vR, kb);
                 const bf16x8 kcf = cfrag(kC, jb);
 #pragma unroll
                 for (int hi = 0; hi < NHS; ++hi) {
-                    f32x4 sa = MFMA16(kfa, qb[hi], f4zero()), sb = MFMA16(kfb, qb[hi], f4zero());
+                    f32x4 sa = MFMA16(kfa, qb[hi], lq[hi]), sb = MFMA16(kfb, qb[hi], lq[hi]);        // S - lse
                     f32x4 pa = MFMA16(vfa, ob[hi], f4zero()), pb = MFMA16(vfb, ob[hi], f4zero());    // dP (dropped P's gradient)
                     unsigned bits = 0xffu;
                     if (d.p > 0.f) bits = pm[hi * PMH + (tcl * NJ + jb) * 4 + g];
+                    const f32x4 ma = *reinterpret_cast<const f32x4*>(lut + 4 * (bits & 15u));      // keep multipliers of the scores
+                    const f32x4 mb = *reinterpret_cast<const f32x4*>(lut + 4 * (bits >> 4));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float Pa = __builtin_amdgcn_exp2f(sa[r] - lq[hi]);
-                        const float Pb = __builtin_amdgcn_exp2f(sb[r] - lq[hi]);
-                        const float ma = ((bits >> r) & 1u) ? d.keep_scale : 0.f;          // keep multiplier of this score
-                        const float mb = ((bits >> (4 + r)) & 1u) ? d.keep_scale : 0.f;
-                        sa[r] = Pa * __builtin_fmaf(pa[r], ma, -dr[hi]);
-                        sb[r] = Pb * __builtin_fmaf(pb[r], mb, -dr[hi]);
+                        const float Pa = __builtin_amdgcn_exp2f(sa[r]);
+                        const float Pb = __builtin_amdgcn_exp2f(sb[r]);
+                        sa[r] = Pa * __builtin_fmaf(pa[r], ma[r], dr[hi]);
+                        sb[r] = Pb * __builtin_fmaf(pb[r], mb[r], dr[hi]);
                     }
                     dq[hi] = MFMA(kcf, pack8(sa, sb), dq[hi]);       // [dim rows][query col] += K^T dS^T
                 }
@@ -1450,15 +1432,13 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
 #pragma unroll
                 for (int hi = 0; hi < NHS; ++hi) { kfh[hi] = headmask(kf, hi); vfh[hi] = headmask(vf, hi); }
             }
-            const int key = kt * 16 + tok, keycl = key < T ? key : T - 1;       // (padded key columns are discarded at the end)
             // keep bits in the key-oriented layout: one 32-bit word per (key, query block) and head holds the four lane groups'
-            // bytes; the next block's words are in flight during the current one
+            // bytes (padded keys: never written, their K / V / dO operands are zero); read one block ahead
             const unsigned char* pt[NHS];
             unsigned wn[NHS];
 #pragma unroll
             for (int hi = 0; hi < NHS; ++hi) {
-                const int head = min(2 * pair + (OH ? hs0 : hi), H - 1);
-                pt[hi] = a.pmaskT + (((size_t)b * H + head) * T + keycl) * NJ * 4;
+                pt[hi] = pmT + hi * PTH + (kt * 16 + tok) * NJ * 4;
                 wn[hi] = 0xffffffffu;
                 if (d.p > 0.f) wn[hi] = *reinterpret_cast<const unsigned*>(pt[hi]);
             }
@@ -1470,30 +1450,30 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
                     wc[hi] = wn[hi];
                     if (d.p > 0.f && jq + 1 < NJ) wn[hi] = *reinterpret_cast<const unsigned*>(pt[hi] + (jq + 1) * 4);
                 }
-                const s16x4 qfa = rfrag(qR, qa_t), qfb = rfrag(qR, qb_t), ofa = rfrag(oR, qa_t), ofb = rfrag(oR, qb_t);
+                const s16x4 qfa = rfrag_loop(qR, qa_t), qfb = rfrag_loop(qR, qb_t), ofa = rfrag_loop(oR, qa_t), ofb = rfrag_loop(oR, qb_t);
                 const bf16x8 qcf = cfrag(qC, jq), ocf = cfrag(oC, jq);
 #pragma unroll
                 for (int hi = 0; hi < NHS; ++hi) {
-                    f32x4 sa = MFMA16(qfa, kfh[hi], f4zero()), sb = MFMA16(qfb, kfh[hi], f4zero());
-                    f32x4 pa = MFMA16(ofa, vfh[hi], f4zero()), pb = MFMA16(ofb, vfh[hi], f4zero());
                     // padded query rows carry lse = 1e30 (P = 0); a missing odd query tile re-reads tile qa_t against zero halves
                     // of the Q / dO column blocks
-                    const f32x4 la = *reinterpret_cast<const f32x4*>(lse + hi * NTOK + qa_t * 16 + 4 * g);
+                    const f32x4 la = *reinterpret_cast<const f32x4*>(lse + hi * NTOK + qa_t * 16 + 4 * g);      // (-lse)
                     const f32x4 lb = *reinterpret_cast<const f32x4*>(lse + hi * NTOK + qb_t * 16 + 4 * g);
-                    const f32x4 da = *reinterpret_cast<const f32x4*>(drow + hi * NTOK + qa_t * 16 + 4 * g);
+                    const f32x4 da = *reinterpret_cast<const f32x4*>(drow + hi * NTOK + qa_t * 16 + 4 * g);     // (-rowsum)
                     const f32x4 db = *reinterpret_cast<const f32x4*>(drow + hi * NTOK + qb_t * 16 + 4 * g);
+                    f32x4 sa = MFMA16(qfa, kfh[hi], la), sb = MFMA16(qfb, kfh[hi], lb);               // S - lse
+                    f32x4 pa = MFMA16(ofa, vfh[hi], f4zero()), pb = MFMA16(ofb, vfh[hi], f4zero());
                     const unsigned bits = (wc[hi] >> (8 * g)) & 0xffu;
+                    const f32x4 ma = *reinterpret_cast<const f32x4*>(lut + 4 * (bits & 15u));      // keep multipliers of the scores
+                    const f32x4 mb = *reinterpret_cast<const f32x4*>(lut + 4 * (bits >> 4));
                     f32x4 pda, pdb;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float ma = ((bits >> r) & 1u) ? d.keep_scale : 0.f;          // keep multiplier of this score
-                        const float mb = ((bits >> (4 + r)) & 1u) ? d.keep_scale : 0.f;
-                        const float Pa = __builtin_amdgcn_exp2f(sa[r] - la[r]);
-                        const float Pb = __builtin_amdgcn_exp2f(sb[r] - lb[r]);
-                        pda[r] = Pa * ma;
-                        pdb[r] = Pb * mb;
-                        sa[r] = Pa * __builtin_fmaf(pa[r], ma, -da[r]);
-                        sb[r] = Pb * __builtin_fmaf(pb[r], mb, -db[r]);
+                        const float Pa = __builtin_amdgcn_exp2f(sa[r]);
+                        const float Pb = __builtin_amdgcn_exp2f(sb[r]);
+                        pda[r] = Pa * ma[r];
+                        pdb[r] = Pb * mb[r];
+                        sa[r] = Pa * __builtin_fmaf(pa[r], ma[r], da[r]);
+                        sb[r] = Pb * __builtin_fmaf(pb[r], mb[r], db[r]);
                     }
                     dv[hi] = MFMA(ocf, pack8(pda, pdb), dv[hi]);     // [dim rows][key col] += dO^T P_drop
                     dk[hi] = MFMA(qcf, pack8(sa, sb), dk[hi]);       // += Q^T dS
@@ -1967,7 +1947,7 @@ struct TrLayerBufs {
     float *x0, *att, *s1, *s2, *lse2;
     __bf16 *x0rb, *x0T, *attT, *doT, *dqkvT;
     char* stage;
-    unsigned char *pmask, *pmaskT, *active, *hkeep, *rb1, *rb3;
+    unsigned char *pmask, *active, *hkeep, *rb1, *rb3;
     unsigned short* activeT;
 };
 struct TrBufs {
@@ -2028,7 +2008,6 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
         b.doT = (__bf16*)take(2 * Mpad * NFT);
         b.dqkvT = (__bf16*)take(2 * Mpad * 3 * NP * 16);
         b.pmask = (unsigned char*)take((size_t)B * H * T * NJ * 4);
-        b.pmaskT = (unsigned char*)take((size_t)B * H * T * NJ * 4);
         b.active = (unsigned char*)take(Mpad * (F / 32) * 4);
         b.hkeep = (unsigned char*)take(Mpad * (F / 32) * 4);
         b.rb1 = (unsigned char*)take(Mpad * ((NFT / 16 + 1) / 2) * 4);
@@ -2074,6 +2053,14 @@ int tr_attn_oh_mode(int KT) {
     const char* e = getenv("FDIFF_TR_ATTN_OH");               // (read per call: the tests switch forms inside one process)
     const int v = e ? atoi(e) : -1;
     return v >= 0 ? v : (KT >= 12 ? 2 : 0);
+}
+
+// dynamic LDS of k_tr_attn_bwd: q / k / v / dO row forms, q / k / dO column forms, -lse and -rowsum(dO . O), the keep bits in
+// both orientations and the keep-multiplier table
+size_t tr_attn_bwd_lds(int T, bool one_head) {
+    const size_t KT = (size_t)(T + 15) / 16, NJ = (KT + 1) / 2, nhs = one_head ? 1 : 2;
+    return 4 * KT * 16 * (one_head ? 16 : 32) + 3 * NJ * (one_head ? 512 : 1024) + 2 * nhs * KT * 16 * sizeof(float) +
+           nhs * (size_t)T * NJ * 4 + 16 + 256 + nhs * KT * 16 * NJ * 4;
 }
 
 TrDims make_dims(const fd_score* m, int B, float p, uint64_t seed) {
@@ -2277,7 +2264,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         hipLaunchKernelGGL((k_tr_prep<KS1, DT>), dim3((tb.Mpad / 16 + 3) / 4), dim3(256), 0, s, h0, tb.layers[0].x0rb, tb.layers[0].x0T,
                            M, tb.Mpad, D);
     if (img_forked) FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[L + 2], 0));      // weight images rebuilt (side stream 2)
-    const size_t lds_attn = (size_t)d.KT * 16 * 32 + (size_t)d.NJ * 1024;
+    const size_t lds_attn = (size_t)d.KT * 16 * 32 + (size_t)d.NJ * 1024 + 128;      // K rows, V^T blocks, keep-mask table
     const int attn_nw = tr_attn_waves(d.KT);
     const size_t scr = std::max((size_t)TW * KS1 * 1024, (size_t)4 * DT * 1024);
     const size_t NSh = (size_t)m->d.dim_ff / 64;
@@ -2288,7 +2275,6 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_fwd<KS1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_fwd<KS1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_ffn_fwd<KS1, DT, KSO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_masks_T, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     if (p > 0.f) {
         // dropout decisions of every layer on the side stream, layer by layer, ahead of the kernels that read them
@@ -2322,13 +2308,6 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             hipLaunchKernelGGL(k_tr_masks, dim3(grid), dim3(256), 0, ctx->side_stream, d, ma);
             FD_HIP(ctx, hipEventRecord(ctx->side_events[l], ctx->side_stream));
         }
-        // key-oriented copies of the attention keep bits: only the backward reads them, so they queue behind the decisions of
-        // every layer (the forward never waits for them); last layer first, the order the backward wants them in
-        for (int l = L - 1; l >= 0; --l)
-            hipLaunchKernelGGL(k_tr_masks_T, dim3(B * m->d.n_head, (d.NJ + 7) / 8), dim3(256), (size_t)256 * (d.NJ * 4 + 4) + (size_t)d.NJ * 32 * 36, ctx->side_stream,
-                               tb.layers[l].pmask, tb.layers[l].pmaskT, T, d.NJ);
-        if (!ctx->tr_masksT_event) FD_HIP(ctx, hipEventCreateWithFlags(&ctx->tr_masksT_event, hipEventDisableTiming));
-        FD_HIP(ctx, hipEventRecord(ctx->tr_masksT_event, ctx->side_stream));
     }
     for (int l = 0; l < L; ++l) {
         const fd_layer_off& lo = m->layers[l];
@@ -2397,10 +2376,9 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     const bool attn_oh = tr_attn_oh_mode(d.KT) != 0;
     const int attn_parts = attn_oh ? 2 * d.NP : d.NP;             // partial tensors of d x written by k_tr_attn_bwd
     const int part_bf16 = tr_attn_oh_mode(d.KT) == 2 ? 1 : 0;
-    const size_t lds_ab = attn_oh ? (size_t)4 * d.KT * 16 * 16 + (size_t)3 * d.NJ * 512 + (size_t)2 * d.KT * 16 * sizeof(float) +
-                                        (size_t)d.T * d.NJ * 4
-                                  : (size_t)4 * d.KT * 16 * 32 + (size_t)3 * d.NJ * 1024 + (size_t)4 * d.KT * 16 * sizeof(float) +
-                                        (size_t)2 * d.T * d.NJ * 4;
+    const size_t lds_ab = tr_attn_bwd_lds(d.T, attn_oh);
+    if (lds_ab > 160 * 1024)
+        return fd_fail(ctx, FD_ERR_UNSUPPORTED, "k_tr_attn_bwd: %zu bytes of LDS for max_len %d (form %d)", lds_ab, d.T, tr_attn_oh_mode(d.KT));
     static unsigned long long attr = 0;
     if (fd_first_on_device(attr, ctx->device)) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_ffn_bwd<KS1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2435,7 +2413,6 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         const long long wn[7] = {3LL * D * D, 3LL * D, (long long)D * D, D, (long long)F * D, F, (long long)D * F};
         for (int k = 0; k < 7; ++k) { ra.wrel[k] = wr[k]; ra.wnum[k] = wn[k]; }
     }
-    if (m->saved_p > 0.f && ctx->tr_masksT_event) FD_HIP(ctx, hipStreamWaitEvent(s, ctx->tr_masksT_event, 0));
     for (int l = L - 1; l >= 0; --l) {
         const fd_layer_off& lo = m->layers[l];
         TrLayerBufs& b = tb.layers[l];
@@ -2461,7 +2438,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
             hipLaunchKernelGGL((k_tr_ffn_bwd<KS1, DT>), dim3(tb.nwg), dim3(TW * 64), lds_bwd, s, d, fa);
         }
         AttnBwdArgs ab{};
-        ab.x0rb = b.x0rb; ab.att = b.att; ab.datt = tb.datt; ab.lse2 = b.lse2; ab.pmask = b.pmask; ab.pmaskT = b.pmaskT;
+        ab.x0rb = b.x0rb; ab.att = b.att; ab.datt = tb.datt; ab.lse2 = b.lse2; ab.pmask = b.pmask;
         ab.dxp = tb.dxp[par]; ab.dqkvT = b.dqkvT;
         ab.wk = limg + im->off_wk; ab.wv = limg + im->off_wv; ab.wq = limg + im->off_wq;
         ab.winT = bl + im->boff_win; ab.part_stride = tb.part_stride; ab.part_bf16 = part_bf16;
@@ -2552,7 +2529,11 @@ bool fd_train_bf16_supported(const fd_score* m) {
     const fd_bf16_images* im = m->bf16;
     // dim_ff: the FFN kernels keep one keep-byte per 32-wide chunk per lane in 16-byte groups (F % 1024 == 0) and their LDS
     // budget covers F <= 2048 (torch's default 2048 is the only value the reference uses)
-    return im && im->train && im->bimg && m->d.dim_ff % 1024 == 0 && m->d.dim_ff <= 2048 && m->d.num_layers > 0 && m->d.max_len <= 1024;
+    // max_len: the attention backward holds a head's q / k / v / dO images and its keep bits (both orientations) for the whole
+    // series in LDS: 592 time steps in the one-head form (37 token tiles), which is the form from 12 tiles on
+    const int KT = (m->d.max_len + 15) / 16;
+    return im && im->train && im->bimg && m->d.dim_ff % 1024 == 0 && m->d.dim_ff <= 2048 && m->d.num_layers > 0 &&
+           tr_attn_bwd_lds(m->d.max_len, KT >= 12) <= 160 * 1024;
 }
 
 size_t fd_train_bf16_workspace(const fd_score* m, int B) { return tr_carve(m, B, nullptr, nullptr); }

@@ -101,6 +101,7 @@ SHAPES = {
     "nasdaq": (dict(T=252, C=6, D=72, L=10, H=12), 3),
     "class_default": (dict(T=50, C=3, D=60, L=3, H=12), 5),
     "ragged_T": (dict(T=37, C=5, D=72, L=2, H=12), 7),
+    "droughts_T365": (dict(T=365, C=3, D=72, L=2, H=12), 2),     # 23 token tiles (odd, ragged): one-head attention backward
 }
 
 
@@ -159,6 +160,19 @@ def test_attention_backward_forms_agree(monkeypatch, cfg, B, p):
         worst = max(np.abs(res[form][2][k] - r).max() / max(np.abs(r).max(), 1e-20) for k, r in res["0"][2].items())
         _log(f"[parity] attention backward form {form} vs pair form ({tag}): worst max-rel over the tensors {worst:.3e}")
         assert worst <= tol, (form, worst)
+
+
+def test_bf16_training_range_in_series_length():
+    """The bf16 attention backward keeps a head's images and keep bits of the whole series in LDS: 592 time steps fit; beyond that
+    the model trains on the exact-f32 path and says so (no silent precision switch the other way either)."""
+    from fourierdiffusion_amd.utils.losses import get_sde_loss_fn
+    for T, want in ((592, "bf16"), (600, "fp32")):
+        cfg = dict(T=T, C=2, D=72, L=1, H=12)
+        m, sch, _ = make_model(cfg, precision="bf16")
+        X = W.randn(f"rng_x_{T}", (1, T, 2), 3)
+        loss = get_sde_loss_fn(sch, train=True)(m, batch_of(X, W.uniform(f"rng_t_{T}", (1,), 3, 0.05, 1.0)))
+        assert np.isfinite(loss.item()) and m.train_mode_effective == want, (T, m.train_mode_effective)
+        assert float(m.grads.abs().max()) > 0 and bool(torch.isfinite(m.grads).all())
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
