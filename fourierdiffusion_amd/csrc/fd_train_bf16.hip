@@ -123,7 +123,22 @@ struct TrDims {
     float p, keep_scale;
     unsigned thr16;
     unsigned long long seed;
+    int xcd;                  // 1: workgroup ids are re-dealt so that neighbours in (x, y) order share an XCD (xcd_deal)
 };
+
+// The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own L2.  Workgroups that read the
+// same rows -- the heads of one series in the attention kernels, the 20 role workgroups of one token split in k_tr_wgrad --
+// are therefore spread over all eight L2s, and every L2 fetches every row from the Infinity Cache.  Re-dealing the ids (XCD k
+// takes the k-th contiguous run of the virtual (x, y) order) keeps such a group on one XCD, or on two where a run ends inside it.
+__device__ __forceinline__ void xcd_deal(const TrDims& d, int& bx, int& by) {
+    bx = blockIdx.x; by = blockIdx.y;
+    if (!d.xcd) return;
+    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int k = lin & 7, slot = lin >> 3, q = nwg >> 3, r = nwg & 7;
+    const int v = k * q + (k < r ? k : r) + slot;
+    by = v / (int)gridDim.x;
+    bx = v - by * (int)gridDim.x;
+}
 
 // ------------------------------------------------------------------------------------------------ shared device pieces
 // C-layout tile (features 16dt+4g+r of token `m`) <- fp32 rows.  Unconditional loads from clamped addresses (row 0 for an
@@ -415,7 +430,8 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = blockIdx.x, b = blockIdx.y;
+    int pair, b;
+    xcd_deal(d, pair, b);                            // (the pairs of a series share an L2)
     const int T = d.T, KT = d.KT, NJ = d.NJ, NTOK = KT * 16, hd = d.hd, H = d.H, D = d.D;
     char* const kbf = smem;                          // [NTOK][4][8 B]
     char* const vbf = smem + (size_t)NTOK * 32;      // [NJ][4][16][16 B]
@@ -1154,8 +1170,10 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
     constexpr int NHS = OH ? 1 : 2;                              // heads swept by this workgroup
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = OH ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, b = blockIdx.y;
-    const int hs0 = OH ? (int)(blockIdx.x & 1) : 0;              // OH: the head of the pair this workgroup owns
+    int bx, b;
+    xcd_deal(d, bx, b);                                          // (the heads of a series share an L2)
+    const int pair = OH ? (bx >> 1) : bx;
+    const int hs0 = OH ? (bx & 1) : 0;                           // OH: the head of the pair this workgroup owns
     const int T = d.T, KT = d.KT, NJ = d.NJ, NTOK = KT * 16, hd = d.hd, H = d.H, D = d.D;
     // "row" form [token][4 g][8 B] (16x16x16 operand with the pair's 16 dim slots as k; OH: [token][2][8 B]) and "column" form
     // [32-token block][4 g][16 dim rows][16 B] (16x16x32 A operand with 32 tokens as k; OH: 8 dim rows) of q, k, v, dO
@@ -1508,7 +1526,7 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
                 }
             }
             const char* wbase = a.winT + (size_t)pair * 3 * DT * 512;
-            const size_t pidx = OH ? (size_t)blockIdx.x : (size_t)pair;
+            const size_t pidx = OH ? (size_t)bx : (size_t)pair;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 f32x4 o = f4zero();
@@ -1565,17 +1583,18 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ts = blockIdx.y;
+    int bx, ts;
+    xcd_deal(d, bx, ts);                                      // (the role workgroups of a token split share an L2)
     const int D = d.D, F = d.F, M = d.M, NFT = d.NFT;
     const int blk0 = (int)(((long long)a.nblk * ts) / a.TS), blk1 = (int)(((long long)a.nblk * (ts + 1)) / a.TS);
     float* const part = a.part + (size_t)ts * a.nparams;
     constexpr int NB = 2 * KS1 + DT;
-    if ((int)blockIdx.x < F / 128) {
+    if (bx < F / 128) {
         using SL = StageL<KS1, DT>;
         constexpr int SB = SL::bytes;                         // staged bytes per 32-token block (one StageL record)
         constexpr int NBUF = 3, NDMA = (SB / 1024 + 3) / 4;
         const int NS = F / 64;
-        const int chunk = blockIdx.x * 4 + wave;              // hidden units 32 chunk .. +31
+        const int chunk = bx * 4 + wave;              // hidden units 32 chunk .. +31
         const int fh = chunk / NS, c = chunk - fh * NS;
         bf16x8 w1[2][KS1], w2[2][KS1];
 #pragma unroll
@@ -1612,7 +1631,7 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
         const int nb = blk1 - blk0;
         // the 16 workgroups of a (split, layer) read the same token blocks: each starts at its own block (fixed per workgroup,
         // so the summation order -- and the result -- is still reproducible)
-        const int brot = nb > 0 ? (int)((blockIdx.x * 3u) % (unsigned)nb) : 0;
+        const int brot = nb > 0 ? (int)(((unsigned)bx * 3u) % (unsigned)nb) : 0;
         auto blk_of = [&](int ib) { int bq = ib + brot; bq -= (bq >= nb) ? nb : 0; return blk0 + bq; };
         if (nb > 0) { issue(blk_of(0), 0); load_masks(blk_of(0), mk[0]); }
         if (nb > 1) { issue(blk_of(1), 1); load_masks(blk_of(1), mk[1]); }
@@ -1717,7 +1736,7 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
         }
     } else {
         // ------------------------------------------------ in_proj (+ bias through the ones row of x0T) and out_proj (+ bias)
-        const int role = blockIdx.x - F / 128;              // 0..2: q | k | v rows of in_proj, 3: out_proj
+        const int role = bx - F / 128;              // 0..2: q | k | v rows of in_proj, 3: out_proj
         const int NRT = (role < 3) ? d.NP : DT;             // 16-row tiles of this role
         const __bf16* At = (role < 3) ? L.dqkvT : L.doT;
         const int ANF = (role < 3) ? 3 * d.NP * 16 : NFT;
@@ -2073,6 +2092,8 @@ TrDims make_dims(const fd_score* m, int B, float p, uint64_t seed) {
     if (p > 0.f && d.thr16 == 0) d.thr16 = 1;
     d.keep_scale = (p > 0.f) ? (float)(65536.0 / (65536.0 - (double)d.thr16)) : 1.0f;
     d.seed = seed;
+    static const int xcd_env = getenv("FDIFF_TR_XCD") ? atoi(getenv("FDIFF_TR_XCD")) : 1;      // (0: hardware order, A/B runs)
+    d.xcd = xcd_env;
     return d;
 }
 
