@@ -419,6 +419,10 @@ struct AttnFwdArgs {
 // NW waves per workgroup: a wave owns the token tiles wave, wave + NW, ... (NW = 8 from five tiles on: the kernels are latency-
 // bound chains per tile, so twice the waves per (series, head pair) halve the critical path at T = 100 and double the waves
 // per SIMD that hide each other's LDS / MFMA / exp latencies at T = 252)
+#ifndef FD_TR_WG_DMA_AT
+#define FD_TR_WG_DMA_AT 1      // k_tr_wgrad: where a block issues the staging DMA of block + 2: 0 behind the barrier (52.1 us per layer), 1 behind the
+                               // H / d H MFMAs (50.0), 2 behind every MFMA of the block (53.0); profiles/r04_train_wgrad_experiments.txt
+#endif
 #ifndef FD_TR_ATTN_MINW
 #define FD_TR_ATTN_MINW 2
 #endif
@@ -1609,6 +1613,11 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) { a1[ft][dt] = f4zero(); a2[ft][dt] = f4zero(); }
+        unsigned* const klut = reinterpret_cast<unsigned*>(smem + NBUF * SB);      // bf16 lane masks by nibble (see the block below)
+        if (threadIdx.x < 32) {
+            const unsigned n = threadIdx.x >> 1, hi = threadIdx.x & 1;
+            klut[threadIdx.x] = ((n >> (2 * hi)) & 1u ? 0x0000ffffu : 0u) | ((n >> (2 * hi + 1)) & 1u ? 0xffff0000u : 0u);
+        }
         // staging: every wave issues exactly NDMA 1-KiB copies + 4 mask loads per block (uniform vmcnt bookkeeping)
         unsigned short mk[NBUF][4];
         auto issue = [&](int blk, int slot) {
@@ -1648,15 +1657,22 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
 #ifndef FD_TR_ABL_WG_NOBAR
             __syncthreads();
 #endif
+            auto prefetch = [&]() {
 #ifdef FD_TR_ABL_WG_NODMA
-            if (false) {
+                if (false) {
 #else
-            if (ib + 2 < nb) {
+                if (ib + 2 < nb) {
 #endif
-                const int bn2 = blk_of(ib + 2);
-                issue(bn2, (slot + 2) % NBUF);
-                load_masks(bn2, mk[(slot + 2) % NBUF]);
-            }
+                    const int bn2 = blk_of(ib + 2);
+                    issue(bn2, (slot + 2) % NBUF);
+#ifndef FD_TR_ABL_WG_NOMASK
+                    load_masks(bn2, mk[(slot + 2) % NBUF]);
+#endif
+                }
+            };
+#if FD_TR_WG_DMA_AT == 0
+            prefetch();
+#endif
             const char* sx = smem + slot * SB + SL::off_xr;
             const char* sd = smem + slot * SB + SL::off_dr;
             const char* tx = smem + slot * SB + SL::off_xT;
@@ -1678,20 +1694,28 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
                 }
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft) {
-                    const unsigned mw = mk[slot][half * 2 + ft];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool on = (mw >> (4 * g + r)) & 1u;
-                        h[ft][r] = on ? h[ft][r] : 0.f;
-                        e[ft][r] = on ? e[ft][r] : 0.f;
-                    }
                     hh[ft][half] = h[ft];
                     dh[ft][half] = e[ft];
                 }
             }
+#if FD_TR_WG_DMA_AT == 1
+            prefetch();          // (behind the H / d H MFMAs of the block)
+#endif
+            // inactive (dropped or h <= 0) units are cleared AFTER packing: the lane's nibble of the activity word selects two
+            // dwords of bf16 lane masks from a 16-entry LDS table (one 8-byte read + four ANDs per (tile, half) instead of and +
+            // compare + two selects per value: 64 of the ~100 VALU instructions of a block)
             bf16x8 hB[2], dB[2];
 #pragma unroll
-            for (int ft = 0; ft < 2; ++ft) { hB[ft] = pack8(hh[ft][0], hh[ft][1]); dB[ft] = pack8(dh[ft][0], dh[ft][1]); }
+            for (int ft = 0; ft < 2; ++ft) {
+                const u32x2 k0 = *reinterpret_cast<const u32x2*>(klut + 2 * ((mk[slot][ft] >> (4 * g)) & 15u));
+                const u32x2 k1 = *reinterpret_cast<const u32x2*>(klut + 2 * ((mk[slot][2 + ft] >> (4 * g)) & 15u));
+                const u32x4 ph = __builtin_bit_cast(u32x4, pack8(hh[ft][0], hh[ft][1])), pd = __builtin_bit_cast(u32x4, pack8(dh[ft][0], dh[ft][1]));
+                hB[ft] = __builtin_bit_cast(bf16x8, u32x4{ph[0] & k0[0], ph[1] & k0[1], ph[2] & k1[0], ph[3] & k1[1]});
+                dB[ft] = __builtin_bit_cast(bf16x8, u32x4{pd[0] & k0[0], pd[1] & k0[1], pd[2] & k1[0], pd[3] & k1[1]});
+            }
+#ifdef FD_TR_ABL_WG_NOT
+            if (ib < 0)
+#endif
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 // T-block A operands in the token order of the packed C tiles: slots 0-3 = tokens 4g.., slots 4-7 = tokens 16+4g..
@@ -1706,6 +1730,9 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
                     a1[ft][dt] = MFMA(ax, dB[ft], a1[ft][dt]);        // d W1[f][d], row D = d b1[f]
                 }
             }
+#if FD_TR_WG_DMA_AT == 2
+            prefetch();          // (behind every MFMA of the block)
+#endif
         };
         for (int ib = 0; ib < nb; ib += NBUF) {
             block(ib, std::integral_constant<int, 0>{});
@@ -2420,7 +2447,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     // FDIFF_TR_WG_LDS_KB pads the request (experiments: above 80 KiB only one weight-gradient workgroup fits a CU, which
     // leaves registers and LDS for the chain's attention-backward workgroups beside it)
     static const size_t wg_pad = getenv("FDIFF_TR_WG_LDS_KB") ? (size_t)atoi(getenv("FDIFF_TR_WG_LDS_KB")) * 1024 : 0;
-    const size_t lds_wg = std::max((size_t)3 * StageL<KS1, DT>::bytes, wg_pad);
+    const size_t lds_wg = std::max((size_t)3 * StageL<KS1, DT>::bytes + 128, wg_pad);      // (ring + the lane-mask table)
     static const bool serial = getenv("FDIFF_TR_SERIAL") != nullptr;
     WgArgs wa{};
     wa.nparams = (long long)tb.layer_params; wa.TS = tb.TS; wa.nblk = (M + 31) / 32;

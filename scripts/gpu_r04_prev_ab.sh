@@ -1,0 +1,22 @@
+#!/bin/bash
+# training step: the working tree's library against fourierdiffusion_amd/libfdiff_hip_prev.so (the last commit), one box, alternating;
+# then solo kernel times of the new one.  usage: bash scripts/gpu_r04_prev_ab.sh TAG
+TAG=${1:-prevab}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+PREV=$GRAFT_REPO_ROOT/fourierdiffusion_amd/libfdiff_hip_prev.so
+sb() { python scripts/shape_bench.py train $1 64 2>/dev/null | tail -1 | cut -c1-110; }
+stats() {  # name, shape, env...
+  n=$1; shp=$2; shift; shift
+  (cd /tmp && export TMPDIR=/tmp && env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$n -o s -- python $GRAFT_REPO_ROOT/scripts/shape_bench.py train $shp 64 > $OUT/$n.log 2>&1)
+  echo "== $n: $@"; python $GRAFT_REPO_ROOT/scripts/kstats.py $OUT/$n/s_kernel_stats.csv ${NK:-7} | cut -c1-70,100-140
+}
+timeout 900 python -m pytest tests/test_gpu_train_bf16.py tests/test_gpu_benched_shapes.py tests/test_gpu_widths.py tests/test_gpu_train.py -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
+for rep in 1 2 3; do
+echo "new  nasdaq: $(sb nasdaq)"
+echo "prev nasdaq: $(FDIFF_LIB=$PREV sb nasdaq)"
+echo "new  ecg:    $(sb ecg)"
+echo "prev ecg:    $(FDIFF_LIB=$PREV sb ecg)"
+done
+stats serial_new nasdaq FDIFF_TR_SERIAL=1
+stats serial_prev nasdaq FDIFF_TR_SERIAL=1 FDIFF_LIB=$PREV
