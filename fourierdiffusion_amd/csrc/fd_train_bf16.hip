@@ -1618,8 +1618,12 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
             const unsigned n = threadIdx.x >> 1, hi = threadIdx.x & 1;
             klut[threadIdx.x] = ((n >> (2 * hi)) & 1u ? 0x0000ffffu : 0u) | ((n >> (2 * hi + 1)) & 1u ? 0xffff0000u : 0u);
         }
-        // staging: every wave issues exactly NDMA 1-KiB copies + 4 mask loads per block (uniform vmcnt bookkeeping)
-        unsigned short mk[NBUF][4];
+        // staging: every wave issues exactly NDMA 1-KiB copies + one 256-byte copy of activity words per block (uniform vmcnt
+        // bookkeeping).  The activity words of the workgroup's 128 hidden units (two token halves x 128 words) ride the same
+        // DMA path into a small LDS ring: as four 2-byte loads into registers per block they were 5 us of the 52 us launch, and
+        // hipcc answered their pending registers with an s_waitcnt vmcnt(0) in front of every third barrier -- which drained
+        // the staging DMA issued a block earlier.  No vector-memory instruction of the loop returns to a register now.
+        char* const mring = smem + NBUF * SB + 128;                   // [NBUF][2 halves][128 words]
         auto issue = [&](int blk, int slot) {
             char* dst = smem + slot * SB;
             const char* src = L.stage + (size_t)blk * SB + lane * 16;
@@ -1629,21 +1633,22 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
                 bb %= SB / 1024;
                 __builtin_amdgcn_global_load_lds(GLB_PTR(src + bb * 1024), LDS_PTR(dst + bb * 1024), 16, 0, 0);
             }
+#ifndef FD_TR_ABL_WG_NOMASK
+            {   // waves 0 / 2 copy token half 0, waves 1 / 3 half 1 (the duplicates write the same words)
+                const int half = wave & 1;
+                const char* msrc = reinterpret_cast<const char*>(L.activeT + ((size_t)blk * 2 + half) * F + (size_t)bx * 128) + lane * 4;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(msrc), LDS_PTR(mring + slot * 512 + half * 256), 4, 0, 0);
+            }
+#endif
         };
-        auto load_masks = [&](int blk, unsigned short (&o)[4]) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int ft = 0; ft < 2; ++ft)
-                    o[half * 2 + ft] = L.activeT[((size_t)blk * 2 + half) * F + chunk * 32 + ft * 16 + (tok & 3) * 4 + (tok >> 2)];
-        };
+        constexpr int NVM = NDMA + 1;                                 // vector-memory instructions per wave and block
         const int nb = blk1 - blk0;
         // the 16 workgroups of a (split, layer) read the same token blocks: each starts at its own block (fixed per workgroup,
         // so the summation order -- and the result -- is still reproducible)
         const int brot = nb > 0 ? (int)(((unsigned)bx * 3u) % (unsigned)nb) : 0;
         auto blk_of = [&](int ib) { int bq = ib + brot; bq -= (bq >= nb) ? nb : 0; return blk0 + bq; };
-        if (nb > 0) { issue(blk_of(0), 0); load_masks(blk_of(0), mk[0]); }
-        if (nb > 1) { issue(blk_of(1), 1); load_masks(blk_of(1), mk[1]); }
+        if (nb > 0) issue(blk_of(0), 0);
+        if (nb > 1) issue(blk_of(1), 1);
         // One block: the ring slot is a compile-time constant (the loop below is unrolled by NBUF), so neither the mask words
         // nor the LDS addresses go through run-time selects.  Tokens beyond M need no masking here: k_tr_ffn_fwd / k_tr_ffn_bwd
         // write ZERO rows and T-block columns for them into the stage records (every workgroup covers 64 tokens up to Mpad), and
@@ -1652,11 +1657,20 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
         auto block = [&](int ib, auto slot_c) {
             constexpr int slot = decltype(slot_c)::value;
             // block ib must have landed (this wave's share), then everybody's
-            if (ib + 1 < nb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + 4) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ib + 1 < nb) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NVM) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifndef FD_TR_ABL_WG_NOBAR
-            __syncthreads();
+            // bare s_barrier: __syncthreads() carries a workgroup fence that may be lowered to s_waitcnt vmcnt(0), which would drain
+            // the DMA of the next block.  What must be ordered is ordered by hand: this wave's share of block ib has landed (above),
+            // its LDS reads of block ib - 1 were consumed by that block's MFMAs, the table writes of the prologue have completed.
+            __builtin_amdgcn_s_barrier();
 #endif
+            // this wave's activity words of the block: [half][tile] (token on tok & 3 / tok >> 2 as in the T-blocks)
+            unsigned short mkw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                mkw[q] = *reinterpret_cast<const unsigned short*>(mring + slot * 512 + (q >> 1) * 256 +
+                                                                  (wave * 32 + (q & 1) * 16 + (tok & 3) * 4 + (tok >> 2)) * 2);
             auto prefetch = [&]() {
 #ifdef FD_TR_ABL_WG_NODMA
                 if (false) {
@@ -1665,9 +1679,6 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
 #endif
                     const int bn2 = blk_of(ib + 2);
                     issue(bn2, (slot + 2) % NBUF);
-#ifndef FD_TR_ABL_WG_NOMASK
-                    load_masks(bn2, mk[(slot + 2) % NBUF]);
-#endif
                 }
             };
 #if FD_TR_WG_DMA_AT == 0
@@ -1707,8 +1718,8 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
             bf16x8 hB[2], dB[2];
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
-                const u32x2 k0 = *reinterpret_cast<const u32x2*>(klut + 2 * ((mk[slot][ft] >> (4 * g)) & 15u));
-                const u32x2 k1 = *reinterpret_cast<const u32x2*>(klut + 2 * ((mk[slot][2 + ft] >> (4 * g)) & 15u));
+                const u32x2 k0 = *reinterpret_cast<const u32x2*>(klut + 2 * ((mkw[ft] >> (4 * g)) & 15u));
+                const u32x2 k1 = *reinterpret_cast<const u32x2*>(klut + 2 * ((mkw[2 + ft] >> (4 * g)) & 15u));
                 const u32x4 ph = __builtin_bit_cast(u32x4, pack8(hh[ft][0], hh[ft][1])), pd = __builtin_bit_cast(u32x4, pack8(dh[ft][0], dh[ft][1]));
                 hB[ft] = __builtin_bit_cast(bf16x8, u32x4{ph[0] & k0[0], ph[1] & k0[1], ph[2] & k1[0], ph[3] & k1[1]});
                 dB[ft] = __builtin_bit_cast(bf16x8, u32x4{pd[0] & k0[0], pd[1] & k0[1], pd[2] & k1[0], pd[3] & k1[1]});
@@ -2447,7 +2458,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     // FDIFF_TR_WG_LDS_KB pads the request (experiments: above 80 KiB only one weight-gradient workgroup fits a CU, which
     // leaves registers and LDS for the chain's attention-backward workgroups beside it)
     static const size_t wg_pad = getenv("FDIFF_TR_WG_LDS_KB") ? (size_t)atoi(getenv("FDIFF_TR_WG_LDS_KB")) * 1024 : 0;
-    const size_t lds_wg = std::max((size_t)3 * StageL<KS1, DT>::bytes + 128, wg_pad);      // (ring + the lane-mask table)
+    const size_t lds_wg = std::max((size_t)3 * StageL<KS1, DT>::bytes + 128 + 3 * 512, wg_pad);      // (ring + lane-mask table + activity words)
     static const bool serial = getenv("FDIFF_TR_SERIAL") != nullptr;
     WgArgs wa{};
     wa.nparams = (long long)tb.layer_params; wa.TS = tb.TS; wa.nblk = (M + 31) / 32;
