@@ -2363,7 +2363,12 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             ma.n_p = (long long)B * m->d.n_head * T * d.NJ * 4;
             ma.n_r = (long long)tb.Mpad * ((DT + 1) / 2) * 4;
             const long long tot = ma.n_h + ma.n_p + 2 * ma.n_r;
-            const unsigned grid = (unsigned)std::min<long long>((tot / 2 + 255) / 256, (long long)ctx->num_cu * 16);
+            // Workgroups per CU of the decision kernel (persistent workgroups, VALU-bound, 66 VGPRs).  16 per CU hold most registers of
+            // the chip while a decision kernel runs, and the forward chain's kernels beside them take 36-50 us instead of 29-41
+            // (rocprofv3 time line) -- but fewer workgroups make the decisions later and the step slower: 16 / 8 / 4 / 2 / 1 per CU
+            // = 2.36 / 2.36 / 2.39 / 2.40 / 2.40 ms per step at T = 252 (scripts/gpu_r04_maskwgs.sh).
+            static const int mask_wgs = getenv("FDIFF_TR_MASK_WGS") ? std::max(1, atoi(getenv("FDIFF_TR_MASK_WGS"))) : 16;
+            const unsigned grid = (unsigned)std::min<long long>((tot / 2 + 255) / 256, (long long)ctx->num_cu * mask_wgs);
             hipLaunchKernelGGL(k_tr_masks, dim3(grid), dim3(256), 0, ctx->side_stream, d, ma);
             FD_HIP(ctx, hipEventRecord(ctx->side_events[l], ctx->side_stream));
         }
