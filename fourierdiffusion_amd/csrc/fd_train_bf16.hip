@@ -10,7 +10,8 @@
 //                             + dropout + residual + LN2                                               -> next layer input
 //   backward  k_tr_ffn_bwd    128 tokens: LN2 bwd, FFN input gradient (d hidden never leaves registers), LN1 bwd,
 //                             out-proj input gradient                                                  -> d att, d residual
-//             k_tr_attn_bwd   (series, head pair): recomputes Q/K/V and P, d Q/K/V, input gradient of in_proj
+//             k_tr_attn_bwd   (series, head pair) -- from 12 token tiles on (series, head) --: recomputes Q/K/V and P, d Q/K/V,
+//                             input gradient of in_proj (per pair / per head partial tensors, summed by the next k_tr_ffn_bwd)
 //   once      k_tr_wgrad      every weight gradient of every layer: each output element is owned by ONE wave that walks the
 //                             tokens of its split in a fixed order (the FFN hidden / d hidden are recomputed per 32-token
 //                             block, never materialised); k_tr_reduce adds the token splits in a fixed order.
