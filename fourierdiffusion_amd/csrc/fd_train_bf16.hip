@@ -2088,6 +2088,10 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
     return off + 4096;
 }
 
+// Events that order the step's streams against each other.  (A device-scope release per record -- hipEventReleaseToDevice -- instead of
+// the default system-scope fence was measured at +-0: 2.34 / 1.43 ms per step either way, scripts/gpu_r04_events.sh.)
+static const unsigned kTrEventFlags = hipEventDisableTiming;
+
 // Side streams carry work that is OFF the step's critical path (dropout decisions one layer ahead, weight gradients behind the
 // input-gradient chain): lowest priority, so that the dispatcher hands free CU slots to the chain's workgroups first.
 hipError_t side_stream_create(hipStream_t* st) {
@@ -2341,7 +2345,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         if (!ctx->side_stream) FD_HIP(ctx, side_stream_create(&ctx->side_stream));
         while ((int)ctx->side_events.size() < L + 3) {
             hipEvent_t e;
-            FD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            FD_HIP(ctx, hipEventCreateWithFlags(&e, kTrEventFlags));
             ctx->side_events.push_back(e);
         }
         // The mask buffers were last read by the previous training forward / backward on `s`: tr_readers_event was recorded
@@ -2350,7 +2354,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         // a cross-stream hand-off plus the first mask kernel (an 80 us hole in every step), so that is only done when some
         // other call has carved the arena since (an eval forward, the sampler, another model on this context: gen_in differs)
         // and may still be running on `s`.
-        if (!ctx->tr_readers_event) FD_HIP(ctx, hipEventCreateWithFlags(&ctx->tr_readers_event, hipEventDisableTiming));
+        if (!ctx->tr_readers_event) FD_HIP(ctx, hipEventCreateWithFlags(&ctx->tr_readers_event, kTrEventFlags));
         if (!ctx->tr_readers_event_valid || gen_in != ctx->tr_readers_gen) FD_HIP(ctx, hipEventRecord(ctx->tr_readers_event, s));
         FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->tr_readers_event, 0));
         for (int l = 0; l < L; ++l) {
@@ -2374,6 +2378,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             FD_HIP(ctx, hipEventRecord(ctx->side_events[l], ctx->side_stream));
         }
     }
+    int mask_waited = -1;                 // highest layer whose dropout decisions `s` has waited for
     for (int l = 0; l < L; ++l) {
         const fd_layer_off& lo = m->layers[l];
         TrLayerBufs& b = tb.layers[l];
@@ -2381,7 +2386,16 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         AttnFwdArgs aa{};
         aa.x0rb = b.x0rb; aa.att = b.att; aa.attT = b.attT; aa.lse2 = b.lse2; aa.pmask = b.pmask;
         aa.wk = limg + im->off_wk; aa.wv = limg + im->off_wv; aa.wq = limg + im->off_wq;
-        if (p > 0.f) FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[l], 0));      // this layer's dropout decisions are ready
+        // This layer's dropout decisions must be ready.  The decision kernels run ahead of the chain (rocprofv3 time line at T = 252:
+        // layer l's at 32 + 40 l us, the chain reaches layer l at 120 + 76 l us), and every wait packet between two chain kernels
+        // costs ~6 us of idle queue: wait for layer min(L - 1, 2 l + 1)'s event and skip the waits that one covers (layers 0, 2, 6
+        // of 10 wait; FDIFF_TR_MASK_WAIT_ALL=1 waits in front of every layer, A/B runs)
+        if (p > 0.f && l > mask_waited) {
+            static const bool wait_all = getenv("FDIFF_TR_MASK_WAIT_ALL") != nullptr;
+            const int upto = wait_all ? l : std::min(L - 1, 2 * l + 1);
+            FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[upto], 0));
+            mask_waited = upto;
+        }
         {
             // measurement hook: Q / K / V projections + scores + P V of M tokens (the softmax itself is not matrix work)
             fd_prof_scope scope(ctx, s, "k_tr_attn_fwd (Q/K/V projections + softmax attention, training forward)",
@@ -2458,7 +2472,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     if (!ctx->side_stream2) FD_HIP(ctx, side_stream_create(&ctx->side_stream2));
     while ((int)ctx->side_events.size() < L + 3) {
         hipEvent_t e;
-        FD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        FD_HIP(ctx, hipEventCreateWithFlags(&e, kTrEventFlags));
         ctx->side_events.push_back(e);
     }
     // FDIFF_TR_WG_LDS_KB pads the request (experiments: above 80 KiB only one weight-gradient workgroup fits a CU, which
@@ -2545,7 +2559,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         hipLaunchKernelGGL(k_tr_reduce, dim3((unsigned)((tb.layer_params / 4 + 255) / 256)), dim3(256), 0, ws, ra);
     }
     if (m->saved_p > 0.f && L > 0) {      // last reader of the dropout-decision buffers on `s` (layer 0's attention backward)
-        if (!ctx->tr_readers_event) FD_HIP(ctx, hipEventCreateWithFlags(&ctx->tr_readers_event, hipEventDisableTiming));
+        if (!ctx->tr_readers_event) FD_HIP(ctx, hipEventCreateWithFlags(&ctx->tr_readers_event, kTrEventFlags));
         FD_HIP(ctx, hipEventRecord(ctx->tr_readers_event, s));
         ctx->tr_readers_event_valid = true;
         ctx->tr_readers_gen = ctx->ws_gen;
@@ -2627,7 +2641,7 @@ int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, flo
         if (!ctx->side_stream2) FD_HIP(ctx, side_stream_create(&ctx->side_stream2));
         while ((int)ctx->side_events.size() < m->d.num_layers + 3) {
             hipEvent_t e;
-            FD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            FD_HIP(ctx, hipEventCreateWithFlags(&e, kTrEventFlags));
             ctx->side_events.push_back(e);
         }
         FD_HIP(ctx, hipEventRecord(ctx->side_events[m->d.num_layers], s));
