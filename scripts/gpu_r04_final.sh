@@ -4,7 +4,7 @@
 TAG=${1:-r04d}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-timeout 2000 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/gpu_suite.txt; cat $OUT/gpu_suite.txt
+timeout 2000 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/gpu_suite.txt; cat $OUT/gpu_suite.txt
 bash scripts/gpu_round.sh $TAG 2>&1 | cut -c1-300 | tail -60
 cd $GRAFT_REPO_ROOT
 python bench.py --workload long --no-cpu-baseline --no-secondary > $OUT/bench_long.json 2> $OUT/bench_long.err; tail -1 $OUT/bench_long.json | cut -c1-500
