@@ -1163,6 +1163,17 @@ struct AttnBwdArgs {
     size_t part_stride;
 };
 
+#ifdef FD_TR_PROF_ATTN      // variant build: in-kernel phase clocks of k_tr_attn_bwd (workgroup (0, 0), per wave), printed after 30 launches
+__device__ unsigned long long fd_tr_attn_dbg[8 * 8];
+#define TRA_STAMP(slot, t_prev)                                                                          \
+    do {                                                                                                 \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                    \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) fd_tr_attn_dbg[wave * 8 + (slot)] += now_ - (t_prev); \
+        (t_prev) = now_;                                                                                 \
+    } while (0)
+#else
+#define TRA_STAMP(slot, t_prev) do { } while (0)
+#endif
 // OH = 0: one workgroup per (head pair, series), both heads of the pair in every sweep iteration.
 // OH = 1: one workgroup per (head, series): H x B workgroups of NW waves with the LDS images of ONE head (row forms 16 B per
 //         token, column forms 8 dim rows), so that three or four workgroups share a CU and the grid is a whole number of rounds
@@ -1201,6 +1212,11 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
     const int PTH = NTOK * NJ * 4;                               // bytes per head
     const size_t pstride = (size_t)KS1 * 1024;
     auto wfrag = [&](const char* img, int ks) { return *reinterpret_cast<const bf16x8*>(img + pair * pstride + ((size_t)ks * 64 + lane) * 16); };
+    unsigned long long tprev = 0;
+    (void)tprev;
+#ifdef FD_TR_PROF_ATTN
+    tprev = __builtin_readcyclecounter();
+#endif
     const bool lo_grp = (g >> 1) == 0;
     const int myhead = 2 * pair + (g >> 1);
     const bool mineR = !OH || (g >> 1) == hs0;                   // this lane's k-slots / C rows belong to a swept head
@@ -1333,8 +1349,10 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
             cdv = ndv; cav = nav; cls = nls; cdoc = ndoc;
         }
     }
+    TRA_STAMP(0, tprev);                                       // staging (this wave's tiles)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the keep-bit DMA)
     __syncthreads();
+    TRA_STAMP(1, tprev);                                       // DMA wait + barrier
     // The key-owner sweep needs, per key, the keep bits of eight QUERIES (gathering them from the query-oriented bytes inside the
     // sweep cost eight LDS byte reads with their address arithmetic per iteration).  Rounds 2-4 had a side-stream kernel write a
     // key-oriented copy to global memory (k_tr_masks_T: 25 us per layer at T = 252 beside the forward chain, and a global load
@@ -1342,12 +1360,12 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
     // of lane group gq} x {8 keys of lane group gk} of (query block jq, key block jb), read as eight bytes (one per query),
     // transposed in registers (three masked exchange steps on a 64-bit word), written as eight bytes (one per key).
     if (d.p > 0.f) {
-        const int RB = NJ * 4, nitem = NJ * NJ * 16;
+        const int RB = NJ * 4;
         for (int hi = 0; hi < NHS; ++hi) {
             const unsigned char* src = pm + hi * PMH;
             unsigned char* dst = pmT + hi * PTH;
-            for (int it = threadIdx.x; it < nitem; it += NW * 64) {
-                const int jq = it / (NJ * 16), rest = it - jq * NJ * 16;
+            for (int jq = wave; jq < NJ; jq += NW)                     // (no run-time division: a wave takes whole query blocks)
+            for (int rest = lane; rest < NJ * 16; rest += 64) {
                 const int jb = rest >> 4, gk = (rest >> 2) & 3, gq = rest & 3;
                 unsigned lo = 0u, hi32 = 0u;
 #pragma unroll
@@ -1369,6 +1387,7 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
         }
         __syncthreads();
     }
+    TRA_STAMP(2, tprev);                                       // keep-bit transposition + barrier
     auto rfrag = [&](const char* base, int tile) {
         if constexpr (OH) {
             const u32x2 v = *reinterpret_cast<const u32x2*>(base + ((size_t)(tile * 16 + tok) * 2 + (g & 1)) * 8);
@@ -1445,6 +1464,17 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
                 }
             }
         }
+        TRA_STAMP(3, tprev);                                   // query-owner sweeps
+        // in-proj^T fragments of the epilogue, requested here: their L2 round trip runs under the key-owner sweep (as 15 loads at the
+        // head of every tile's epilogue they were exposed: 3.1 K of a tile's 20 K clocks went into the epilogue)
+        s16x4 wie[3][DT];
+        {
+            const char* wbase = a.winT + (size_t)pair * 3 * DT * 512;
+#pragma unroll
+            for (int wh = 0; wh < 3; ++wh)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) wie[wh][dt] = *reinterpret_cast<const s16x4*>(wbase + ((size_t)(wh * DT + dt) * 64 + lane) * 8);
+        }
         // ---------------- as key tile: S tiles [query rows 4g+r][key col]
         {
             const int kt = tt;
@@ -1503,6 +1533,7 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
                 }
             }
         }
+        TRA_STAMP(4, tprev);                                   // key-owner sweeps
         // ---------------- combine the heads' rows, scale, write d(qkv) and the in_proj input gradient
         {
             const int t = tt * 16 + tok, mm = b * T + t;
@@ -1530,14 +1561,13 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
                     }
                 }
             }
-            const char* wbase = a.winT + (size_t)pair * 3 * DT * 512;
             const size_t pidx = OH ? (size_t)bx : (size_t)pair;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 f32x4 o = f4zero();
-                o = MFMA16(*reinterpret_cast<const s16x4*>(wbase + ((size_t)(0 * DT + dt) * 64 + lane) * 8), bq, o);
-                o = MFMA16(*reinterpret_cast<const s16x4*>(wbase + ((size_t)(1 * DT + dt) * 64 + lane) * 8), bk, o);
-                o = MFMA16(*reinterpret_cast<const s16x4*>(wbase + ((size_t)(2 * DT + dt) * 64 + lane) * 8), bv, o);
+                o = MFMA16(wie[0][dt], bq, o);
+                o = MFMA16(wie[1][dt], bk, o);
+                o = MFMA16(wie[2][dt], bv, o);
                 const int d0 = 16 * dt + 4 * g;
                 if (tv && d0 < D) {
                     if (OH && a.part_bf16)
@@ -1547,6 +1577,7 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
                 }
             }
         }
+        TRA_STAMP(5, tprev);                                   // epilogues
     }
 }
 
@@ -2529,6 +2560,23 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
             if (attn_oh) hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 4, 1>), dim3(2 * d.NP, B), dim3(256), lds_ab, s, d, ab);
             else if (attn_nw == 8) hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 8, 0>), dim3(d.NP, B), dim3(512), lds_ab, s, d, ab);
             else hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 4, 0>), dim3(d.NP, B), dim3(256), lds_ab, s, d, ab);
+#ifdef FD_TR_PROF_ATTN
+            {
+                static int calls = 0;
+                if (++calls == 30) {
+                    unsigned long long h[64];
+                    hipStreamSynchronize(s);
+                    hipMemcpyFromSymbol(h, HIP_SYMBOL(fd_tr_attn_dbg), sizeof(h));
+                    static const char* nm[6] = {"staging", "DMA wait + barrier", "bit transposition", "query sweeps", "key sweeps", "epilogues"};
+                    fprintf(stderr, "[k_tr_attn_bwd phase clocks, workgroup (0,0), average of %d launches, per wave]\n", calls);
+                    for (int w = 0; w < (attn_oh ? 4 : attn_nw); ++w) {
+                        fprintf(stderr, "  wave %d:", w);
+                        for (int q = 0; q < 6; ++q) fprintf(stderr, " %s %.1f K |", nm[q], (double)h[w * 8 + q] / calls / 1000.0);
+                        fprintf(stderr, "\n");
+                    }
+                }
+            }
+#endif
         }
         WgLayer w{};
         w.x0T = b.x0T; w.attT = b.attT; w.doT = b.doT; w.dqkvT = b.dqkvT;
