@@ -46,6 +46,12 @@ struct fd_ctx {
     hipEvent_t tr_readers_event = nullptr;
     bool tr_readers_event_valid = false;
     uint64_t tr_readers_gen = 0;
+    // F-split of the training FFN kernels (fd_train_bf16.hip, struct FSplit): partial accumulators handed from the producer to the
+    // finisher workgroup of a token block, one flag per token tile (zeroed at allocation; a launch writes its own epoch)
+    float* tr_ypart = nullptr;
+    unsigned* tr_yflag = nullptr;
+    size_t tr_fsplit_blocks = 0;
+    unsigned tr_epoch = 0;
     // FFT twiddle tables (T, device pointer), built on first use of a length
     std::vector<std::pair<int, void*>> fft_tw;
     // measurement hooks (fd_prof_begin / fd_prof_end)

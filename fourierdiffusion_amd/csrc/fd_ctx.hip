@@ -27,6 +27,8 @@ extern "C" int fd_ctx_destroy(fd_ctx* ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->gemm_scratch) (void)hipFree(ctx->gemm_scratch);
     if (ctx->red_scratch) (void)hipFree(ctx->red_scratch);
+    if (ctx->tr_ypart) (void)hipFree(ctx->tr_ypart);
+    if (ctx->tr_yflag) (void)hipFree(ctx->tr_yflag);
     for (hipEvent_t e : ctx->side_events) (void)hipEventDestroy(e);
     if (ctx->tr_readers_event) (void)hipEventDestroy(ctx->tr_readers_event);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);

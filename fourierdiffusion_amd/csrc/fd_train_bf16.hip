@@ -125,7 +125,45 @@ struct TrDims {
     unsigned thr16;
     unsigned long long seed;
     int xcd;                  // 1: workgroup ids are re-dealt so that neighbours in (x, y) order share an XCD (xcd_deal)
+    int fsplit;               // FFN kernels: 1, or 2 = the hidden dimension of a 64-token block split over a PAIR of workgroups (small M)
 };
+
+// F-split of the FFN kernels (fsplit == 2).  A 64-token workgroup of k_tr_ffn_fwd / k_tr_ffn_bwd is a chain of F / 64 barrier
+// steps whatever the token count: with M = 6400 tokens (T = 100, B = 64) 100 workgroups hold 100 of the 256 CUs for 40 us.
+// Workgroups 2 i (producer) and 2 i + 1 (finisher) share token block i and take half of the chunk steps each; both run the
+// prologue, the producer's owner waves hand their partial accumulators over through global memory (one flag per token tile,
+// set to the launch's epoch behind an agent-scope release) and leave, the finisher adds them (own half + partner's half, a
+// fixed order) and runs the epilogue.  The finisher has the HIGHER workgroup id, so its producer was dispatched before it, and
+// the host enables the split only when 2 x blocks <= CUs (every workgroup finds a CU without another one of the grid retiring).
+struct FSplit {
+    float* ypart;             // [blocks][4 tiles][DT][64 lanes] f32x4
+    unsigned* flag;           // [blocks][4 tiles]
+    unsigned epoch;           // unique per launch
+};
+// The hand-over moves 5 KiB per token tile between two workgroups that may sit on different XCDs (separate, mutually
+// non-coherent L2s).  An agent-scope release / acquire FENCE would write back / invalidate the whole L2 of the XCD (measured:
+// both FFN kernels at 1.4 x their unsplit time); instead every element is itself an agent-scope relaxed atomic access -- a
+// write-through store / an L2-bypassing load -- and the flag is stored once the element stores have been acknowledged.
+template <int DT>
+__device__ __forceinline__ void fsplit_hand_over(const FSplit& fs, int blk, int tile, int lane, const f32x4 (&acc)[DT]) {
+    float* yp = fs.ypart + (((size_t)(blk * 4 + tile) * DT) * 64 + lane) * 4;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) __hip_atomic_store(yp + dt * 256 + r, acc[dt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(fs.flag + blk * 4 + tile, fs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int DT>
+__device__ __forceinline__ void fsplit_take_over(const FSplit& fs, int blk, int tile, int lane, f32x4 (&acc)[DT]) {
+    while (__hip_atomic_load(fs.flag + blk * 4 + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fs.epoch) __builtin_amdgcn_s_sleep(16);
+    asm volatile("" ::: "memory");
+    const float* yp = fs.ypart + (((size_t)(blk * 4 + tile) * DT) * 64 + lane) * 4;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[dt][r] += __hip_atomic_load(yp + dt * 256 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own L2.  Workgroups that read the
 // same rows -- the heads of one series in the attention kernels, the 20 role workgroups of one token split in k_tr_wgrad --
@@ -579,6 +617,7 @@ struct FfnFwdArgs {
     const char* ffn_img;      // chunk-major forward image of the layer
     const float* bo; const float* g1; const float* be1; const float* b2; const float* g2; const float* be2;
     const unsigned char* hkeep; const unsigned char* rb1; const unsigned char* rb3;   // dropout decisions (k_tr_masks)
+    FSplit fs;
 };
 
 // 8 waves = 4 token tiles (64 tokens) x 2 halves of F.  The weight stream (one 32-wide chunk per F-half per step, 2*NB KiB)
@@ -599,16 +638,21 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     unsigned char* const actB = reinterpret_cast<unsigned char*>(smem + NBUF * WB + SCR) + wave * (64 * NS);   // [64 lanes][NS]
     unsigned short* const actT = reinterpret_cast<unsigned short*>(smem + NBUF * WB + SCR + TW * 64 * NS) + wave * (NS * 32);   // [NS][32]
     char* const tscr = smem + NBUF * WB + SCR + TW * 64 * NS + TW * NS * 32 * 2 + (wave & 3) * (32 * DT * 16);   // owners' T-store transpose
-    const int m = (blockIdx.x * 4 + tile) * 16 + tok;
+    // F-split (struct FSplit): token block, chunk range and role of this workgroup
+    const int nsp = d.fsplit, blk = nsp == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, fq = nsp == 2 ? (int)(blockIdx.x & 1) : 0;
+    const int NSH = NS / nsp, cbase = fq * NSH;
+    const bool finisher = fq == nsp - 1;
+    const int m = (blk * 4 + tile) * 16 + tok;
     const bool valid = m < M;
     const bool owner = fhw == 0;
     // Every workgroup streams the SAME weights: marching through them in lockstep makes all CUs hit the same L2 channel at the
     // same time (measured in the persistent kernel: ~25 GB/s per CU).  The chunks are summed, so each workgroup walks them in
     // its own rotated order.
-    const int rot = (int)((blockIdx.x * 5u) % (unsigned)NS);
+    const int rot = (int)(((unsigned)blk * 5u) % (unsigned)NSH);
     auto issue = [&](int st) {
         int ce = st + rot;
-        ce -= (ce >= NS) ? NS : 0;
+        ce -= (ce >= NSH) ? NSH : 0;
+        ce += cbase;
         const char* src = a.ffn_img + (size_t)ce * WB + lane * 16;
         char* dst = ring + (st % NBUF) * WB;
 #pragma unroll
@@ -619,8 +663,8 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         }
     };
     issue(0);
-    if (NS > 1) issue(1);
-    if (NS > 2) issue(2);
+    if (NSH > 1) issue(1);
+    if (NSH > 2) issue(2);
     // ---- out-projection + bias + dropout + residual -> s1  (both waves of a tile compute it; the owner stores)
     // Every global read of the prologue is issued before the first MFMA waits (attention rows, W_o fragments, residual rows,
     // dropout bytes, bias and LayerNorm vectors): read where they were used, hipcc put an `s_waitcnt vmcnt(0)` behind each
@@ -733,7 +777,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     // trip = two register sets, the read for the step after the last one is clamped (no branch, no copies at the back edge).
     unsigned bits_cur = 0u;
     auto frags = [&](int c, bf16x8 (&w1)[2 * KS1], bf16x8 (&w2)[DT]) {
-        const int cc = c < NS ? c : NS - 1;
+        const int cc = c < NSH ? c : NSH - 1;
         const char* wb = ring + (cc % NBUF) * WB + fhw * NB * 1024 + lane * 16;
 #pragma unroll
         for (int i = 0; i < 2 * KS1; ++i) w1[i] = *reinterpret_cast<const bf16x8*>(wb + i * 1024);
@@ -741,7 +785,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         for (int dt = 0; dt < DT; ++dt) w2[dt] = *reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024);
     };
     auto step = [&](int c, const bf16x8 (&w1)[2 * KS1], const bf16x8 (&w2)[DT], bf16x8 (&n1)[2 * KS1], bf16x8 (&n2)[DT]) {
-        if (c + 3 < NS) issue(c + 3);
+        if (c + 3 < NSH) issue(c + 3);
         frags(c + 1, n1, n2);
         f32x4 h0 = f4zero(), h1 = f4zero();
 #pragma unroll
@@ -750,9 +794,11 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
             h1 = MFMA(w1[KS1 + ks], xf[ks], h1);
         }
         int ce = c + rot;
-        ce -= (ce >= NS) ? NS : 0;
+        ce -= (ce >= NSH) ? NSH : 0;
         int cn = ce + 1;                                           // next step's chunk (clamped read after the last step)
-        cn -= (cn >= NS) ? NS : 0;
+        cn -= (cn >= NSH) ? NSH : 0;
+        ce += cbase;
+        cn += cbase;
         const unsigned bits = bits_cur;                            // dropout decisions of this chunk (staged before the loop),
         bits_cur = actB[lane * NS + cn];                           // read one step ahead like the fragments
         unsigned act = 0u;
@@ -782,7 +828,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         const bf16x8 hb = pack8(h0, h1);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(w2[dt], hb, acc[dt]);
-        if (c + 3 < NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        if (c + 3 < NSH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the prefetch reads and this step's LDS writes are done
         __builtin_amdgcn_s_barrier();
@@ -790,14 +836,14 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     {
         bf16x8 wa1[2 * KS1], wa2[DT], wb1[2 * KS1], wb2[DT];
         frags(0, wa1, wa2);
-        bits_cur = actB[lane * NS + rot];
-        for (int c = 0; c < NS; c += 2) {        // (NS = F / 64 is even: F % 1024 == 0)
+        bits_cur = actB[lane * NS + cbase + rot];
+        for (int c = 0; c < NSH; c += 2) {       // (NS = F / 64 is a multiple of 4: F % 1024 == 0)
             step(c, wa1, wa2, wb1, wb2);
             step(c + 1, wb1, wb2, wa1, wa2);
         }
     }
-    if (owner) {
-        const int m0w = (blockIdx.x * 4 + tile) * 16;
+    if (owner && finisher) {
+        const int m0w = (blk * 4 + tile) * 16;
         store_ctile<DT>(a.s1, m, valid, D, g, s1keep);
         stage_rows<DT, KS1>(a.stage, StageL<KS1, DT>::off_xr, m, valid, D, g, v, true);
         store_T16<DT>(tscr, reinterpret_cast<__bf16*>(a.stage + (size_t)(m0w >> 5) * StageL<KS1, DT>::bytes + StageL<KS1, DT>::off_xT) + (m0w & 31),
@@ -806,15 +852,22 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     // ---- mask bits out: bytes [token][g][chunk] (token-on-lane backward), words [32-token block][half][hidden unit]
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // (F-split: the chunks this workgroup ran, [cbase, cbase + NSH): NSH is a multiple of 8, so both ranges keep 16-byte accesses
+    //  when it is a multiple of 16 and fall back to 8-byte ones otherwise)
     if (valid) {
         unsigned char* dstb = a.active + ((size_t)m * 4 + g) * (2 * NS) + fhw * NS;
-        for (int c = 0; c < NS; c += 16)
-            *reinterpret_cast<u32x4*>(dstb + c) = *reinterpret_cast<const u32x4*>(actB + lane * NS + c);
+        if ((NSH & 15) == 0) {
+            for (int c = cbase; c < cbase + NSH; c += 16)
+                *reinterpret_cast<u32x4*>(dstb + c) = *reinterpret_cast<const u32x4*>(actB + lane * NS + c);
+        } else {
+            for (int c = cbase; c < cbase + NSH; c += 8)
+                *reinterpret_cast<u32x2*>(dstb + c) = *reinterpret_cast<const u32x2*>(actB + lane * NS + c);
+        }
     }
     {
-        const int m0 = (blockIdx.x * 4 + tile) * 16;
+        const int m0 = (blk * 4 + tile) * 16;
         unsigned short* dstw = a.activeT + ((size_t)(m0 >> 5) * 2 + ((m0 >> 4) & 1)) * F + fhw * (F / 2);
-        for (int i = lane * 8; i < NS * 32; i += 64 * 8)
+        for (int i = cbase * 32 + lane * 8; i < (cbase + NSH) * 32; i += 64 * 8)
             *reinterpret_cast<u32x4*>(dstw + i) = *reinterpret_cast<const u32x4*>(actT + i);
     }
     // ---- combine the F-halves; the owner finishes the tile
@@ -827,6 +880,10 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     if (!owner) return;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = (acc[dt] + xch[(tile * DT + dt) * 64 + lane]) * d.keep_scale;      // hidden-unit keep scale
+    if (nsp == 2) {
+        if (!finisher) { fsplit_hand_over<DT>(a.fs, blk, tile, lane, acc); return; }
+        fsplit_take_over<DT>(a.fs, blk, tile, lane, acc);
+    }
     {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -859,7 +916,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     }
     store_ctile<DT>(a.out, m, valid, D, g, v);
     if (a.outrb) {
-        const int m0w = (blockIdx.x * 4 + tile) * 16;
+        const int m0w = (blk * 4 + tile) * 16;
         store_rows<DT, KS1>(a.outrb, m, valid, D, g, v, true);
         store_T16<DT>(tscr, a.outT + ((size_t)(m0w >> 5) * (16 * DT)) * 32 + (m0w & 31), 32, lane, D, v, true, valid);
     }
@@ -881,6 +938,7 @@ struct FfnBwdArgs {
     const char* wot;          // [DT][KS1]
     const float* g1; const float* be1; const float* g2;
     const unsigned char* rb1; const unsigned char* rb3;
+    FSplit fs;
 };
 
 // LayerNorm backward on a C-layout tile: dy -> ds (in place), xhat given; returns nothing (column sums done by the caller)
@@ -932,12 +990,17 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     char* const scratch2 = smem + NBUF * WB + SCR + TW * 64 * NS + 4 * 5 * 16 * DT * sizeof(float) + wave * KS1 * 1024;
     // (the second half of the scratch2 area belongs to the non-owner waves, which never use it: 4 KS1 KiB >= 4 x 512 DT bytes)
     char* const tscr = smem + NBUF * WB + SCR + TW * 64 * NS + 4 * 5 * 16 * DT * sizeof(float) + 4 * KS1 * 1024 + (wave & 3) * (32 * DT * 16);
-    const int m = (blockIdx.x * 4 + tile) * 16 + tok;
+    // F-split (struct FSplit): token block, chunk range and role of this workgroup
+    const int nsp = d.fsplit, blk = nsp == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, fq = nsp == 2 ? (int)(blockIdx.x & 1) : 0;
+    const int NSH = NS / nsp, cbase = fq * NSH;
+    const bool finisher = fq == nsp - 1;
+    const int m = (blk * 4 + tile) * 16 + tok;
     const bool valid = m < M;
-    const int rot = (int)((blockIdx.x * 5u) % (unsigned)NS);      // rotated chunk order per workgroup (see k_tr_ffn_fwd)
+    const int rot = (int)(((unsigned)blk * 5u) % (unsigned)NSH);      // rotated chunk order per workgroup (see k_tr_ffn_fwd)
     auto issue = [&](int st) {
         int ce = st + rot;
-        ce -= (ce >= NS) ? NS : 0;
+        ce -= (ce >= NSH) ? NSH : 0;
+        ce += cbase;
         const char* src = a.bffn + (size_t)ce * WB + lane * 16;
         char* dst = ring + (st % NBUF) * WB;
 #pragma unroll
@@ -948,8 +1011,8 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
         }
     };
     issue(0);
-    if (NS > 1) issue(1);
-    if (NS > 2) issue(2);
+    if (NSH > 1) issue(1);
+    if (NSH > 2) issue(2);
     // column sums over this tile's 16 tokens -> colred[tile][slot][feature] (owner waves only)
     auto colsum = [&](int slot, const f32x4 (&t)[DT]) {
 #pragma unroll
@@ -1037,7 +1100,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     // scale of the hidden units is applied once to the accumulators behind the loop.
     unsigned act_cur = 0u;
     auto frags = [&](int c, bf16x8 (&w1)[2 * KS1], bf16x8 (&w2)[DT]) {
-        const int cc = c < NS ? c : NS - 1;
+        const int cc = c < NSH ? c : NSH - 1;
         const char* wb = ring + (cc % NBUF) * WB + fhw * NB * 1024 + lane * 16;
 #pragma unroll
         for (int i = 0; i < 2 * KS1; ++i) w1[i] = *reinterpret_cast<const bf16x8*>(wb + i * 1024);
@@ -1046,7 +1109,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     };
     auto step = [&](int c, const bf16x8 (&w1)[2 * KS1], const bf16x8 (&w2)[DT], bf16x8 (&n1)[2 * KS1], bf16x8 (&n2)[DT]) {
 #ifndef FD_TR_ABL_NODMA
-        if (c + 3 < NS) issue(c + 3);
+        if (c + 3 < NSH) issue(c + 3);
 #endif
         frags(c + 1, n1, n2);
         f32x4 h0 = f4zero(), h1 = f4zero();
@@ -1056,10 +1119,10 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
             h1 = MFMA(w1[KS1 + ks], dfr[ks], h1);
         }
         int cn = c + 1 + rot;
-        cn -= (cn >= NS) ? NS : 0;
-        cn -= (cn >= NS) ? NS : 0;                    // (c + 1 == NS: the clamped read of the step after the last)
+        cn -= (cn >= NSH) ? NSH : 0;
+        cn -= (cn >= NSH) ? NSH : 0;                  // (c + 1 == NSH: the clamped read of the step after the last)
         const unsigned act = act_cur;
-        act_cur = actB[lane * NS + cn];
+        act_cur = actB[lane * NS + cbase + cn];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             h0[r] = (act & (1u << r)) ? h0[r] : 0.f;
@@ -1068,7 +1131,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
         const bf16x8 hb = pack8(h0, h1);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(w2[dt], hb, acc[dt]);
-        if (c + 3 < NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        if (c + 3 < NSH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xc07f);
 #ifndef FD_TR_ABL_NOBAR
@@ -1078,8 +1141,8 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     {
         bf16x8 wa1[2 * KS1], wa2[DT], wb1[2 * KS1], wb2[DT];
         frags(0, wa1, wa2);
-        act_cur = actB[lane * NS + rot];
-        for (int c = 0; c < NS; c += 2) {        // (NS = F / 64 is even: F % 1024 == 0)
+        act_cur = actB[lane * NS + cbase + rot];
+        for (int c = 0; c < NSH; c += 2) {       // (NS = F / 64 is a multiple of 4: F % 1024 == 0)
             step(c, wa1, wa2, wb1, wb2);
             step(c + 1, wb1, wb2, wa1, wa2);
         }
@@ -1092,13 +1155,24 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
         for (int dt = 0; dt < DT; ++dt) xch[(tile * DT + dt) * 64 + lane] = acc[dt];
     }
     __syncthreads();
+    if (nsp == 2 && !finisher) {          // F-split producer: hand the FFN branch's partial d x1 over and leave (every wave of it)
+        if (owner) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] += xch[(tile * DT + dt) * 64 + lane];
+            fsplit_hand_over<DT>(a.fs, blk, tile, lane, acc);
+        }
+        return;
+    }
     if (owner) {
-        const int m0w = (blockIdx.x * 4 + tile) * 16;
+        const int m0w = (blk * 4 + tile) * 16;
         store_T16<DT>(tscr, reinterpret_cast<__bf16*>(a.stage + (size_t)(m0w >> 5) * StageL<KS1, DT>::bytes + StageL<KS1, DT>::off_dT) + (m0w & 31),
                       StageL<KS1, DT>::TBS, lane, D, df, false, valid);
         stage_rows<DT, KS1>(a.stage, StageL<KS1, DT>::off_dr, m, valid, D, g, df, false);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) dy[dt] += acc[dt] + xch[(tile * DT + dt) * 64 + lane];     // d x1 = residual path + FFN branch
+        for (int dt = 0; dt < DT; ++dt) acc[dt] += xch[(tile * DT + dt) * 64 + lane];
+        if (nsp == 2) fsplit_take_over<DT>(a.fs, blk, tile, lane, acc);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dy[dt] += acc[dt];                                          // d x1 = residual path + FFN branch
         // ---- LayerNorm1 backward
         float rstd1;
         {
@@ -1144,7 +1218,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
         const int slot = i / (16 * DT), f = i - slot * (16 * DT);
         float sres = 0.f;
         for (int w = 0; w < 4; ++w) sres += colred[(w * 5 + slot) * (16 * DT) + f];
-        if (f < D) a.vecpart[((size_t)blockIdx.x * 5 + slot) * D + f] = sres;
+        if (f < D) a.vecpart[((size_t)blk * 5 + slot) * D + f] = sres;
     }
 }
 
@@ -2156,6 +2230,27 @@ size_t tr_attn_bwd_lds(int T, bool one_head) {
            nhs * (size_t)T * NJ * 4 + 16 + 256 + nhs * KT * 16 * NJ * 4;
 }
 
+// buffers + a fresh epoch for one F-split launch (fs stays empty when the launch is not split)
+int tr_fsplit_prepare(fd_ctx* ctx, const TrDims& d, int blocks, int DT, FSplit* fs, hipStream_t s) {
+    *fs = FSplit{};
+    if (d.fsplit != 2) return FD_OK;
+    if ((size_t)blocks > ctx->tr_fsplit_blocks) {
+        // (the old buffers may still be read by a launch in flight on `s`)
+        FD_HIP(ctx, hipStreamSynchronize(s));
+        if (ctx->tr_ypart) (void)hipFree(ctx->tr_ypart);
+        if (ctx->tr_yflag) (void)hipFree(ctx->tr_yflag);
+        ctx->tr_ypart = nullptr; ctx->tr_yflag = nullptr; ctx->tr_fsplit_blocks = 0;
+        const size_t nb = (size_t)std::max(blocks, ctx->num_cu / 2);
+        FD_HIP(ctx, hipMalloc((void**)&ctx->tr_ypart, nb * 4 * 9 * 64 * sizeof(float) * 4));      // (DT <= 9 in every class)
+        FD_HIP(ctx, hipMalloc((void**)&ctx->tr_yflag, nb * 4 * sizeof(unsigned)));
+        FD_HIP(ctx, hipMemsetAsync(ctx->tr_yflag, 0, nb * 4 * sizeof(unsigned), s));
+        ctx->tr_fsplit_blocks = nb;
+    }
+    (void)DT;
+    fs->ypart = ctx->tr_ypart; fs->flag = ctx->tr_yflag; fs->epoch = ++ctx->tr_epoch;
+    return FD_OK;
+}
+
 TrDims make_dims(const fd_score* m, int B, float p, uint64_t seed) {
     const fd_bf16_images* im = m->bf16;
     TrDims d{};
@@ -2168,6 +2263,19 @@ TrDims make_dims(const fd_score* m, int B, float p, uint64_t seed) {
     d.seed = seed;
     static const int xcd_env = getenv("FDIFF_TR_XCD") ? atoi(getenv("FDIFF_TR_XCD")) : 1;      // (0: hardware order, A/B runs)
     d.xcd = xcd_env;
+    // F-split of the FFN kernels (struct FSplit): when the doubled grid still leaves half of the CUs to the side streams -- every
+    // workgroup of it finds its own CU (the finisher of a pair spins until its producer has handed over; two processes sharing
+    // a GPU at this size still fit), and the weight-gradient / decision kernels keep the CUs they ran on beside the unsplit form
+    // (at 100 blocks = 200 workgroups the FFN kernels got faster, 40 -> 31 and 36 -> 33 us, and the step slower, 1.43 -> 1.45 ms:
+    // profiles/r04_train_fsplit_ab.txt) -- and the halves keep whole two-step trips.  FDIFF_TR_FSPLIT=0 disables, =2 forces
+    // it up to blocks <= CUs / 2.
+    {
+        const char* e = getenv("FDIFF_TR_FSPLIT");
+        const int mode = e ? atoi(e) : 1;
+        const long long blocks = ((long long)d.M + 63) / 64;
+        const long long cap = mode == 2 ? m->ctx->num_cu / 2 : m->ctx->num_cu / 4;
+        d.fsplit = (mode != 0 && blocks <= cap && (d.F / 64) % 4 == 0) ? 2 : 1;
+    }
     return d;
 }
 
@@ -2448,7 +2556,8 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             // measurement hook (bench.py --mode train): algorithmic flops of this launch = out-projection + FFN of M tokens
             fd_prof_scope scope(ctx, s, "k_tr_ffn_fwd (out-proj + LN1 + FFN + LN2, training forward)",
                                 (double)M * (4.0 * D * m->d.dim_ff + 2.0 * D * D));
-            hipLaunchKernelGGL((k_tr_ffn_fwd<KS1, DT, KSO>), dim3(tb.nwg), dim3(TW * 64), lds_ffn, s, d, fa);
+            if (int rc = tr_fsplit_prepare(ctx, d, tb.nwg, DT, &fa.fs, s)) return rc;
+            hipLaunchKernelGGL((k_tr_ffn_fwd<KS1, DT, KSO>), dim3(tb.nwg * d.fsplit), dim3(TW * 64), lds_ffn, s, d, fa);
         }
     }
     if (out) fdgemm::linear_fwd(tb.hL, P + m->un_w, P + m->un_b, out, M, C, D, false, s);      // (null: the fused loss head reads hL)
@@ -2545,7 +2654,8 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
             // not algorithmic work)
             fd_prof_scope scope(ctx, s, "k_tr_ffn_bwd (LN2 bwd + FFN input gradient + LN1 bwd + out-proj^T, training backward)",
                                 (double)M * (4.0 * D * F + 2.0 * D * D));
-            hipLaunchKernelGGL((k_tr_ffn_bwd<KS1, DT>), dim3(tb.nwg), dim3(TW * 64), lds_bwd, s, d, fa);
+            if (int rc = tr_fsplit_prepare(ctx, d, tb.nwg, DT, &fa.fs, s)) return rc;
+            hipLaunchKernelGGL((k_tr_ffn_bwd<KS1, DT>), dim3(tb.nwg * d.fsplit), dim3(TW * 64), lds_bwd, s, d, fa);
         }
         AttnBwdArgs ab{};
         ab.x0rb = b.x0rb; ab.att = b.att; ab.datt = tb.datt; ab.lse2 = b.lse2; ab.pmask = b.pmask;
