@@ -162,6 +162,44 @@ def test_attention_backward_forms_agree(monkeypatch, cfg, B, p):
         assert worst <= tol, (form, worst)
 
 
+@pytest.mark.parametrize("cfg,B,p", [(dict(T=100, C=12, D=72, L=3, H=12), 9, 0.1), (dict(T=37, C=5, D=72, L=2, H=12), 7, 0.0),
+                                      (dict(T=48, C=3, D=32, L=2, H=4), 5, 0.1)])
+def test_ffn_f_split_agrees_with_the_unsplit_kernels(monkeypatch, cfg, B, p):
+    """Below CUs / 4 blocks of 64 tokens the FFN kernels split the hidden dimension of a block over a producer / finisher pair of
+    workgroups that exchange a partial accumulator through global memory (struct FSplit in fd_train_bf16.hip).  Same Philox key:
+    the split step is bit-reproducible (no atomics in the sums: the finisher adds own half + partner's half in a fixed order),
+    its loss equals the unsplit one to fp32 rounding and its gradients agree to the bf16 flips a different summation order of the
+    FFN output causes downstream: a last-bit difference in the FFN output flips single relu / activity decisions of the next layer, so single
+    elements of the linear1 gradients move by per cent (bounds: this file's per-tensor max-rel 8e-2, and l2-rel 1.5e-2; measured values logged)."""
+    from fourierdiffusion_amd.utils.losses import get_sde_loss_fn
+    tag = f"T{cfg['T']}_D{cfg['D']}_p{p}"
+    X = W.randn(f"fs_x_{tag}", (B, cfg["T"], cfg["C"]), 3)
+    z = W.randn(f"fs_z_{tag}", (B, cfg["T"], cfg["C"]), 3)
+    t = W.uniform(f"fs_t_{tag}", (B,), 3, 0.05, 1.0)
+    m, sch, _ = make_model(cfg, precision="bf16")
+    m.dropout = p
+    fn = get_sde_loss_fn(sch, train=True)
+    res = {}
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("FDIFF_TR_FSPLIT", mode)
+        m.zero_grad()
+        torch.manual_seed(55)
+        loss = fn(m, batch_of(X, t), noise=dev(z)).item()
+        assert m.train_mode_effective == "bf16"
+        g = m.grads.clone()
+        if mode in res:
+            assert loss == res[mode][0] and torch.equal(g, res[mode][1]), "F-split step is not bit-reproducible"
+        res[mode] = (loss, g, _grads_of(m))
+    assert abs(res["1"][0] - res["0"][0]) <= 2e-4 * abs(res["0"][0]), (res["1"][0], res["0"][0])
+    assert not torch.equal(res["0"][1], res["1"][1]), "the split form did not run (same bits as the unsplit kernels)"
+    rows = [(np.abs(res["1"][2][k] - r).max() / max(np.abs(r).max(), 1e-20),
+             np.linalg.norm(res["1"][2][k] - r) / max(np.linalg.norm(r), 1e-20), k) for k, r in res["0"][2].items()]
+    wm, wl = max(rows), max(rows, key=lambda x: x[1])
+    _log(f"[parity] FFN F-split vs unsplit kernels ({tag}): loss {res['1'][0]:.6f} vs {res['0'][0]:.6f}, worst max-rel {wm[0]:.3e} ({wm[2]}), "
+         f"worst l2-rel {wl[1]:.3e} ({wl[2]})")
+    assert wm[0] <= 8e-2 and wl[1] <= 1.5e-2, (wm, wl)
+
+
 def test_bf16_training_range_in_series_length():
     """The bf16 attention backward keeps a head's images and keep bits of the whole series in LDS: 592 time steps fit; beyond that
     the model trains on the exact-f32 path and says so (no silent precision switch the other way either)."""
