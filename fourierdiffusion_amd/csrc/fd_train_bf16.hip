@@ -2251,6 +2251,21 @@ int tr_fsplit_prepare(fd_ctx* ctx, const TrDims& d, int blocks, int DT, FSplit* 
     return FD_OK;
 }
 
+// F-split of the FFN kernels (struct FSplit): every workgroup of the doubled grid must find its own CU (the finisher of a pair spins
+// until its producer has handed over), and the halves must keep whole two-step trips.  The BACKWARD kernel splits only while the
+// doubled grid leaves half of the CUs free: the weight-gradient launches run beside it on the CUs it does not use, and at 100 blocks
+// (T = 100, B = 64) the faster FFN kernels made the step slower (1.43 -> 1.45 ms, profiles/r04_train_fsplit_ab.txt).  The FORWARD
+// kernel has only the register-light decision kernels beside it and splits up to CUs / 2 blocks.
+// FDIFF_TR_FSPLIT: 0 never; 1 (default) forward <= CUs / 2, backward <= CUs / 4; 2 both <= CUs / 2; 3 both <= CUs / 4.
+int tr_fsplit_rule(const fd_score* m, int M, int F, bool forward) {
+    const char* e = getenv("FDIFF_TR_FSPLIT");
+    const int mode = e ? atoi(e) : 1;
+    const long long blocks = ((long long)M + 63) / 64;
+    const int cu = m->ctx->num_cu;
+    const long long cap = mode == 2 ? cu / 2 : mode == 3 ? cu / 4 : (forward ? cu / 2 : cu / 4);
+    return (mode != 0 && blocks <= cap && (F / 64) % 4 == 0) ? 2 : 1;
+}
+
 TrDims make_dims(const fd_score* m, int B, float p, uint64_t seed) {
     const fd_bf16_images* im = m->bf16;
     TrDims d{};
@@ -2263,19 +2278,7 @@ TrDims make_dims(const fd_score* m, int B, float p, uint64_t seed) {
     d.seed = seed;
     static const int xcd_env = getenv("FDIFF_TR_XCD") ? atoi(getenv("FDIFF_TR_XCD")) : 1;      // (0: hardware order, A/B runs)
     d.xcd = xcd_env;
-    // F-split of the FFN kernels (struct FSplit): when the doubled grid still leaves half of the CUs to the side streams -- every
-    // workgroup of it finds its own CU (the finisher of a pair spins until its producer has handed over; two processes sharing
-    // a GPU at this size still fit), and the weight-gradient / decision kernels keep the CUs they ran on beside the unsplit form
-    // (at 100 blocks = 200 workgroups the FFN kernels got faster, 40 -> 31 and 36 -> 33 us, and the step slower, 1.43 -> 1.45 ms:
-    // profiles/r04_train_fsplit_ab.txt) -- and the halves keep whole two-step trips.  FDIFF_TR_FSPLIT=0 disables, =2 forces
-    // it up to blocks <= CUs / 2.
-    {
-        const char* e = getenv("FDIFF_TR_FSPLIT");
-        const int mode = e ? atoi(e) : 1;
-        const long long blocks = ((long long)d.M + 63) / 64;
-        const long long cap = mode == 2 ? m->ctx->num_cu / 2 : m->ctx->num_cu / 4;
-        d.fsplit = (mode != 0 && blocks <= cap && (d.F / 64) % 4 == 0) ? 2 : 1;
-    }
+    d.fsplit = tr_fsplit_rule(m, d.M, d.F, false);      // (the forward launch applies its own rule, see there)
     return d;
 }
 
@@ -2556,8 +2559,10 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             // measurement hook (bench.py --mode train): algorithmic flops of this launch = out-projection + FFN of M tokens
             fd_prof_scope scope(ctx, s, "k_tr_ffn_fwd (out-proj + LN1 + FFN + LN2, training forward)",
                                 (double)M * (4.0 * D * m->d.dim_ff + 2.0 * D * D));
-            if (int rc = tr_fsplit_prepare(ctx, d, tb.nwg, DT, &fa.fs, s)) return rc;
-            hipLaunchKernelGGL((k_tr_ffn_fwd<KS1, DT, KSO>), dim3(tb.nwg * d.fsplit), dim3(TW * 64), lds_ffn, s, d, fa);
+            TrDims df = d;
+            df.fsplit = tr_fsplit_rule(m, d.M, d.F, true);
+            if (int rc = tr_fsplit_prepare(ctx, df, tb.nwg, DT, &fa.fs, s)) return rc;
+            hipLaunchKernelGGL((k_tr_ffn_fwd<KS1, DT, KSO>), dim3(tb.nwg * df.fsplit), dim3(TW * 64), lds_ffn, s, df, fa);
         }
     }
     if (out) fdgemm::linear_fwd(tb.hL, P + m->un_w, P + m->un_b, out, M, C, D, false, s);      // (null: the fused loss head reads hL)
