@@ -5,10 +5,10 @@ TAG=${1:-prevab}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 PREV=$GRAFT_REPO_ROOT/fourierdiffusion_amd/libfdiff_hip_prev.so
-sb() { python scripts/shape_bench.py train $1 64 2>/dev/null | tail -1 | cut -c1-110; }
+sb() { timeout 120 python scripts/shape_bench.py train $1 64 2>/dev/null | tail -1 | cut -c1-110; }
 stats() {  # name, shape, env...
   n=$1; shp=$2; shift; shift
-  (cd /tmp && export TMPDIR=/tmp && env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$n -o s -- python $GRAFT_REPO_ROOT/scripts/shape_bench.py train $shp 64 > $OUT/$n.log 2>&1)
+  (cd /tmp && export TMPDIR=/tmp && env "$@" timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$n -o s -- python $GRAFT_REPO_ROOT/scripts/shape_bench.py train $shp 64 > $OUT/$n.log 2>&1)
   echo "== $n: $@"; python $GRAFT_REPO_ROOT/scripts/kstats.py $OUT/$n/s_kernel_stats.csv ${NK:-7} | cut -c1-70,100-140
 }
 timeout 900 python -m pytest tests/test_gpu_train_bf16.py tests/test_gpu_benched_shapes.py tests/test_gpu_widths.py tests/test_gpu_train.py -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
