@@ -52,6 +52,10 @@ struct fd_ctx {
     unsigned* tr_yflag = nullptr;
     size_t tr_fsplit_blocks = 0;
     unsigned tr_epoch = 0;
+    // error word of the device-side bounded waits (pinned host memory mapped into the device; a kernel sets it with a
+    // system-scope atomic, the host reads it without synchronising): fd_train_async_check turns it into FD_ERR_STATE
+    unsigned* tr_err_host = nullptr;
+    unsigned* tr_err_dev = nullptr;
     // FFT twiddle tables (T, device pointer), built on first use of a length
     std::vector<std::pair<int, void*>> fft_tw;
     // measurement hooks (fd_prof_begin / fd_prof_end)
@@ -68,6 +72,9 @@ struct fd_ctx {
 };
 
 float* fd_gemm_scratch(fd_ctx* ctx, size_t* n_floats);   // fd_ctx.hip
+// FD_OK, or FD_ERR_STATE when a kernel of an EARLIER training call on this context gave up a bounded inter-workgroup wait
+// (fd_train_bf16.hip, struct FSplit); called at the entry of every training / optimizer call, never synchronises (fd_ctx.hip)
+int fd_train_async_check(fd_ctx* ctx);
 float* fd_red_scratch(fd_ctx* ctx, size_t n_floats);      // fd_ctx.hip; nullptr when the allocation fails
 // out[n] (+)= sum_r part[r][n], r in ascending order (fd_score_bwd.hip)
 void fd_sum_rows(const float* part, int R, int N, float* out, bool accumulate, hipStream_t s);

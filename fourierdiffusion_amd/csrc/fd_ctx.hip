@@ -29,6 +29,7 @@ extern "C" int fd_ctx_destroy(fd_ctx* ctx) {
     if (ctx->red_scratch) (void)hipFree(ctx->red_scratch);
     if (ctx->tr_ypart) (void)hipFree(ctx->tr_ypart);
     if (ctx->tr_yflag) (void)hipFree(ctx->tr_yflag);
+    if (ctx->tr_err_host) (void)hipHostFree(ctx->tr_err_host);
     for (hipEvent_t e : ctx->side_events) (void)hipEventDestroy(e);
     if (ctx->tr_readers_event) (void)hipEventDestroy(ctx->tr_readers_event);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
@@ -36,6 +37,24 @@ extern "C" int fd_ctx_destroy(fd_ctx* ctx) {
     for (auto& e : ctx->fft_tw) (void)hipFree(e.second);
     delete ctx;
     return FD_OK;
+}
+
+int fd_train_async_check(fd_ctx* ctx) {
+    if (!ctx || !ctx->tr_err_host) return FD_OK;
+    const unsigned e = __atomic_load_n(ctx->tr_err_host, __ATOMIC_RELAXED);
+    if (!e) return FD_OK;
+    __atomic_store_n(ctx->tr_err_host, 0u, __ATOMIC_RELAXED);
+    const unsigned id = e & 0x7fffffffu;
+    return fd_fail(ctx, FD_ERR_STATE,
+                   "an earlier training step's F-split hand-over timed out at token block %u, tile %u: the finisher workgroup never saw "
+                   "its producer's partial sums (producer not scheduled -- CU-masked queue / partitioned device / a co-tenant kernel "
+                   "holding the CUs -- or faulted).  That step's gradients are invalid.  FDIFF_TR_FSPLIT=0 disables the split, "
+                   "FDIFF_TR_FSPLIT_TIMEOUT_MS (default 2000) sets the bound.", id >> 2, id & 3u);
+}
+
+extern "C" int fd_ctx_check(fd_ctx* ctx) {
+    if (!ctx) return FD_ERR_ARG;
+    return fd_train_async_check(ctx);
 }
 
 extern "C" const char* fd_last_error(fd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }

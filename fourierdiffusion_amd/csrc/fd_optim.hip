@@ -81,6 +81,7 @@ extern "C" int fd_adamw_step(fd_ctx* ctx, float* params, const float* grads, flo
                              int64_t frozen_end, void* stream) {
     if (!ctx) return FD_ERR_ARG;
     FD_REQUIRE(ctx, params && grads && exp_avg && exp_avg_sq && n > 0, "fd_adamw_step: null pointer or n <= 0");
+    if (int rc = fd_train_async_check(ctx)) return rc;      // (a timed-out hand-over of the step whose gradients these are)
     FD_REQUIRE(ctx, step >= 1, "fd_adamw_step: step is 1-based, got %d", step);
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);

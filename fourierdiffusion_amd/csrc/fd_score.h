@@ -75,7 +75,7 @@ size_t fd_score_bwd_workspace(const fd_score* m, int B);   // fd_score_bwd.hip
 // fd_score_bf16.hip
 int fd_bf16_create(fd_score* m);
 void fd_bf16_destroy(fd_score* m);
-int fd_bf16_prepare(fd_score* m, hipStream_t s, bool training_only = false);
+int fd_bf16_prepare(fd_score* m, hipStream_t s, bool training_only = false, bool ffn32_only = false);
 int fd_bf16_refresh(fd_score* m, hipStream_t s, bool training_only = false);   // (training_only: without the sampler-only images)
 // rebuilds the images if the masters changed since the last build
 int fd_score_forward_bf16(fd_score* m, const float* x, const float* t, float* out, int B, hipStream_t s);

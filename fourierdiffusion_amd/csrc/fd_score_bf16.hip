@@ -220,10 +220,11 @@ struct fd_img_build {
     int n_qkv, n_wo, n_ffn, n_wot, n_win, n_lp;   // block counts per layer (n_qkv = NP*KS1 per matrix)
     int mega, train;
     float qscale;
+    int blk_first;      // block index of grid block 0 (a partial rebuild starts inside the block list)
 };
 __global__ __launch_bounds__(64) void k_build_layer_images(const fd_img_build B) {
     const int l = blockIdx.y, lane = threadIdx.x;
-    int blk = blockIdx.x;
+    int blk = blockIdx.x + B.blk_first;
     const long long* lo = B.lofs + (size_t)l * 12;      // in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, ...
     const float* P = B.P;
     // (1) inference FFN image [F-half][chunk][block]
@@ -841,7 +842,7 @@ void fd_bf16_destroy(fd_score* m) {
     m->bf16 = nullptr;
 }
 
-int fd_bf16_prepare(fd_score* m, hipStream_t s, bool training_only) {
+int fd_bf16_prepare(fd_score* m, hipStream_t s, bool training_only, bool ffn32_only) {
     fd_bf16_images* im = m->bf16;
     if (!im || !im->supported) return FD_OK;
     // the pair-form FFN image is read by the persistent sampler kernel only: a training step's rebuild skips it (a quarter of the
@@ -866,6 +867,14 @@ int fd_bf16_prepare(fd_score* m, hipStream_t s, bool training_only) {
     int per_layer = B.n_ffn;
     if (B.mega) per_layer += 3 * B.n_qkv + B.n_wo + B.n_ffn + B.n_lp + B.n_ffn32;
     if (B.mega && B.train) per_layer += B.n_ffn + B.n_wot + B.n_win;
+    if (ffn32_only) {
+        // the parameters have not changed since a training-step rebuild that skipped the pair-form FFN image: build just that
+        // (a quarter of the blocks; ADVICE r4: the first inference call after a training step rebuilt everything)
+        B.blk_first = B.n_ffn + 3 * B.n_qkv + B.n_wo + B.n_ffn + B.n_lp;
+        if (L > 0 && B.n_ffn32 > 0) hipLaunchKernelGGL(k_build_layer_images, dim3(B.n_ffn32, L), dim3(64), 0, s, B);
+        FD_LAUNCH_CHECK(m->ctx);
+        return FD_OK;
+    }
     if (L > 0) hipLaunchKernelGGL(k_build_layer_images, dim3(per_layer, L), dim3(64), 0, s, B);
     if (im->pimg) {
         for (int i = 0; i < L; ++i) {
@@ -993,7 +1002,8 @@ void add_layernorm(const float* a, const float* r, const float* gamma, const flo
 
 int fd_bf16_refresh(fd_score* m, hipStream_t s, bool training_only) {
     if (!m->bf16_stale && (training_only || !m->bf16 || !m->bf16->ffn32_stale)) return FD_OK;
-    if (int rc = fd_bf16_prepare(m, s, training_only)) return rc;
+    const bool ffn32_only = !m->bf16_stale;          // (=> !training_only && ffn32_stale)
+    if (int rc = fd_bf16_prepare(m, s, training_only, ffn32_only)) return rc;
     m->bf16_stale = false;
     return FD_OK;
 }

@@ -139,26 +139,74 @@ struct FSplit {
     float* ypart;             // [blocks][4 tiles][DT][64 lanes] f32x4
     unsigned* flag;           // [blocks][4 tiles]
     unsigned epoch;           // unique per launch
+    unsigned* err;            // host-visible error word (pinned, mapped): 0, or 0x80000000 | (block << 2 | tile) of the first hand-over
+                              // that timed out -- the host checks it at the entry of the next training call (fd_train_async_check)
+    unsigned long long timeout;   // bound of the finisher's wait in ticks of the constant 100 MHz clock (s_memrealtime)
+    int fence;                // 1: release / acquire fences instead of per-element coherent accesses (FDIFF_TR_FSPLIT_FENCE=1)
+    int stall;                // test hook (FDIFF_TR_FSPLIT_TEST_STALL=1): the producer never raises its flags
 };
 // The hand-over moves 5 KiB per token tile between two workgroups that may sit on different XCDs (separate, mutually
 // non-coherent L2s).  An agent-scope release / acquire FENCE would write back / invalidate the whole L2 of the XCD (measured:
-// both FFN kernels at 1.4 x their unsplit time); instead every element is itself an agent-scope relaxed atomic access -- a
-// write-through store / an L2-bypassing load -- and the flag is stored once the element stores have been acknowledged.
+// both FFN kernels at 1.4 x their unsplit time; that form stays selectable, `fence`); instead every element is itself an
+// agent-scope relaxed atomic access -- a write-through store (sc1) / an L2-bypassing load -- and the flag is stored once the
+// element stores have been acknowledged.
+// Why this orders the data without a fence (it is outside the HIP memory model, which only speaks of fences and
+// acquire / release; it rests on the gfx950 memory pipeline): (1) an agent-scope atomic store is written through to the
+// memory-side coherence point shared by all XCDs and is counted in vmcnt until that write is ACKNOWLEDGED, so after
+// `s_waitcnt vmcnt(0)` every element is visible to any agent-scope access from any XCD; (2) the flag store is issued only
+// after that wait (the asm statement is a compiler barrier and the hardware issues in order); (3) the finisher's element
+// loads are issued after the loop that saw the flag (control dependence on a loaded value + compiler barrier), and as
+// agent-scope atomic loads they bypass its own XCD's non-coherent L2 lines.
+// The finisher's wait is BOUNDED: a producer that is never scheduled (a CU-masked queue, a partition mode with fewer CUs than
+// 2 x blocks, a co-tenant kernel that never retires) or that faulted would otherwise hang the device without a diagnostic.  After
+// `timeout` ticks the finisher records (block, tile) in the error word and carries on with its own half -- the step's gradients
+// are then wrong, and the next training call on the context fails with FD_ERR_STATE naming the block.
 template <int DT>
 __device__ __forceinline__ void fsplit_hand_over(const FSplit& fs, int blk, int tile, int lane, const f32x4 (&acc)[DT]) {
     float* yp = fs.ypart + (((size_t)(blk * 4 + tile) * DT) * 64 + lane) * 4;
+    if (fs.fence) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(yp + dt * 256) = acc[dt];
+        if (fs.stall) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(fs.flag + blk * 4 + tile, fs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) __hip_atomic_store(yp + dt * 256 + r, acc[dt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(fs.flag + blk * 4 + tile, fs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0 && !fs.stall) __hip_atomic_store(fs.flag + blk * 4 + tile, fs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int DT>
 __device__ __forceinline__ void fsplit_take_over(const FSplit& fs, int blk, int tile, int lane, f32x4 (&acc)[DT]) {
-    while (__hip_atomic_load(fs.flag + blk * 4 + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fs.epoch) __builtin_amdgcn_s_sleep(16);
-    asm volatile("" ::: "memory");
+    if (__hip_atomic_load(fs.flag + blk * 4 + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fs.epoch) {
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0u;
+        bool seen = false;
+        for (;;) {
+            __builtin_amdgcn_s_sleep(16);
+            if (__hip_atomic_load(fs.flag + blk * 4 + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fs.epoch) { seen = true; break; }
+            if ((++spins & 63u) == 0u && wall_clock64() - t0 > fs.timeout) break;
+        }
+        if (!seen) {          // (wave-uniform: the flag address and the clock are)
+            if (lane == 0) {
+                unsigned expected = 0u;
+                __hip_atomic_compare_exchange_strong(fs.err, &expected, 0x80000000u | (unsigned)(blk * 4 + tile), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+    }
     const float* yp = fs.ypart + (((size_t)(blk * 4 + tile) * DT) * 64 + lane) * 4;
+    if (fs.fence) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[dt] += *reinterpret_cast<const f32x4*>(yp + dt * 256);
+        return;
+    }
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -2234,12 +2282,24 @@ size_t tr_attn_bwd_lds(int T, bool one_head) {
            nhs * (size_t)T * NJ * 4 + 16 + 256 + nhs * KT * 16 * NJ * 4;
 }
 
-// buffers + a fresh epoch for one F-split launch (fs stays empty when the launch is not split)
+// buffers + a fresh epoch for one F-split launch (fs stays empty when the launch is not split).
+// Constraints of the split, stated here because nothing in the signature does: (1) the partial-sum buffer, the flags, the epoch
+// counter and the error word belong to the CONTEXT -- one training step at a time per context, on one stream (the library's
+// general rule: a context is not thread-safe), two models may alternate on a context but not overlap; (2) the epoch is a kernel
+// argument, so a training step must not be stream-captured and replayed (a replay would meet flags that already equal its
+// epoch and add stale partial sums; the Philox offsets of the dropout decisions change per step as well); (3) the buffers
+// are sized once for CUs / 2 token blocks -- the rule below never splits more -- so the steady state neither allocates nor
+// synchronises.
 int tr_fsplit_prepare(fd_ctx* ctx, const TrDims& d, int blocks, int DT, FSplit* fs, hipStream_t s) {
     *fs = FSplit{};
     if (d.fsplit != 2) return FD_OK;
+    if (!ctx->tr_err_host) {
+        FD_HIP(ctx, hipHostMalloc((void**)&ctx->tr_err_host, 64, hipHostMallocMapped));
+        *ctx->tr_err_host = 0u;
+        FD_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->tr_err_dev, ctx->tr_err_host, 0));
+    }
     if ((size_t)blocks > ctx->tr_fsplit_blocks) {
-        // (the old buffers may still be read by a launch in flight on `s`)
+        // (first use on this context; or a device whose CU count changed under us: the old buffers may still be read by a launch in flight)
         FD_HIP(ctx, hipStreamSynchronize(s));
         if (ctx->tr_ypart) (void)hipFree(ctx->tr_ypart);
         if (ctx->tr_yflag) (void)hipFree(ctx->tr_yflag);
@@ -2252,6 +2312,15 @@ int tr_fsplit_prepare(fd_ctx* ctx, const TrDims& d, int blocks, int DT, FSplit* 
     }
     (void)DT;
     fs->ypart = ctx->tr_ypart; fs->flag = ctx->tr_yflag; fs->epoch = ++ctx->tr_epoch;
+    if (fs->epoch == 0u) fs->epoch = ++ctx->tr_epoch;      // (0 is the flags' initial value)
+    fs->err = ctx->tr_err_dev;
+    const char* e = getenv("FDIFF_TR_FSPLIT_TIMEOUT_MS");      // (read per call: the tests set it inside one process)
+    const double ms = e ? std::max(1.0, atof(e)) : 2000.0;
+    fs->timeout = (unsigned long long)(ms * 1.0e5);           // 100 MHz constant clock
+    e = getenv("FDIFF_TR_FSPLIT_FENCE");
+    fs->fence = (e && atoi(e) != 0) ? 1 : 0;
+    e = getenv("FDIFF_TR_FSPLIT_TEST_STALL");
+    fs->stall = (e && atoi(e) != 0) ? 1 : 0;
     return FD_OK;
 }
 
@@ -2799,6 +2868,7 @@ size_t fd_train_bf16_workspace(const fd_score* m, int B) { return tr_carve(m, B,
 int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, float* out, int B, float p, uint64_t seed,
                                 uint64_t offset, hipStream_t s) {
     fd_ctx* ctx = m->ctx;
+    if (int rc = fd_train_async_check(ctx)) return rc;
     if (!fd_train_bf16_supported(m)) return fd_fail(ctx, FD_ERR_UNSUPPORTED, "bf16 training path unsupported for this model");
     // The optimizer step made the bf16 weight images stale.  Rebuilding them (~50 us of small kernels) needs nothing but the
     // parameters, and the step's prologue on `s` (time embedding, embedding, first layer's operand preparation) does not need
@@ -2836,6 +2906,7 @@ int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, flo
 
 int fd_score_backward_bf16(fd_score* m, const float* dout, float* grads, int accumulate, hipStream_t s) {
     fd_ctx* ctx = m->ctx;
+    if (int rc = fd_train_async_check(ctx)) return rc;
     const size_t need = fd_train_bf16_workspace(m, m->saved_B);
     if (ctx->ws_bytes < need) return fd_fail(ctx, FD_ERR_STATE, "fd_score_backward: workspace was resized since the training forward");
     TrBufs tb;
@@ -2880,6 +2951,7 @@ int fd_score_train_dsm_bf16(fd_score* m, const float* x, const float* t, const f
                             float grad_weight, int B, float p, uint64_t seed, uint64_t offset, float* loss_out, float* grads,
                             int accumulate, hipStream_t s) {
     fd_ctx* ctx = m->ctx;
+    if (int rc = fd_train_async_check(ctx)) return rc;
     if (!fd_train_bf16_supported(m)) return fd_fail(ctx, FD_ERR_UNSUPPORTED, "bf16 training path unsupported for this model");
     const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model;
     const int CD = C * D;

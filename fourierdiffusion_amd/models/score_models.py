@@ -319,11 +319,14 @@ class ScoreModule:
         # capability per batch size, asked BEFORE a Philox key is drawn (an unsupported batch must not consume one: the trainer
         # counts keys per step to keep empty-slice ranks in step) and cached per B -- one oversized batch does not switch the
         # fused step off for later, smaller ones
+        # (key: the engine handle the answer was given for, the batch size, and the one environment switch the C side reads per
+        # call -- a recreated handle or a toggled FDIFF_TRAIN_DSM_UNFUSED must not meet a stale verdict)
         Bn = int(x_noisy.shape[0])
         cache = self.__dict__.setdefault("_fused_dsm_ok", {})
-        ok = cache.get(Bn)
+        ckey = (int(h.value) if hasattr(h, "value") else int(h), Bn, os.environ.get("FDIFF_TRAIN_DSM_UNFUSED"))
+        ok = cache.get(ckey)
         if ok is None:
-            ok = cache[Bn] = bool(_C.lib().fd_score_train_dsm_supported(h, Bn))
+            ok = cache[ckey] = bool(_C.lib().fd_score_train_dsm_supported(h, Bn))
         if not ok:
             return None
         Xd = _C.dev_f32(x_noisy.to(self.device), "x_noisy")

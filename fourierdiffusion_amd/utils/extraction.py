@@ -31,6 +31,11 @@ def _plain(node):
     return node
 
 
+class _ItemKey(str):
+    """Key of a list ITEM's event (`name[i]`, made up by _walk): marked by type, not by spelling, so that a genuine user key that
+    happens to look like one (`layers[0]: x`) is never mistaken for it."""
+
+
 def _walk(cfg) -> Iterator[Tuple[str, Any]]:
     """Depth-first (key, value) events of a config tree in document order.  A mapping that names a `_target_` reports that name
     under its own key before its children; a list reports the `_target_` names of its mapping items (a list) after their children;
@@ -56,7 +61,7 @@ def _walk(cfg) -> Iterator[Tuple[str, Any]]:
             maps = [v for v in items if isinstance(v, dict)]
             names = [v["_target_"] for v in maps if "_target_" in v]
             # children of every mapping item first, then the list's own entry
-            stack.append(iter([(f"{key}[{i}]", v) for i, v in enumerate(maps)]))
+            stack.append(iter([(_ItemKey(f"{key}[{i}]"), v) for i, v in enumerate(maps)]))
             pending.append((len(stack), key, names))
         elif key not in _META_KEYS:
             yield key, val
@@ -67,7 +72,7 @@ def flatten_config(cfg) -> Dict[str, Any]:
     (same result as the reference's recursive version :20-55, e.g. its tests/test_utils.py example)."""
     flat: Dict[str, Any] = {}
     for key, val in _walk(cfg):
-        if "[" in key and key.endswith("]") and isinstance(val, str):
+        if isinstance(key, _ItemKey):
             continue                               # the `_target_` of a list item is reported through the list's own entry
         flat[key] = val
     return flat

@@ -46,6 +46,12 @@ int fd_ctx_destroy(fd_ctx* ctx);
 const char* fd_last_error(fd_ctx* ctx);   /* host string, valid until the next call on ctx */
 /* number of bytes currently held by the ctx workspace (activations, scratch) */
 size_t fd_ctx_workspace_bytes(fd_ctx* ctx);
+/* Asynchronous device-side errors recorded since the last report: FD_OK, or FD_ERR_STATE when a kernel of an earlier training
+ * call gave up a bounded inter-workgroup wait (the F-split hand-over of the training FFN kernels: fd_last_error names the token
+ * block; that step's gradients are invalid).  Never synchronises -- call it behind a stream synchronisation to cover everything
+ * enqueued so far.  Every training / optimizer entry point performs the same check on entry.  (The reference has no
+ * counterpart: torch autograd, src/fdiff/models/score_models.py:96-108, has no inter-workgroup protocol to fail.) */
+int fd_ctx_check(fd_ctx* ctx);
 
 /* ---------------------------------------------------------- measurement hooks
  * bench.py's roofline leg: between fd_prof_begin and fd_prof_end the engine brackets every launch of its

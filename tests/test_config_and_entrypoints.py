@@ -90,6 +90,8 @@ def test_flatten_config_matches_reference_example():
            "Option6": "Value6"}
     assert flatten_config(cfg) == {"Option1": "Value1", "Option2": "Value2", "Option3": "Value3", "Option4": "Value4",
                                    "Option5": ["Value5_0", "Value5_1"], "Option6": "Value6"}
+    # a genuine user key that is spelled like a list item's event survives (the reference keeps it: its recursion never invents keys)
+    assert flatten_config({"layers[0]": "x", "a": [{"_target_": "T0", "b": 1}]}) == {"layers[0]": "x", "b": 1, "a": ["T0"]}
 
 
 def test_best_checkpoint_and_model_type(tmp_path):

@@ -29,7 +29,9 @@ LONG = dict(T=1024, C=16, D=72, L=10, H=12)
 
 
 @pytest.mark.parametrize("name", sorted(TRAIN_SHAPES))
-def test_training_gradients_at_the_benched_batch(name):
+def test_training_gradients_at_the_benched_batch_vs_exact_f32_engine_reference_anchored_at_B_le_6(name):
+    """TRANSITIVE parity: bf16 kernels against the exact-f32 ENGINE at B = 64; the exact-f32 engine itself is held to the
+    reference's autograd fixtures at B = 2 ... 6 only (test_gpu_train_bf16.py / test_gpu_score_bwd.py)."""
     from fourierdiffusion_amd.utils.losses import get_sde_loss_fn
     cfg, B = TRAIN_SHAPES[name], 64
     X = W.randn(f"bs_x_{name}", (B, cfg["T"], cfg["C"]), 3)

@@ -5,7 +5,8 @@ kernels per encoder layer.  Anchors:
     BASELINE training shape (nasdaq T=252, C=6),
 at bf16 tolerances, stated per test and logged with the measured values (profiles/r02_parity_errors.txt):
   * every tensor: ||g - ref|| <= 3e-2 ||ref|| and max |g - ref| <= 8e-2 max |ref| for d_model >= 60 (measured: 0.4-2.5e-2
-    and 0.5-7e-2); the toy models (d_model 8 / 24: 8- and 24-term dot products, linear1 gradients of 1e-6) 8e-2 and 0.5;
+    and 0.5-7e-2); the toy models (d_model 8 / 24: 8- and 24-term dot products, linear1 gradients of 1e-6) l2 <= 8e-2 and NO
+    per-tensor max bound (one relu flip is 0.44 of a few-hundred-element tensor's maximum: a bound that passes asserts nothing);
   * whole gradient: cosine with the reference >= 0.9995, ||g - ref|| <= 2e-2 ||ref||;
   * loss (bf16 forward) within 1e-2 relative.
 linear1.weight/bias carry the largest error of all tensors by construction: relu' is discontinuous, so a hidden unit whose
@@ -58,7 +59,8 @@ def _compare_grads(tag, got, ref, max_tol=8e-2, l2_tol=3e-2):
     glob = float(np.linalg.norm(gf - rf) / np.linalg.norm(rf))
     _log(f"[parity] bf16 training gradients {tag}: worst max-rel {wm[0]:.3e} ({wm[2]}), worst l2-rel {wl[1]:.3e} ({wl[2]}), "
          f"whole gradient: cosine {cos:.6f}, l2-rel {glob:.3e}")
-    bad = [(k, f"{a:.3e}", f"{b:.3e}") for a, b, k in rows if not (a <= max_tol and b <= l2_tol)]
+    # max_tol None: no per-tensor max bound (toy widths, where it would have to be ~0.5 and assert nothing) -- per-tensor l2 + cosine only
+    bad = [(k, f"{a:.3e}", f"{b:.3e}") for a, b, k in rows if not ((max_tol is None or a <= max_tol) and b <= l2_tol)]
     if bad:
         for a, b, k in sorted(rows, reverse=True)[:8]:
             g, r = got[k], ref[k]
@@ -91,9 +93,11 @@ def test_loss_and_gradients_vs_reference_autograd(golden, name, B):
         ref = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(f"grad_{tag}/")}
         got = _grads_of(m)
         assert float(m.grad_views()["time_encoder.W"].abs().max()) == 0.0
-        # d_model = 8 (tiny): 8-term dot products, one bf16 rounding (2^-9) is a larger share of every sum
-        # d_model = 8 / 24 (toys): 8- and 24-term dot products, one bf16 rounding (2^-9) is a larger share of every sum
-        _compare_grads(tag, got, ref, max_tol=0.5, l2_tol=8e-2)
+        # d_model = 8 / 24 (toys): 8- and 24-term dot products, one bf16 rounding (2^-9) is a larger share of every sum, and a
+        # tensor has a few hundred elements: a single relu flip moves ONE element of linear1.weight by up to 0.44 of the tensor
+        # maximum (measured, logged).  A per-tensor max bound loose enough to pass (0.5) asserts nothing, so these cases assert
+        # what does hold them: every tensor's l2-rel <= 8e-2 and the whole gradient's cosine >= 0.9995 / l2-rel <= 7e-2.
+        _compare_grads(tag, got, ref, max_tol=None, l2_tol=8e-2)
 
 
 SHAPES = {
@@ -198,6 +202,95 @@ def test_ffn_f_split_agrees_with_the_unsplit_kernels(monkeypatch, cfg, B, p):
     _log(f"[parity] FFN F-split vs unsplit kernels ({tag}): loss {res['1'][0]:.6f} vs {res['0'][0]:.6f}, worst max-rel {wm[0]:.3e} ({wm[2]}), "
          f"worst l2-rel {wl[1]:.3e} ({wl[2]})")
     assert wm[0] <= 8e-2 and wl[1] <= 1.5e-2, (wm, wl)
+
+
+def test_ffn_f_split_survives_a_cotenant_kernel_and_its_fence_form_agrees(monkeypatch):
+    """The F-split finisher waits for a producer workgroup of the SAME grid (a bounded spin, struct FSplit).  Stress: the split at
+    its largest allowed grid (125 token blocks -> 250 workgroups on 256 CUs, both FFN kernels: FDIFF_TR_FSPLIT=2) while a
+    co-tenant stream keeps every CU busy with large GEMMs, 150 optimizer-free steps = 150 x 2 layers x 2 kernels x 500 hand-overs;
+    every step must reproduce the first one bit for bit, no hand-over may time out (fd_ctx_check), and the release / acquire
+    FENCE form of the hand-over (FDIFF_TR_FSPLIT_FENCE=1, the memory-model-conforming fallback) must give the same bits as the
+    per-element coherent accesses (same sums in the same order)."""
+    from fourierdiffusion_amd import _C
+    from fourierdiffusion_amd.utils.losses import get_sde_loss_fn
+    cfg, B = dict(T=100, C=12, D=72, L=2, H=12), 80
+    X = W.randn("fsx_x", (B, cfg["T"], cfg["C"]), 3)
+    z = W.randn("fsx_z", (B, cfg["T"], cfg["C"]), 3)
+    t = W.uniform("fsx_t", (B,), 3, 0.05, 1.0)
+    m, sch, _ = make_model(cfg, precision="bf16")
+    fn = get_sde_loss_fn(sch, train=True)
+    bt = batch_of(X, t)
+    zd = dev(z)
+    ctx, _h = m._engine()
+
+    def step():
+        m.zero_grad()
+        torch.manual_seed(91)
+        loss = fn(m, bt, noise=zd)
+        return loss, m.grads.clone()
+    monkeypatch.setenv("FDIFF_TR_FSPLIT", "0")
+    l0, g0 = step()
+    monkeypatch.setenv("FDIFF_TR_FSPLIT", "2")
+    l1, g1 = step()
+    assert not torch.equal(g0, g1), "the split form did not run"
+    assert abs(l1.item() - l0.item()) <= 2e-4 * abs(l0.item())
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV)
+    stop_after = 150
+    bad = 0
+    for it in range(stop_after):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                a = torch.mm(a, a) * 1e-4          # ~140 GFLOP each: a few hundred microseconds of every CU
+        l, g = step()
+        bad += int(not torch.equal(g, g1)) + int(l.item() != l1.item())
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} of {stop_after} split steps beside the co-tenant kernel differ from the solo split step"
+    assert _C.lib().fd_ctx_check(ctx) == 0, _C.lib().fd_last_error(ctx)
+    monkeypatch.setenv("FDIFF_TR_FSPLIT_FENCE", "1")
+    lf, gf = step()
+    torch.cuda.synchronize()
+    assert lf.item() == l1.item() and torch.equal(gf, g1), "fence form and coherent-access form of the hand-over disagree"
+    assert _C.lib().fd_ctx_check(ctx) == 0
+
+
+def test_ffn_f_split_timeout_is_reported_not_hung(monkeypatch):
+    """A producer that never raises its flags (test hook FDIFF_TR_FSPLIT_TEST_STALL=1: what an unscheduled or faulted producer
+    looks like to the finisher) must not hang the device: the finisher gives up after FDIFF_TR_FSPLIT_TIMEOUT_MS, the step
+    completes, and the NEXT call on the context fails with FD_ERR_STATE naming the token block; after that the context works
+    again and reproduces the healthy gradient."""
+    from fourierdiffusion_amd import _C
+    from fourierdiffusion_amd.utils.losses import get_sde_loss_fn
+    cfg, B = dict(T=100, C=12, D=72, L=2, H=12), 9
+    X = W.randn("fst_x", (B, cfg["T"], cfg["C"]), 3)
+    z = W.randn("fst_z", (B, cfg["T"], cfg["C"]), 3)
+    t = W.uniform("fst_t", (B,), 3, 0.05, 1.0)
+    m, sch, _ = make_model(cfg, precision="bf16")
+    fn = get_sde_loss_fn(sch, train=True)
+    ctx, _h = m._engine()
+    lib = _C.lib()
+
+    def step():
+        m.zero_grad()
+        torch.manual_seed(92)
+        fn(m, batch_of(X, t), noise=dev(z))
+        torch.cuda.synchronize()
+        return m.grads.clone()
+    good = step()
+    assert lib.fd_ctx_check(ctx) == 0
+    monkeypatch.setenv("FDIFF_TR_FSPLIT_TEST_STALL", "1")
+    monkeypatch.setenv("FDIFF_TR_FSPLIT_TIMEOUT_MS", "5")
+    import time
+    t0 = time.perf_counter()
+    stalled = step()                                   # completes: every wait is bounded
+    assert time.perf_counter() - t0 < 5.0
+    assert not torch.equal(stalled, good)
+    monkeypatch.delenv("FDIFF_TR_FSPLIT_TEST_STALL")
+    monkeypatch.delenv("FDIFF_TR_FSPLIT_TIMEOUT_MS")
+    with pytest.raises(_C.FdError, match="F-split hand-over timed out at token block"):
+        step()                                         # the entry check of the next training call reports it ...
+    assert lib.fd_ctx_check(ctx) == 0                  # ... once
+    assert torch.equal(step(), good)
 
 
 def test_bf16_training_range_in_series_length():

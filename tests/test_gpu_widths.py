@@ -117,7 +117,7 @@ def test_bf16_training_at_head_dim_8(cfg):
     lf, lb = res["fp32"][0], res["bf16"][0]
     assert abs(lb - lf) <= 1e-2 * abs(lf), (lb, lf)
     _compare_grads(f"d_model {cfg['D']} / {cfg['H']} heads (head_dim 8), bf16 vs exact-f32 engine, dropout off", res["bf16"][1], res["fp32"][1],
-                   **(dict(max_tol=0.5, l2_tol=8e-2) if cfg["D"] < 64 else {}))      # (toy-width tolerances of test_gpu_train_bf16.py: tensors of a few hundred elements)
+                   **(dict(max_tol=None, l2_tol=8e-2) if cfg["D"] < 64 else {}))      # (toy-width rule of test_gpu_train_bf16.py: per-tensor l2 + whole-gradient cosine, no per-tensor max bound)
     # dropout on: one optimizer step through the fused training call
     m, _, _ = make_model(cfg, precision="bf16")
     m.train()
