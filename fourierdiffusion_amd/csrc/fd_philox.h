@@ -2,9 +2,14 @@
 // One counter value yields 4 standard normals; element e of a tensor uses counter
 // (offset + e/4) and lane e%4, so any kernel shape reproduces the same stream.
 #pragma once
+#ifdef __HIPCC_RTC__      // run-time compilation (fd_mega_rtc.hip): the HIP device runtime is implicit, host headers do not exist
+typedef unsigned int uint32_t;
+typedef unsigned long uint64_t;
+#else
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#endif
 
 struct fd_u4 {
     uint32_t x, y, z, w;

@@ -227,6 +227,16 @@ int fd_score_forward(fd_score* m, const float* x, const float* t, float* out, in
  * is `ShapeStatic<100,72,12,12,2,...>` with S = 2 on a 256-CU device).  No reference counterpart. */
 int fd_score_plan(fd_score* m, int B, int mode, char* out /* >= 192 bytes */, int* series_per_workgroup /* nullable */);
 
+/* Run-time specialisation of the persistent kernel (csrc/fd_mega_rtc.hip).  The library carries static-shape instantiations of
+ * k_mega for the BASELINE shapes only; any other (model class, series shape, workgroup plan) gets its own through hiprtc on first use
+ * -- FDIFF_MEGA_JIT: unset = sampler loops of >= 100 diffusion steps, 1 = every launch, 0 = never -- cached on disk under
+ * $FDIFF_CACHE_DIR (default ~/.cache/fdiff_hip).  This entry compiles ONE instantiation into that cache without loading it (no GPU
+ * needed): key14 = {KS1, DT, KSO, MT, T, D, C, H, S, NPG, rot, L, F, FFN32} as fd_score_plan prints them; msg (nullable, n bytes)
+ * receives the instantiation and where its code object came from.  FD_ERR_UNSUPPORTED when hiprtc is missing or the compilation
+ * fails (the engine then runs its run-time-shape instantiation).  Replaces nothing in the reference: torch specialises nothing per
+ * dataset shape (src/fdiff/models/score_models.py:57-62 builds one nn.TransformerEncoder for every (max_len, n_channels)). */
+int fd_mega_jit_compile(const int* key14, char* msg, int n);
+
 /* Arithmetic of the training pair below: FD_MODE_F32 (default; exact-f32 kernels, the parity anchor, any model) or
  * FD_MODE_BF16 (bf16 MFMA operands, fp32 accumulate/LayerNorm/softmax; five fused kernels per encoder layer, weight
  * gradients reduced in a fixed order: bit-reproducible).  FD_ERR_UNSUPPORTED when the bf16 kernels are not instantiated

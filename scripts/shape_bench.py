@@ -12,7 +12,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = {"ecg": (100, 12), "nasdaq": (252, 6), "mimic": (256, 28), "long": (1024, 16), "ecg187": (187, 1), "mimic24": (24, 40),
-          "nasa": (134, 10)}
+          "nasa": (134, 10),
+          # the shapes the reference's datamodules produce (datamodules.py:194-201, 404-410, 471-476; mimiciii.yaml:7)
+          "nasdaq5": (252, 5), "nasa251": (251, 4), "nasa134": (134, 5)}
 
 
 def flops_fwd(T, Cn, D=72, L=10, F=2048):
@@ -64,8 +66,10 @@ def main():
         run()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / N
+        tf = B * flops_fwd(T, Cn) / dt / 1e12
         print(f"{name} sample B={B} T={T} C={Cn} {m.precision}: {1e3 * dt:.3f} ms per diffusion step, "
-              f"{B * flops_fwd(T, Cn) / dt / 1e12:.1f} TFLOP/s algorithmic, {B / (dt * 1000):.1f} series/s at N=1000")
+              f"{tf:.1f} TFLOP/s algorithmic = {tf / 2500:.4f} of the bf16 peak, {B / (dt * 1000):.1f} series/s at N=1000 "
+              f"[N={N}, FDIFF_MEGA_JIT={os.environ.get('FDIFF_MEGA_JIT', 'auto')}; {m.plan(B)[0].split(' S=')[0]}]")
     else:
         from fourierdiffusion_amd.optim import FusedAdamW
         m.train()
