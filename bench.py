@@ -431,6 +431,11 @@ def main():
                         "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
                         "avg_kernel_us": avg_us.value, "launches_timed": cnt.value,
                         "flops_per_launch": flops.value}
+                # the shader clock the persistent kernel ran at (its own shader-clock counter against the wall clock): the chip is
+                # power-limited on this kernel and boxes of the pool differ by +-2.5 % -- the record carries the clock beside the time
+                mhz = C.c_double(0)
+                if lib.fd_prof_shader_clock_mhz(ctx, C.byref(mhz)) == 0 and mhz.value > 0:
+                    roof["shader_clock_mhz"] = round(mhz.value, 1)
         out["roofline"] = roof
         if ranks_info is not None:
             out["ranks"] = ranks_info

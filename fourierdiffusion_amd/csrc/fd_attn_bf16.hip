@@ -118,10 +118,17 @@ struct fd_attn_w {
 //      the registers that die during the current block.  scripts/ubench/attn_pattern.hip prices the steady state at
 //      ~1.6 K cycles per block and SIMD (VALU: 128 exp2 x 8 + 64 cvt_pk x 4 = 1.28 K); draining and refilling the pipeline at
 //      every block boundary cost 2.0 K.
-template <int KS1>
+//   ROWS (with KS1 > 0): the layer input also exists as bf16 rows `xrows` (B*T, 32 KS1 k-slots, 1.0 in slot D, zero padding --
+//      written by the producer of the layer input: k_ffn_ln's epilogue / k_unembed_step_embed): a token tile's B fragment is
+//      then ONE 16-byte load per k-step and lane, three instructions walking 16 x 64 contiguous bytes each, against six fp32
+//      loads walking 32 half-used lines each plus twelve conversions and their selects.  The staging phase of this kernel is
+//      bound by the CU's vector-memory address path (phase clocks at T = 1024: 20 K of a workgroup's 88 K cycles with fp32 rows,
+//      profiles/r05_attn_long_phase_clocks_before.txt).
+template <int KS1, int ROWS = 0>
 __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const float* __restrict__ in, float* __restrict__ out, int T,
                                                            int H, int hd, int D, float qscale, int du_per_block, int exact_only,
-                                                           fd_attn_w wimg, size_t pair_stride, int slices, int B, int out_bf16) {
+                                                           fd_attn_w wimg, size_t pair_stride, int slices, int B, int out_bf16,
+                                                           const __bf16* __restrict__ xrows) {
     constexpr bool PROJ = KS1 > 0;
     constexpr int KSN = PROJ ? KS1 : 1;
     // Workgroup -> (series, head pair, query slice).  Hardware workgroup ids go round-robin over the 8 XCDs; all
@@ -189,6 +196,48 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
             const u32x4 pk = {cvt_pk_bf16(a.x, a.y), cvt_pk_bf16(a.z, a.w), cvt_pk_bf16(c.x, c.y), cvt_pk_bf16(c.z, c.w)};
             return __builtin_bit_cast(bf16x8, pk);
         };
+        if constexpr (ROWS != 0) {
+            constexpr int RBW = 32 * KSN;
+            const __bf16* rbase = xrows + (size_t)b * T * RBW + 8 * g;
+            // fragments of a tile straight from the bf16 rows (clamped row; rows beyond T are cleared at their use)
+            auto rload = [&](int tile, u32x4 (&r)[KSN]) {
+                const int t = min(tile * 16 + tok, T - 1);
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) r[ks] = *reinterpret_cast<const u32x4*>(rbase + (size_t)t * RBW + 32 * ks);
+            };
+            u32x4 cur[KSN], nxt[KSN];
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) nxt[ks] = u32x4{0u, 0u, 0u, 0u};
+            if (wave < KT) rload(wave, cur);
+            for (int kt = wave; kt < (ABL == 2 ? min(KT, NW) : KT); kt += NW) {
+                if (kt + NW < KT) rload(kt + NW, nxt);
+                f32x4 a = f4zero(), c = f4zero(), qa = f4zero();
+                const bool isq = kt >= qt0 && kt < qt1;        // wave-uniform
+                const unsigned keep = (kt * 16 + tok < T) ? ~0u : 0u;
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {
+                    const bf16x8 xf = __builtin_bit_cast(bf16x8, u32x4{cur[ks][0] & keep, cur[ks][1] & keep, cur[ks][2] & keep, cur[ks][3] & keep});
+                    a = MFMA(wkf[ks], xf, a);
+                    c = MFMA(xf, wvf[ks], c);
+                    if (isq) qa = MFMA(wqf[ks], xf, qa);
+                }
+                *reinterpret_cast<u32x2*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8) = u32x2{cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
+                char* dst = vbf + ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16;
+                if (!(kmax_in_v && kt == 0 && lane == 7))          // (that row's first 8 bytes hold kmax)
+                    *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = u32x2{cvt_pk_bf16(c[0], c[1]), cvt_pk_bf16(c[2], c[3])};
+                if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
+                if (isq)
+                    *reinterpret_cast<u32x2*>(qbf + ((size_t)(kt - qt0) * 64 + lane) * 8) = u32x2{cvt_pk_bf16(qa[0], qa[1]), cvt_pk_bf16(qa[2], qa[3])};
+                float n2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+                float ea, eb;
+                swap16(n2, ea, eb);
+                n2 = row_max16(ea + eb);
+                if (tok == 0 && (g & 1) == 0)
+                    __hip_atomic_fetch_max(&kmax[g >> 1], __builtin_bit_cast(unsigned, n2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) cur[ks] = nxt[ks];
+            }
+        } else {
         float4 cur_lo[KSN], cur_hi[KSN], nxt_lo[KSN], nxt_hi[KSN];
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) nxt_lo[ks] = nxt_hi[ks] = float4{0.f, 0.f, 0.f, 0.f};
@@ -222,6 +271,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
                 cur_lo[ks] = nxt_lo[ks];
                 cur_hi[ks] = nxt_hi[ks];
             }
+        }
         }
     } else {
     // K: one thread per (token, lane group gq): the 4 dims 4(gq&1)..+3 of head gq>>1 -> one 8-byte row; dim slot hd
@@ -718,18 +768,21 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
 // head pair).  Returns FD_ERR_UNSUPPORTED when the shape does not fit (head_dim > 7, K/V^T of one series exceed the
 // LDS, or no instantiation for ks1): the caller then runs the unfused / exact-f32 path.
 // out_bf16: `out` receives bf16 rows (M, D) instead of fp32 ones (even head_dim only; the consumer is k_ffn_ln's fused prologue).
+// in_rows (nullable; fused projections only): the layer input as bf16 rows (B*T, 32 ks1), see the kernel's ROWS form.
 int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, int H, int hd, hipStream_t s, const char* wk,
-                      const char* wv, const char* wq, int ks1, int out_bf16) {
+                      const char* wv, const char* wq, int ks1, int out_bf16, const void* in_rows) {
     const int KT = (T + 15) / 16, NJ = (KT + 1) / 2, D = H * hd;
     const size_t lds_kv = (size_t)KT * 16 * 32 + (size_t)NJ * 1024 + (hd == 7 ? 16 : 0);
     if (hd > 7 || lds_kv + NQ * 512 > 160 * 1024) return FD_ERR_UNSUPPORTED;
     if (out_bf16 && (hd & 1)) return FD_ERR_UNSUPPORTED;
     const bool proj = wk != nullptr;
     if (proj && ((ks1 != 3 && ks1 != 2) || (D & 3))) return FD_ERR_UNSUPPORTED;   // (raw x rows are read as float4)
-    const void* kern = proj ? (ks1 == 3 ? (const void*)k_attention_bf16<3> : (const void*)k_attention_bf16<2>)
+    const bool rows = proj && in_rows != nullptr;
+    const void* kern = proj ? (ks1 == 3 ? (rows ? (const void*)k_attention_bf16<3, 1> : (const void*)k_attention_bf16<3>)
+                                        : (rows ? (const void*)k_attention_bf16<2, 1> : (const void*)k_attention_bf16<2>))
                             : (const void*)k_attention_bf16<0>;
-    static unsigned long long attr[3] = {};
-    if (fd_first_on_device(attr[proj ? (ks1 == 3 ? 2 : 1) : 0], ctx->device))
+    static unsigned long long attr[5] = {};
+    if (fd_first_on_device(attr[proj ? (ks1 == 3 ? 2 : 1) + (rows ? 2 : 0) : 0], ctx->device))
         FD_HIP(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int NP = (H + 1) / 2, DUS = (KT + NQ - 1) / NQ;
     // Query slices per (series, pair): every slice restages K/V (~16 % of a full slice's work) and keeps its own Q tiles in
@@ -759,9 +812,12 @@ int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, in
     const fd_attn_w w{wk, wv, wq};
     const size_t pair_stride = (size_t)ks1 * 1024;
     const dim3 grid((unsigned)(((B + 7) / 8) * 8 * NP * slices)), block(NTH);
-    if (!proj) hipLaunchKernelGGL(k_attention_bf16<0>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B, out_bf16);
-    else if (ks1 == 3) hipLaunchKernelGGL(k_attention_bf16<3>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B, out_bf16);
-    else hipLaunchKernelGGL(k_attention_bf16<2>, grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B, out_bf16);
+    const __bf16* xr = reinterpret_cast<const __bf16*>(in_rows);
+#define FD_ATT_GO(K, R) hipLaunchKernelGGL((k_attention_bf16<K, R>), grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B, out_bf16, xr)
+    if (!proj) FD_ATT_GO(0, 0);
+    else if (ks1 == 3) { if (rows) FD_ATT_GO(3, 1); else FD_ATT_GO(3, 0); }
+    else { if (rows) FD_ATT_GO(2, 1); else FD_ATT_GO(2, 0); }
+#undef FD_ATT_GO
     FD_LAUNCH_CHECK(ctx);
 #if defined(FD_ATTN_ABL) && FD_ATTN_ABL == 3
     {

@@ -64,6 +64,8 @@ struct fd_ctx {
     // timing event is a barrier packet: bracketing all 20 000 layer launches of a step-by-step sampler run would slow the run
     // it measures; every bracketed name of a window is launched equally often, so the totals stay comparable)
     bool prof_on = false;
+    unsigned long long* prof_clk = nullptr;   // device, 4 words: the persistent kernel's clock stamps of the window's last launch (fd_mega_params::clk_out)
+    double prof_clock_mhz = 0.0;              // shader clock of that launch (fd_prof_end), 0 when none was measured
     struct prof_kernel { std::string name; double flops; int scopes = 0; int seen = 0; };
     int prof_stride = 1;       // bracket every prof_stride-th launch of a name (fd_prof_stride)
     std::vector<prof_kernel> prof_kernels;

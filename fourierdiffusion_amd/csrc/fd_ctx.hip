@@ -30,6 +30,7 @@ extern "C" int fd_ctx_destroy(fd_ctx* ctx) {
     if (ctx->tr_ypart) (void)hipFree(ctx->tr_ypart);
     if (ctx->tr_yflag) (void)hipFree(ctx->tr_yflag);
     if (ctx->tr_err_host) (void)hipHostFree(ctx->tr_err_host);
+    if (ctx->prof_clk) (void)hipFree(ctx->prof_clk);
     for (hipEvent_t e : ctx->side_events) (void)hipEventDestroy(e);
     if (ctx->tr_readers_event) (void)hipEventDestroy(ctx->tr_readers_event);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
@@ -50,6 +51,12 @@ int fd_train_async_check(fd_ctx* ctx) {
                    "its producer's partial sums (producer not scheduled -- CU-masked queue / partitioned device / a co-tenant kernel "
                    "holding the CUs -- or faulted).  That step's gradients are invalid.  FDIFF_TR_FSPLIT=0 disables the split, "
                    "FDIFF_TR_FSPLIT_TIMEOUT_MS (default 2000) sets the bound.", id >> 2, id & 3u);
+}
+
+extern "C" int fd_prof_shader_clock_mhz(fd_ctx* ctx, double* mhz) {
+    if (!ctx || !mhz) return FD_ERR_ARG;
+    *mhz = ctx->prof_clock_mhz;
+    return FD_OK;
 }
 
 extern "C" int fd_ctx_check(fd_ctx* ctx) {
@@ -145,6 +152,12 @@ extern "C" int fd_prof_end(fd_ctx* ctx, char* name_out, double* avg_us, int* lau
         (void)hipEventDestroy(e.b);
     }
     ctx->prof_events.clear();
+    ctx->prof_clock_mhz = 0.0;
+    if (ctx->prof_clk) {        // (the events above are synchronised: the launch that wrote the stamps has completed)
+        unsigned long long c[4] = {0, 0, 0, 0};
+        if (hipMemcpy(c, ctx->prof_clk, sizeof c, hipMemcpyDeviceToHost) == hipSuccess && c[3] > c[1] && c[2] > c[0])
+            ctx->prof_clock_mhz = (double)(c[2] - c[0]) / ((double)(c[3] - c[1]) / 100.0);      // wall clock: 100 MHz
+    }
     if (getenv("FDIFF_PROF_VERBOSE"))     // every bracketed kernel of the window, not only the dominant one
         for (size_t k = 0; k < total_ms.size(); ++k)
             if (n[k] > 0)

@@ -436,6 +436,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
     __syncthreads();
 
     const int nsteps = (P.mode == FD_MEGA_SAMPLE) ? P.nsteps : 1;
+    if (P.clk_out && blockIdx.x == 0 && wave == 0 && lane == 0) {     // (stored at once: nothing stays live across the kernel)
+        P.clk_out[0] = __builtin_readcyclecounter();
+        P.clk_out[1] = wall_clock64();
+    }
     if (P.prof && wave == 0 && lane == 0 && blockIdx.x < 2048) {     // residency trace: start time + hardware id
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -1638,6 +1642,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mega(const fd_mega_params P) {
         mark(8, step);
         if (P.prof && step == nsteps - 1 && wave == 0 && lane == 0 && blockIdx.x < 2048)
             P.prof[2 * (4100 + blockIdx.x) + 1] = wall_clock64();
+        if (P.clk_out && step == nsteps - 1 && blockIdx.x == 0 && wave == 0 && lane == 0) {
+            P.clk_out[2] = __builtin_readcyclecounter();
+            P.clk_out[3] = wall_clock64();
+        }
         __syncthreads();   // x of this step is complete before the next step's embed reads it (same wave, but
                            // also fences the fragment region against the next embed's writes)
     }

@@ -29,6 +29,8 @@ struct fd_mega_params {
     int lds_afr;  // byte offset of the attention-output fragments in LDS
     int dbg;      // debugging aid (FDIFF_MEGA_DBG): bit0 zero the attention output, bit1 skip the FFN
     unsigned long long* prof;   // profiling aid (FDIFF_MEGA_PROF): (phase, s_memtime) pairs of WG 0 / wave 0, steps 0-3
+    unsigned long long* clk_out;   // measurement aid (fd_prof_begin .. fd_prof_end): workgroup 0 stores {shader-clock counter, 100 MHz wall
+                                   // clock} at entry ([0], [1]) and behind its last step ([2], [3]): the shader clock the launch ran at
     unsigned* dbg_out;   // debugging aid: LDS image of workgroup 0 after layer 0's attention
     int dbg_bytes;
     // tensors

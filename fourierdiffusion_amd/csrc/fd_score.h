@@ -106,4 +106,5 @@ int fd_linear_res_ln_bf16(fd_ctx* ctx, const float* x, const char* img, const fl
 // head_dim 8 .. 32, one head per contraction (fd_attn_wide.hip); qkv = packed projections (B*T, 3D)
 int fd_attention_bf16_wide(fd_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int hd, hipStream_t s);
 int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, int H, int hd, hipStream_t s,
-                      const char* wk = nullptr, const char* wv = nullptr, const char* wq = nullptr, int ks1 = 0, int out_bf16 = 0);
+                      const char* wk = nullptr, const char* wv = nullptr, const char* wq = nullptr, int ks1 = 0, int out_bf16 = 0,
+                      const void* in_rows = nullptr);

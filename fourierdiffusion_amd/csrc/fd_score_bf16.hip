@@ -319,6 +319,9 @@ struct fd_ffn_pre {
     const float* g1;
     const float* b1;
     int H, hd;
+    // the layer OUTPUT also as bf16 rows (M, 32 KS1 k-slots; 1.0 in slot D, zero padding) for the next layer's attention staging
+    // (k_attention_bf16's ROWS form), or null
+    __bf16* out_rows;
 };
 
 template <int KS1, int DT, int MT, int KSO>
@@ -643,6 +646,22 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
                     o.z = (v[dt][2] - mean) * rstd * gm.z + bt.z;
                     o.w = (v[dt][3] - mean) * rstd * gm.w + bt.w;
                     *reinterpret_cast<float4*>(out + (size_t)m * D + d0) = o;
+                    v[dt][0] = o.x; v[dt][1] = o.y; v[dt][2] = o.z; v[dt][3] = o.w;
+                }
+            }
+            if (pre.out_rows) {
+                __bf16* rrow = pre.out_rows + (size_t)m * (32 * KS1);
+#pragma unroll
+                for (int dt = 0; dt < 2 * KS1; ++dt) {
+                    const int d0 = 16 * dt + 4 * g;
+                    u32x2 pk = {0u, 0u};
+                    if (dt < DT && d0 < D) {
+                        pk[0] = cvt_pk_bf16(v[dt < DT ? dt : 0][0], v[dt < DT ? dt : 0][1]);
+                        pk[1] = cvt_pk_bf16(v[dt < DT ? dt : 0][2], v[dt < DT ? dt : 0][3]);
+                    } else if (d0 == D) {
+                        pk[0] = 0x00003F80u;
+                    }
+                    *reinterpret_cast<u32x2*>(rrow + d0) = pk;
                 }
             }
         }
@@ -692,7 +711,7 @@ int dispatch_ffn(fd_ctx* ctx, const float* x, float* out, const char* wimg, cons
 // x != nullptr: out = LN2(x + FFN(x)).  x == nullptr: x = LN1(h0 + att Wo^T + bo) is computed in the kernel (fused
 // prologue; needs the persistent kernel's W_o image), then the same.
 int run_ffn(fd_score* m, const float* x, float* out, int layer, int M, hipStream_t s, const float* att = nullptr,
-            const float* h0 = nullptr, int att_bf16 = 0) {
+            const float* h0 = nullptr, int att_bf16 = 0, __bf16* out_rows = nullptr) {
     fd_ctx* ctx = m->ctx;
     const fd_bf16_images* im = m->bf16;
     const fd_layer_off& lo = m->layers[layer];
@@ -700,6 +719,7 @@ int run_ffn(fd_score* m, const float* x, float* out, int layer, int M, hipStream
     const char* wimg = im->ffn + (size_t)layer * im->ffn_layer_bytes;
     const int D = m->d.d_model, F = m->d.dim_ff;
     fd_ffn_pre pre{};
+    pre.out_rows = out_rows;
     if (!x) {
         pre.att = att; pre.h0 = h0; pre.att_bf16 = att_bf16;
         pre.wo_img = im->mimg + im->off_layers + (size_t)layer * im->layer_stride + im->off_wo;
@@ -1011,6 +1031,8 @@ int fd_bf16_refresh(fd_score* m, hipStream_t s, bool training_only) {
 // activation buffers of the step-by-step path, carved from the context arena (fd_score_f32_workspace covers them)
 struct LayerBufs {
     float *temb, *h0, *h1, *qkv, *att, *tmp;
+    __bf16* xrb;          // (M, 32 ks1) bf16 rows of the CURRENT layer input h0 when xrb_ok (k_attention_bf16's ROWS form)
+    bool xrb_ok;
 };
 static LayerBufs carve_layer_bufs(const fd_score* m, int B, fd_ws& ws) {
     const size_t M = (size_t)B * m->d.max_len, D = m->d.d_model;
@@ -1023,6 +1045,8 @@ static LayerBufs carve_layer_bufs(const fd_score* m, int B, fd_ws& ws) {
     // last row's last head when head_dim < 8 (values discarded by the select that follows) -- the slack is part of the contract
     lb.att = ws.take<float>(M * D + 8);
     lb.tmp = ws.take<float>(M * D);
+    lb.xrb = m->bf16 ? ws.take<__bf16>(M * 32 * (size_t)m->bf16->ks1) : nullptr;
+    lb.xrb_ok = false;
     return lb;
 }
 static int bf16_layer_stack(fd_score* m, int B, LayerBufs& lb, hipStream_t s);
@@ -1105,7 +1129,8 @@ static int bf16_layer_stack(fd_score* m, int B, LayerBufs& lb, hipStream_t s) {
             // measurement hook (bench.py --workload long): in-projection + attention of M tokens
             fd_prof_scope scope(ctx, s, "k_attention_bf16 (fused Q/K/V projection + softmax attention, one launch per layer)",
                                 (double)M * (6.0 * D * D + 4.0 * T * D));
-            arc = fd_attention_bf16(ctx, h0, att, B, T, H, hd, s, limg + imq->off_wk, limg + imq->off_wv, limg + imq->off_wq, imq->ks1, att_bf16);
+            arc = fd_attention_bf16(ctx, h0, att, B, T, H, hd, s, limg + imq->off_wk, limg + imq->off_wv, limg + imq->off_wq, imq->ks1, att_bf16,
+                                    lb.xrb_ok ? lb.xrb : nullptr);
         }
         if (arc == FD_ERR_UNSUPPORTED) att_bf16 = 0;
         if (arc == FD_ERR_UNSUPPORTED) {
@@ -1129,7 +1154,12 @@ static int bf16_layer_stack(fd_score* m, int B, LayerBufs& lb, hipStream_t s) {
             // a different buffer from the residual input h0)
             fd_prof_scope scope(ctx, s, "k_ffn_ln (out-proj + LN1 + FFN + LN2, one launch per layer)",
                                 (double)M * (2.0 * D * D + 4.0 * D * m->d.dim_ff));
-            if (int rc = run_ffn(m, nullptr, h1, i, M, s, att, h0, att_bf16)) return rc;
+            // the layer output also as bf16 rows for the next layer's attention staging (not behind the last layer: its reader is the
+            // unembedding; FDIFF_ATT_XROWS=0 keeps the fp32 staging for A/B runs)
+            static const bool xrows_on = !(getenv("FDIFF_ATT_XROWS") && atoi(getenv("FDIFF_ATT_XROWS")) == 0);
+            const bool rows_next = xrows_on && lb.xrb && i + 1 < L && imq->mega && hd <= 7;
+            if (int rc = run_ffn(m, nullptr, h1, i, M, s, att, h0, att_bf16, rows_next ? lb.xrb : nullptr)) return rc;
+            lb.xrb_ok = rows_next;
             std::swap(h0, h1);
         } else {
             int orc = FD_ERR_UNSUPPORTED;
@@ -1143,8 +1173,10 @@ static int bf16_layer_stack(fd_score* m, int B, LayerBufs& lb, hipStream_t s) {
                 return orc;
             }
             if (int rc = run_ffn(m, h1, h0, i, M, s)) return rc;
+            lb.xrb_ok = false;
         }
     }
+    lb.xrb_ok = false;
     return FD_OK;
 }
 
@@ -1161,6 +1193,7 @@ struct StepFuseArgs {
     const float* h;        // (M, D) last layer's output, or null
     float* x;              // (B, T, C) state, updated in place
     float* hn;             // (M, D) next step's layer-0 input, or null (last step)
+    __bf16* hn_rows;       // the same as bf16 rows (M, 32 KS1) for k_attention_bf16's ROWS form, or null
     const float* G;        // (T) noise scaling
     const float* z;        // (B, T, C) injected noise of this step, or null (Philox)
     const float* pos;      // (max_len, D) positional table
@@ -1290,6 +1323,22 @@ __global__ __launch_bounds__(256) void k_unembed_step_embed(const StepFuseArgs A
             o.z = acc[dt][2] + (pe.z + te.z);
             o.w = acc[dt][3] + (pe.w + te.w);
             *reinterpret_cast<float4*>(A.hn + (size_t)m * D + d0) = o;
+            acc[dt] = f32x4{o.x, o.y, o.z, o.w};
+        }
+    }
+    if (A.hn_rows && valid) {
+        __bf16* rrow = A.hn_rows + (size_t)m * (32 * KS1);
+#pragma unroll
+        for (int dt = 0; dt < 2 * KS1; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            u32x2 pk = {0u, 0u};
+            if (dt < DT && d0 < D) {
+                pk[0] = cvt_pk_bf16(acc[dt < DT ? dt : 0][0], acc[dt < DT ? dt : 0][1]);
+                pk[1] = cvt_pk_bf16(acc[dt < DT ? dt : 0][2], acc[dt < DT ? dt : 0][3]);
+            } else if (d0 == D) {
+                pk[0] = 0x00003F80u;
+            }
+            *reinterpret_cast<u32x2*>(rrow + d0) = pk;
         }
     }
 }
@@ -1344,17 +1393,23 @@ int fd_sampler_run_layers(fd_score* m, const fd_sde_params* sde, const float* G,
         else hipLaunchKernelGGL((k_unembed_step_embed<1, 1>), grid, block, 0, s, a);
     };
     // first step's embedding
-    A.h = nullptr; A.hn = lb.h0; A.temb = temb_table; A.cf = tab[0];
+    static const bool xrows_on = !(getenv("FDIFF_ATT_XROWS") && atoi(getenv("FDIFF_ATT_XROWS")) == 0);
+    const bool rows0 = xrows_on && lb.xrb && m->d.num_layers > 0 && m->d.d_model / m->d.n_head <= 7 && (im->ks1 == 3 || im->ks1 == 2) &&
+                       im->kso == 3;      // (the layer stack's fused attention + k_ffn_ln path: its first attention reads the rows)
+    A.h = nullptr; A.hn = lb.h0; A.hn_rows = rows0 ? lb.xrb : nullptr; A.temb = temb_table; A.cf = tab[0];
     launch(A);
+    lb.xrb_ok = rows0;
     for (int i = 0; i < n_steps; ++i) {
         if (int rc = bf16_layer_stack(m, B, lb, s)) return rc;
         A.h = lb.h0;
         A.hn = (i + 1 < n_steps) ? lb.h1 : nullptr;
+        A.hn_rows = (rows0 && i + 1 < n_steps) ? lb.xrb : nullptr;
         A.temb = temb_table + (size_t)(i + 1 < n_steps ? i + 1 : i) * D;
         A.z = z_steps ? z_steps + (size_t)i * n : nullptr;
         A.cf = tab[i];
         A.ctr0 = offset + (unsigned long long)i * per_step;
         launch(A);
+        lb.xrb_ok = rows0 && i + 1 < n_steps;
         std::swap(lb.h0, lb.h1);
     }
     FD_LAUNCH_CHECK(ctx);
@@ -1479,6 +1534,11 @@ int fd_sampler_run_mega(fd_score* m, const fd_sde_params* sde, const float* G, c
         const double T = m->d.max_len, D = m->d.d_model, F = m->d.dim_ff, C = m->d.n_channels, L = m->d.num_layers;
         const double per_fwd = T * (L * (2 * D * 3 * D + 2 * D * D + 4 * D * F + 4 * T * D) + 4 * C * D) + 2 * D * D;
         fd_prof_scope scope(ctx, s, "k_mega (persistent score-net + reverse-SDE loop)", per_fwd * B * n_steps);
+        if (ctx->prof_on) {
+            if (!ctx->prof_clk) FD_HIP(ctx, hipMalloc((void**)&ctx->prof_clk, 4 * sizeof(unsigned long long)));
+            FD_HIP(ctx, hipMemsetAsync(ctx->prof_clk, 0, 4 * sizeof(unsigned long long), s));
+            MP.clk_out = ctx->prof_clk;
+        }
         return fd_mega_launch(ctx, MP, m->bf16->ks1, m->bf16->dt, m->bf16->kso, pl.mt, pl.nw, pl.grid, pl.lds, s);
     }
 }

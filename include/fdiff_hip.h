@@ -65,6 +65,10 @@ int fd_prof_begin(fd_ctx* ctx);
 int fd_prof_stride(fd_ctx* ctx, int every);
 int fd_prof_end(fd_ctx* ctx, char* name_out /* >= 128 bytes */, double* avg_us, int* launches,
                 double* flops_per_launch);
+/* after fd_prof_end: the shader clock (MHz) the window's last persistent-kernel launch ran at -- workgroup 0's shader-clock counter
+ * against the 100 MHz wall clock between its entry and the end of its last step; 0 when the window held no such launch.  The chip is
+ * power-limited on this kernel and boxes differ by +-2.5 %: the bench line records the clock beside the time. */
+int fd_prof_shader_clock_mhz(fd_ctx* ctx, double* mhz);
 
 /* --------------------------------------------- a1/a2 spectral representation
  * replaces fdiff.utils.fourier.dft   (src/fdiff/utils/fourier.py:8-45)

@@ -5,7 +5,7 @@ set -e
 NAME=$1; shift
 cd /root/repo/fourierdiffusion_amd/csrc
 make -s -j8
-/opt/rocm/bin/hipcc -O3 -fno-honor-nans -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function "$@" -c fd_mega.hip -o build/fd_mega_$NAME.o
-OBJS=$(ls build/fd_*.o | grep -v "fd_mega")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libfdiff_hip_$NAME.so $OBJS build/fd_mega_$NAME.o -ldl
+/opt/rocm/bin/hipcc -O3 -fno-honor-nans -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function "$@" -c fd_mega.hip -o build/var_fd_mega_$NAME.o
+OBJS=$(ls build/fd_*.o | grep -v "build/fd_mega.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libfdiff_hip_$NAME.so $OBJS build/var_fd_mega_$NAME.o -ldl
 echo built libfdiff_hip_$NAME.so

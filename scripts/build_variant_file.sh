@@ -7,6 +7,6 @@ STEM=${FILE%.hip}
 cd /root/repo/fourierdiffusion_amd/csrc
 make -s -j8
 /opt/rocm/bin/hipcc -O3 -fno-honor-nans -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function "$@" -c $FILE -o build/var_${STEM}_$NAME.o
-OBJS=$(ls build/fd_*.o | grep -v "build/${STEM}.o" | grep -v "fd_mega_")
+OBJS=$(ls build/fd_*.o | grep -v "build/${STEM}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libfdiff_hip_$NAME.so $OBJS build/var_${STEM}_$NAME.o -ldl
 echo built libfdiff_hip_$NAME.so
