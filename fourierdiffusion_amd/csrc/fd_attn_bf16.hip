@@ -205,37 +205,44 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
 #pragma unroll
                 for (int ks = 0; ks < KS1; ++ks) r[ks] = *reinterpret_cast<const u32x4*>(rbase + (size_t)t * RBW + 32 * ks);
             };
-            u32x4 cur[KSN], nxt[KSN];
+            // PB tiles' rows in flight per wave (a ring of register slots: a tile's slot is reloaded with the tile PB steps ahead as
+            // soon as its MFMAs have consumed it): with one tile ahead the staging phase was a chain of exposed L2 / Infinity-Cache
+            // round trips, 14.4 K cycles for a wave's 8 tiles at T = 1024 (profiles/r05_attn_long_phase_clocks_xrows.txt)
+            constexpr int PB = 4;
+            u32x4 rr[PB][KSN];
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) nxt[ks] = u32x4{0u, 0u, 0u, 0u};
-            if (wave < KT) rload(wave, cur);
-            for (int kt = wave; kt < (ABL == 2 ? min(KT, NW) : KT); kt += NW) {
-                if (kt + NW < KT) rload(kt + NW, nxt);
-                f32x4 a = f4zero(), c = f4zero(), qa = f4zero();
-                const bool isq = kt >= qt0 && kt < qt1;        // wave-uniform
-                const unsigned keep = (kt * 16 + tok < T) ? ~0u : 0u;
+            for (int p = 0; p < PB; ++p) rload(min(wave + p * NW, KT - 1), rr[p]);
+            const int kt_end = (ABL == 2 ? min(KT, NW) : KT);
+            for (int kt0 = wave; kt0 < kt_end; kt0 += NW * PB) {
 #pragma unroll
-                for (int ks = 0; ks < KS1; ++ks) {
-                    const bf16x8 xf = __builtin_bit_cast(bf16x8, u32x4{cur[ks][0] & keep, cur[ks][1] & keep, cur[ks][2] & keep, cur[ks][3] & keep});
-                    a = MFMA(wkf[ks], xf, a);
-                    c = MFMA(xf, wvf[ks], c);
-                    if (isq) qa = MFMA(wqf[ks], xf, qa);
+                for (int p = 0; p < PB; ++p) {
+                    const int kt = kt0 + p * NW;
+                    if (kt >= kt_end) break;                       // wave-uniform
+                    f32x4 a = f4zero(), c = f4zero(), qa = f4zero();
+                    const bool isq = kt >= qt0 && kt < qt1;        // wave-uniform
+                    const unsigned keep = (kt * 16 + tok < T) ? ~0u : 0u;
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks) {
+                        const bf16x8 xf = __builtin_bit_cast(bf16x8, u32x4{rr[p][ks][0] & keep, rr[p][ks][1] & keep, rr[p][ks][2] & keep, rr[p][ks][3] & keep});
+                        a = MFMA(wkf[ks], xf, a);
+                        c = MFMA(xf, wvf[ks], c);
+                        if (isq) qa = MFMA(wqf[ks], xf, qa);
+                    }
+                    if (kt + NW * PB < kt_end) rload(kt + NW * PB, rr[p]);
+                    *reinterpret_cast<u32x2*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8) = u32x2{cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
+                    char* dst = vbf + ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16;
+                    if (!(kmax_in_v && kt == 0 && lane == 7))          // (that row's first 8 bytes hold kmax)
+                        *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = u32x2{cvt_pk_bf16(c[0], c[1]), cvt_pk_bf16(c[2], c[3])};
+                    if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
+                    if (isq)
+                        *reinterpret_cast<u32x2*>(qbf + ((size_t)(kt - qt0) * 64 + lane) * 8) = u32x2{cvt_pk_bf16(qa[0], qa[1]), cvt_pk_bf16(qa[2], qa[3])};
+                    float n2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+                    float ea, eb;
+                    swap16(n2, ea, eb);
+                    n2 = row_max16(ea + eb);
+                    if (tok == 0 && (g & 1) == 0)
+                        __hip_atomic_fetch_max(&kmax[g >> 1], __builtin_bit_cast(unsigned, n2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                *reinterpret_cast<u32x2*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8) = u32x2{cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
-                char* dst = vbf + ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16;
-                if (!(kmax_in_v && kt == 0 && lane == 7))          // (that row's first 8 bytes hold kmax)
-                    *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = u32x2{cvt_pk_bf16(c[0], c[1]), cvt_pk_bf16(c[2], c[3])};
-                if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
-                if (isq)
-                    *reinterpret_cast<u32x2*>(qbf + ((size_t)(kt - qt0) * 64 + lane) * 8) = u32x2{cvt_pk_bf16(qa[0], qa[1]), cvt_pk_bf16(qa[2], qa[3])};
-                float n2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
-                float ea, eb;
-                swap16(n2, ea, eb);
-                n2 = row_max16(ea + eb);
-                if (tok == 0 && (g & 1) == 0)
-                    __hip_atomic_fetch_max(&kmax[g >> 1], __builtin_bit_cast(unsigned, n2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-                for (int ks = 0; ks < KS1; ++ks) cur[ks] = nxt[ks];
             }
         } else {
         float4 cur_lo[KSN], cur_hi[KSN], nxt_lo[KSN], nxt_hi[KSN];
@@ -360,6 +367,9 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
         return *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(jb * 4 + gl) * 16 + tl) * 16);
     };
     bool prefer_exact = exact_only != 0;                              // wave-uniform
+#ifdef FD_ATTN_PRIO_YOUNG        // experiment: the second wave of every SIMD (it loses every arbitration against the first) runs its units preferred
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(FD_ATTN_PRIO_YOUNG);
+#endif
     for (int du = du0 + wave; du < du1; du += NW) {
         // the lane's fragment addresses are rebuilt per unit (a few VALU) from opaque copies of (tok, g): hoisted out of this
         // loop they were kept alive -- i.e. spilled -- across it, one VGPR per address stream of the key pipeline
