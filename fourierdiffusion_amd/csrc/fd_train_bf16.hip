@@ -517,6 +517,10 @@ struct AttnFwdArgs {
 #ifndef FD_TR_ATTN_MINW
 #define FD_TR_ATTN_MINW 2
 #endif
+#ifndef FD_TR_ABL_FWD
+#define FD_TR_ABL_FWD 0           // k_tr_ffn_fwd timing ablations (wrong results): 1 no weight DMA in the loop, 2 no barrier, 4 no mask /
+#endif                            // activity block, 16 no chunk loop at all (prologue + epilogue only), 64 no ballots / activity words, 128 no
+                                  // activity byte, 256 no keep-mask table
 #ifndef FD_TR_ATTN_OH_MINW
 #define FD_TR_ATTN_OH_MINW 3          // one-head attention backward: three 4-wave workgroups per CU
 #endif
@@ -655,6 +659,17 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
 }
 
 // ------------------------------------------------------------------------------------------------ FFN-side forward
+#ifdef FD_TR_PROF_FFN       // variant build: in-kernel phase clocks of k_tr_ffn_fwd (workgroup 7, waves 0 and 4), printed after 30 launches
+__device__ unsigned long long fd_tr_ffn_dbg[2 * 8];
+#define TRF_STAMP(slot, t_prev)                                                                          \
+    do {                                                                                                 \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                    \
+        if (blockIdx.x == 7 && lane == 0 && (wave & 3) == 0) fd_tr_ffn_dbg[(wave >> 2) * 8 + (slot)] += now_ - (t_prev); \
+        (t_prev) = now_;                                                                                 \
+    } while (0)
+#else
+#define TRF_STAMP(slot, t_prev) do { } while (0)
+#endif
 struct FfnFwdArgs {
     const float* x0;          // (M, D) layer input (residual)
     const float* att;         // (M, D)
@@ -683,6 +698,8 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile = wave & 3, fhw = wave >> 2;
     const int D = d.D, M = d.M, NS = d.F / 64, F = d.F;
+    unsigned long long tprev = __builtin_readcyclecounter();
+    (void)tprev;
     char* const ring = smem;
     char* const scratch = smem + NBUF * WB + wave * KS1 * 1024;            // wave-private fragment scratch (prologue)
     f32x4* const xch = reinterpret_cast<f32x4*>(smem + NBUF * WB);          // [4 tiles][DT][64] (after the loop: aliases scratch)
@@ -690,6 +707,12 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     unsigned char* const actB = reinterpret_cast<unsigned char*>(smem + NBUF * WB + SCR) + wave * (64 * NS);   // [64 lanes][NS]
     unsigned short* const actT = reinterpret_cast<unsigned short*>(smem + NBUF * WB + SCR + TW * 64 * NS) + wave * (NS * 32);   // [NS][32]
     char* const tscr = smem + NBUF * WB + SCR + TW * 64 * NS + TW * NS * 32 * 2 + (wave & 3) * (32 * DT * 16);   // owners' T-store transpose
+    // keep masks of four packed bf16 values by nibble of keep bits (see the chunk loop): klut[2 n], klut[2 n + 1] = lane masks of values 0-1 / 2-3
+    unsigned* const klut = reinterpret_cast<unsigned*>(smem + NBUF * WB + SCR + TW * 64 * NS + TW * NS * 32 * 2 + 4 * (32 * DT * 16));
+    if (threadIdx.x < 32) {
+        const unsigned n = threadIdx.x >> 1, hi = threadIdx.x & 1;
+        klut[threadIdx.x] = ((n >> (2 * hi)) & 1u ? 0x0000ffffu : 0u) | ((n >> (2 * hi + 1)) & 1u ? 0xffff0000u : 0u);
+    }
     // F-split (struct FSplit): token block, chunk range and role of this workgroup
     const int nsp = d.fsplit, blk = nsp == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, fq = nsp == 2 ? (int)(blockIdx.x & 1) : 0;
     const int NSH = NS / nsp, cbase = fq * NSH;
@@ -760,6 +783,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
             be14[dt] = *reinterpret_cast<const float4*>(a.be1 + dr);
         }
         __builtin_amdgcn_sched_barrier(0);
+        TRF_STAMP(0, tprev);      // entry, DMA issue, every prologue load issued
         f32x4 o[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = f4zero();
@@ -805,6 +829,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     }
     bf16x8 xf[KS1];
     ctile_to_frags<DT, KS1>(scratch, lane, D, v, true, xf);
+    TRF_STAMP(1, tprev);          // loads landed, out-projection, LayerNorm1, fragments
     // this wave's dropout bytes of its F-half -> LDS (overwritten chunk by chunk with kept-AND-positive), and the epilogue's
     // dropout bits, fetched now (a dependent global round trip after the loop otherwise)
     if (d.p > 0.f && valid) {
@@ -821,7 +846,9 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f4zero();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TRF_STAMP(2, tprev);          // dropout bytes staged, first weight chunks landed (own share)
     __syncthreads();
+    TRF_STAMP(3, tprev);          // barrier
     // ---- FFN: this wave's F-half, hidden in registers.  A step's W1 / W2 fragments are read from the ring into registers
     // during the PREVIOUS step (its buffer became visible one barrier earlier: the wait below leaves only the newest DMA batch
     // in flight), so no LDS round trip sits between the barrier and the step's MFMAs (five of them per step before: the
@@ -837,7 +864,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         for (int dt = 0; dt < DT; ++dt) w2[dt] = *reinterpret_cast<const bf16x8*>(wb + (2 * KS1 + dt) * 1024);
     };
     auto step = [&](int c, const bf16x8 (&w1)[2 * KS1], const bf16x8 (&w2)[DT], bf16x8 (&n1)[2 * KS1], bf16x8 (&n2)[DT]) {
-        if (c + 3 < NSH) issue(c + 3);
+        if (!(FD_TR_ABL_FWD & 1) && c + 3 < NSH) issue(c + 3);
         frags(c + 1, n1, n2);
         f32x4 h0 = f4zero(), h1 = f4zero();
 #pragma unroll
@@ -845,6 +872,20 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
             h0 = MFMA(w1[ks], xf[ks], h0);
             h1 = MFMA(w1[KS1 + ks], xf[ks], h1);
         }
+#if FD_TR_ABL_FWD & 4
+        {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { h0[r] = fmaxf(h0[r], 0.f); h1[r] = fmaxf(h1[r], 0.f); }
+            const bf16x8 hb0 = pack8(h0, h1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(w2[dt], hb0, acc[dt]);
+            if (!(FD_TR_ABL_FWD & 1) && c + 3 < NSH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (!(FD_TR_ABL_FWD & 2)) __builtin_amdgcn_s_barrier();
+            return;
+        }
+#endif
         int ce = c + rot;
         ce -= (ce >= NSH) ? NSH : 0;
         int cn = ce + 1;                                           // next step's chunk (clamped read after the last step)
@@ -853,47 +894,68 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         cn += cbase;
         const unsigned bits = bits_cur;                            // dropout decisions of this chunk (staged before the loop),
         bits_cur = actB[lane * NS + cn];                           // read one step ahead like the fragments
-        unsigned act = 0u;
-        unsigned long long bal[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            // branch-free (bitwise & on the two tests; the staged byte is 0 for tokens beyond M): the `valid && .. && ..` form
-            // made hipcc wrap every register's tests in exec-mask save / restore pairs -- 90 SALU instructions per step in a
-            // loop whose waves are bound by their own instruction count (two per SIMD, 40 % of their cycles waiting)
-            const bool p0 = h0[r] > 0.f, b0 = (bits & (1u << r)) != 0u, p1 = h1[r] > 0.f, b1 = (bits & (16u << r)) != 0u;
-            const bool k0 = p0 & b0, k1 = p1 & b1;
-            act |= k0 ? (1u << r) : 0u;
-            act |= k1 ? (16u << r) : 0u;
-            h0[r] = k0 ? h0[r] : 0.f;                 // (the keep scale is applied once to the accumulators after the loop)
-            h1[r] = k1 ? h1[r] : 0.f;
-            // the same decisions with the 16 tokens of the tile as the bits of one word per hidden unit (weight-gradient
-            // kernel): ballot bit 16 g + tok of register r <-> hidden unit 4 g + r (+16 for the second tile)
-            // (ballot of each test, combined on the scalar unit: the ballot of the combined bool goes through a 0 / 1 VGPR)
-            bal[r] = __builtin_amdgcn_ballot_w64(p0) & __builtin_amdgcn_ballot_w64(b0);
-            bal[4 + r] = __builtin_amdgcn_ballot_w64(p1) & __builtin_amdgcn_ballot_w64(b1);
+        // relu + dropout on the PACKED hidden values: v_cvt_pk_bf16_f32, v_pk_max_i16 against 0 (a negative bf16 is a negative
+        // int16), and the keep decisions as bf16 lane masks from a 16-entry LDS table indexed by the byte's nibbles -- 16 VALU
+        // and two 8-byte LDS reads per 8 values.  The per-value form (compare, bit test, s_and of the two ballots, two selects)
+        // was ~90 VALU + ~60 SALU in dependent VALU -> SGPR -> SALU -> VALU chains: 12.6 of the kernel's 45 us at 16 128 tokens
+        // (timing ablation -DFD_TR_ABL_FWD=4, profiles/r05_train_ffn_fwd_ablations.txt).
+        u32x4 pk;
+        {
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            pk = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, pack8(h0, h1)), z8));
+#if !(FD_TR_ABL_FWD & 256)
+            const u32x2 k0 = *reinterpret_cast<const u32x2*>(klut + 2 * (bits & 15u)), k1 = *reinterpret_cast<const u32x2*>(klut + 2 * (bits >> 4));
+            pk = u32x4{pk[0] & k0[0], pk[1] & k0[1], pk[2] & k1[0], pk[3] & k1[1]};
+#endif
         }
-        if (lane == 0) {
-#pragma unroll
-            for (int w8 = 0; w8 < 8; ++w8) reinterpret_cast<unsigned long long*>(actT)[ce * 8 + w8] = bal[w8];
+        // activity = kept AND > 0 = a non-zero packed value.  As a byte per (token, lane group) for the token-on-lane backward:
+        // v_pk_min_i16 against 1 turns each half into 0 / 1, shifts gather the eight bits ...
+#if !(FD_TR_ABL_FWD & 128)
+        {
+            // (one 8-wide min: hipcc folded the per-dword two-wide form of this into "all four dwords equal" -- t = mm[0] * 0x55)
+            // (signed: the values are non-negative after the relu, and the signed form selects v_pk_min_i16)
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x8 one8 = {1, 1, 1, 1, 1, 1, 1, 1};
+            const u32x4 mm = __builtin_bit_cast(u32x4, __builtin_elementwise_min(__builtin_bit_cast(s16x8, pk), one8));
+            const unsigned t = mm[0] | (mm[1] << 2) | (mm[2] << 4) | (mm[3] << 6);     // low halves on bits 0, 2, 4, 6; high halves on 16, 18, 20, 22
+            actB[lane * NS + ce] = (unsigned char)((t & 0x55u) | ((t >> 15) & 0xAAu));
         }
-        actB[lane * NS + ce] = (unsigned char)act;
-        const bf16x8 hb = pack8(h0, h1);
+#endif
+        // ... and with the 16 tokens of the tile as the bits of one word per hidden unit (weight-gradient kernel): the compare's
+        // SGPR pair IS the ballot -- bit 16 g + tok of unit 4 g + r (+16 for the second row tile); one compare per half
+#if !(FD_TR_ABL_FWD & 64)
+        {
+            unsigned long long bal[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bal[2 * q] = __builtin_amdgcn_ballot_w64((pk[q] & 0xffffu) != 0u);
+                bal[2 * q + 1] = __builtin_amdgcn_ballot_w64(pk[q] > 0xffffu);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) reinterpret_cast<unsigned long long*>(actT)[ce * 8 + w8] = bal[w8];
+            }
+        }
+#endif
+        const bf16x8 hb = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(w2[dt], hb, acc[dt]);
-        if (c + 3 < NSH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        if (!(FD_TR_ABL_FWD & 1) && c + 3 < NSH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the prefetch reads and this step's LDS writes are done
-        __builtin_amdgcn_s_barrier();
+        if (!(FD_TR_ABL_FWD & 2)) __builtin_amdgcn_s_barrier();
     };
     {
         bf16x8 wa1[2 * KS1], wa2[DT], wb1[2 * KS1], wb2[DT];
         frags(0, wa1, wa2);
         bits_cur = actB[lane * NS + cbase + rot];
-        for (int c = 0; c < NSH; c += 2) {       // (NS = F / 64 is a multiple of 4: F % 1024 == 0)
+        for (int c = 0; c < ((FD_TR_ABL_FWD & 16) ? 0 : NSH); c += 2) {       // (NS = F / 64 is a multiple of 4: F % 1024 == 0)
             step(c, wa1, wa2, wb1, wb2);
             step(c + 1, wb1, wb2, wa1, wa2);
         }
     }
+    TRF_STAMP(4, tprev);          // chunk loop
     if (owner && finisher) {
         const int m0w = (blk * 4 + tile) * 16;
         store_ctile<DT>(a.s1, m, valid, D, g, s1keep);
@@ -922,6 +984,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         for (int i = cbase * 32 + lane * 8; i < (cbase + NSH) * 32; i += 64 * 8)
             *reinterpret_cast<u32x4*>(dstw + i) = *reinterpret_cast<const u32x4*>(actT + i);
     }
+    TRF_STAMP(5, tprev);          // s1 / stage stores issued, mask bits out
     // ---- combine the F-halves; the owner finishes the tile
     __syncthreads();
     if (!owner) {
@@ -929,6 +992,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         for (int dt = 0; dt < DT; ++dt) xch[(tile * DT + dt) * 64 + lane] = acc[dt];
     }
     __syncthreads();
+    TRF_STAMP(6, tprev);          // two barriers + exchange
     if (!owner) return;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = (acc[dt] + xch[(tile * DT + dt) * 64 + lane]) * d.keep_scale;      // hidden-unit keep scale
@@ -972,6 +1036,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         store_rows<DT, KS1>(a.outrb, m, valid, D, g, v, true);
         store_T16<DT>(tscr, a.outT + ((size_t)(m0w >> 5) * (16 * DT)) * 32 + (m0w & 31), 32, lane, D, v, true, valid);
     }
+    TRF_STAMP(7, tprev);          // epilogue of the owner (hand-over, LN2, stores issued)
 }
 
 // ------------------------------------------------------------------------------------------------ FFN-side backward
@@ -2548,7 +2613,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
     const size_t scr = std::max((size_t)TW * KS1 * 1024, (size_t)4 * DT * 1024);
     const size_t NSh = (size_t)m->d.dim_ff / 64;
     const size_t lds_ffn = (size_t)4 * 2 * (2 * KS1 + DT) * 1024 + scr + (size_t)TW * 64 * NSh + (size_t)TW * NSh * 32 * sizeof(unsigned short) +
-                           (size_t)4 * 32 * DT * 16;
+                           (size_t)4 * 32 * DT * 16 + 128;      // (+ the keep-mask table)
     static unsigned long long attr = 0;
     if (fd_first_on_device(attr, ctx->device)) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_fwd<KS1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2636,6 +2701,24 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             df.fsplit = tr_fsplit_rule(m, d.M, d.F, true);
             if (int rc = tr_fsplit_prepare(ctx, df, tb.nwg, DT, &fa.fs, s)) return rc;
             hipLaunchKernelGGL((k_tr_ffn_fwd<KS1, DT, KSO>), dim3(tb.nwg * df.fsplit), dim3(TW * 64), lds_ffn, s, df, fa);
+#ifdef FD_TR_PROF_FFN
+            {
+                static int calls = 0;
+                if (++calls == 60) {
+                    unsigned long long h[16];
+                    hipStreamSynchronize(s);
+                    hipMemcpyFromSymbol(h, HIP_SYMBOL(fd_tr_ffn_dbg), sizeof(h));
+                    static const char* nm[8] = {"entry + loads issued", "loads landed + out-proj + LN1", "staging + DMA wait", "barrier", "chunk loop",
+                                                "stores + mask bits out", "exchange barriers", "owner epilogue"};
+                    fprintf(stderr, "[k_tr_ffn_fwd phase clocks, workgroup 7, average of %d launches]\n", calls);
+                    for (int w = 0; w < 2; ++w) {
+                        fprintf(stderr, "  wave %d:", 4 * w);
+                        for (int q = 0; q < 8; ++q) fprintf(stderr, " %s %.1f K |", nm[q], (double)h[w * 8 + q] / calls / 1000.0);
+                        fprintf(stderr, "\n");
+                    }
+                }
+            }
+#endif
         }
     }
     if (out) fdgemm::linear_fwd(tb.hL, P + m->un_w, P + m->un_b, out, M, C, D, false, s);      // (null: the fused loss head reads hL)
