@@ -107,9 +107,11 @@ class DiffusionSampler:
         large batch) x (CUs), at most eight rounds of workgroups per launch; the step-by-step path (T > 256, other backbones) keeps
         the caller's batch size (its workspace grows with the batch)."""
         model = self.score_model
+        # (the partition depends on the model and the device only, NOT on the arithmetic mode: a seed then gives the fp32 parity
+        # path and the bf16 path the same launches, Philox keys and noise -- tests/test_gpu_bf16_distribution.py couples the two)
         try:
-            _desc, spw = model.plan(1 << 16, "bf16" if mode == _PRECISIONS["bf16"] else "fp32")
-        except Exception:       # a model without a plan (other backbones): the reference's launches
+            _desc, spw = model.plan(1 << 16, "bf16")
+        except Exception:       # no bf16 persistent kernel for this model (other backbones, widths): the reference's launches
             spw = 0
         if spw <= 0:
             n = self.sample_batch_size
