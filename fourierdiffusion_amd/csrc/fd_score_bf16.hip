@@ -865,9 +865,12 @@ void fd_bf16_destroy(fd_score* m) {
 int fd_bf16_prepare(fd_score* m, hipStream_t s, bool training_only, bool ffn32_only) {
     fd_bf16_images* im = m->bf16;
     if (!im || !im->supported) return FD_OK;
-    // the pair-form FFN image is read by the persistent sampler kernel only: a training step's rebuild skips it (a quarter of the
-    // rebuild's blocks) and leaves it marked stale for the next inference call
-    if (im->ffn32_layer_bytes) im->ffn32_stale = training_only;
+    // Images only the INFERENCE kernels read -- the step-by-step path's FFN image, the persistent kernel's pair-form FFN image and
+    // fp32 layer vectors, the embedding / unembedding images, the projection images of the other widths -- are skipped by a training
+    // step's rebuild (`training_only`: it sits on the step's critical path, in front of the first attention kernel: 53 us of builds
+    // on a side stream against 81 us of prologue on the caller's, rocprofv3 time line) and left marked stale; the next inference
+    // call then builds just those (`ffn32_only` = inference-only part; the parameters have not changed in between).
+    im->ffn32_stale = training_only;
     const int D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, C = m->d.n_channels, hd = D / H, L = m->d.num_layers;
     const int NB = 2 * im->ks1 + im->dt;
     const float* P = m->params;
@@ -888,13 +891,19 @@ int fd_bf16_prepare(fd_score* m, hipStream_t s, bool training_only, bool ffn32_o
     if (B.mega) per_layer += 3 * B.n_qkv + B.n_wo + B.n_ffn + B.n_lp + B.n_ffn32;
     if (B.mega && B.train) per_layer += B.n_ffn + B.n_wot + B.n_win;
     if (ffn32_only) {
-        // the parameters have not changed since a training-step rebuild that skipped the pair-form FFN image: build just that
-        // (a quarter of the blocks; ADVICE r4: the first inference call after a training step rebuilt everything)
-        B.blk_first = B.n_ffn + 3 * B.n_qkv + B.n_wo + B.n_ffn + B.n_lp;
-        if (L > 0 && B.n_ffn32 > 0) hipLaunchKernelGGL(k_build_layer_images, dim3(B.n_ffn32, L), dim3(64), 0, s, B);
+        // inference-only part: blocks [0, n_ffn) (step-by-step FFN image) and the layer vectors + pair-form image of the persistent kernel
+        if (L > 0) hipLaunchKernelGGL(k_build_layer_images, dim3(B.n_ffn, L), dim3(64), 0, s, B);
+        if (L > 0 && B.mega && B.n_lp + B.n_ffn32 > 0) {
+            fd_img_build B2 = B;
+            B2.blk_first = B.n_ffn + 3 * B.n_qkv + B.n_wo + B.n_ffn;
+            hipLaunchKernelGGL(k_build_layer_images, dim3(B.n_lp + B.n_ffn32, L), dim3(64), 0, s, B2);
+        }
+    } else if (training_only && B.mega) {
+        B.blk_first = B.n_ffn;                                 // (skips the step-by-step FFN image; n_ffn32 is already 0)
+        if (L > 0) hipLaunchKernelGGL(k_build_layer_images, dim3(per_layer - B.n_ffn, L), dim3(64), 0, s, B);
         FD_LAUNCH_CHECK(m->ctx);
         return FD_OK;
-    }
+    } else
     if (L > 0) hipLaunchKernelGGL(k_build_layer_images, dim3(per_layer, L), dim3(64), 0, s, B);
     if (im->pimg) {
         for (int i = 0; i < L; ++i) {
