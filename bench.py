@@ -50,6 +50,9 @@ WORKLOADS = {
     "nasdaq": dict(T=252, C=6, sde=("vp", 0.1, 20.0), batch=512, n_steps=1000, strong_total=4096,
                    desc="nasdaq-synth (T=252, C=6; the shape of BASELINE.json configs[2]), default transformer, VP-SDE, "
                         "fourier_noise_scaling"),
+    "ecg187": dict(T=187, C=1, sde=("vp", 0.1, 20.0), batch=512, n_steps=1000, strong_total=4096,
+                   desc="the reference's ECG dataset shape (T=187, C=1: src/fdiff/dataloaders/datamodules.py:194-201), default "
+                        "transformer, VP-SDE, fourier_noise_scaling; persistent kernel specialised at run time (hiprtc)"),
     "long": dict(T=1024, C=16, sde=("vp", 0.1, 20.0), batch=64, n_steps=1000, strong_total=512,
                  desc="BASELINE.json configs[4]: synthetic long-horizon (T=1024, C=16), default transformer, VP-SDE, "
                       "fourier_noise_scaling, two launches per encoder layer (the series does not fit one workgroup)"),
@@ -73,7 +76,7 @@ def hbm_traffic_per_launch():
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_hbm_traffic.json,
     collected with separate rocprofv3 --pmc runs of this same command; FETCH_SIZE doubled per the gfx950 note in
     MI355X_MICROARCH.md).  (None, None) when no measurement is committed; the second element names the source."""
-    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 v = json.load(f).get("hbm_bytes_per_launch")
@@ -120,6 +123,7 @@ def secondary_rows():
         "sample_long_T1024_B64": [me, "--workload", "long", "--steps", "2", "--warmup", "1"] + nd,
         "sample_mimic_T256_B512": [me, "--workload", "mimic", "--steps", "2", "--warmup", "1"] + nd,
         "sample_nasdaq_T252_B512": [me, "--workload", "nasdaq", "--steps", "2", "--warmup", "1"] + nd,
+        "sample_ecg187_T187_B512": [me, "--workload", "ecg187", "--steps", "2", "--warmup", "1"] + nd,
     }
     keep = ("metric", "value", "unit", "steps", "ms_per_step", "score_net_step_ms", "dtype", "achieved_tflops_whole_step")
     out = {}
@@ -136,6 +140,13 @@ def secondary_rows():
             out[name] = row
         except Exception as e:
             out[name] = {"error": repr(e)[:300]}
+    try:   # the reference's default sampling run through the Python boundary (10 000 samples in batches of 200, 1000 steps; PCIe-inclusive)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "api_default_run.py"), "100", "12", "2000" if quick else "10000",
+                            "100" if quick else "1000"], capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("DiffusionSampler")][-1]
+        out["api_default_run_T100_C12"] = {"what": line, "series_per_s": float(line.split(" = ")[1].split(" series/s")[0])}
+    except Exception as e:
+        out["api_default_run_T100_C12"] = {"error": repr(e)[:300]}
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "hbm_kernels_bench.py"), "--json"] +
                            (["--quick"] if quick else []), capture_output=True, text=True, timeout=300)
