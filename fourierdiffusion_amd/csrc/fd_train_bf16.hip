@@ -44,7 +44,15 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#ifndef FD_TR_WG_NBUF
+#define FD_TR_WG_NBUF 4          // LDS ring of k_tr_wgrad: 13-KiB stage records, NBUF - 1 blocks in flight (3 / 4 / 5: same time)
+#endif
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+// ds_read_b64_tr_b16: the 16 lanes of a group hand in 16 8-byte-aligned addresses, together a [4][16] bf16 matrix (row j =
+// the four runs of lanes 4j..4j+3); lane i of the group gets column i (element j = row j).
+__device__ __forceinline__ s16x4 lds_read_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
 
 uint64_t fd_dropout_site_offset(uint64_t base, int layer, int site);   // fd_score_f32.hip
 namespace fdf32 {
@@ -308,15 +316,17 @@ __device__ __forceinline__ void store_rows(__bf16* __restrict__ rb, int m, bool 
     }
 }
 // "Stage" layout of the operands the weight-gradient kernel streams through LDS: per 32-token block ONE contiguous record
-//   [x1 rows 32 x RBS][d f rows 32 x RBS][x1 T-block NFT x TBS][d f T-block NFT x TBS]   (bf16, record padded to 1 KiB)
-// with row strides padded off the LDS bank period (RBS = 32 KS1 + 8 -> 16-lane b128 reads hit every bank twice, the
-// minimum; TBS = 40 -> b64 reads two-way) -- the natural strides (192 B / 64 B) made every fragment read an 8-way conflict,
-// 2.7 us per 32-token block.  global_load_lds copies a record verbatim.
+//   [x1 rows 32 x RBS][d f rows 32 x RBS]   (bf16, record padded to 1 KiB: 13 KiB at d_model 72)
+// with the row stride padded off the LDS bank period (RBS = 32 KS1 + 8 -> 16-lane b128 reads hit every bank once; the
+// natural stride of 192 B made every fragment read an 8-way conflict, 2.7 us per 32-token block).  global_load_lds copies
+// a record verbatim.  The feature-major ("T-block") operands of the d W products are NOT stored: k_tr_wgrad reads them out
+// of the same rows with ds_read_b64_tr_b16 (a 16-lane group reads a [4 tokens][16 features] block transposed), which
+// halved the record, the staging DMA of k_tr_wgrad and the epilogue stores of k_tr_ffn_fwd / k_tr_ffn_bwd.
 template <int KS1, int DT>
 struct StageL {
-    static constexpr int RBS = 32 * KS1 + 8, TBS = 40, NFT = 16 * DT;
-    static constexpr int off_xr = 0, off_dr = 32 * RBS * 2, off_xT = 2 * 32 * RBS * 2, off_dT = off_xT + NFT * TBS * 2;
-    static constexpr int bytes = (off_dT + NFT * TBS * 2 + 1023) & ~1023;
+    static constexpr int RBS = 32 * KS1 + 8, NFT = 16 * DT;
+    static constexpr int off_xr = 0, off_dr = 32 * RBS * 2;
+    static constexpr int bytes = (2 * 32 * RBS * 2 + 1023) & ~1023;
 };
 template <int DT, int KS1>
 __device__ __forceinline__ void stage_rows(char* __restrict__ stage, int region_off, int m, bool valid, int D, int g,
@@ -337,21 +347,6 @@ __device__ __forceinline__ void stage_rows(char* __restrict__ stage, int region_
         }
         *reinterpret_cast<u32x2*>(row + d0) = pk;
     }
-}
-template <int DT, int KS1>
-__device__ __forceinline__ void stage_T(char* __restrict__ stage, int region_off, int m, bool valid, int D, int g,
-                                        const f32x4 (&v)[DT], bool ones) {
-    using SL = StageL<KS1, DT>;
-    __bf16* col = reinterpret_cast<__bf16*>(stage + (size_t)(m >> 5) * SL::bytes + region_off) + (m & 31);
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = 16 * dt + 4 * g + r;
-            float x = 0.f;
-            if (valid) x = (f < D) ? v[dt][r] : ((f == D && ones) ? 1.0f : 0.f);
-            col[(size_t)f * SL::TBS] = (__bf16)x;
-        }
 }
 // C-layout tile of 16 tokens -> T-layout rows through a wave-private LDS transpose: 4 lanes write one 32-byte run of a
 // feature row (16 tokens x bf16) instead of 64 scattered 2-byte stores per instruction (20 store instructions per tile
@@ -957,11 +952,8 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     }
     TRF_STAMP(4, tprev);          // chunk loop
     if (owner && finisher) {
-        const int m0w = (blk * 4 + tile) * 16;
         store_ctile<DT>(a.s1, m, valid, D, g, s1keep);
         stage_rows<DT, KS1>(a.stage, StageL<KS1, DT>::off_xr, m, valid, D, g, v, true);
-        store_T16<DT>(tscr, reinterpret_cast<__bf16*>(a.stage + (size_t)(m0w >> 5) * StageL<KS1, DT>::bytes + StageL<KS1, DT>::off_xT) + (m0w & 31),
-                      StageL<KS1, DT>::TBS, lane, D, v, true, valid);
     }
     // ---- mask bits out: bytes [token][g][chunk] (token-on-lane backward), words [32-token block][half][hidden unit]
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1282,8 +1274,6 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     }
     if (owner) {
         const int m0w = (blk * 4 + tile) * 16;
-        store_T16<DT>(tscr, reinterpret_cast<__bf16*>(a.stage + (size_t)(m0w >> 5) * StageL<KS1, DT>::bytes + StageL<KS1, DT>::off_dT) + (m0w & 31),
-                      StageL<KS1, DT>::TBS, lane, D, df, false, valid);
         stage_rows<DT, KS1>(a.stage, StageL<KS1, DT>::off_dr, m, valid, D, g, df, false);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[dt] += xch[(tile * DT + dt) * 64 + lane];
@@ -1819,7 +1809,7 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
     if (bx < F / 128) {
         using SL = StageL<KS1, DT>;
         constexpr int SB = SL::bytes;                         // staged bytes per 32-token block (one StageL record)
-        constexpr int NBUF = 3, NDMA = (SB / 1024 + 3) / 4;
+        constexpr int NBUF = FD_TR_WG_NBUF, PD = NBUF - 1, NDMA = (SB / 1024 + 3) / 4;       // ring slots, blocks in flight
         const int NS = F / 64;
         const int chunk = bx * 4 + wave;              // hidden units 32 chunk .. +31
         const int fh = chunk / NS, c = chunk - fh * NS;
@@ -1870,8 +1860,9 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
         // so the summation order -- and the result -- is still reproducible)
         const int brot = nb > 0 ? (int)(((unsigned)bx * 3u) % (unsigned)nb) : 0;
         auto blk_of = [&](int ib) { int bq = ib + brot; bq -= (bq >= nb) ? nb : 0; return blk0 + bq; };
-        if (nb > 0) issue(blk_of(0), 0);
-        if (nb > 1) issue(blk_of(1), 1);
+#pragma unroll
+        for (int q = 0; q < PD; ++q)
+            if (nb > q) issue(blk_of(q), q);
         // One block: the ring slot is a compile-time constant (the loop below is unrolled by NBUF), so neither the mask words
         // nor the LDS addresses go through run-time selects.  Tokens beyond M need no masking here: k_tr_ffn_fwd / k_tr_ffn_bwd
         // write ZERO rows and T-block columns for them into the stage records (every workgroup covers 64 tokens up to Mpad), and
@@ -1880,8 +1871,13 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
         auto block = [&](int ib, auto slot_c) {
             constexpr int slot = decltype(slot_c)::value;
             // block ib must have landed (this wave's share), then everybody's
-            if (ib + 1 < nb) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NVM) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            {
+                const int after = min(PD - 1, nb - 1 - ib);                 // later blocks already issued (wave-uniform)
+                if (after >= 3 && PD >= 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * NVM) : "memory");
+                else if (after == 2 && PD >= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NVM) : "memory");
+                else if (after == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NVM) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
 #ifndef FD_TR_ABL_WG_NOBAR
             // bare s_barrier: __syncthreads() carries a workgroup fence that may be lowered to s_waitcnt vmcnt(0), which would drain
             // the DMA of the next block.  What must be ordered is ordered by hand: this wave's share of block ib has landed (above),
@@ -1898,10 +1894,10 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
 #ifdef FD_TR_ABL_WG_NODMA
                 if (false) {
 #else
-                if (ib + 2 < nb) {
+                if (ib + PD < nb) {
 #endif
-                    const int bn2 = blk_of(ib + 2);
-                    issue(bn2, (slot + 2) % NBUF);
+                    const int bn2 = blk_of(ib + PD);
+                    issue(bn2, (slot + PD) % NBUF);           // (the slot of block ib - 1: every wave is past its reads)
                 }
             };
 #if FD_TR_WG_DMA_AT == 0
@@ -1909,8 +1905,6 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
 #endif
             const char* sx = smem + slot * SB + SL::off_xr;
             const char* sd = smem + slot * SB + SL::off_dr;
-            const char* tx = smem + slot * SB + SL::off_xT;
-            const char* td = smem + slot * SB + SL::off_dT;
             f32x4 hh[2][2], dh[2][2];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -1952,12 +1946,14 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
 #endif
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                // T-block A operands in the token order of the packed C tiles: slots 0-3 = tokens 4g.., slots 4-7 = tokens 16+4g..
-                const char* px = tx + (size_t)(16 * dt + tok) * (SL::TBS * 2), *pd = td + (size_t)(16 * dt + tok) * (SL::TBS * 2);
-                const u32x2 xl = *reinterpret_cast<const u32x2*>(px + 8 * g), xh = *reinterpret_cast<const u32x2*>(px + 32 + 8 * g);
-                const u32x2 dl = *reinterpret_cast<const u32x2*>(pd + 8 * g), dhh = *reinterpret_cast<const u32x2*>(pd + 32 + 8 * g);
-                const bf16x8 ax = __builtin_bit_cast(bf16x8, u32x4{xl[0], xl[1], xh[0], xh[1]});
-                const bf16x8 ad = __builtin_bit_cast(bf16x8, u32x4{dl[0], dl[1], dhh[0], dhh[1]});
+                // feature-major A operands (rows = features 16 dt + tok) in the token order of the packed C tiles: slots 0-3 =
+                // tokens 4g.., slots 4-7 = tokens 16+4g...  ds_read_b64_tr_b16: lane 4j + q of a 16-lane group hands in the
+                // address of features 16 dt + 4q.. of token row 4g + j, lane tok gets feature 16 dt + tok of the four rows.
+                const int toff = (4 * g + (tok >> 2)) * (SL::RBS * 2) + (16 * dt + 4 * (tok & 3)) * 2;
+                const s16x4 xl = lds_read_tr16(sx + toff), xh = lds_read_tr16(sx + toff + 16 * (SL::RBS * 2));
+                const s16x4 dl = lds_read_tr16(sd + toff), dhh = lds_read_tr16(sd + toff + 16 * (SL::RBS * 2));
+                const bf16x8 ax = __builtin_bit_cast(bf16x8, __builtin_shufflevector(xl, xh, 0, 1, 2, 3, 4, 5, 6, 7));
+                const bf16x8 ad = __builtin_bit_cast(bf16x8, __builtin_shufflevector(dl, dhh, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft) {
                     a2[ft][dt] = MFMA(ad, hB[ft], a2[ft][dt]);        // d W2[d][f]
@@ -1968,10 +1964,13 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
             prefetch();          // (behind every MFMA of the block)
 #endif
         };
+        static_assert(NBUF >= 3 && NBUF <= 5, "ring depth");
         for (int ib = 0; ib < nb; ib += NBUF) {
             block(ib, std::integral_constant<int, 0>{});
             if (ib + 1 < nb) block(ib + 1, std::integral_constant<int, 1>{});
             if (ib + 2 < nb) block(ib + 2, std::integral_constant<int, 2>{});
+            if constexpr (NBUF > 3) { if (ib + 3 < nb) block(ib + 3, std::integral_constant<int, 3>{}); }
+            if constexpr (NBUF > 4) { if (ib + 4 < nb) block(ib + 4, std::integral_constant<int, 4>{}); }
         }
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
@@ -2262,7 +2261,7 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
     const size_t T = m->d.max_len, D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, L = m->d.num_layers;
     const size_t M = (size_t)B * T, Mpad = (M + 63) & ~size_t(63);
     const size_t NFT = 16 * (size_t)im->dt, RBW = 32 * (size_t)im->ks1, NP = im->np, NJ = ((T + 15) / 16 + 1) / 2;
-    const size_t stage_bytes = (((size_t)2 * 32 * (RBW + 8) * 2 + (size_t)2 * NFT * 40 * 2) + 1023) & ~size_t(1023);
+    const size_t stage_bytes = ((size_t)2 * 32 * (RBW + 8) * 2 + 1023) & ~size_t(1023);        // == StageL<KS1, DT>::bytes
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al(bytes); return p; };
     TrBufs tb;
@@ -2776,10 +2775,13 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         FD_HIP(ctx, hipEventCreateWithFlags(&e, kTrEventFlags));
         ctx->side_events.push_back(e);
     }
-    // FDIFF_TR_WG_LDS_KB pads the request (experiments: above 80 KiB only one weight-gradient workgroup fits a CU, which
-    // leaves registers and LDS for the chain's attention-backward workgroups beside it)
-    static const size_t wg_pad = getenv("FDIFF_TR_WG_LDS_KB") ? (size_t)atoi(getenv("FDIFF_TR_WG_LDS_KB")) * 1024 : 0;
-    const size_t lds_wg = std::max((size_t)3 * StageL<KS1, DT>::bytes + 128 + 3 * 512, wg_pad);      // (ring + lane-mask table + activity words)
+    // The request is never below 56 KiB: with the 13-KiB records the ring alone is 41-54 KiB, and at 41 KiB a third kind of
+    // workgroup (the chain's backward kernels run beside this launch) became resident on the CUs next to the two
+    // weight-gradient ones -- the T = 252 step went 2.32 -> 2.39 ms, against 2.28 ms with the footprint held at >= 56 KiB
+    // (profiles/r05_tr16_stage.txt).  FDIFF_TR_WG_LDS_KB overrides the floor (experiments; above 80 KiB only one
+    // weight-gradient workgroup fits a CU).
+    static const size_t wg_pad = getenv("FDIFF_TR_WG_LDS_KB") ? (size_t)atoi(getenv("FDIFF_TR_WG_LDS_KB")) * 1024 : (size_t)56 * 1024;
+    const size_t lds_wg = std::max((size_t)FD_TR_WG_NBUF * StageL<KS1, DT>::bytes + 128 + FD_TR_WG_NBUF * 512, wg_pad);      // (ring + lane-mask table + activity words)
     static const bool serial = getenv("FDIFF_TR_SERIAL") != nullptr;
     WgArgs wa{};
     wa.nparams = (long long)tb.layer_params; wa.TS = tb.TS; wa.nblk = (M + 31) / 32;
