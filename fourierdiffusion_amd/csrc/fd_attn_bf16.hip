@@ -128,7 +128,7 @@ template <int KS1, int ROWS = 0>
 __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const float* __restrict__ in, float* __restrict__ out, int T,
                                                            int H, int hd, int D, float qscale, int du_per_block, int exact_only,
                                                            fd_attn_w wimg, size_t pair_stride, int slices, int B, int out_bf16,
-                                                           const __bf16* __restrict__ xrows) {
+                                                           const __bf16* __restrict__ xrows, int KTP) {
     constexpr bool PROJ = KS1 > 0;
     constexpr int KSN = PROJ ? KS1 : 1;
     // Workgroup -> (series, head pair, query slice).  Hardware workgroup ids go round-robin over the 8 XCDs; all
@@ -143,7 +143,9 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int KT = (T + 15) >> 4, NJ = (KT + 1) >> 1, NTOK = KT * 16;
+    // KTP >= KT: key tiles in LDS.  A series whose last 128-key block is partial may be padded to whole blocks with all-zero key
+    // tiles (host policy): the fast path then runs the block through the software pipeline instead of the rolled pair loop.
+    const int KT = (T + 15) >> 4, NJ = (KTP + 1) >> 1, NTOK = KTP * 16;
     char* const kbf = smem;                       // [NTOK][4 g][8 B]: lane group g = 2*hs + (d >> 2), element d & 3
     char* const vbf = smem + (size_t)NTOK * 32;   // [NJ][4 g][16 dim slots][16 B]: (half, r) -> token (2jj+half)*16 + 4g + r
     char* const qbf = vbf + (size_t)NJ * 1024;    // [slice tile][64 lanes][8 B]: Q^T C tile as bf16 (scaled by log2e/sqrt(hd))
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
                     char* dst = vbf + ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16;
                     if (!(kmax_in_v && kt == 0 && lane == 7))          // (that row's first 8 bytes hold kmax)
                         *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = u32x2{cvt_pk_bf16(c[0], c[1]), cvt_pk_bf16(c[2], c[3])};
-                    if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
+                    if ((KT & 1) && kt == KT - 1 && KTP == KT) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
                     if (isq)
                         *reinterpret_cast<u32x2*>(qbf + ((size_t)(kt - qt0) * 64 + lane) * 8) = u32x2{cvt_pk_bf16(qa[0], qa[1]), cvt_pk_bf16(qa[2], qa[3])};
                     float n2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
             char* dst = vbf + ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16;
             if (!(kmax_in_v && kt == 0 && lane == 7))          // (that row's first 8 bytes hold kmax)
                 *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = u32x2{cvt_pk_bf16(c[0], c[1]), cvt_pk_bf16(c[2], c[3])};
-            if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
+            if ((KT & 1) && kt == KT - 1 && KTP == KT) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
             if (isq)
                 *reinterpret_cast<u32x2*>(qbf + ((size_t)(kt - qt0) * 64 + lane) * 8) = u32x2{cvt_pk_bf16(qa[0], qa[1]), cvt_pk_bf16(qa[2], qa[3])};
             float n2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
@@ -279,6 +281,11 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
                 cur_hi[ks] = nxt_hi[ks];
             }
         }
+        }
+        // padding tiles: zero K rows and V^T halves (scores 0 -> exp2 = 1 against zero V^T / ones-row entries: no contribution)
+        for (int kt = KT + wave; kt < KTP; kt += NW) {
+            *reinterpret_cast<u32x2*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8) = u32x2{0u, 0u};
+            *reinterpret_cast<u32x2*>(vbf + ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16 + 8 * (kt & 1)) = u32x2{0u, 0u};
         }
     } else {
     // K: one thread per (token, lane group gq): the 4 dims 4(gq&1)..+3 of head gq>>1 -> one 8-byte row; dim slot hd
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
             bf16x8 vprev;
             f32x4 cpe[LAG];          // carried over the block boundary: scores of the block's last LAG tiles (before exp2),
             bf16x8 cpk[HL];          // its packed pairs not yet multiplied, and (vprev) its last V^T fragment
-            const int NFULL = KT >> 3;
+            const int NFULL = KTP >> 3;
             if (NFULL > 0) {
                 // K / V^T fragments are read from LDS one 32-key group (8 slots, ~400 cycles) ahead of their use: two groups of K
                 // and three of V^T are live at a time instead of a whole block's (the kernel must stay under 128 VGPRs: two
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
                     m2[q][hs] = mnew;
                     negm[q][hs] = f32x4{-mnew, -mnew, -mnew, -mnew};
                 }
-            for (int jb = kb >> 1; jb < NJ; ++jb) {
+            for (int jb = kb >> 1; jb < ((KT + 1) >> 1); ++jb) {          // (the series' own tiles only: no padding tiles here)
                 const int ka = 2 * jb, kb2 = (2 * jb + 1 < KT) ? 2 * jb + 1 : ka;
                 const s16x4 kfa = kfrag_cold(ka), kfb = kfrag_cold(kb2);
                 const bf16x8 vfj = vfrag_cold(jb);
@@ -781,8 +788,14 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
 // in_rows (nullable; fused projections only): the layer input as bf16 rows (B*T, 32 ks1), see the kernel's ROWS form.
 int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, int H, int hd, hipStream_t s, const char* wk,
                       const char* wv, const char* wq, int ks1, int out_bf16, const void* in_rows) {
-    const int KT = (T + 15) / 16, NJ = (KT + 1) / 2, D = H * hd;
-    const size_t lds_kv = (size_t)KT * 16 * 32 + (size_t)NJ * 1024 + (hd == 7 ? 16 : 0);
+    const int KT = (T + 15) / 16, D = H * hd;
+    // A partial last 128-key block of >= FDIFF_ATTN_PAD_MIN (default 3) tiles is padded to a whole one with zero tiles when the LDS
+    // allows: the fast path then has no rolled remainder loop (T = 365: 23 -> 24 tiles, 114.7 -> ?? us per layer at B = 512).
+    const int pad_min = getenv("FDIFF_ATTN_PAD_MIN") ? atoi(getenv("FDIFF_ATTN_PAD_MIN")) : 3;
+    auto kv_bytes = [&](int ktp) { return (size_t)ktp * 16 * 32 + (size_t)((ktp + 1) / 2) * 1024 + (hd == 7 ? 16 : 0); };
+    int KTP = KT;
+    if ((KT & 7) >= pad_min && kv_bytes((KT + 7) & ~7) + NQ * 512 <= 160 * 1024) KTP = (KT + 7) & ~7;
+    const size_t lds_kv = kv_bytes(KTP);
     if (hd > 7 || lds_kv + NQ * 512 > 160 * 1024) return FD_ERR_UNSUPPORTED;
     if (out_bf16 && (hd & 1)) return FD_ERR_UNSUPPORTED;
     const bool proj = wk != nullptr;
@@ -823,7 +836,7 @@ int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, in
     const size_t pair_stride = (size_t)ks1 * 1024;
     const dim3 grid((unsigned)(((B + 7) / 8) * 8 * NP * slices)), block(NTH);
     const __bf16* xr = reinterpret_cast<const __bf16*>(in_rows);
-#define FD_ATT_GO(K, R) hipLaunchKernelGGL((k_attention_bf16<K, R>), grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B, out_bf16, xr)
+#define FD_ATT_GO(K, R) hipLaunchKernelGGL((k_attention_bf16<K, R>), grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B, out_bf16, xr, KTP)
     if (!proj) FD_ATT_GO(0, 0);
     else if (ks1 == 3) { if (rows) FD_ATT_GO(3, 1); else FD_ATT_GO(3, 0); }
     else { if (rows) FD_ATT_GO(2, 1); else FD_ATT_GO(2, 0); }

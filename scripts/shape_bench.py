@@ -14,7 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = {"ecg": (100, 12), "nasdaq": (252, 6), "mimic": (256, 28), "long": (1024, 16), "ecg187": (187, 1), "mimic24": (24, 40),
           "nasa": (134, 10),
           # the shapes the reference's datamodules produce (datamodules.py:194-201, 404-410, 471-476; mimiciii.yaml:7)
-          "nasdaq5": (252, 5), "nasa251": (251, 4), "nasa134": (134, 5)}
+          "nasdaq5": (252, 5), "nasa251": (251, 4), "nasa134": (134, 5),
+          # droughts: one year of 18 daily indicators minus the five the datamodule removes (datamodules.py:528-537)
+          "droughts": (365, 13)}
 
 
 def flops_fwd(T, Cn, D=72, L=10, F=2048):

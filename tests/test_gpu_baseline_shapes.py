@@ -232,16 +232,19 @@ ATTN_SHAPES = {
 
 
 @pytest.mark.parametrize("env", [{}, {"FDIFF_ATTN_UNFUSED": "1"}, {"FDIFF_ATTN_SLICES": "4"}, {"FDIFF_ATTN_SLICES": "1"},
-                                 {"FDIFF_ATTN_EXACT": "1"}, {"FDIFF_ATTN_UNFUSED": "1", "FDIFF_ATTN_SLICES": "2"}],
+                                 {"FDIFF_ATTN_EXACT": "1"}, {"FDIFF_ATTN_UNFUSED": "1", "FDIFF_ATTN_SLICES": "2"},
+                                 {"FDIFF_ATTN_PAD_MIN": "1"}, {"FDIFF_ATTN_PAD_MIN": "9"},
+                                 {"FDIFF_ATTN_PAD_MIN": "1", "FDIFF_ATTN_UNFUSED": "1"}],
                          ids=lambda e: ",".join(f"{k[6:]}={v}" for k, v in e.items()) or "default")
 @pytest.mark.parametrize("name", sorted(ATTN_SHAPES))
 def test_layer_attention_kernel_variants(name, env):
     """Every instantiation / launch shape of k_attention_bf16 against the oracle: projections fused (the persistent kernel's
     weight images) or packed q|k|v input (FDIFF_ATTN_UNFUSED), 1 / 2 / 4 query slices per (series, head pair), the exact two-pass
-    softmax, and the bound-shifted fast path (default)."""
+    softmax, the bound-shifted fast path (default), and the last partial key block padded to a whole one with zero tiles (default
+    from three tiles on; FDIFF_ATTN_PAD_MIN=1 always, =9 never)."""
     cfg = ATTN_SHAPES[name]
     B = 2
-    saved = {k: os.environ.get(k) for k in ("FDIFF_ATTN_UNFUSED", "FDIFF_ATTN_SLICES", "FDIFF_ATTN_EXACT")}
+    saved = {k: os.environ.get(k) for k in ("FDIFF_ATTN_UNFUSED", "FDIFF_ATTN_SLICES", "FDIFF_ATTN_EXACT", "FDIFF_ATTN_PAD_MIN")}
     try:
         for k in saved:
             os.environ.pop(k, None)
