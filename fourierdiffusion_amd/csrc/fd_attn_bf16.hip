@@ -790,7 +790,7 @@ int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, in
                       const char* wv, const char* wq, int ks1, int out_bf16, const void* in_rows) {
     const int KT = (T + 15) / 16, D = H * hd;
     // A partial last 128-key block of >= FDIFF_ATTN_PAD_MIN (default 3) tiles is padded to a whole one with zero tiles when the LDS
-    // allows: the fast path then has no rolled remainder loop (T = 365: 23 -> 24 tiles, 114.7 -> ?? us per layer at B = 512).
+    // allows: the fast path then has no rolled remainder loop (T = 365: 23 -> 24 tiles, 115.0 -> 112.2 us per layer at B = 512; profiles/r05_droughts_shape.txt).
     const int pad_min = getenv("FDIFF_ATTN_PAD_MIN") ? atoi(getenv("FDIFF_ATTN_PAD_MIN")) : 3;
     auto kv_bytes = [&](int ktp) { return (size_t)ktp * 16 * 32 + (size_t)((ktp + 1) / 2) * 1024 + (hd == 7 ? 16 : 0); };
     int KTP = KT;
