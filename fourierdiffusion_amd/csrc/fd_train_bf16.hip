@@ -670,7 +670,7 @@ struct FfnFwdArgs {
     const float* att;         // (M, D)
     float* s1; float* s2;     // (M, D) pre-LayerNorm sums (saved)
     float* out;               // (M, D) layer output
-    char* stage;              // StageL records of the layer (x1 rows / T here, d f rows / T by the backward)
+    char* stage;              // StageL records of the layer (x1 rows here, d f rows by the backward)
     __bf16* outrb; __bf16* outT;   // next layer's input in operand form (null for the last layer)
     unsigned char* active;    // (Mpad, 4, F/32): bit e of byte (m, g, chunk): hidden unit kept by dropout AND > 0
     unsigned short* activeT;  // (Mpad/32, 2, F/32, 8, 4): bit j of word (block, half, chunk, w, gq): the same for token
@@ -1791,8 +1791,9 @@ __device__ __forceinline__ bf16x8 t_frag(const __bf16* __restrict__ tb, int blk,
 
 // One launch per layer: grid (F/128 + 4, TS), 256 threads.
 //   blockIdx.x < F/128 : linear1 / linear2.  A wave owns one 32-wide chunk of hidden units (two 16-wide tiles) and walks the
-//                        32-token blocks of its split; the operands every wave needs (x1 / d f rows and T-blocks of the
-//                        block: 4 KS1 + 2 DT KiB) are staged once per workgroup in a 3-deep LDS ring by global_load_lds.
+//                        32-token blocks of its split; the operands every wave needs (the x1 / d f rows of the block, one
+//                        StageL record of 4 KS1 + 1 KiB) are staged once per workgroup in an LDS ring by global_load_lds;
+//                        the feature-major operands of the d W products are transpose reads of the same rows.
 //   the other four     : in_proj rows of q | k | v, and out_proj (operands straight from the T-blocks, next block's
 //                        fragments prefetched into registers).
 template <int KS1, int DT>
