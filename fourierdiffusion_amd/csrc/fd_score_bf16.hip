@@ -324,6 +324,20 @@ struct fd_ffn_pre {
     __bf16* out_rows;
 };
 
+#ifndef FD_FFN_JOINT
+#define FD_FFN_JOINT 1          // bit 0: the fused prologue runs a wave's two tiles in one basic block; bit 1: the epilogue too (measured slower)
+#endif
+#ifdef FD_FFN_PROF           // variant build: in-kernel phase clocks of k_ffn_ln (workgroup 3, waves 0 and 4), printed after 40 launches
+__device__ unsigned long long fd_ffn_dbg[2 * 8];
+#define FFN_STAMP(slot, t_prev)                                                                          \
+    do {                                                                                                 \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                    \
+        if (blockIdx.x == 3 && lane == 0 && (wave & 3) == 0) fd_ffn_dbg[(wave >> 2) * 8 + (slot)] += now_ - (t_prev); \
+        (t_prev) = now_;                                                                                 \
+    } while (0)
+#else
+#define FFN_STAMP(slot, t_prev) do { } while (0)
+#endif
 template <int KS1, int DT, int MT, int KSO>
 __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, float* __restrict__ out,
                                                     const char* __restrict__ wimg, const float* __restrict__ b2,
@@ -349,11 +363,13 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
 
     // ---- weight stream: L2 -> LDS, 1 KiB per wave-instruction, blocks dealt round-robin to the 8 waves.
     // image order: [fh][step][sub][NB]  ->  LDS buffer [fh][sub][NB]
+    constexpr int NDMA = (2 * SUB * NB + 7) / 8;           // DMA instructions per wave and step (padding copies repeat a block)
     auto issue_dma = [&](int st, int buf) {
 #pragma unroll
-        for (int i = 0; i < (2 * SUB * NB + 7) / 8; ++i) {
-            const int b = wave + 8 * i;
-            if (b < 2 * SUB * NB) {
+        for (int i = 0; i < NDMA; ++i) {
+            int b = wave + 8 * i;
+            b -= (b >= 2 * SUB * NB) ? 2 * SUB * NB : 0;
+            {
                 const int h = b / (SUB * NB);
                 const int j = b - h * (SUB * NB);
                 const char* src = wimg + ((((size_t)h * NS + st) * SUB * NB + j) * 64 + lane) * 16;
@@ -362,7 +378,25 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
             }
         }
     };
+    unsigned long long tprev = __builtin_readcyclecounter();
+    (void)tprev;
     issue_dma(0, 0);
+    // The six small fp32 vectors of the kernel (b_o, gamma1, beta1 of the fused prologue; b2, gamma2, beta2 of the epilogue) go to
+    // LDS once per workgroup, [vector][4 DT float4], zero beyond D.  Read where they were used -- inside the lane-divergent
+    // `if (d0 < D)` / `if (valid)` branches of the per-tile code -- every load was waited for at the end of its branch: about ten
+    // dependent L2 round trips per token tile, 11.7 K cycles per tile in the phase clocks (profiles/r05_long_ffn_ln_phase_clocks.txt);
+    // hoisted into registers instead they pushed the kernel (256 VGPRs, two waves per SIMD) into spills and made it slower.
+    constexpr size_t XFR_BYTES = KSO > 0 ? (size_t)4 * MT * KS1 * 1024 : 0;
+    float4* const lvec = reinterpret_cast<float4*>(smem + 2 * WBUF + XFR_BYTES);       // (behind the ring and the x fragments)
+    float4 lval = {0.f, 0.f, 0.f, 0.f};
+    if (threadIdx.x < 6 * 4 * DT) {
+        const int v = threadIdx.x / (4 * DT), c = threadIdx.x - v * (4 * DT);
+        const float* src = v == 0 ? pre.bo : v == 1 ? pre.g1 : v == 2 ? pre.b1 : v == 3 ? b2 : v == 4 ? gamma : beta;
+        if (4 * c < D && (KSO > 0 || v >= 3)) lval = *reinterpret_cast<const float4*>(src + 4 * c);
+    }
+    auto lvec_store = [&]() {                               // (in front of the first barrier behind the load)
+        if (threadIdx.x < 6 * 4 * DT) lvec[threadIdx.x] = lval;
+    };
 
     // ---- activations -> bf16 B fragments in registers (token on lane&15, 8 features per lane, "1.0" in slot D)
     bf16x8 xf[MT][KS1];
@@ -373,114 +407,197 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
         for (int tt = 0; tt < MT; ++tt) acc[dt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (KSO > 0) {
         char* const xfr = smem + 2 * WBUF;                 // [4*MT tiles][KS1][64][16 B]: x fragments of this workgroup
-        bf16x8 wo[DT][KSO > 0 ? KSO : 1];
+        // W_o fragment image -> ring buffer 1 (free until the chunk loop's first step refills it behind the prologue's barrier):
+        // 60 VGPRs of fragments per wave became 15 LDS reads per tile, which is what lets a wave hold BOTH of its tiles' input
+        // rows in flight below.
+        char* const wos = smem + WBUF;
+        constexpr int KSOn = KSO > 0 ? KSO : 1;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+        for (int i = 0; i < (DT * KSOn + 7) / 8; ++i) {
+            const int bq = wave + 8 * i;
+            if (bq < DT * KSOn)
+                __builtin_amdgcn_global_load_lds(GLB_PTR(pre.wo_img + ((size_t)bq * 64 + lane) * 16), LDS_PTR(wos + bq * 1024), 16, 0, 0);
+        }
+        // The input rows of this wave's (at most two) tiles: the attention rows of its heads and the residual rows, unconditional
+        // loads from clamped addresses (selected at their use), all issued before the first wait.
+        typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+        struct TileIn {
+            u32x4 a[KSOn];
+            float4 r[DT];
+        };
+        TileIn tin[2];
+        auto tile_load = [&](int tt, TileIn& in) {
+            const int m = m_wg + (tile0 + tt) * 16 + tok;
+            const int mr = m < m_end ? m : m_wg;
+            if (pre.att_bf16) {
 #pragma unroll
-            for (int ks = 0; ks < KSO; ++ks)
-                wo[dt][ks] = *reinterpret_cast<const bf16x8*>(pre.wo_img + ((size_t)(dt * KSO + ks) * 64 + lane) * 16);
+                for (int ks = 0; ks < KSO; ++ks) {
+                    const int head = 4 * ks + g, hc = head < pre.H ? head : pre.H - 1;
+                    in.a[ks] = *reinterpret_cast<const u32x4_a4*>(reinterpret_cast<const __bf16*>(pre.att) + (size_t)mr * D + hc * pre.hd);
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d0 = 16 * dt + 4 * g, dr = d0 < D ? d0 : 0;
+                in.r[dt] = *reinterpret_cast<const float4*>(pre.h0 + (size_t)mr * D + dr);
+            }
+        };
 #pragma unroll
         for (int tt = 0; tt < MT; ++tt) {
             if (tt >= ntile || (tt & 1) != fh) continue;   // the two waves of a token quarter split its tiles
-            const int m = m_wg + (tile0 + tt) * 16 + tok;
-            const bool valid = m < m_end;
-            f32x4 o[DT];
+            tile_load(tt, tin[tt >> 1]);
+        }
+        // (the first weight buffer requested LAST and not waited for here -- all 256 workgroups fetch the same 44 KiB at the same
+        //  moment -- measured slower: 2.456 -> 2.495 ms per step at the droughts shape, 1.340 -> 1.348 at T = 1024)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // first weight buffer (own share), W_o image, vectors, the tiles' rows
+        lvec_store();
+        __syncthreads();
+        FFN_STAMP(6, tprev);          // requests issued, landed, barrier
+        // out-projection + residual + LayerNorm1 of NT (1 or 2) tiles in ONE basic block: the two tiles a wave owns in the common
+        // case (tt = fh, fh + 2 of a full quarter) are two independent chains of LDS reads -> MFMAs -> cross-lane sums -> LDS writes;
+        // one after the other (a predicated `continue` per tile) each ran at its own latency, 5 K cycles per tile in the phase clocks.
+        auto pro_tiles = [&](auto t0c, auto t1c) {
+            constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value, NT = T1 >= 0 ? 2 : 1;
+            constexpr int TT[2] = {T0, T1 >= 0 ? T1 : T0};
+            int m[NT];
+            bool valid[NT];
+            f32x4 o[NT][DT];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NT; ++i) {
+                m[i] = m_wg + (tile0 + TT[i]) * 16 + tok;
+                valid[i] = m[i] < m_end;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int ks = 0; ks < KSO; ++ks) {
                 const int head = 4 * ks + g;               // k-slot group g of k-step ks = the 8 (padded) dims of one head
-                // the head's 8 dim slots as two dword-aligned 16-byte loads from a clamped address, selected afterwards (eight
-                // conditional scalar loads per (token, head) were eight divergent branches and eight instructions that each walk
-                // 64 cache lines; slots >= head_dim read the next head / row: `att` is carved with 8 floats of slack for the last one)
-                u32x4 pk;
-                const int mc = valid ? m : m_wg, hc = head < pre.H ? head : pre.H - 1;
-                const bool ok = valid && head < pre.H;
-                if (pre.att_bf16) {
-                    // bf16 rows written by k_attention_bf16 (the rounding this prologue would do, done at the producer): ONE 16-byte
-                    // load per (token, head) at a dword-aligned address (head_dim even), slot pairs >= head_dim cleared
-                    typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-                    const u32x4_a4 raw = *reinterpret_cast<const u32x4_a4*>(reinterpret_cast<const __bf16*>(pre.att) + (size_t)mc * D + hc * pre.hd);
+                bf16x8 af[NT];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = (ok && 2 * e < pre.hd) ? raw[e] : 0u;
-                } else {
-                    float v[8];
-                    typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-                    const f32x4_a4* p8 = reinterpret_cast<const f32x4_a4*>(pre.att + (size_t)mc * D + hc * pre.hd);
-                    const f32x4_a4 lo = p8[0], hi = p8[1];
+                for (int i = 0; i < NT; ++i) {
+                    const TileIn& in = tin[TT[i] >> 1];
+                    u32x4 pk;
+                    const int mc = valid[i] ? m[i] : m_wg, hc = head < pre.H ? head : pre.H - 1;
+                    const bool ok = valid[i] && head < pre.H;
+                    if (pre.att_bf16) {
+                        // bf16 rows written by k_attention_bf16 (the rounding this prologue would do, done at the producer): ONE
+                        // 16-byte load per (token, head) at a dword-aligned address (head_dim even), slot pairs >= head_dim cleared
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = (ok && e < pre.hd) ? lo[e] : 0.f;
-                        v[4 + e] = (ok && 4 + e < pre.hd) ? hi[e] : 0.f;
+                        for (int e = 0; e < 4; ++e) pk[e] = (ok && 2 * e < pre.hd) ? in.a[ks][e] : 0u;
+                    } else {
+                        // fp32 rows (odd head_dim): the head's 8 dim slots as two dword-aligned 16-byte loads from a clamped address,
+                        // selected afterwards (slots >= head_dim read the next head / row: `att` is carved with 8 floats of slack)
+                        float v[8];
+                        typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                        const f32x4_a4* p8 = reinterpret_cast<const f32x4_a4*>(pre.att + (size_t)mc * D + hc * pre.hd);
+                        const f32x4_a4 lo = p8[0], hi = p8[1];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = (ok && e < pre.hd) ? lo[e] : 0.f;
+                            v[4 + e] = (ok && 4 + e < pre.hd) ? hi[e] : 0.f;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
                     }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
+                    af[i] = __builtin_bit_cast(bf16x8, pk);
                 }
-                const bf16x8 af = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo[dt][ks], af, o[dt], 0, 0, 0);
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wos + ((size_t)(dt * KSOn + ks) * 64 + lane) * 16);
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[i], o[i][dt], 0, 0, 0);
+                }
             }
-            float sm = 0.f;
+            float sm[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) sm[i] = 0.f;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int d0 = 16 * dt + 4 * g;
-                if (d0 < D) {
-                    const float4 bb = *reinterpret_cast<const float4*>(pre.bo + d0);
-                    float4 r0 = {0.f, 0.f, 0.f, 0.f};
-                    if (valid) r0 = *reinterpret_cast<const float4*>(pre.h0 + (size_t)m * D + d0);
-                    o[dt][0] += bb.x + r0.x; o[dt][1] += bb.y + r0.y; o[dt][2] += bb.z + r0.z; o[dt][3] += bb.w + r0.w;
-                    sm += (o[dt][0] + o[dt][1]) + (o[dt][2] + o[dt][3]);
-                } else {
-                    o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            sm += __shfl_xor(sm, 16);
-            sm += __shfl_xor(sm, 32);
-            const float mean = sm / (float)D;
-            float q = 0.f;
+                const float4 bb = lvec[0 * 4 * DT + 4 * dt + g];        // (zero beyond D)
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-                if (16 * dt + 4 * g < D) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float c = o[dt][r] - mean;
-                        q += c * c;
+                for (int i = 0; i < NT; ++i) {
+                    const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                    const float4 r0 = valid[i] ? tin[TT[i] >> 1].r[dt] : zero4;
+                    if (d0 < D) {
+                        o[i][dt][0] += bb.x + r0.x; o[i][dt][1] += bb.y + r0.y; o[i][dt][2] += bb.z + r0.z; o[i][dt][3] += bb.w + r0.w;
+                        sm[i] += (o[i][dt][0] + o[i][dt][1]) + (o[i][dt][2] + o[i][dt][3]);
+                    } else {
+                        o[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
-            q += __shfl_xor(q, 16);
-            q += __shfl_xor(q, 32);
-            const float rstd = rsqrtf(q / (float)D + 1e-5f);
+            }
+            float mean[NT], rstd[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                sm[i] += __shfl_xor(sm[i], 16);
+                sm[i] += __shfl_xor(sm[i], 32);
+                mean[i] = sm[i] / (float)D;
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                float q = 0.f;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    if (16 * dt + 4 * g < D) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float c = o[i][dt][r] - mean[i];
+                            q += c * c;
+                        }
+                    }
+                q += __shfl_xor(q, 16);
+                q += __shfl_xor(q, 32);
+                rstd[i] = rsqrtf(q / (float)D + 1e-5f);
+            }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int d0 = 16 * dt + 4 * g;
-                u32x2 pk = {0u, 0u};
-                if (d0 < D) {
-                    const float4 gm = *reinterpret_cast<const float4*>(pre.g1 + d0);
-                    const float4 bt = *reinterpret_cast<const float4*>(pre.b1 + d0);
-                    o[dt][0] = valid ? (o[dt][0] - mean) * rstd * gm.x + bt.x : 0.f;
-                    o[dt][1] = valid ? (o[dt][1] - mean) * rstd * gm.y + bt.y : 0.f;
-                    o[dt][2] = valid ? (o[dt][2] - mean) * rstd * gm.z + bt.z : 0.f;
-                    o[dt][3] = valid ? (o[dt][3] - mean) * rstd * gm.w + bt.w : 0.f;
-                    pk[0] = cvt_pk_bf16(o[dt][0], o[dt][1]);
-                    pk[1] = cvt_pk_bf16(o[dt][2], o[dt][3]);
-                } else if (d0 == D && valid) {
-                    pk[0] = 0x00003F80u;                   // bf16(1.0): bias row of the K padding
-                }
+                const float4 gm = lvec[1 * 4 * DT + 4 * dt + g];
+                const float4 bt = lvec[2 * 4 * DT + 4 * dt + g];
                 // C layout (feature 16dt + 4g + r) -> B fragment k-slot of the same feature index
                 const int ks = dt >> 1, gd = 2 * (dt & 1) + (g >> 1);
-                if (ks < KS1)
-                    *reinterpret_cast<u32x2*>(xfr + (((size_t)(tile0 + tt) * KS1 + ks) * 64 + gd * 16 + tok) * 16 + 8 * (g & 1)) = pk;
-                acc[dt][tt] = o[dt];                       // residual of the FFN block: out = x + b2 + W2 relu(..)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    u32x2 pk = {0u, 0u};
+                    if (d0 < D) {
+                        o[i][dt][0] = valid[i] ? (o[i][dt][0] - mean[i]) * rstd[i] * gm.x + bt.x : 0.f;
+                        o[i][dt][1] = valid[i] ? (o[i][dt][1] - mean[i]) * rstd[i] * gm.y + bt.y : 0.f;
+                        o[i][dt][2] = valid[i] ? (o[i][dt][2] - mean[i]) * rstd[i] * gm.z + bt.z : 0.f;
+                        o[i][dt][3] = valid[i] ? (o[i][dt][3] - mean[i]) * rstd[i] * gm.w + bt.w : 0.f;
+                        pk[0] = cvt_pk_bf16(o[i][dt][0], o[i][dt][1]);
+                        pk[1] = cvt_pk_bf16(o[i][dt][2], o[i][dt][3]);
+                    } else if (d0 == D && valid[i]) {
+                        pk[0] = 0x00003F80u;                   // bf16(1.0): bias row of the K padding
+                    }
+                    if (ks < KS1)
+                        *reinterpret_cast<u32x2*>(xfr + (((size_t)(tile0 + TT[i]) * KS1 + ks) * 64 + gd * 16 + tok) * 16 + 8 * (g & 1)) = pk;
+                    acc[dt][TT[i]] = o[i][dt];                 // residual of the FFN block: out = x + b2 + W2 relu(..)
+                }
             }
             // k-slots beyond 16*DT (K padding of the last k-step) must read as zero
             if (16 * DT < 32 * KS1) {
 #pragma unroll
-                for (int slot = 16 * DT + 4 * g; slot < 32 * KS1; slot += 16)
-                    *reinterpret_cast<u32x2*>(xfr + (((size_t)(tile0 + tt) * KS1 + (slot >> 5)) * 64 + ((slot & 31) >> 3) * 16 + tok) * 16 +
-                                              8 * ((slot >> 2) & 1)) = u32x2{0u, 0u};
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int slot = 16 * DT + 4 * g; slot < 32 * KS1; slot += 16)
+                        *reinterpret_cast<u32x2*>(xfr + (((size_t)(tile0 + TT[i]) * KS1 + (slot >> 5)) * 64 + ((slot & 31) >> 3) * 16 + tok) * 16 +
+                                                  8 * ((slot >> 2) & 1)) = u32x2{0u, 0u};
             }
+        };
+        using std::integral_constant;
+        if ((FD_FFN_JOINT & 1) && MT == 4 && ntile == MT) {
+            if (fh == 0) pro_tiles(integral_constant<int, 0>{}, integral_constant<int, (MT == 4 ? 2 : -1)>{});
+            else pro_tiles(integral_constant<int, (MT == 4 ? 1 : 0)>{}, integral_constant<int, (MT == 4 ? 3 : -1)>{});
+        } else {
+            if (0 < ntile && fh == 0) pro_tiles(integral_constant<int, 0>{}, integral_constant<int, -1>{});
+            if (MT > 1 && 1 < ntile && fh == 1) pro_tiles(integral_constant<int, (MT > 1 ? 1 : 0)>{}, integral_constant<int, -1>{});
+            if (MT > 2 && 2 < ntile && fh == 0) pro_tiles(integral_constant<int, (MT > 2 ? 2 : 0)>{}, integral_constant<int, -1>{});
+            if (MT > 3 && 3 < ntile && fh == 1) pro_tiles(integral_constant<int, (MT > 3 ? 3 : 0)>{}, integral_constant<int, -1>{});
         }
+        FFN_STAMP(0, tprev);          // prologue: out-projection + LN1 of this wave's tiles, fragments written
         __syncthreads();
+        FFN_STAMP(1, tprev);          // barrier
 #pragma unroll
         for (int tt = 0; tt < MT; ++tt)
 #pragma unroll
@@ -520,8 +637,10 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
         }
     }
 
+    if (KSO == 0) lvec_store();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    FFN_STAMP(2, tprev);              // fragments read, first weight buffer landed, barrier
 
     // The chunk loop is instantiated for "every tile present" (the common case: one basic block per chunk, the tiles' LDS reads /
     // MFMAs / relu interleave) and once with the per-tile guard; with the guard alone every tile was its own basic block and
@@ -579,6 +698,7 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
     };
     if (ntile == MT) chunk_loop(std::true_type{});
     else chunk_loop(std::false_type{});
+    FFN_STAMP(3, tprev);              // chunk loop
 
 #ifdef FD_ABLATE_NOEPI
     if (acc[0][0][0] != 12345.678f) return;
@@ -593,71 +713,96 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
         }
     }
     __syncthreads();
+    FFN_STAMP(4, tprev);              // exchange of the F-halves
+    // residual + b2 + LayerNorm2 + stores of NT (1 or 2) tiles in one basic block (see the prologue)
+    auto epi_tiles = [&](auto t0c, auto t1c) {
+        constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value, NT = T1 >= 0 ? 2 : 1;
+        constexpr int TT[2] = {T0, T1 >= 0 ? T1 : T0};
+        int m[NT];
+        bool valid[NT];
+        float v[NT][DT][4];
+        float sum[NT];
 #pragma unroll
-    for (int tt = 0; tt < MT; ++tt) {
-        if (tt >= ntile || (tt & 1) != fh) continue;
-        const int m = m_wg + (tile0 + tt) * 16 + tok;
-        const bool valid = m < m_end;
-        float v[DT][4];
-        float s = 0.f;
+        for (int i = 0; i < NT; ++i) {
+            m[i] = m_wg + (tile0 + TT[i]) * 16 + tok;
+            valid[i] = m[i] < m_end;
+            sum[i] = 0.f;
+        }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const f32x4 tot = acc[dt][tt] + xch[((mq * MT + tt) * DT + dt) * 64 + lane];
             const int d0 = 16 * dt + 4 * g;
             const bool dv = d0 < D;                          // D % 4 == 0: a 4-group is all-valid or all-pad
-            float4 res = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
-            if (dv) {
-                bb = *reinterpret_cast<const float4*>(b2 + d0);
-                if (valid && KSO == 0) res = *reinterpret_cast<const float4*>(x + (size_t)m * D + d0);   // (fused: already in acc)
-            }
-            v[dt][0] = dv ? tot[0] + bb.x + res.x : 0.f;
-            v[dt][1] = dv ? tot[1] + bb.y + res.y : 0.f;
-            v[dt][2] = dv ? tot[2] + bb.z + res.z : 0.f;
-            v[dt][3] = dv ? tot[3] + bb.w + res.w : 0.f;
-            s += (v[dt][0] + v[dt][1]) + (v[dt][2] + v[dt][3]);
-        }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        const float mean = s / (float)D;
-        float q = 0.f;
+            const float4 bb = lvec[3 * 4 * DT + 4 * dt + g];     // (zero beyond D)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            if (16 * dt + 4 * g < D) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float cdev = v[dt][r] - mean;
-                    q += cdev * cdev;
+            for (int i = 0; i < NT; ++i) {
+                const f32x4 tot = acc[dt][TT[i]] + xch[((mq * MT + TT[i]) * DT + dt) * 64 + lane];
+                float4 res = {0.f, 0.f, 0.f, 0.f};
+                if (KSO == 0) {                              // (fused prologue: the residual is already in acc)
+                    const int mr = valid[i] ? m[i] : m_wg, dr = dv ? d0 : 0;
+                    const float4 rr = *reinterpret_cast<const float4*>(x + (size_t)mr * D + dr);
+                    if (valid[i] && dv) res = rr;
                 }
+                v[i][dt][0] = dv ? tot[0] + bb.x + res.x : 0.f;
+                v[i][dt][1] = dv ? tot[1] + bb.y + res.y : 0.f;
+                v[i][dt][2] = dv ? tot[2] + bb.z + res.z : 0.f;
+                v[i][dt][3] = dv ? tot[3] + bb.w + res.w : 0.f;
+                sum[i] += (v[i][dt][0] + v[i][dt][1]) + (v[i][dt][2] + v[i][dt][3]);
             }
         }
-        q += __shfl_xor(q, 16);
-        q += __shfl_xor(q, 32);
-        const float rstd = rsqrtf(q / (float)D + 1e-5f);
-        if (valid) {
+        float mean[NT], rstd[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            sum[i] += __shfl_xor(sum[i], 16);
+            sum[i] += __shfl_xor(sum[i], 32);
+            mean[i] = sum[i] / (float)D;
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            float q = 0.f;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const int d0 = 16 * dt + 4 * g;
-                if (d0 < D) {
-                    const float4 gm = *reinterpret_cast<const float4*>(gamma + d0);
-                    const float4 bt = *reinterpret_cast<const float4*>(beta + d0);
-                    float4 o;
-                    o.x = (v[dt][0] - mean) * rstd * gm.x + bt.x;
-                    o.y = (v[dt][1] - mean) * rstd * gm.y + bt.y;
-                    o.z = (v[dt][2] - mean) * rstd * gm.z + bt.z;
-                    o.w = (v[dt][3] - mean) * rstd * gm.w + bt.w;
-                    *reinterpret_cast<float4*>(out + (size_t)m * D + d0) = o;
-                    v[dt][0] = o.x; v[dt][1] = o.y; v[dt][2] = o.z; v[dt][3] = o.w;
+                if (16 * dt + 4 * g < D) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float cdev = v[i][dt][r] - mean[i];
+                        q += cdev * cdev;
+                    }
                 }
             }
-            if (pre.out_rows) {
-                __bf16* rrow = pre.out_rows + (size_t)m * (32 * KS1);
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            rstd[i] = rsqrtf(q / (float)D + 1e-5f);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            const float4 gm = lvec[4 * 4 * DT + 4 * dt + g];
+            const float4 bt = lvec[5 * 4 * DT + 4 * dt + g];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                if (valid[i] && d0 < D) {
+                    float4 o;
+                    o.x = (v[i][dt][0] - mean[i]) * rstd[i] * gm.x + bt.x;
+                    o.y = (v[i][dt][1] - mean[i]) * rstd[i] * gm.y + bt.y;
+                    o.z = (v[i][dt][2] - mean[i]) * rstd[i] * gm.z + bt.z;
+                    o.w = (v[i][dt][3] - mean[i]) * rstd[i] * gm.w + bt.w;
+                    *reinterpret_cast<float4*>(out + (size_t)m[i] * D + d0) = o;
+                    v[i][dt][0] = o.x; v[i][dt][1] = o.y; v[i][dt][2] = o.z; v[i][dt][3] = o.w;
+                }
+            }
+        }
+        if (pre.out_rows) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                if (!valid[i]) continue;
+                __bf16* rrow = pre.out_rows + (size_t)m[i] * (32 * KS1);
 #pragma unroll
                 for (int dt = 0; dt < 2 * KS1; ++dt) {
                     const int d0 = 16 * dt + 4 * g;
                     u32x2 pk = {0u, 0u};
                     if (dt < DT && d0 < D) {
-                        pk[0] = cvt_pk_bf16(v[dt < DT ? dt : 0][0], v[dt < DT ? dt : 0][1]);
-                        pk[1] = cvt_pk_bf16(v[dt < DT ? dt : 0][2], v[dt < DT ? dt : 0][3]);
+                        pk[0] = cvt_pk_bf16(v[i][dt < DT ? dt : 0][0], v[i][dt < DT ? dt : 0][1]);
+                        pk[1] = cvt_pk_bf16(v[i][dt < DT ? dt : 0][2], v[i][dt < DT ? dt : 0][3]);
                     } else if (d0 == D) {
                         pk[0] = 0x00003F80u;
                     }
@@ -665,7 +810,20 @@ __global__ __launch_bounds__(512, 2) void k_ffn_ln(const float* __restrict__ x, 
                 }
             }
         }
+    };
+    {
+        using std::integral_constant;
+        if ((FD_FFN_JOINT & 2) && MT == 4 && ntile == MT) {
+            if (fh == 0) epi_tiles(integral_constant<int, 0>{}, integral_constant<int, (MT == 4 ? 2 : -1)>{});
+            else epi_tiles(integral_constant<int, (MT == 4 ? 1 : 0)>{}, integral_constant<int, (MT == 4 ? 3 : -1)>{});
+        } else {
+            if (0 < ntile && fh == 0) epi_tiles(integral_constant<int, 0>{}, integral_constant<int, -1>{});
+            if (MT > 1 && 1 < ntile && fh == 1) epi_tiles(integral_constant<int, (MT > 1 ? 1 : 0)>{}, integral_constant<int, -1>{});
+            if (MT > 2 && 2 < ntile && fh == 0) epi_tiles(integral_constant<int, (MT > 2 ? 2 : 0)>{}, integral_constant<int, -1>{});
+            if (MT > 3 && 3 < ntile && fh == 1) epi_tiles(integral_constant<int, (MT > 3 ? 3 : 0)>{}, integral_constant<int, -1>{});
+        }
     }
+    FFN_STAMP(5, tprev);              // LN2 + stores of this wave's tiles
 }
 
 template <int KS1, int DT, int MT, int KSO>
@@ -675,7 +833,9 @@ int launch_ffn(fd_ctx* ctx, const float* x, float* out, const char* wimg, const 
     constexpr size_t lds_main = 2 * (size_t)2 * 2 * NB * 1024;         // 2 buffers x 2 F-halves x SUB chunks
     constexpr size_t lds_xch = (size_t)4 * MT * DT * 1024;
     constexpr size_t lds_xfr = KSO > 0 ? (size_t)4 * MT * KS1 * 1024 : 0;   // fused prologue: x fragments behind the ring
-    const size_t lds = (lds_main > lds_xch ? lds_main : lds_xch) + lds_xfr;
+    constexpr size_t lds_vec = (size_t)6 * 4 * DT * 16;                       // the six fp32 vectors as float4 [vector][4 DT]
+    static_assert(lds_main >= lds_xch, "the vectors sit behind ring + x fragments: the exchange area must not reach them");
+    const size_t lds = lds_main + lds_xfr + lds_vec;
     auto kern = k_ffn_ln<KS1, DT, MT, KSO>;
     static unsigned long long attr = 0;
     if (fd_first_on_device(attr, ctx->device))
@@ -683,6 +843,20 @@ int launch_ffn(fd_ctx* ctx, const float* x, float* out, const char* wimg, const 
     const int grid = (M + tok_per_wg - 1) / tok_per_wg;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, x, out, wimg, b2, gamma, beta, M, D, F, tok_per_wg, pre);
     FD_LAUNCH_CHECK(ctx);
+#ifdef FD_FFN_PROF
+    {
+        static int calls = 0;
+        if (++calls == 40) {
+            unsigned long long h[16];
+            hipStreamSynchronize(s);
+            hipMemcpyFromSymbol(h, HIP_SYMBOL(fd_ffn_dbg), sizeof(h));
+            for (int w = 0; w < 2; ++w)
+                fprintf(stderr, "[ffn_ln dbg] MT=%d tok_per_wg=%d grid=%d wave %d over %d launches: requests + wait + barrier %llu, out-proj + LN1 of the tiles %llu, barrier %llu, frags + first buffer %llu, chunk loop %llu, exchange %llu, epilogue %llu cycles\n",
+                        MT, tok_per_wg, grid, 4 * w, calls, h[w * 8 + 6] / calls, h[w * 8 + 0] / calls, h[w * 8 + 1] / calls, h[w * 8 + 2] / calls, h[w * 8 + 3] / calls,
+                        h[w * 8 + 4] / calls, h[w * 8 + 5] / calls);
+        }
+    }
+#endif
     return FD_OK;
 }
 
