@@ -595,10 +595,31 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
             mx[hs] = group_max(mx[hs]);
             negm[hs] = f32x4{-mx[hs], -mx[hs], -mx[hs], -mx[hs]};
         }
-        // pass 2: P = exp2(S - max); row sums of the UNDROPPED P; dropped P (unscaled) times V
+        // pass 2: P = exp2(S - max); row sums of the UNDROPPED P; dropped P (unscaled) times V.  The keep bytes of key block jb + 1
+        // are requested while block jb runs (unconditional loads from clamped addresses: a padded query row or a missing odd head
+        // reads some other row's bits and its output is never stored).  Inside `if (t < T && head < H)` each byte was waited for
+        // where it was requested, a dependent L2 round trip between the exponentials and the P V MFMA of every (block, head)
+        // iteration: the timing ablation without the loads says 4.4 of the kernel's 31.3 us (profiles/r05_train_attn_fwd_keep_bytes.txt).
         float ls[2] = {0.f, 0.f};
         f32x4 o2[2] = {f4zero(), f4zero()};
+        const unsigned char* prow[2];
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+            const int head = 2 * pair + hs, hc = head < H ? head : H - 1;
+            prow[hs] = a.pmask + ((((size_t)b * H + hc) * T + (t < T ? t : 0)) * NJ) * 4 + g;
+        }
+        unsigned bnext[2] = {0xffu, 0xffu};
+        if (d.p > 0.f) {
+            bnext[0] = prow[0][0];
+            bnext[1] = prow[1][0];
+        }
         for (int jb = 0; jb < NJ; ++jb) {
+            const unsigned bcur[2] = {bnext[0], bnext[1]};
+            if (d.p > 0.f) {
+                const int jn = jb + 1 < NJ ? jb + 1 : jb;
+                bnext[0] = prow[0][(size_t)jn * 4];
+                bnext[1] = prow[1][(size_t)jn * 4];
+            }
             const int ka = 2 * jb, kb = (2 * jb + 1 < KT) ? 2 * jb + 1 : ka;
             const s16x4 kfa = kfrag(ka), kfb = kfrag(kb);
             const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(jb * 4 + g) * 16 + tok) * 16);
@@ -614,10 +635,7 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
                     pb[r] = __builtin_amdgcn_exp2f(pb[r]);
                 }
                 ls[hs] += (pa[0] + pa[1]) + (pa[2] + pa[3]) + (pb[0] + pb[1]) + (pb[2] + pb[3]);
-                const int head = 2 * pair + hs;
-                const size_t bidx = ((((size_t)b * H + head) * T + (t < T ? t : 0)) * NJ + jb) * 4 + g;
-                unsigned bits = 0xffu;
-                if (d.p > 0.f && t < T && head < H) bits = a.pmask[bidx];
+                const unsigned bits = bcur[hs];
                 const u32x2 ka2 = *reinterpret_cast<const u32x2*>(klut + 2 * (bits & 15u)), kb2 = *reinterpret_cast<const u32x2*>(klut + 2 * (bits >> 4));
                 const u32x4 pk = __builtin_bit_cast(u32x4, pack8(pa, pb));
                 o2[hs] = MFMA(vf, __builtin_bit_cast(bf16x8, u32x4{pk[0] & ka2[0], pk[1] & ka2[1], pk[2] & kb2[0], pk[3] & kb2[1]}), o2[hs]);
@@ -707,6 +725,17 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     if (threadIdx.x < 32) {
         const unsigned n = threadIdx.x >> 1, hi = threadIdx.x & 1;
         klut[threadIdx.x] = ((n >> (2 * hi)) & 1u ? 0x0000ffffu : 0u) | ((n >> (2 * hi + 1)) & 1u ? 0xffff0000u : 0u);
+    }
+    // the epilogue's small vectors (b2, gamma2, beta2) through LDS, [vector][4 DT float4], zero beyond D: read where they were used
+    // -- inside the epilogue's lane-divergent `if (d0 < D)` branches -- every one of the ten loads was waited for at the end of its
+    // branch, ten dependent L2 round trips in the owner's epilogue (9 K of the kernel's 88 K cycles; the finding of k_ffn_ln,
+    // profiles/r05_long_ffn_ln_phase_clocks.txt).  Requested here, written in front of the barrier that precedes the chunk loop.
+    float4* const lvec = reinterpret_cast<float4*>(klut + 32);
+    float4 lval = {0.f, 0.f, 0.f, 0.f};
+    if (threadIdx.x < 3 * 4 * DT) {
+        const int vq = threadIdx.x / (4 * DT), cq = threadIdx.x - vq * (4 * DT);
+        const float* src = vq == 0 ? a.b2 : vq == 1 ? a.g2 : a.be2;
+        if (4 * cq < d.D) lval = *reinterpret_cast<const float4*>(src + 4 * cq);
     }
     // F-split (struct FSplit): token block, chunk range and role of this workgroup
     const int nsp = d.fsplit, blk = nsp == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, fq = nsp == 2 ? (int)(blockIdx.x & 1) : 0;
@@ -841,6 +870,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f4zero();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x < 3 * 4 * DT) lvec[threadIdx.x] = lval;
     TRF_STAMP(2, tprev);          // dropout bytes staged, first weight chunks landed (own share)
     __syncthreads();
     TRF_STAMP(3, tprev);          // barrier
@@ -997,7 +1027,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         for (int dt = 0; dt < DT; ++dt) {
             const int d0 = 16 * dt + 4 * g;
             if (d0 < D) {
-                const float4 bb = *reinterpret_cast<const float4*>(a.b2 + d0);
+                const float4 bb = lvec[0 * 4 * DT + 4 * dt + g];
                 const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[dt][r] += ((bits3[dt] >> r) & 1u) ? (acc[dt][r] + bv[r]) * d.keep_scale : 0.f;
@@ -1012,7 +1042,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
         for (int dt = 0; dt < DT; ++dt) {
             const int d0 = 16 * dt + 4 * g;
             if (d0 < D) {
-                const float4 gm = *reinterpret_cast<const float4*>(a.g2 + d0), bt = *reinterpret_cast<const float4*>(a.be2 + d0);
+                const float4 gm = lvec[1 * 4 * DT + 4 * dt + g], bt = lvec[2 * 4 * DT + 4 * dt + g];
                 v[dt][0] = (v[dt][0] - mean) * rstd * gm.x + bt.x;
                 v[dt][1] = (v[dt][1] - mean) * rstd * gm.y + bt.y;
                 v[dt][2] = (v[dt][2] - mean) * rstd * gm.z + bt.z;
@@ -1055,11 +1085,19 @@ template <int DT>
 __device__ __forceinline__ void ln_bwd_tile(f32x4 (&dy)[DT], const f32x4 (&xhat)[DT], const float* __restrict__ gamma, float rstd,
                                             int D, int g) {
     float s1 = 0.f, s2 = 0.f;
+    // (gamma: unconditional loads from clamped addresses, all issued before the first use -- inside the lane-divergent branch below
+    //  each of them was waited for at the end of its branch, DT dependent L2 round trips per call)
+    float4 gm4[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int d0 = 16 * dt + 4 * g;
+        gm4[dt] = *reinterpret_cast<const float4*>(gamma + (d0 < D ? d0 : 0));
+    }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
         const int d0 = 16 * dt + 4 * g;
         if (d0 < D) {
-            const float4 gm = *reinterpret_cast<const float4*>(gamma + d0);
+            const float4 gm = gm4[dt];
             const float gv[4] = {gm.x, gm.y, gm.z, gm.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -2613,7 +2651,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
     const size_t scr = std::max((size_t)TW * KS1 * 1024, (size_t)4 * DT * 1024);
     const size_t NSh = (size_t)m->d.dim_ff / 64;
     const size_t lds_ffn = (size_t)4 * 2 * (2 * KS1 + DT) * 1024 + scr + (size_t)TW * 64 * NSh + (size_t)TW * NSh * 32 * sizeof(unsigned short) +
-                           (size_t)4 * 32 * DT * 16 + 128;      // (+ the keep-mask table)
+                           (size_t)4 * 32 * DT * 16 + 128 + (size_t)3 * 4 * DT * 16;      // (+ the keep-mask table, + the epilogue's vectors)
     static unsigned long long attr = 0;
     if (fd_first_on_device(attr, ctx->device)) {
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_attn_fwd<KS1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
