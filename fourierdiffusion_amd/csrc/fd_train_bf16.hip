@@ -519,11 +519,24 @@ struct AttnFwdArgs {
 #ifndef FD_TR_ATTN_OH_MINW
 #define FD_TR_ATTN_OH_MINW 3          // one-head attention backward: three 4-wave workgroups per CU
 #endif
+#ifdef FD_TR_PROF_AF        // variant build: phase clocks of k_tr_attn_fwd (workgroup (5, 0), every wave), printed after 30 launches
+__device__ unsigned long long fd_tr_af_dbg[8 * 8];
+#define TAF_STAMP(slot, t_prev)                                                                          \
+    do {                                                                                                 \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                    \
+        if (blockIdx.x == 5 && blockIdx.y == 0 && lane == 0) fd_tr_af_dbg[wave * 8 + (slot)] += now_ - (t_prev); \
+        (t_prev) = now_;                                                                                 \
+    } while (0)
+#else
+#define TAF_STAMP(slot, t_prev) do { } while (0)
+#endif
 template <int KS1, int NW>
 __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const AttnFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned long long tprev = __builtin_readcyclecounter();
+    (void)tprev;
     int pair, b;
     xcd_deal(d, pair, b);                            // (the pairs of a series share an L2)
     const int T = d.T, KT = d.KT, NJ = d.NJ, NTOK = KT * 16, hd = d.hd, H = d.H, D = d.D;
@@ -539,26 +552,44 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
     }
     const size_t pstride = (size_t)KS1 * 1024;
     auto wfrag = [&](const char* img, int ks) { return *reinterpret_cast<const bf16x8*>(img + pair * pstride + ((size_t)ks * 64 + lane) * 16); };
-    auto xfrag = [&](int tile, int ks) { const int t = tile * 16 + tok; return row_frag(a.x0rb, b * T + t, t < T, d.RBW, ks, g); };
+    // a token tile's B fragments from the bf16 rows: unconditional loads from a clamped row, cleared afterwards (inside row_frag's
+    // `if (!valid)` every fragment was waited for where it was requested: 4.1 K cycles per staged tile, 2.4 K per Q projection in
+    // the phase clocks, profiles/r05_train_attn_fwd_keep_bytes.txt)
+    auto xload = [&](int tile, u32x4 (&r)[KS1]) {
+        const int t = tile * 16 + tok, tc = t < T ? t : T - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) r[ks] = *reinterpret_cast<const u32x4*>(a.x0rb + (size_t)(b * T + tc) * d.RBW + 32 * ks + 8 * g);
+    };
+    auto xfrag_of = [&](int tile, const u32x4 (&r)[KS1], int ks) -> bf16x8 {
+        const unsigned keep = (tile * 16 + tok < T) ? ~0u : 0u;
+        return __builtin_bit_cast(bf16x8, u32x4{r[ks][0] & keep, r[ks][1] & keep, r[ks][2] & keep, r[ks][3] & keep});
+    };
     {
         bf16x8 wkf[KS1], wvf[KS1];
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) { wkf[ks] = wfrag(a.wk, ks); wvf[ks] = wfrag(a.wv, ks); }
+        u32x4 xc[KS1], xn[KS1];
+        xload(wave < KT ? wave : KT - 1, xc);
         for (int kt = wave; kt < KT; kt += NW) {
+            xload(kt + NW < KT ? kt + NW : kt, xn);           // (the next tile's rows in flight under this tile's MFMAs)
             f32x4 ka = f4zero(), vc = f4zero();
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
-                const bf16x8 xf = xfrag(kt, ks);
+                const bf16x8 xf = xfrag_of(kt, xc, ks);
                 ka = MFMA(wkf[ks], xf, ka);
                 vc = MFMA(xf, wvf[ks], vc);
             }
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) xc[ks] = xn[ks];
             *reinterpret_cast<u32x2*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8) = u32x2{cvt_pk_bf16(ka[0], ka[1]), cvt_pk_bf16(ka[2], ka[3])};
             char* dst = vbf + ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16;
             *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = u32x2{cvt_pk_bf16(vc[0], vc[1]), cvt_pk_bf16(vc[2], vc[3])};
             if ((KT & 1) && kt == KT - 1) *reinterpret_cast<u32x2*>(dst + 8) = u32x2{0u, 0u};
         }
     }
+    TAF_STAMP(0, tprev);          // K / V staging of this wave's tiles
     __syncthreads();
+    TAF_STAMP(1, tprev);          // barrier
     bf16x8 wqf[KS1];
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) wqf[ks] = wfrag(a.wq, ks);
@@ -572,15 +603,25 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
     for (int qt = wave; qt < KT; qt += NW) {
         const int t = qt * 16 + tok;
         f32x4 qa = f4zero();
+        {
+            u32x4 xq[KS1];
+            xload(qt, xq);
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) qa = MFMA(wqf[ks], xfrag(qt, ks), qa);
+            for (int ks = 0; ks < KS1; ++ks) qa = MFMA(wqf[ks], xfrag_of(qt, xq, ks), qa);
+        }
         const unsigned q01 = cvt_pk_bf16(qa[0], qa[1]), q23 = cvt_pk_bf16(qa[2], qa[3]);
         s16x4 qb[2];
         qb[0] = __builtin_bit_cast(s16x4, u32x2{lo_grp ? q01 : 0u, lo_grp ? q23 : 0u});
         qb[1] = __builtin_bit_cast(s16x4, u32x2{lo_grp ? 0u : q01, lo_grp ? 0u : q23});
+        TAF_STAMP(2, tprev);      // Q projection of the tile
         // pass 1: exact row maxima (base-2 logits: log2(e)/sqrt(hd) is folded into W_q)
         float mx[2] = {kNegBig, kNegBig};
+#ifdef FD_TR_ABL_AF1          // (timing ablation, wrong results: no pass 1)
+        mx[0] = mx[1] = 0.f;
+        for (int kt = 0; kt < 0; ++kt) {
+#else
         for (int kt = 0; kt < KT; ++kt) {
+#endif
             const s16x4 kf = kfrag(kt);
             const f32x4 c0 = (kt == KT - 1) ? cmask : f4zero();
 #pragma unroll
@@ -595,6 +636,7 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
             mx[hs] = group_max(mx[hs]);
             negm[hs] = f32x4{-mx[hs], -mx[hs], -mx[hs], -mx[hs]};
         }
+        TAF_STAMP(3, tprev);      // pass 1
         // pass 2: P = exp2(S - max); row sums of the UNDROPPED P; dropped P (unscaled) times V.  The keep bytes of key block jb + 1
         // are requested while block jb runs (unconditional loads from clamped addresses: a padded query row or a missing odd head
         // reads some other row's bits and its output is never stored).  Inside `if (t < T && head < H)` each byte was waited for
@@ -641,6 +683,7 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
                 o2[hs] = MFMA(vf, __builtin_bit_cast(bf16x8, u32x4{pk[0] & ka2[0], pk[1] & ka2[1], pk[2] & kb2[0], pk[3] & kb2[1]}), o2[hs]);
             }
         }
+        TAF_STAMP(4, tprev);      // pass 2
 #pragma unroll
         for (int hs = 0; hs < 2; ++hs) ls[hs] = group_sum(ls[hs]);
         const float lmine = lo_grp ? ls[0] : ls[1], mmine = lo_grp ? mx[0] : mx[1];
@@ -668,6 +711,7 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
             for (int f = D + g; f < d.NFT; f += 4)
                 a.attT[((size_t)(m >> 5) * d.NFT + f) * 32 + (m & 31)] = (__bf16)((f == D) ? 1.0f : 0.f);
         }
+        TAF_STAMP(5, tprev);      // epilogue stores of the tile
     }
 }
 
@@ -2720,6 +2764,19 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
                                 (double)M * (6.0 * D * D + 4.0 * (double)T * D));
             if (attn_nw == 8) hipLaunchKernelGGL((k_tr_attn_fwd<KS1, 8>), dim3(d.NP, B), dim3(512), lds_attn, s, d, aa);
             else hipLaunchKernelGGL((k_tr_attn_fwd<KS1, 4>), dim3(d.NP, B), dim3(256), lds_attn, s, d, aa);
+#ifdef FD_TR_PROF_AF
+            {
+                static int calls = 0;
+                if (++calls == 30) {
+                    unsigned long long h[64];
+                    hipStreamSynchronize(s);
+                    hipMemcpyFromSymbol(h, HIP_SYMBOL(fd_tr_af_dbg), sizeof(h));
+                    for (int w = 0; w < attn_nw; ++w)
+                        fprintf(stderr, "[attn_fwd dbg] wave %d over %d launches: staging %llu, barrier %llu, Q projection %llu, pass 1 %llu, pass 2 %llu, epilogue %llu cycles\n",
+                                w, calls, h[w * 8 + 0] / calls, h[w * 8 + 1] / calls, h[w * 8 + 2] / calls, h[w * 8 + 3] / calls, h[w * 8 + 4] / calls, h[w * 8 + 5] / calls);
+                }
+            }
+#endif
         }
         FfnFwdArgs fa{};
         fa.x0 = b.x0; fa.att = b.att; fa.s1 = b.s1; fa.s2 = b.s2;
