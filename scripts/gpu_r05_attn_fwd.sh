@@ -1,6 +1,7 @@
 #!/bin/bash
-# k_tr_attn_fwd, pipelined unit form: parity, then solo kernel time (FDIFF_TR_SERIAL=1) and step time against the previous library,
-# with four / eight waves per workgroup
+# k_tr_attn_fwd, pipelined unit form (EXPERIMENT, not in the tree: see profiles/r05_train_attn_fwd_keep_bytes.txt item (4); the switch
+# FDIFF_TR_ATTN_FWD_NW existed only in that build): parity, then solo kernel time (FDIFF_TR_SERIAL=1) and step time against the
+# previous library, with four / eight waves per workgroup
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-r05_attn_fwd}; mkdir -p $OUT
 L=$GRAFT_REPO_ROOT/fourierdiffusion_amd
 timeout 900 python -m pytest tests/test_gpu_train_bf16.py tests/test_gpu_benched_shapes.py tests/test_gpu_widths.py tests/test_gpu_train.py -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
