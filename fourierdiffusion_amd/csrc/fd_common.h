@@ -38,14 +38,19 @@ struct fd_ctx {
     // side stream + events: the training backward runs each layer's weight-gradient kernel beside the (latency-bound)
     // input-gradient chain of the earlier layers
     hipStream_t side_stream = nullptr;
+    hipStream_t mask_stream = nullptr;    // dropout decisions of the NEXT training step: their own stream, so that they start behind the last
+                                          // reader of the decision buffers instead of behind the previous step's last weight-gradient launch
     hipStream_t side_stream2 = nullptr;   // weight-gradient launches alternate between the two (they are latency-bound on ~80 CUs each)
     std::vector<hipEvent_t> side_events;
     // recorded behind the last reader (training forward / backward) of the dropout-decision buffers, which live in the arena;
     // tr_readers_gen = ws_gen at that moment: a different ws_gen at the next training forward means some other call carved the
     // arena in between and may still be running on the caller's stream, so the side stream must wait for a FRESH event
-    hipEvent_t tr_readers_event = nullptr;
-    bool tr_readers_event_valid = false;
+    hipEvent_t tr_readers_event[2] = {nullptr, nullptr};      // one per set of decision buffers (alternating training steps)
+    bool tr_readers_event_valid[2] = {false, false};
     uint64_t tr_readers_gen = 0;
+    unsigned tr_mask_steps = 0;
+    const void* tr_last_model = nullptr;      // (model, batch) of the last bf16 training forward: another one lays the arena out differently
+    int tr_last_B = 0;
     // F-split of the training FFN kernels (fd_train_bf16.hip, struct FSplit): partial accumulators handed from the producer to the
     // finisher workgroup of a token block, one flag per token tile (zeroed at allocation; a launch writes its own epoch)
     float* tr_ypart = nullptr;
@@ -56,6 +61,12 @@ struct fd_ctx {
     // system-scope atomic, the host reads it without synchronising): fd_train_async_check turns it into FD_ERR_STATE
     unsigned* tr_err_host = nullptr;
     unsigned* tr_err_dev = nullptr;
+    unsigned* tr_err_gpu = nullptr;      // device-resident copy (set with the host word): what the optimizer kernel tests in stream order
+    // persistent training forward (fd_train_persist.hip): one 64-bit flag per (series, token tile), zeroed at allocation, and the launch
+    // counter their values are built from
+    unsigned long long* trp_flags = nullptr;
+    size_t trp_flag_count = 0;
+    unsigned long long trp_epoch = 0;
     // FFT twiddle tables (T, device pointer), built on first use of a length
     std::vector<std::pair<int, void*>> fft_tw;
     // measurement hooks (fd_prof_begin / fd_prof_end)

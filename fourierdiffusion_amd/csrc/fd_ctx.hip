@@ -30,10 +30,14 @@ extern "C" int fd_ctx_destroy(fd_ctx* ctx) {
     if (ctx->tr_ypart) (void)hipFree(ctx->tr_ypart);
     if (ctx->tr_yflag) (void)hipFree(ctx->tr_yflag);
     if (ctx->tr_err_host) (void)hipHostFree(ctx->tr_err_host);
+    if (ctx->tr_err_gpu) (void)hipFree(ctx->tr_err_gpu);
+    if (ctx->trp_flags) (void)hipFree(ctx->trp_flags);
     if (ctx->prof_clk) (void)hipFree(ctx->prof_clk);
     for (hipEvent_t e : ctx->side_events) (void)hipEventDestroy(e);
-    if (ctx->tr_readers_event) (void)hipEventDestroy(ctx->tr_readers_event);
+    for (hipEvent_t e : ctx->tr_readers_event)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->mask_stream) (void)hipStreamDestroy(ctx->mask_stream);
     if (ctx->side_stream2) (void)hipStreamDestroy(ctx->side_stream2);
     for (auto& e : ctx->fft_tw) (void)hipFree(e.second);
     delete ctx;
@@ -45,7 +49,15 @@ int fd_train_async_check(fd_ctx* ctx) {
     const unsigned e = __atomic_load_n(ctx->tr_err_host, __ATOMIC_RELAXED);
     if (!e) return FD_OK;
     __atomic_store_n(ctx->tr_err_host, 0u, __ATOMIC_RELAXED);
-    const unsigned id = e & 0x7fffffffu;
+    if (ctx->tr_err_gpu) (void)hipMemsetAsync(ctx->tr_err_gpu, 0, sizeof(unsigned), nullptr);      // (reported: the optimizer may update again)
+    if (e & 0x40000000u)
+        return fd_fail(ctx, FD_ERR_STATE,
+                       "an earlier training step's persistent forward (k_tr_fwd_layers) gave up waiting in layer %u, series %u, for %s %u: a "
+                       "workgroup of the series' cluster never published its rows (not scheduled -- CU-masked queue / partitioned device / a "
+                       "co-tenant kernel holding the CUs -- or faulted).  That step's gradients are invalid.  FDIFF_TR_PERSIST=0 selects the "
+                       "per-layer kernels, FDIFF_TR_TIMEOUT_MS (default 2000) sets the bound.",
+                       (e >> 20) & 0x3ffu, (e >> 4) & 0xffffu, (e & 0x80000u) ? "the dropout decisions, lane" : "token tile", e & 15u);
+    const unsigned id = e & 0x3fffffffu;
     return fd_fail(ctx, FD_ERR_STATE,
                    "an earlier training step's F-split hand-over timed out at token block %u, tile %u: the finisher workgroup never saw "
                    "its producer's partial sums (producer not scheduled -- CU-masked queue / partitioned device / a co-tenant kernel "

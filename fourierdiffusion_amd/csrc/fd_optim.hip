@@ -33,7 +33,12 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
                                                 float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                 float beta1, float beta2, float eps, float wd, float bc1,
                                                 float bc2_sqrt, const float* __restrict__ sqnorm, float max_norm,
-                                                float grad_scale, int64_t fz0, int64_t fz1) {
+                                                float grad_scale, int64_t fz0, int64_t fz1, const unsigned* __restrict__ err) {
+    // The device copy of the error word of the training kernels' bounded waits (set together with the host-visible word when a
+    // hand-over of THIS step timed out): its gradients are invalid, so the update is skipped IN STREAM ORDER -- parameters and
+    // moments stay what they were -- and the host check at the next call entry (fd_train_async_check) only has to report it.
+    // (Device memory: the host-mapped word itself cost one PCIe read per wave, 0.7 ms per optimizer step.)
+    if (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     float coef = grad_scale;
     if (sqnorm) {
         // clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
@@ -81,13 +86,15 @@ extern "C" int fd_adamw_step(fd_ctx* ctx, float* params, const float* grads, flo
                              int64_t frozen_end, void* stream) {
     if (!ctx) return FD_ERR_ARG;
     FD_REQUIRE(ctx, params && grads && exp_avg && exp_avg_sq && n > 0, "fd_adamw_step: null pointer or n <= 0");
-    if (int rc = fd_train_async_check(ctx)) return rc;      // (a timed-out hand-over of the step whose gradients these are)
+    // (an EARLIER call's timed-out hand-over; one of the step whose gradients these are may not have happened yet when this host
+    // check runs -- the kernel below re-reads the error word on the device, in stream order, and skips the update then)
+    if (int rc = fd_train_async_check(ctx)) return rc;
     FD_REQUIRE(ctx, step >= 1, "fd_adamw_step: step is 1-based, got %d", step);
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(k_adamw, dim3(grid_for(ctx, n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                        exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), sqnorm,
-                       max_norm, grad_scale, frozen_begin, frozen_end);
+                       max_norm, grad_scale, frozen_begin, frozen_end, (const unsigned*)ctx->tr_err_gpu);
     FD_LAUNCH_CHECK(ctx);
     return FD_OK;
 }

@@ -38,6 +38,7 @@ struct fd_score {
     uint64_t saved_seed = 0, saved_offset = 0;
     const float* saved_x = nullptr;
     const float* saved_t = nullptr;
+    int saved_mask_set = 0;         // which of the two sets of dropout-decision buffers the saved forward used (fd_train_bf16.hip)
     bool saved_bf16 = false;        // the training forward ran the bf16 MFMA kernels (fd_train_bf16.hip)
     int train_mode = 0;             // FD_MODE_F32 (exact-f32 kernels) or FD_MODE_BF16 for fd_score_forward_train
     uint64_t saved_ws_gen = 0;      // ctx->ws_gen right after the training forward carved the arena

@@ -24,35 +24,8 @@
 // with the constant 1.0 in k-slot D (the bias row of the weight images).  Dropout decisions are stored as bits by the forward
 // (hidden: kept AND h > 0; attention: kept) -- the two orientations in which the backward needs them (token on lane /
 // feature on lane) cannot both be regenerated from one counter layout without 4x the Philox evaluations.
-#include <algorithm>
-#include <cmath>
-#include <type_traits>
-
-#include "fd_bf16_images.h"
 #include "fd_gemm_f32.h"
-#include "fd_philox.h"
-#include "fd_score.h"
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte access at a dword-aligned address
-typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
-#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-#ifndef FD_TR_WG_NBUF
-#define FD_TR_WG_NBUF 4          // LDS ring of k_tr_wgrad: 13-KiB stage records, NBUF - 1 blocks in flight (3 / 4 / 5: same time)
-#endif
-#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
-// ds_read_b64_tr_b16: the 16 lanes of a group hand in 16 8-byte-aligned addresses, together a [4][16] bf16 matrix (row j =
-// the four runs of lanes 4j..4j+3); lane i of the group gets column i (element j = row j).
-__device__ __forceinline__ s16x4 lds_read_tr16(const char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-}
+#include "fd_train_dev.h"
 
 uint64_t fd_dropout_site_offset(uint64_t base, int layer, int site);   // fd_score_f32.hip
 namespace fdf32 {
@@ -67,381 +40,6 @@ int fd_embed_backward(fd_score* m, const float* dh, const float* emb, float* dte
 
 namespace {
 
-constexpr float kNegBig = -1.0e30f;
-constexpr int TW = 8;            // waves per token-parallel workgroup (one 16-token tile each)
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
-__device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
-    u32x4 r = {cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3]), cvt_pk_bf16(b[0], b[1]), cvt_pk_bf16(b[2], b[3])};
-    return __builtin_bit_cast(bf16x8, r);
-}
-__device__ __forceinline__ s16x4 pack4(f32x4 a) {
-    u32x2 r = {cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
-    return __builtin_bit_cast(s16x4, r);
-}
-__device__ __forceinline__ f32x4 f4zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-__device__ __forceinline__ bf16x8 frag_zero() {
-    u32x4 z = {0u, 0u, 0u, 0u};
-    return __builtin_bit_cast(bf16x8, z);
-}
-__device__ __forceinline__ void swap32(float v, float& a, float& b) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    const unsigned r0 = r.x, r1 = r.y;
-    a = __builtin_bit_cast(float, r0);
-    b = __builtin_bit_cast(float, r1);
-}
-__device__ __forceinline__ void swap16(float v, float& a, float& b) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    const unsigned r0 = r.x, r1 = r.y;
-    a = __builtin_bit_cast(float, r0);
-    b = __builtin_bit_cast(float, r1);
-}
-__device__ __forceinline__ float group_sum(float v) {      // over the 4 lane groups (same lane&15)
-    float a, b;
-    swap32(v, a, b);
-    swap16(a + b, a, b);
-    return a + b;
-}
-__device__ __forceinline__ float group_max(float v) {
-    float a, b;
-    swap32(v, a, b);
-    swap16(fmaxf(a, b), a, b);
-    return fmaxf(a, b);
-}
-template <int N>
-__device__ __forceinline__ float row_ror(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float row_sum16(float v) {      // over the 16 lanes of a row (fixed order: deterministic)
-    v += row_ror<8>(v);
-    v += row_ror<4>(v);
-    v += row_ror<2>(v);
-    v += row_ror<1>(v);
-    return v;
-}
-
-struct TrDims {
-    int B, T, M, D, F, H, hd, NP, KT, NJ, NFT, RBW;   // NFT = 16*DT feature rows of a T-block, RBW = 32*KS1 slots of a row
-    float p, keep_scale;
-    unsigned thr16;
-    unsigned long long seed;
-    int xcd;                  // 1: workgroup ids are re-dealt so that neighbours in (x, y) order share an XCD (xcd_deal)
-    int fsplit;               // FFN kernels: 1, or 2 = the hidden dimension of a 64-token block split over a PAIR of workgroups (small M)
-};
-
-// F-split of the FFN kernels (fsplit == 2).  A 64-token workgroup of k_tr_ffn_fwd / k_tr_ffn_bwd is a chain of F / 64 barrier
-// steps whatever the token count: with M = 6400 tokens (T = 100, B = 64) 100 workgroups hold 100 of the 256 CUs for 40 us.
-// Workgroups 2 i (producer) and 2 i + 1 (finisher) share token block i and take half of the chunk steps each; both run the
-// prologue, the producer's owner waves hand their partial accumulators over through global memory (one flag per token tile,
-// set to the launch's epoch behind an agent-scope release) and leave, the finisher adds them (own half + partner's half, a
-// fixed order) and runs the epilogue.  The finisher has the HIGHER workgroup id, so its producer was dispatched before it, and
-// the host enables the split only when 2 x blocks <= CUs (every workgroup finds a CU without another one of the grid retiring).
-struct FSplit {
-    float* ypart;             // [blocks][4 tiles][DT][64 lanes] f32x4
-    unsigned* flag;           // [blocks][4 tiles]
-    unsigned epoch;           // unique per launch
-    unsigned* err;            // host-visible error word (pinned, mapped): 0, or 0x80000000 | (block << 2 | tile) of the first hand-over
-                              // that timed out -- the host checks it at the entry of the next training call (fd_train_async_check)
-    unsigned long long timeout;   // bound of the finisher's wait in ticks of the constant 100 MHz clock (s_memrealtime)
-    int fence;                // 1: release / acquire fences instead of per-element coherent accesses (FDIFF_TR_FSPLIT_FENCE=1)
-    int stall;                // test hook (FDIFF_TR_FSPLIT_TEST_STALL=1): the producer never raises its flags
-};
-// The hand-over moves 5 KiB per token tile between two workgroups that may sit on different XCDs (separate, mutually
-// non-coherent L2s).  An agent-scope release / acquire FENCE would write back / invalidate the whole L2 of the XCD (measured:
-// both FFN kernels at 1.4 x their unsplit time; that form stays selectable, `fence`); instead every element is itself an
-// agent-scope relaxed atomic access -- a write-through store (sc1) / an L2-bypassing load -- and the flag is stored once the
-// element stores have been acknowledged.
-// Why this orders the data without a fence (it is outside the HIP memory model, which only speaks of fences and
-// acquire / release; it rests on the gfx950 memory pipeline): (1) an agent-scope atomic store is written through to the
-// memory-side coherence point shared by all XCDs and is counted in vmcnt until that write is ACKNOWLEDGED, so after
-// `s_waitcnt vmcnt(0)` every element is visible to any agent-scope access from any XCD; (2) the flag store is issued only
-// after that wait (the asm statement is a compiler barrier and the hardware issues in order); (3) the finisher's element
-// loads are issued after the loop that saw the flag (control dependence on a loaded value + compiler barrier), and as
-// agent-scope atomic loads they bypass its own XCD's non-coherent L2 lines.
-// The finisher's wait is BOUNDED: a producer that is never scheduled (a CU-masked queue, a partition mode with fewer CUs than
-// 2 x blocks, a co-tenant kernel that never retires) or that faulted would otherwise hang the device without a diagnostic.  After
-// `timeout` ticks the finisher records (block, tile) in the error word and carries on with its own half -- the step's gradients
-// are then wrong, and the next training call on the context fails with FD_ERR_STATE naming the block.
-template <int DT>
-__device__ __forceinline__ void fsplit_hand_over(const FSplit& fs, int blk, int tile, int lane, const f32x4 (&acc)[DT]) {
-    float* yp = fs.ypart + (((size_t)(blk * 4 + tile) * DT) * 64 + lane) * 4;
-    if (fs.fence) {
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(yp + dt * 256) = acc[dt];
-        if (fs.stall) return;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (lane == 0) __hip_atomic_store(fs.flag + blk * 4 + tile, fs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) __hip_atomic_store(yp + dt * 256 + r, acc[dt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0 && !fs.stall) __hip_atomic_store(fs.flag + blk * 4 + tile, fs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <int DT>
-__device__ __forceinline__ void fsplit_take_over(const FSplit& fs, int blk, int tile, int lane, f32x4 (&acc)[DT]) {
-    if (__hip_atomic_load(fs.flag + blk * 4 + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fs.epoch) {
-        const unsigned long long t0 = wall_clock64();
-        unsigned spins = 0u;
-        bool seen = false;
-        for (;;) {
-            __builtin_amdgcn_s_sleep(16);
-            if (__hip_atomic_load(fs.flag + blk * 4 + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fs.epoch) { seen = true; break; }
-            if ((++spins & 63u) == 0u && wall_clock64() - t0 > fs.timeout) break;
-        }
-        if (!seen) {          // (wave-uniform: the flag address and the clock are)
-            if (lane == 0) {
-                unsigned expected = 0u;
-                __hip_atomic_compare_exchange_strong(fs.err, &expected, 0x80000000u | (unsigned)(blk * 4 + tile), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            return;
-        }
-    }
-    const float* yp = fs.ypart + (((size_t)(blk * 4 + tile) * DT) * 64 + lane) * 4;
-    if (fs.fence) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) acc[dt] += *reinterpret_cast<const f32x4*>(yp + dt * 256);
-        return;
-    }
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[dt][r] += __hip_atomic_load(yp + dt * 256 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own L2.  Workgroups that read the
-// same rows -- the heads of one series in the attention kernels, the 20 role workgroups of one token split in k_tr_wgrad --
-// are therefore spread over all eight L2s, and every L2 fetches every row from the Infinity Cache.  Re-dealing the ids (XCD k
-// takes the k-th contiguous run of the virtual (x, y) order) keeps such a group on one XCD, or on two where a run ends inside it.
-__device__ __forceinline__ void xcd_deal(const TrDims& d, int& bx, int& by) {
-    bx = blockIdx.x; by = blockIdx.y;
-    if (!d.xcd) return;
-    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-    const int k = lin & 7, slot = lin >> 3, q = nwg >> 3, r = nwg & 7;
-    const int v = k * q + (k < r ? k : r) + slot;
-    by = v / (int)gridDim.x;
-    bx = v - by * (int)gridDim.x;
-}
-
-// ------------------------------------------------------------------------------------------------ shared device pieces
-// C-layout tile (features 16dt+4g+r of token `m`) <- fp32 rows.  Unconditional loads from clamped addresses (row 0 for an
-// invalid token, D % 4 == 0) and a select afterwards: a load inside a divergent branch makes hipcc wait for it (vmcnt(0)) at
-// the end of the branch -- one exposed L2 round trip per row tile, ~25 of them in the prologue of k_tr_ffn_bwd.
-template <int DT>
-__device__ __forceinline__ void load_ctile(const float* __restrict__ base, int m, bool valid, int D, int g, f32x4 (&v)[DT]) {
-    const int mc = valid ? m : 0;
-    float4 raw[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const int d0 = 16 * dt + 4 * g;
-        raw[dt] = *reinterpret_cast<const float4*>(base + (size_t)mc * D + (d0 < D ? d0 : D - 4));
-    }
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const bool ok = valid && (16 * dt + 4 * g < D);
-        v[dt] = f32x4{ok ? raw[dt].x : 0.f, ok ? raw[dt].y : 0.f, ok ? raw[dt].z : 0.f, ok ? raw[dt].w : 0.f};
-    }
-}
-template <int DT>
-__device__ __forceinline__ void store_ctile(float* __restrict__ base, int m, bool valid, int D, int g, const f32x4 (&v)[DT]) {
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const int d0 = 16 * dt + 4 * g;
-        if (valid && d0 < D) *reinterpret_cast<float4*>(base + (size_t)m * D + d0) = float4{v[dt][0], v[dt][1], v[dt][2], v[dt][3]};
-    }
-}
-// the same tile from a bf16 (M, D) tensor (the per-head partial tensors of d x, k_tr_attn_bwd OH form): 8-byte loads
-template <int DT>
-__device__ __forceinline__ void load_ctile_bf16(const __bf16* __restrict__ base, int m, bool valid, int D, int g, f32x4 (&v)[DT]) {
-    const int mc = valid ? m : 0;
-    u32x2 raw[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const int d0 = 16 * dt + 4 * g;
-        raw[dt] = *reinterpret_cast<const u32x2*>(base + (size_t)mc * D + (d0 < D ? d0 : D - 4));
-    }
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const bool ok = valid && (16 * dt + 4 * g < D);
-        const unsigned lo = ok ? raw[dt][0] : 0u, hi = ok ? raw[dt][1] : 0u;
-        v[dt] = f32x4{__builtin_bit_cast(float, lo << 16), __builtin_bit_cast(float, lo & 0xffff0000u),
-                      __builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
-    }
-}
-// T-block store: feature rows 16dt+4g+r, column m&31; `ones` puts 1.0 into row D (bias column of the weight gradients).
-// Every row of the 16*DT block rows is written for this token (pads as 0), invalid tokens write zeros.
-template <int DT>
-__device__ __forceinline__ void store_T(__bf16* __restrict__ tb, int m, bool valid, int D, int g, const f32x4 (&v)[DT], bool ones) {
-    const int NFT = 16 * DT;
-    __bf16* col = tb + ((size_t)(m >> 5) * NFT) * 32 + (m & 31);
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = 16 * dt + 4 * g + r;
-            float x = 0.f;
-            if (valid) x = (f < D) ? v[dt][r] : ((f == D && ones) ? 1.0f : 0.f);
-            col[(size_t)f * 32] = (__bf16)x;
-        }
-}
-// Row store (k-slot layout of the weight images): slots d < D, slot D = 1.0 when `ones`, zero padding up to 32*KS1.
-template <int DT, int KS1>
-__device__ __forceinline__ void store_rows(__bf16* __restrict__ rb, int m, bool valid, int D, int g, const f32x4 (&v)[DT], bool ones) {
-    __bf16* row = rb + (size_t)m * (32 * KS1);
-#pragma unroll
-    for (int dt = 0; dt < 2 * KS1; ++dt) {
-        const int d0 = 16 * dt + 4 * g;
-        u32x2 pk = {0u, 0u};
-        if (valid) {
-            if (dt < DT && d0 < D) {
-                pk[0] = cvt_pk_bf16(v[dt < DT ? dt : 0][0], v[dt < DT ? dt : 0][1]);
-                pk[1] = cvt_pk_bf16(v[dt < DT ? dt : 0][2], v[dt < DT ? dt : 0][3]);
-            } else if (d0 == D && ones) {
-                pk[0] = 0x00003F80u;
-            }
-        }
-        *reinterpret_cast<u32x2*>(row + d0) = pk;
-    }
-}
-// "Stage" layout of the operands the weight-gradient kernel streams through LDS: per 32-token block ONE contiguous record
-//   [x1 rows 32 x RBS][d f rows 32 x RBS]   (bf16, record padded to 1 KiB: 13 KiB at d_model 72)
-// with the row stride padded off the LDS bank period (RBS = 32 KS1 + 8 -> 16-lane b128 reads hit every bank once; the
-// natural stride of 192 B made every fragment read an 8-way conflict, 2.7 us per 32-token block).  global_load_lds copies
-// a record verbatim.  The feature-major ("T-block") operands of the d W products are NOT stored: k_tr_wgrad reads them out
-// of the same rows with ds_read_b64_tr_b16 (a 16-lane group reads a [4 tokens][16 features] block transposed), which
-// halved the record, the staging DMA of k_tr_wgrad and the epilogue stores of k_tr_ffn_fwd / k_tr_ffn_bwd.
-template <int KS1, int DT>
-struct StageL {
-    static constexpr int RBS = 32 * KS1 + 8, NFT = 16 * DT;
-    static constexpr int off_xr = 0, off_dr = 32 * RBS * 2;
-    static constexpr int bytes = (2 * 32 * RBS * 2 + 1023) & ~1023;
-};
-template <int DT, int KS1>
-__device__ __forceinline__ void stage_rows(char* __restrict__ stage, int region_off, int m, bool valid, int D, int g,
-                                           const f32x4 (&v)[DT], bool ones) {
-    using SL = StageL<KS1, DT>;
-    __bf16* row = reinterpret_cast<__bf16*>(stage + (size_t)(m >> 5) * SL::bytes + region_off) + (size_t)(m & 31) * SL::RBS;
-#pragma unroll
-    for (int dt = 0; dt < 2 * KS1; ++dt) {
-        const int d0 = 16 * dt + 4 * g;
-        u32x2 pk = {0u, 0u};
-        if (valid) {
-            if (dt < DT && d0 < D) {
-                pk[0] = cvt_pk_bf16(v[dt < DT ? dt : 0][0], v[dt < DT ? dt : 0][1]);
-                pk[1] = cvt_pk_bf16(v[dt < DT ? dt : 0][2], v[dt < DT ? dt : 0][3]);
-            } else if (d0 == D && ones) {
-                pk[0] = 0x00003F80u;
-            }
-        }
-        *reinterpret_cast<u32x2*>(row + d0) = pk;
-    }
-}
-// C-layout tile of 16 tokens -> T-layout rows through a wave-private LDS transpose: 4 lanes write one 32-byte run of a
-// feature row (16 tokens x bf16) instead of 64 scattered 2-byte stores per instruction (20 store instructions per tile
-// became 5).  trow0 = &T[row 0][first token of the tile], ts = row stride in elements, tscr = 32 * DT * 16 bytes of LDS.
-template <int DT>
-__device__ __forceinline__ void store_T16(char* tscr, __bf16* __restrict__ trow0, int ts, int lane, int D, const f32x4 (&v)[DT],
-                                          bool ones, bool valid) {
-    const int tok = lane & 15, g = lane >> 4;
-    __bf16* l = reinterpret_cast<__bf16*>(tscr);
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = 16 * dt + 4 * g + r;
-            float x = 0.f;
-            if (valid) x = (f < D) ? v[dt][r] : ((f == D && ones) ? 1.0f : 0.f);
-            l[f * 16 + tok] = (__bf16)x;
-        }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < (16 * DT * 4 + 63) / 64; ++i) {
-        const int idx = lane + 64 * i;
-        if (idx < 16 * DT * 4) {
-            const int f = idx >> 2, q = idx & 3;
-            *reinterpret_cast<u32x2*>(trow0 + (size_t)f * ts + 4 * q) = *reinterpret_cast<const u32x2*>(l + f * 16 + 4 * q);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ bf16x8 row_frag(const __bf16* __restrict__ rb, int m, bool valid, int RBW, int ks, int g) {
-    if (!valid) return frag_zero();
-    return *reinterpret_cast<const bf16x8*>(rb + (size_t)m * RBW + 32 * ks + 8 * g);
-}
-// C layout -> B fragments through a wave-private LDS scratch of KS1 KiB (same lanes write and read; LDS is in order per wave)
-template <int DT, int KS1>
-__device__ __forceinline__ void ctile_to_frags(char* scratch, int lane, int D, const f32x4 (&v)[DT], bool ones, bf16x8 (&xf)[KS1]) {
-    const int tok = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int dt = 0; dt < 2 * KS1; ++dt) {
-        const int d0 = 16 * dt + 4 * g;
-        u32x2 pk = {0u, 0u};
-        if (dt < DT && d0 < D) {
-            pk[0] = cvt_pk_bf16(v[dt < DT ? dt : 0][0], v[dt < DT ? dt : 0][1]);
-            pk[1] = cvt_pk_bf16(v[dt < DT ? dt : 0][2], v[dt < DT ? dt : 0][3]);
-        } else if (d0 == D && ones) {
-            pk[0] = 0x00003F80u;
-        }
-        const int ks = dt >> 1, gd = 2 * (dt & 1) + (g >> 1);
-        *reinterpret_cast<u32x2*>(scratch + ((ks * 64 + gd * 16 + tok) * 16 + 8 * (g & 1))) = pk;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int ks = 0; ks < KS1; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(scratch + (ks * 64 + lane) * 16);
-    __builtin_amdgcn_wave_barrier();
-}
-// LayerNorm statistics of a C-layout tile over the D features of token lane&15
-template <int DT>
-__device__ __forceinline__ void ln_stats(const f32x4 (&v)[DT], int D, int g, float& mean, float& rstd) {
-    float s = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-        if (16 * dt + 4 * g < D) s += (v[dt][0] + v[dt][1]) + (v[dt][2] + v[dt][3]);
-    const float invD = 1.0f / (float)D;      // (one reciprocal instead of two IEEE divisions on the serial path)
-    mean = group_sum(s) * invD;
-    float q = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-        if (16 * dt + 4 * g < D) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float c = v[dt][r] - mean;
-                q += c * c;
-            }
-        }
-    rstd = __builtin_amdgcn_rsqf(group_sum(q) * invD + 1e-5f);
-}
-// dropout bits of a (token, D features) row in C layout: bytes (m, j, g) written by k_tr_masks, byte j covers the C tiles
-// 2j (low nibble) and 2j+1 (high nibble)
-template <int DT>
-__device__ __forceinline__ void row_drop_bits(const TrDims& d, const unsigned char* __restrict__ rbits, int m, bool valid, int g,
-                                              unsigned (&bits)[DT]) {      // (unconditional loads + select, see load_ctile)
-    const int mc = valid ? m : 0;
-    unsigned char raw[(DT + 1) / 2];
-#pragma unroll
-    for (int j = 0; j < (DT + 1) / 2; ++j) raw[j] = rbits[((size_t)mc * ((DT + 1) / 2) + j) * 4 + g];
-#pragma unroll
-    for (int j = 0; j < (DT + 1) / 2; ++j) {
-        const unsigned b8 = (d.p > 0.f && valid) ? (unsigned)raw[j] : 0xffu;
-        bits[2 * j] = b8 & 15u;
-        if (2 * j + 1 < DT) bits[2 * j + 1] = b8 >> 4;
-    }
-}
 
 // Every dropout decision of one encoder layer (16 per Philox4x32-10 evaluation), generated AHEAD of the kernels that use
 // them on the context's side stream: the RNG has no data dependency, and inside the latency-bound forward kernels a Philox
@@ -516,6 +114,9 @@ struct AttnFwdArgs {
 #define FD_TR_ABL_FWD 0           // k_tr_ffn_fwd timing ablations (wrong results): 1 no weight DMA in the loop, 2 no barrier, 4 no mask /
 #endif                            // activity block, 16 no chunk loop at all (prologue + epilogue only), 64 no ballots / activity words, 128 no
                                   // activity byte, 256 no keep-mask table
+#ifndef FD_TR_BALLOTS
+#define FD_TR_BALLOTS 0           // (rounds 3-5: k_tr_ffn_fwd also wrote the activity bits as 16-token ballots per hidden unit for k_tr_wgrad, 4.8 us
+#endif                            // of its chunk loop; k_tr_wgrad reads them out of the activity bytes now.  1 keeps the ballots for timing A/Bs only.)
 #ifndef FD_TR_ATTN_OH_MINW
 #define FD_TR_ATTN_OH_MINW 3          // one-head attention backward: three 4-wave workgroups per CU
 #endif
@@ -735,8 +336,6 @@ struct FfnFwdArgs {
     char* stage;              // StageL records of the layer (x1 rows here, d f rows by the backward)
     __bf16* outrb; __bf16* outT;   // next layer's input in operand form (null for the last layer)
     unsigned char* active;    // (Mpad, 4, F/32): bit e of byte (m, g, chunk): hidden unit kept by dropout AND > 0
-    unsigned short* activeT;  // (Mpad/32, 2, F/32, 8, 4): bit j of word (block, half, chunk, w, gq): the same for token
-                              // 32 block + 16 half + j and hidden unit 32 chunk + 16 (w >> 2) + 4 gq + (w & 3)
     const char* wo_img;       // [DT][KSO]
     const char* ffn_img;      // chunk-major forward image of the layer
     const float* bo; const float* g1; const float* be1; const float* b2; const float* g2; const float* be2;
@@ -763,6 +362,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     constexpr int SCR = (TW * KS1 * 1024 > 4 * DT * 1024) ? TW * KS1 * 1024 : 4 * DT * 1024;
     unsigned char* const actB = reinterpret_cast<unsigned char*>(smem + NBUF * WB + SCR) + wave * (64 * NS);   // [64 lanes][NS]
     unsigned short* const actT = reinterpret_cast<unsigned short*>(smem + NBUF * WB + SCR + TW * 64 * NS) + wave * (NS * 32);   // [NS][32]
+    (void)actT;               // (only -DFD_TR_BALLOTS=1 builds fill it)
     char* const tscr = smem + NBUF * WB + SCR + TW * 64 * NS + TW * NS * 32 * 2 + (wave & 3) * (32 * DT * 16);   // owners' T-store transpose
     // keep masks of four packed bf16 values by nibble of keep bits (see the chunk loop): klut[2 n], klut[2 n + 1] = lane masks of values 0-1 / 2-3
     unsigned* const klut = reinterpret_cast<unsigned*>(smem + NBUF * WB + SCR + TW * 64 * NS + TW * NS * 32 * 2 + 4 * (32 * DT * 16));
@@ -791,7 +391,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     // Every workgroup streams the SAME weights: marching through them in lockstep makes all CUs hit the same L2 channel at the
     // same time (measured in the persistent kernel: ~25 GB/s per CU).  The chunks are summed, so each workgroup walks them in
     // its own rotated order.
-    const int rot = (int)(((unsigned)blk * 5u) % (unsigned)NSH);
+    const int rot = d.norot ? 0 : (int)(((unsigned)blk * 5u) % (unsigned)NSH);
     auto issue = [&](int st) {
         int ce = st + rot;
         ce -= (ce >= NSH) ? NSH : 0;
@@ -993,7 +593,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
 #endif
         // ... and with the 16 tokens of the tile as the bits of one word per hidden unit (weight-gradient kernel): the compare's
         // SGPR pair IS the ballot -- bit 16 g + tok of unit 4 g + r (+16 for the second row tile); one compare per half
-#if !(FD_TR_ABL_FWD & 64)
+#if FD_TR_BALLOTS && !(FD_TR_ABL_FWD & 64)
         {
             unsigned long long bal[8];
 #pragma unroll
@@ -1043,12 +643,6 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
             for (int c = cbase; c < cbase + NSH; c += 8)
                 *reinterpret_cast<u32x2*>(dstb + c) = *reinterpret_cast<const u32x2*>(actB + lane * NS + c);
         }
-    }
-    {
-        const int m0 = (blk * 4 + tile) * 16;
-        unsigned short* dstw = a.activeT + ((size_t)(m0 >> 5) * 2 + ((m0 >> 4) & 1)) * F + fhw * (F / 2);
-        for (int i = cbase * 32 + lane * 8; i < (cbase + NSH) * 32; i += 64 * 8)
-            *reinterpret_cast<u32x4*>(dstw + i) = *reinterpret_cast<const u32x4*>(actT + i);
     }
     TRF_STAMP(5, tprev);          // s1 / stage stores issued, mask bits out
     // ---- combine the F-halves; the owner finishes the tile
@@ -1848,7 +1442,7 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
 struct WgLayer {
     const __bf16* x0T; const __bf16* attT; const __bf16* doT; const __bf16* dqkvT;
     const char* stage;
-    const unsigned short* activeT;
+    const unsigned char* active;      // (Mpad, 4, F/32) activity bytes of the layer (k_tr_ffn_fwd / k_tr_fwd_layers)
     const char* ffn_img; const char* bffn;
     long long in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w;
 };
@@ -1930,9 +1524,12 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
                 __builtin_amdgcn_global_load_lds(GLB_PTR(src + bb * 1024), LDS_PTR(dst + bb * 1024), 16, 0, 0);
             }
 #ifndef FD_TR_ABL_WG_NOMASK
-            {   // waves 0 / 2 copy token half 0, waves 1 / 3 half 1 (the duplicates write the same words)
+            {   // the block's activity BYTES of the workgroup's four 32-unit chunks: one dword per (token, lane group) = 512 bytes; waves
+                // 0 / 2 copy the tokens 0-15, waves 1 / 3 the tokens 16-31 (the duplicates write the same bytes).  (Round 6: the forward used
+                // to write a second, transposed copy -- a 16-token ballot per hidden unit -- for this kernel; the persistent forward's
+                // tiles are not 16-aligned in the flat token index, and the bits can be picked out of the bytes here for ~20 VALU per block.)
                 const int half = wave & 1;
-                const char* msrc = reinterpret_cast<const char*>(L.activeT + ((size_t)blk * 2 + half) * F + (size_t)bx * 128) + lane * 4;
+                const unsigned char* msrc = L.active + (((size_t)blk * 32 + half * 16 + (lane >> 2)) * 4 + (lane & 3)) * (size_t)(F / 32) + (size_t)bx * 4;
                 __builtin_amdgcn_global_load_lds(GLB_PTR(msrc), LDS_PTR(mring + slot * 512 + half * 256), 4, 0, 0);
             }
 #endif
@@ -1968,11 +1565,24 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
             __builtin_amdgcn_s_barrier();
 #endif
             // this wave's activity words of the block: [half][tile] (token on tok & 3 / tok >> 2 as in the T-blocks)
-            unsigned short mkw[4];
+            // this wave's activity nibbles [half][tile]: bit r = token 4 g + r of the half, hidden unit 16 tile + tok -- bit 4 tile + (tok & 3)
+            // of the wave's byte of dword (token, lane group tok >> 2)
+            unsigned mkw[4];
+            {
+                unsigned dwr[2][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                mkw[q] = *reinterpret_cast<const unsigned short*>(mring + slot * 512 + (q >> 1) * 256 +
-                                                                  (wave * 32 + (q & 1) * 16 + (tok & 3) * 4 + (tok >> 2)) * 2);
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dwr[half][r] = *reinterpret_cast<const unsigned*>(mring + slot * 512 + half * 256 + ((4 * g + r) * 4 + (tok >> 2)) * 4);
+                const unsigned sh = 8u * (unsigned)wave + (unsigned)(tok & 3);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned sq = sh + 4u * (unsigned)(q & 1);
+                    mkw[q] = ((dwr[q >> 1][0] >> sq) & 1u) | (((dwr[q >> 1][1] >> sq) & 1u) << 1) | (((dwr[q >> 1][2] >> sq) & 1u) << 2) |
+                             (((dwr[q >> 1][3] >> sq) & 1u) << 3);
+                }
+            }
             auto prefetch = [&]() {
 #ifdef FD_TR_ABL_WG_NODMA
                 if (false) {
@@ -2018,8 +1628,8 @@ __global__ __launch_bounds__(256, 2) void k_tr_wgrad(const TrDims d, const WgLay
             bf16x8 hB[2], dB[2];
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
-                const u32x2 k0 = *reinterpret_cast<const u32x2*>(klut + 2 * ((mkw[ft] >> (4 * g)) & 15u));
-                const u32x2 k1 = *reinterpret_cast<const u32x2*>(klut + 2 * ((mkw[2 + ft] >> (4 * g)) & 15u));
+                const u32x2 k0 = *reinterpret_cast<const u32x2*>(klut + 2 * mkw[ft]);
+                const u32x2 k1 = *reinterpret_cast<const u32x2*>(klut + 2 * mkw[2 + ft]);
                 const u32x4 ph = __builtin_bit_cast(u32x4, pack8(hh[ft][0], hh[ft][1])), pd = __builtin_bit_cast(u32x4, pack8(dh[ft][0], dh[ft][1]));
                 hB[ft] = __builtin_bit_cast(bf16x8, u32x4{ph[0] & k0[0], ph[1] & k0[1], ph[2] & k1[0], ph[3] & k1[1]});
                 dB[ft] = __builtin_bit_cast(bf16x8, u32x4{pd[0] & k0[0], pd[1] & k0[1], pd[2] & k1[0], pd[3] & k1[1]});
@@ -2309,8 +1919,8 @@ struct TrLayerBufs {
     float *x0, *att, *s1, *s2, *lse2;
     __bf16 *x0rb, *x0T, *attT, *doT, *dqkvT;
     char* stage;
-    unsigned char *pmask, *active, *hkeep, *rb1, *rb3;
-    unsigned short* activeT;
+    unsigned char* active;
+    unsigned char *pmask, *hkeep, *rb1, *rb3;      // the decision buffers of the step's set (tr_carve picks it)
 };
 struct TrBufs {
     std::vector<TrLayerBufs> layers;
@@ -2339,7 +1949,7 @@ int tr_TS(const fd_score* m, int B) {
 size_t al(size_t b) { return fd_ws::padded(b); }
 
 // one carve routine for size computation (base == nullptr) and pointer assignment
-size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
+size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out, int mask_set = 0) {
     const fd_bf16_images* im = m->bf16;
     const size_t T = m->d.max_len, D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, L = m->d.num_layers;
     const size_t M = (size_t)B * T, Mpad = (M + 63) & ~size_t(63);
@@ -2369,12 +1979,17 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out) {
         b.attT = (__bf16*)take(2 * Mpad * NFT);
         b.doT = (__bf16*)take(2 * Mpad * NFT);
         b.dqkvT = (__bf16*)take(2 * Mpad * 3 * NP * 16);
-        b.pmask = (unsigned char*)take((size_t)B * H * T * NJ * 4);
         b.active = (unsigned char*)take(Mpad * (F / 32) * 4);
-        b.hkeep = (unsigned char*)take(Mpad * (F / 32) * 4);
-        b.rb1 = (unsigned char*)take(Mpad * ((NFT / 16 + 1) / 2) * 4);
-        b.rb3 = (unsigned char*)take(Mpad * ((NFT / 16 + 1) / 2) * 4);
-        b.activeT = (unsigned short*)take((Mpad / 32) * 2 * F * sizeof(unsigned short));
+        // Two sets of dropout-decision buffers, used by alternating training steps: the decisions of step n + 1 are generated (on
+        // their own stream) while step n still reads its own set -- beside step n's backward instead of in front of step n + 1's
+        // forward, where the persistent forward (which leaves no register for a decision kernel beside it) had to wait for all of them
+        for (int set = 0; set < 2; ++set) {
+            unsigned char* pm = (unsigned char*)take((size_t)B * H * T * NJ * 4);
+            unsigned char* hk = (unsigned char*)take(Mpad * (F / 32) * 4);
+            unsigned char* r1 = (unsigned char*)take(Mpad * ((NFT / 16 + 1) / 2) * 4);
+            unsigned char* r3 = (unsigned char*)take(Mpad * ((NFT / 16 + 1) / 2) * 4);
+            if (set == mask_set) { b.pmask = pm; b.hkeep = hk; b.rb1 = r1; b.rb3 = r3; }
+        }
     }
     tb.dh = (float*)take(sizeof(float) * M * D);
     tb.datt = (float*)take(sizeof(float) * M * D);
@@ -2429,6 +2044,24 @@ size_t tr_attn_bwd_lds(int T, bool one_head) {
            nhs * (size_t)T * NJ * 4 + 16 + 256 + nhs * KT * 16 * NJ * 4;
 }
 
+// the context's error word of the device-side bounded waits (pinned, mapped into the device)
+int tr_err_word(fd_ctx* ctx) {
+    if (!ctx->tr_err_host) {
+        FD_HIP(ctx, hipHostMalloc((void**)&ctx->tr_err_host, 64, hipHostMallocMapped));
+        *ctx->tr_err_host = 0u;
+        FD_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->tr_err_dev, ctx->tr_err_host, 0));
+        FD_HIP(ctx, hipMalloc((void**)&ctx->tr_err_gpu, 64));
+        FD_HIP(ctx, hipMemset(ctx->tr_err_gpu, 0, 64));
+    }
+    return FD_OK;
+}
+unsigned long long tr_wait_timeout_ticks() {      // bound of a device-side wait in ticks of the constant 100 MHz clock
+    const char* e = getenv("FDIFF_TR_TIMEOUT_MS");           // (read per call: the tests set it inside one process)
+    if (!e) e = getenv("FDIFF_TR_FSPLIT_TIMEOUT_MS");
+    const double ms = e ? std::max(1.0, atof(e)) : 2000.0;
+    return (unsigned long long)(ms * 1.0e5);
+}
+
 // buffers + a fresh epoch for one F-split launch (fs stays empty when the launch is not split).
 // Constraints of the split, stated here because nothing in the signature does: (1) the partial-sum buffer, the flags, the epoch
 // counter and the error word belong to the CONTEXT -- one training step at a time per context, on one stream (the library's
@@ -2440,11 +2073,7 @@ size_t tr_attn_bwd_lds(int T, bool one_head) {
 int tr_fsplit_prepare(fd_ctx* ctx, const TrDims& d, int blocks, int DT, FSplit* fs, hipStream_t s) {
     *fs = FSplit{};
     if (d.fsplit != 2) return FD_OK;
-    if (!ctx->tr_err_host) {
-        FD_HIP(ctx, hipHostMalloc((void**)&ctx->tr_err_host, 64, hipHostMallocMapped));
-        *ctx->tr_err_host = 0u;
-        FD_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->tr_err_dev, ctx->tr_err_host, 0));
-    }
+    if (int rc = tr_err_word(ctx)) return rc;
     if ((size_t)blocks > ctx->tr_fsplit_blocks) {
         // (first use on this context; or a device whose CU count changed under us: the old buffers may still be read by a launch in flight)
         FD_HIP(ctx, hipStreamSynchronize(s));
@@ -2460,11 +2089,9 @@ int tr_fsplit_prepare(fd_ctx* ctx, const TrDims& d, int blocks, int DT, FSplit* 
     (void)DT;
     fs->ypart = ctx->tr_ypart; fs->flag = ctx->tr_yflag; fs->epoch = ++ctx->tr_epoch;
     if (fs->epoch == 0u) fs->epoch = ++ctx->tr_epoch;      // (0 is the flags' initial value)
-    fs->err = ctx->tr_err_dev;
-    const char* e = getenv("FDIFF_TR_FSPLIT_TIMEOUT_MS");      // (read per call: the tests set it inside one process)
-    const double ms = e ? std::max(1.0, atof(e)) : 2000.0;
-    fs->timeout = (unsigned long long)(ms * 1.0e5);           // 100 MHz constant clock
-    e = getenv("FDIFF_TR_FSPLIT_FENCE");
+    fs->err = ctx->tr_err_dev; fs->err_gpu = ctx->tr_err_gpu;
+    fs->timeout = tr_wait_timeout_ticks();
+    const char* e = getenv("FDIFF_TR_FSPLIT_FENCE");
     fs->fence = (e && atoi(e) != 0) ? 1 : 0;
     e = getenv("FDIFF_TR_FSPLIT_TEST_STALL");
     fs->stall = (e && atoi(e) != 0) ? 1 : 0;
@@ -2499,6 +2126,7 @@ TrDims make_dims(const fd_score* m, int B, float p, uint64_t seed) {
     static const int xcd_env = getenv("FDIFF_TR_XCD") ? atoi(getenv("FDIFF_TR_XCD")) : 1;      // (0: hardware order, A/B runs)
     d.xcd = xcd_env;
     d.fsplit = tr_fsplit_rule(m, d.M, d.F, false);      // (the forward launch applies its own rule, see there)
+    { const char* e = getenv("FDIFF_TR_ROT"); d.norot = (e && atoi(e) == 0) ? 1 : 0; }      // (read per call: a test switches it)
     return d;
 }
 
@@ -2676,7 +2304,7 @@ __global__ __launch_bounds__(256) void k_tr_head_final(const float* __restrict__
 
 template <int KS1, int DT, int KSO>
 int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B, float p, uint64_t seed, uint64_t offset,
-                 hipStream_t s, TrBufs& tb, uint64_t gen_in, bool img_forked) {
+                 hipStream_t s, TrBufs& tb, uint64_t gen_in, bool img_forked, int mask_set) {
     fd_ctx* ctx = m->ctx;
     const fd_bf16_images* im = m->bf16;
     const int T = m->d.max_len, C = m->d.n_channels, D = m->d.d_model, L = m->d.num_layers;
@@ -2705,6 +2333,13 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
     if (p > 0.f) {
         // dropout decisions of every layer on the side stream, layer by layer, ahead of the kernels that read them
         if (!ctx->side_stream) FD_HIP(ctx, side_stream_create(&ctx->side_stream));
+        // (round 6: the decision kernels have a stream of their own.  On side stream 1 they queued behind the previous step's last
+        // weight-gradient launch -- the very end of that step -- although all they wait for is the last READER of the decision buffers,
+        // the attention backward of layer 0: now they run beside that step's tail (layer 0's weight gradients, the embedding
+        // backward, AdamW) and this step's prologue.  FDIFF_TR_MASK_STREAM=0: side stream 1 as before.)
+        static const bool own_mask_stream = !(getenv("FDIFF_TR_MASK_STREAM") && atoi(getenv("FDIFF_TR_MASK_STREAM")) == 0);
+        if (own_mask_stream && !ctx->mask_stream) FD_HIP(ctx, side_stream_create(&ctx->mask_stream));
+        const hipStream_t mstream = own_mask_stream ? ctx->mask_stream : ctx->side_stream;
         while ((int)ctx->side_events.size() < L + 3) {
             hipEvent_t e;
             FD_HIP(ctx, hipEventCreateWithFlags(&e, kTrEventFlags));
@@ -2716,9 +2351,12 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         // a cross-stream hand-off plus the first mask kernel (an 80 us hole in every step), so that is only done when some
         // other call has carved the arena since (an eval forward, the sampler, another model on this context: gen_in differs)
         // and may still be running on `s`.
-        if (!ctx->tr_readers_event) FD_HIP(ctx, hipEventCreateWithFlags(&ctx->tr_readers_event, kTrEventFlags));
-        if (!ctx->tr_readers_event_valid || gen_in != ctx->tr_readers_gen) FD_HIP(ctx, hipEventRecord(ctx->tr_readers_event, s));
-        FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->tr_readers_event, 0));
+        // (round 6: two sets of decision buffers; this step's set was last read two training steps ago)
+        (void)gen_in;
+        hipEvent_t& rev = ctx->tr_readers_event[mask_set];
+        if (!rev) FD_HIP(ctx, hipEventCreateWithFlags(&rev, kTrEventFlags));
+        if (!ctx->tr_readers_event_valid[mask_set]) FD_HIP(ctx, hipEventRecord(rev, s));
+        FD_HIP(ctx, hipStreamWaitEvent(mstream, rev, 0));
         for (int l = 0; l < L; ++l) {
             TrLayerBufs& b = tb.layers[l];
             MaskArgs ma{};
@@ -2736,12 +2374,65 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             // = 2.36 / 2.36 / 2.39 / 2.40 / 2.40 ms per step at T = 252 (scripts/gpu_r04_maskwgs.sh).
             static const int mask_wgs = getenv("FDIFF_TR_MASK_WGS") ? std::max(1, atoi(getenv("FDIFF_TR_MASK_WGS"))) : 16;
             const unsigned grid = (unsigned)std::min<long long>((tot / 2 + 255) / 256, (long long)ctx->num_cu * mask_wgs);
-            hipLaunchKernelGGL(k_tr_masks, dim3(grid), dim3(256), 0, ctx->side_stream, d, ma);
-            FD_HIP(ctx, hipEventRecord(ctx->side_events[l], ctx->side_stream));
+            hipLaunchKernelGGL(k_tr_masks, dim3(grid), dim3(256), 0, mstream, d, ma);
+            FD_HIP(ctx, hipEventRecord(ctx->side_events[l], mstream));
+        }
+    }
+    // ---- every encoder layer as ONE persistent launch (fd_train_persist.hip) where it applies: T <= 256, the workgroups of a launch
+    // all resident.  FDIFF_TR_PERSIST: 0 = the per-layer kernels below, 1 (default) = persistent, 2 = the same kernel launched once
+    // per layer (A/B runs and debugging: no inter-workgroup wait is ever exercised).  Read per call: the tests compare the forms.
+    int trp_nq = 0, trp_spl = 0;
+    const int trp_mode = [] { const char* e = getenv("FDIFF_TR_PERSIST"); return e ? atoi(e) : 1; }();
+    const int trp_nt = (trp_mode != 0 && L > 0) ? fd_trp_tiles(m, B, &trp_nq, &trp_spl) : 0;
+    if (trp_nt) {
+        if (int rc = tr_err_word(ctx)) return rc;
+        const size_t nflag = (size_t)B * d.KT;
+        if (nflag > ctx->trp_flag_count) {
+            FD_HIP(ctx, hipStreamSynchronize(s));              // (first use, or a larger batch: a launch in flight may still poll the old flags)
+            if (ctx->trp_flags) (void)hipFree(ctx->trp_flags);
+            ctx->trp_flags = nullptr; ctx->trp_flag_count = 0;
+            FD_HIP(ctx, hipMalloc((void**)&ctx->trp_flags, nflag * sizeof(unsigned long long)));
+            FD_HIP(ctx, hipMemsetAsync(ctx->trp_flags, 0, nflag * sizeof(unsigned long long), s));
+            ctx->trp_flag_count = nflag;
+        }
+        // The dropout decisions of EVERY layer must be written before the launch: its workgroups hold every register of every CU
+        // (8 waves x 256 VGPRs), so a decision kernel on the side stream could not become resident beside them, and a wait inside the
+        // kernel for decisions that cannot be produced would only end at its timeout.  They were launched above, ahead of the step's
+        // prologue kernels on `s` (time embedding, embedding, operand preparation, the weight-image rebuild beside them).
+        if (p > 0.f) FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[L - 1], 0));
+        const TrLayerBufs& b0 = tb.layers[0];
+        const fd_layer_off& l0 = m->layers[0];
+        fd_trp_args ta{};
+        ta.x0 = b0.x0; ta.x0rb = b0.x0rb; ta.x0T = b0.x0T; ta.att = b0.att; ta.attT = b0.attT; ta.lse2 = b0.lse2;
+        ta.s1 = b0.s1; ta.s2 = b0.s2; ta.stage = b0.stage; ta.active = b0.active;
+        ta.pmask = b0.pmask; ta.hkeep = b0.hkeep; ta.rb1 = b0.rb1; ta.rb3 = b0.rb3;
+        ta.lstride = L > 1 ? (size_t)((const char*)tb.layers[1].x0 - (const char*)b0.x0) : 0;
+        ta.hL = tb.hL;
+        ta.limg = im->mimg + im->off_layers; ta.limg_stride = im->layer_stride;
+        ta.off_wk = im->off_wk; ta.off_wv = im->off_wv; ta.off_wq = im->off_wq; ta.off_wo = im->off_wo; ta.off_ffn = im->off_ffn;
+        ta.P = P; ta.pstride = (long long)tb.layer_params;
+        ta.o_bo = l0.out_b; ta.o_g1 = l0.n1_w; ta.o_be1 = l0.n1_b; ta.o_b2 = l0.l2_b; ta.o_g2 = l0.n2_w; ta.o_be2 = l0.n2_b;
+        ta.L = L; ta.Mpad = tb.Mpad;
+        ta.xflag = ctx->trp_flags; ta.mflag = nullptr;
+        ta.err = ctx->tr_err_dev; ta.err_gpu = ctx->tr_err_gpu; ta.timeout = tr_wait_timeout_ticks();
+        { const char* e = getenv("FDIFF_TR_PERSIST_TEST_STALL"); ta.stall = (e && atoi(e) != 0) ? 1 : 0; }
+        {
+            // measurement hook: every matrix product of the L layers (projections, scores, P V, out-projection, FFN) of M tokens
+            fd_prof_scope scope(ctx, s, "k_tr_fwd_layers (all encoder layers, training forward, one persistent launch)",
+                                (double)L * M * (8.0 * D * D + 4.0 * (double)T * D + 4.0 * D * m->d.dim_ff));
+            if (trp_mode == 2) {
+                for (int l = 0; l < L; ++l) {
+                    ta.l0 = l; ta.l1 = l + 1; ta.epoch = ++ctx->trp_epoch;
+                    if (int rc = fd_trp_forward(m, d, ta, trp_nt, trp_nq, trp_spl, s)) return rc;
+                }
+            } else {
+                ta.l0 = 0; ta.l1 = L; ta.epoch = ++ctx->trp_epoch;
+                if (int rc = fd_trp_forward(m, d, ta, trp_nt, trp_nq, trp_spl, s)) return rc;
+            }
         }
     }
     int mask_waited = -1;                 // highest layer whose dropout decisions `s` has waited for
-    for (int l = 0; l < L; ++l) {
+    for (int l = 0; l < (trp_nt ? 0 : L); ++l) {
         const fd_layer_off& lo = m->layers[l];
         TrLayerBufs& b = tb.layers[l];
         const char* limg = im->mimg + im->off_layers + (size_t)l * im->layer_stride;
@@ -2784,7 +2475,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
         fa.stage = b.stage;
         fa.outrb = (l + 1 < L) ? tb.layers[l + 1].x0rb : nullptr;
         fa.outT = (l + 1 < L) ? tb.layers[l + 1].x0T : nullptr;
-        fa.active = b.active; fa.activeT = b.activeT;
+        fa.active = b.active;
         fa.wo_img = limg + im->off_wo; fa.ffn_img = limg + im->off_ffn;
         fa.bo = P + lo.out_b; fa.g1 = P + lo.n1_w; fa.be1 = P + lo.n1_b; fa.b2 = P + lo.l2_b; fa.g2 = P + lo.n2_w; fa.be2 = P + lo.n2_b;
         fa.hkeep = b.hkeep; fa.rb1 = b.rb1; fa.rb3 = b.rb3;
@@ -2819,8 +2510,8 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
     if (out) fdgemm::linear_fwd(tb.hL, P + m->un_w, P + m->un_b, out, M, C, D, false, s);      // (null: the fused loss head reads hL)
     FD_LAUNCH_CHECK(ctx);
     if (p > 0.f) {      // the dropout-decision buffers may be rewritten once everything enqueued so far has run
-        FD_HIP(ctx, hipEventRecord(ctx->tr_readers_event, s));
-        ctx->tr_readers_event_valid = true;
+        FD_HIP(ctx, hipEventRecord(ctx->tr_readers_event[mask_set], s));
+        ctx->tr_readers_event_valid[mask_set] = true;
         ctx->tr_readers_gen = ctx->ws_gen;
     }
     return FD_OK;
@@ -2949,7 +2640,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         }
         WgLayer w{};
         w.x0T = b.x0T; w.attT = b.attT; w.doT = b.doT; w.dqkvT = b.dqkvT;
-        w.stage = b.stage; w.activeT = b.activeT;
+        w.stage = b.stage; w.active = b.active;
         w.ffn_img = limg + im->off_ffn; w.bffn = bl + im->boff_ffn;
         // offsets relative to the layer's first parameter: the partials hold one layer
         w.in_w = 0; w.in_b = lo.in_b - lo.in_w; w.out_w = lo.out_w - lo.in_w; w.out_b = lo.out_b - lo.in_w;
@@ -2976,9 +2667,10 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         hipLaunchKernelGGL(k_tr_reduce, dim3((unsigned)((tb.layer_params / 4 + 255) / 256)), dim3(256), 0, ws, ra);
     }
     if (m->saved_p > 0.f && L > 0) {      // last reader of the dropout-decision buffers on `s` (layer 0's attention backward)
-        if (!ctx->tr_readers_event) FD_HIP(ctx, hipEventCreateWithFlags(&ctx->tr_readers_event, kTrEventFlags));
-        FD_HIP(ctx, hipEventRecord(ctx->tr_readers_event, s));
-        ctx->tr_readers_event_valid = true;
+        hipEvent_t& rev = ctx->tr_readers_event[m->saved_mask_set & 1];
+        if (!rev) FD_HIP(ctx, hipEventCreateWithFlags(&rev, kTrEventFlags));
+        FD_HIP(ctx, hipEventRecord(rev, s));
+        ctx->tr_readers_event_valid[m->saved_mask_set & 1] = true;
         ctx->tr_readers_gen = ctx->ws_gen;
     }
     // The input-gradient chain is complete; the last weight-gradient launches are still running on the side streams.  The
@@ -3077,10 +2769,19 @@ int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, flo
     const void* ws_before = ctx->ws;
     if (int rc = fd_ws_reserve(ctx, need)) return rc;
     fd_ws ws(ctx);
-    if (ctx->ws != ws_before) ctx->tr_readers_event_valid = false;      // regrown: the reserve synchronised the device
+    // Somebody else carved the arena since the last training call (an eval forward, the sampler, another model on this context) and may
+    // still be running on `s` over memory the decision kernels are about to write, or the arena moved: both sets take the conservative
+    // path at their next use (an event recorded on `s` in front of the decision kernels instead of behind the set's last reader).
+    // (A different model or batch size also counts: its carve puts the decision buffers where the other layout keeps activations.)
+    if (gen_in != ctx->tr_readers_gen || ctx->ws != ws_before || ctx->tr_last_model != (const void*)m || ctx->tr_last_B != B)
+        ctx->tr_readers_event_valid[0] = ctx->tr_readers_event_valid[1] = false;
+    ctx->tr_last_model = m; ctx->tr_last_B = B;
+    const int mask_set = (int)(ctx->tr_mask_steps++ & 1u);
+    m->saved_mask_set = mask_set;
     TrBufs tb;
-    tr_carve(m, B, (char*)ctx->ws, &tb);
-#define CALL_F(K, T_, O) tr_forward_t<K, T_, O>(m, x, t, out, B, p, seed, offset, s, tb, gen_in, img_forked)
+    tr_carve(m, B, (char*)ctx->ws, &tb, mask_set);
+    ctx->tr_readers_gen = ctx->ws_gen;      // (own carve accounted for: a training forward that ends without reaching its last event record keeps the sets usable)
+#define CALL_F(K, T_, O) tr_forward_t<K, T_, O>(m, x, t, out, B, p, seed, offset, s, tb, gen_in, img_forked, mask_set)
     FD_TR_DISPATCH(CALL_F);
 #undef CALL_F
 }
@@ -3091,7 +2792,7 @@ int fd_score_backward_bf16(fd_score* m, const float* dout, float* grads, int acc
     const size_t need = fd_train_bf16_workspace(m, m->saved_B);
     if (ctx->ws_bytes < need) return fd_fail(ctx, FD_ERR_STATE, "fd_score_backward: workspace was resized since the training forward");
     TrBufs tb;
-    tr_carve(m, m->saved_B, (char*)ctx->ws, &tb);
+    tr_carve(m, m->saved_B, (char*)ctx->ws, &tb, m->saved_mask_set);
 #define CALL_B(K, T_, O) tr_backward_t<K, T_, O>(m, dout, grads, accumulate, s, tb, false)
     FD_TR_DISPATCH(CALL_B);
 #undef CALL_B
@@ -3146,7 +2847,7 @@ int fd_score_train_dsm_bf16(fd_score* m, const float* x, const float* t, const f
     m->saved_B = B; m->saved_p = p; m->saved_seed = seed; m->saved_offset = offset; m->saved_x = x; m->saved_t = t;
     m->saved_ws_gen = ctx->ws_gen; m->saved_ws = ctx->ws;
     TrBufs tb;
-    tr_carve(m, B, (char*)ctx->ws, &tb);
+    tr_carve(m, B, (char*)ctx->ws, &tb, m->saved_mask_set);
     HeadArgs ha{};
     ha.hL = tb.hL; ha.Wu = m->params + m->un_w; ha.bu = m->params + m->un_b; ha.target = target; ha.stdv = stdv;
     ha.dh = tb.dh; ha.part = tb.skp; ha.T = T; ha.C = C; ha.D = D; ha.TS = TS; ha.lw = lw;

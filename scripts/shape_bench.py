@@ -88,7 +88,7 @@ def main():
         for _ in range(3):
             step()
         torch.cuda.synchronize()
-        nrep = 20
+        nrep = int(os.environ.get("FDIFF_BENCH_NREP", "100"))
         t0 = time.perf_counter()
         for _ in range(nrep):
             step()
@@ -100,7 +100,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         if denv.rank == 0:
-            print(f"{name} train ({m.train_mode_effective}) B={B}/GPU x {denv.world} T={T} C={Cn}: {1e3 * dt:.2f} ms per optimizer step "
+            print(f"{name} train ({m.train_mode_effective}) B={B}/GPU x {denv.world} T={T} C={Cn}: {1e3 * dt:.3f} ms per optimizer step "
                   f"(fwd+bwd+all-reduce+AdamW), {3 * denv.world * B * flops_fwd(T, Cn) / dt / 1e12:.2f} TFLOP/s algorithmic, "
                   f"{denv.world * B / dt:.0f} series/s")
 
