@@ -217,20 +217,21 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
         TAF_STAMP(2, tprev);      // Q projection of the tile
         // pass 1: exact row maxima (base-2 logits: log2(e)/sqrt(hd) is folded into W_q)
         float mx[2] = {kNegBig, kNegBig};
-#ifdef FD_TR_ABL_AF1          // (timing ablation, wrong results: no pass 1)
-        mx[0] = mx[1] = 0.f;
-        for (int kt = 0; kt < 0; ++kt) {
-#else
-        for (int kt = 0; kt < KT; ++kt) {
-#endif
+        // (round 6: the last key tile alone carries the padding mask -- peeled, no select per tile; the same in pass 2 below)
+        auto maxtile = [&](int kt, const f32x4 c0) {
             const s16x4 kf = kfrag(kt);
-            const f32x4 c0 = (kt == KT - 1) ? cmask : f4zero();
 #pragma unroll
             for (int hs = 0; hs < 2; ++hs) {
                 const f32x4 v = MFMA16(kf, qb[hs], c0);
                 mx[hs] = fmaxf(fmaxf(fmaxf(mx[hs], v[0]), v[1]), fmaxf(v[2], v[3]));
             }
-        }
+        };
+#ifdef FD_TR_ABL_AF1          // (timing ablation, wrong results: no pass 1)
+        mx[0] = mx[1] = 0.f;
+#else
+        for (int kt = 0; kt < KT - 1; ++kt) maxtile(kt, f4zero());
+        maxtile(KT - 1, cmask);
+#endif
         f32x4 negm[2];
 #pragma unroll
         for (int hs = 0; hs < 2; ++hs) {
@@ -256,7 +257,10 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
             bnext[0] = prow[0][0];
             bnext[1] = prow[1][0];
         }
-        for (int jb = 0; jb < NJ; ++jb) {
+        // one key block; only the LAST one carries a mask in the C operand of its score MFMAs (x + 0.0f = x bit for bit, and the eight
+        // adds per (block, head) were 14 % of the loop's VALU cycles)
+        auto keyblock = [&](int jb, auto last_c) {
+            constexpr bool LAST = decltype(last_c)::value;
             const unsigned bcur[2] = {bnext[0], bnext[1]};
             if (d.p > 0.f) {
                 const int jn = jb + 1 < NJ ? jb + 1 : jb;
@@ -270,8 +274,8 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
             const f32x4 mb = (2 * jb + 1 >= KT) ? allneg : ((kb == KT - 1) ? cmask : f4zero());
 #pragma unroll
             for (int hs = 0; hs < 2; ++hs) {
-                f32x4 pa = MFMA16(kfa, qb[hs], ma + negm[hs]);
-                f32x4 pb = MFMA16(kfb, qb[hs], mb + negm[hs]);
+                f32x4 pa = MFMA16(kfa, qb[hs], LAST ? (ma + negm[hs]) : negm[hs]);
+                f32x4 pb = MFMA16(kfb, qb[hs], LAST ? (mb + negm[hs]) : negm[hs]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     pa[r] = __builtin_amdgcn_exp2f(pa[r]);
@@ -283,7 +287,9 @@ __global__ __launch_bounds__(NW * 64) void k_tr_attn_fwd(const TrDims d, const A
                 const u32x4 pk = __builtin_bit_cast(u32x4, pack8(pa, pb));
                 o2[hs] = MFMA(vf, __builtin_bit_cast(bf16x8, u32x4{pk[0] & ka2[0], pk[1] & ka2[1], pk[2] & kb2[0], pk[3] & kb2[1]}), o2[hs]);
             }
-        }
+        };
+        for (int jb = 0; jb < NJ - 1; ++jb) keyblock(jb, std::false_type{});
+        keyblock(NJ - 1, std::true_type{});
         TAF_STAMP(4, tprev);      // pass 2
 #pragma unroll
         for (int hs = 0; hs < 2; ++hs) ls[hs] = group_sum(ls[hs]);

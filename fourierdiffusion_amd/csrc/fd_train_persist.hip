@@ -46,6 +46,12 @@ __device__ __forceinline__ void st_coh8(void* p, u32x2 v) {     // 8 bytes, agen
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifndef FD_TRP_UNROLL1
+#define FD_TRP_UNROLL1 1    // unroll of the units' key loops (pass 1: row maxima; pass 2: exp + P V)
+#endif
+#ifndef FD_TRP_UNROLL2
+#define FD_TRP_UNROLL2 1
+#endif
 #ifndef FD_TRP_NUMAX
 #define FD_TRP_NUMAX 1      // attention units a wave interleaves at four tiles per workgroup (3 = all of its head pairs at d_model 72: spills)
 #endif
@@ -222,7 +228,8 @@ __global__ __launch_bounds__(512, 2) void k_tr_fwd_layers(const TrDims d, const 
         };
         // ---- (2) K and V^T of every token of the series, every head pair: wave w projects the tiles w and w + 8
         u32x4 xq[KS1];
-        unsigned bits1[DT], bits3[DT];           // owners: dropout bits of the two residual sites (requested here, used behind the units)
+        unsigned bits1p = 0u, bits3p = 0u;       // owners: dropout bits of the two residual sites (requested here, used behind the units),
+                                                 // one nibble per C tile (two registers live across the units instead of 2 DT)
         {
             {   // W_o image -> LDS (asynchronous: nothing waits for it before barrier (3))
                 const char* wo = limg + a.off_wo + (size_t)lane * 16;
@@ -236,8 +243,11 @@ __global__ __launch_bounds__(512, 2) void k_tr_fwd_layers(const TrDims d, const 
             xload(kt1, xb);
             xload(tile_ok ? kt_own : KT - 1, xq);             // (the own tile's rows for the Q projections of phase (3))
             if (owner) {
-                row_drop_bits<DT>(d, a.rb1 + lo, m, valid, g, bits1);
-                row_drop_bits<DT>(d, a.rb3 + lo, m, valid, g, bits3);
+                unsigned bt1[DT], bt3[DT];
+                row_drop_bits<DT>(d, a.rb1 + lo, m, valid, g, bt1);
+                row_drop_bits<DT>(d, a.rb3 + lo, m, valid, g, bt3);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) { bits1p |= (bt1[dt] & 15u) << (4 * dt); bits3p |= (bt3[dt] & 15u) << (4 * dt); }
             }
             const char* wkb = limg + a.off_wk + (size_t)lane * 16;
             const char* wvb = limg + a.off_wv + (size_t)lane * 16;
@@ -327,8 +337,7 @@ __global__ __launch_bounds__(512, 2) void k_tr_fwd_layers(const TrDims d, const 
             float mx[NU][2];
 #pragma unroll
             for (int u = 0; u < NU; ++u) mx[u][0] = mx[u][1] = kNegBig;
-            for (int kt = 0; kt < KT; ++kt) {
-                const f32x4 c0 = (kt == KT - 1) ? cmask : f4zero();
+            auto maxtile = [&](int kt, const f32x4 c0) {          // (the last key tile alone carries the padding mask: peeled, no select per tile)
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     const s16x4 kf = *reinterpret_cast<const s16x4*>(kbf[u] + (size_t)kt * 512);
@@ -338,7 +347,10 @@ __global__ __launch_bounds__(512, 2) void k_tr_fwd_layers(const TrDims d, const 
                         mx[u][hs] = fmaxf(fmaxf(fmaxf(mx[u][hs], sv[0]), sv[1]), fmaxf(sv[2], sv[3]));
                     }
                 }
-            }
+            };
+#pragma unroll FD_TRP_UNROLL1
+            for (int kt = 0; kt < KT - 1; ++kt) maxtile(kt, f4zero());
+            maxtile(KT - 1, cmask);
 #pragma unroll
             for (int u = 0; u < NU; ++u)
 #pragma unroll
@@ -359,13 +371,19 @@ __global__ __launch_bounds__(512, 2) void k_tr_fwd_layers(const TrDims d, const 
                     bnext[u][hs] = pmask[prow[u][hs]];      // (unconditional: the buffer exists without dropout too; selected below)
                 }
             const bool nodrop = !(d.p > 0.f);
-            for (int jb = 0; jb < NJ; ++jb) {
+            // one key block (32 keys) of every unit of the wave.  Only the LAST block carries a mask in the C operand of its score MFMAs
+            // (padded keys, a missing odd tile); everywhere else C is the plain -max splat: adding the zero mask cost eight VALU adds
+            // per (block, head), 14 % of the loop's VALU cycles (x + 0.0f = x bit for bit, so the results do not change)
+            auto keyblock = [&](int jb, auto last_c) {
+                constexpr bool LAST = decltype(last_c)::value;
                 const int ka = 2 * jb, kb = (2 * jb + 1 < KT) ? 2 * jb + 1 : ka;
                 const f32x4 ma = (ka == KT - 1) ? cmask : f4zero();
                 const f32x4 mb = (2 * jb + 1 >= KT) ? allneg : ((kb == KT - 1) ? cmask : f4zero());
                 const int jn = jb + 1 < NJ ? jb + 1 : jb;
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
+                    // (K / V^T fragments requested one block ahead instead -- eight more registers -- measured slower: 42.0 -> 42.9 K cycles per
+                    // layer for the units, 2.136 -> 2.153 ms per step; the units are bound by VALU issue, not by the LDS round trip)
                     const s16x4 kfa = *reinterpret_cast<const s16x4*>(kbf[u] + (size_t)ka * 512), kfb = *reinterpret_cast<const s16x4*>(kbf[u] + (size_t)kb * 512);
                     const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vbf[u] + (size_t)jb * 1024);
 #pragma unroll
@@ -375,8 +393,9 @@ __global__ __launch_bounds__(512, 2) void k_tr_fwd_layers(const TrDims d, const 
                         const unsigned bits = nodrop ? 0xffu : bnext[u][hs];
                         bnext[u][hs] = pmask[prow[u][hs] + (unsigned)jn * 4u];
                         const float nm = -mx[u][hs];
-                        f32x4 pa = MFMA16(kfa, qb[u][hs], (ma + f32x4{nm, nm, nm, nm}));
-                        f32x4 pb = MFMA16(kfb, qb[u][hs], (mb + f32x4{nm, nm, nm, nm}));
+                        const f32x4 nmv = {nm, nm, nm, nm};
+                        f32x4 pa = MFMA16(kfa, qb[u][hs], LAST ? (ma + nmv) : nmv);
+                        f32x4 pb = MFMA16(kfb, qb[u][hs], LAST ? (mb + nmv) : nmv);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             pa[r] = __builtin_amdgcn_exp2f(pa[r]);
@@ -388,7 +407,10 @@ __global__ __launch_bounds__(512, 2) void k_tr_fwd_layers(const TrDims d, const 
                         o2[u][hs] = MFMA(vf, __builtin_bit_cast(bf16x8, u32x4{pk[0] & ka2[0], pk[1] & ka2[1], pk[2] & kb2[0], pk[3] & kb2[1]}), o2[u][hs]);
                     }
                 }
-            }
+            };
+#pragma unroll FD_TRP_UNROLL2
+            for (int jb = 0; jb < NJ - 1; ++jb) keyblock(jb, std::false_type{});
+            keyblock(NJ - 1, std::true_type{});
             const int mq = b * T + (t < T ? t : 0);
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
@@ -495,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void k_tr_fwd_layers(const TrDims d, const 
                     const float4 bo4 = lvec[0 * 4 * DT + 4 * dt + g];
                     const float bv[4] = {bo4.x, bo4.y, bo4.z, bo4.w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[dt][r] += ((bits1[dt] >> r) & 1u) ? (o[dt][r] + bv[r]) * d.keep_scale : 0.f;
+                    for (int r = 0; r < 4; ++r) v[dt][r] += ((bits1p >> (4 * dt + r)) & 1u) ? (o[dt][r] + bv[r]) * d.keep_scale : 0.f;
                 }
             }
 #pragma unroll
@@ -640,7 +662,7 @@ __global__ __launch_bounds__(512, 2) void k_tr_fwd_layers(const TrDims d, const 
                     const float4 bb = lvec[3 * 4 * DT + 4 * dt + g];
                     const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[dt][r] += ((bits3[dt] >> r) & 1u) ? (acc[dt][r] + bv[r]) * d.keep_scale : 0.f;
+                    for (int r = 0; r < 4; ++r) v[dt][r] += ((bits3p >> (4 * dt + r)) & 1u) ? (acc[dt][r] + bv[r]) * d.keep_scale : 0.f;
                 }
             }
             TRP_SUB(15, tprev);       // [variant] partial sums added, bias + dropout + residual
