@@ -107,6 +107,61 @@ def cpu_baseline(batch: int, T: int, CH: int, n_timed: int = 3):
     return cb.time_sampler_steps(batch=batch, T=T, C=CH, d_model=D, num_layers=L, n_head=H, n_timed=n_timed)
 
 
+class BoardSampler:
+    """Board power and shader clock of the first amdgpu device as its hwmon reports them (sysfs: power1_average / power1_input in
+    microwatts, freq1_input in Hz), sampled twice a second while the timed region runs.  The persistent kernel is power-limited
+    (DESIGN.md section 3.3): the record carries what the board drew and clocked beside the time.  None when sysfs has no such node."""
+
+    def __init__(self):
+        import glob
+        self.nodes = None
+        for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            pw = [p for p in (os.path.join(hw, "power1_average"), os.path.join(hw, "power1_input")) if os.path.exists(p)]
+            fq = os.path.join(hw, "freq1_input")
+            if pw:
+                self.nodes = (pw[0], fq if os.path.exists(fq) else None)
+                break
+        self.samples = []
+        self._stop = None
+        self._thread = None
+
+    def _read(self):
+        try:
+            w = int(open(self.nodes[0]).read().strip()) / 1e6
+            f = int(open(self.nodes[1]).read().strip()) / 1e6 if self.nodes[1] else None
+            self.samples.append((w, f))
+        except (OSError, ValueError):
+            pass
+
+    def start(self):
+        if not self.nodes:
+            return
+        import threading
+        self._stop = threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                self._read()
+                self._stop.wait(0.5)
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if not self._thread:
+            return None
+        self._stop.set()
+        self._thread.join(timeout=2)
+        if not self.samples:
+            return None
+        ws = [w for w, _ in self.samples]
+        fs = [f for _, f in self.samples if f]
+        out = {"samples": len(ws), "power_w_mean": round(sum(ws) / len(ws), 1), "power_w_max": round(max(ws), 1), "source": self.nodes[0]}
+        if fs:
+            out["sclk_mhz_mean"] = round(sum(fs) / len(fs), 1)
+            out["sclk_mhz_min"] = round(min(fs), 1)
+        return out
+
+
 def secondary_rows():
     """The rows of the path that are not the headline (the training step, the other BASELINE.json shapes, the
     HBM-bound transforms), each measured by its own process AFTER the headline's timed region and reported inside the same
@@ -135,8 +190,8 @@ def secondary_rows():
             row = {k: j[k] for k in keep if k in j}
             row["workload"] = j["config"]["workload"]
             if j.get("roofline"):
-                row["roofline"] = {k: j["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_kernel_us")
-                                   if k in j["roofline"]}
+                row["roofline"] = {k: j["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_kernel_us",
+                                                                 "shader_clock_mhz", "frac_at_nominal_clock") if k in j["roofline"]}
             out[name] = row
         except Exception as e:
             out[name] = {"error": repr(e)[:300]}
@@ -389,11 +444,15 @@ def main():
     barrier()
     prof = True
     _C.check(lib.fd_prof_begin(ctx), ctx)
+    sampler = BoardSampler() if rank == 0 else None      # (a thread that reads two sysfs nodes twice a second: no device work)
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
     barrier()
     elapsed = time.perf_counter() - t0
+    board = sampler.stop() if sampler else None
     assert torch.isfinite(X).all(), "sampler produced non-finite values"
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -447,6 +506,11 @@ def main():
                 mhz = C.c_double(0)
                 if lib.fd_prof_shader_clock_mhz(ctx, C.byref(mhz)) == 0 and mhz.value > 0:
                     roof["shader_clock_mhz"] = round(mhz.value, 1)
+                    # the same cycles at the nominal 2.4 GHz: comparable across boxes and rounds (the delivered `frac` above is not --
+                    # the same library gave 0.308-0.322 on boxes that clocked 2266-2354 MHz under the power cap)
+                    roof["frac_at_nominal_clock"] = roof["frac"] * 2400.0 / mhz.value
+                if board:
+                    roof["board"] = board
         out["roofline"] = roof
         if ranks_info is not None:
             out["ranks"] = ranks_info

@@ -98,7 +98,7 @@ int fd_mega_launch(fd_ctx* ctx, const fd_mega_params& P, int ks1, int dt, int ks
         if (wanted) {
             void* fn = nullptr;
             std::string why;
-            if (fd_mega_rtc_get(ctx, key, &fn, &why)) {
+            if (fd_mega_rtc_get(ctx, key, &fn, &why, /*compile=*/describe == nullptr)) {      // (a description compiles nothing)
                 if (describe) {
                     snprintf(describe, 192, "k_mega<%d,%d,%d,%d,ShapeStatic<%d,%d,%d,%d,%d,%d,%d,%d,%d> (hiprtc)> S=%d NPG=%d rot=%d grid=%d lds=%zu%s", ks1, dt,
                              kso, mt, P.T, P.D, P.C, P.H, P.S, P.NPG, P.rot, P.L, P.F, P.S, P.NPG, P.rot, grid, lds, key.ffn32 ? " ffn32" : "");

@@ -22,5 +22,8 @@ struct fd_mega_rtc_key {
 int fd_mega_rtc_mode();
 // true + the loaded kernel (hipFunction_t) of this device, compiled or read from the disk cache on first use; false when there is no
 // hiprtc / the compilation failed (`why` says which, or where the code object came from)
-bool fd_mega_rtc_get(fd_ctx* ctx, const fd_mega_rtc_key& key, void** fn_out, std::string* why);
+// (compile = false: nothing is compiled -- true when the kernel is loaded already or can be produced at the first launch)
+bool fd_mega_rtc_get(fd_ctx* ctx, const fd_mega_rtc_key& key, void** fn_out, std::string* why, bool compile = true);
+// "-DFD_W1_SWAP34=..." as the image builder (fd_score_bf16.hip) was compiled: the run-time compilation must see the same layout macros
+const char* fd_bf16_image_layout_defines();
 int fd_mega_rtc_launch(fd_ctx* ctx, void* fn, const fd_mega_params& P, int grid, size_t lds, hipStream_t s);

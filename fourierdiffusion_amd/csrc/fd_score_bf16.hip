@@ -1764,3 +1764,9 @@ extern "C" int fd_score_plan(fd_score* m, int B, int mode, char* out /* >= 192 b
     }
     return FD_OK;
 }
+
+// The macros of THIS translation unit that fix the layout of the images the persistent kernel reads (fd_mega_params.h); the run-time
+// compilation (fd_mega_rtc.hip) passes them on, so that a variant build of the image builder never meets a default-macro kernel.
+#define FD_STR2(x) #x
+#define FD_STR(x) FD_STR2(x)
+const char* fd_bf16_image_layout_defines() { return "-DFD_W1_SWAP34=" FD_STR(FD_W1_SWAP34); }

@@ -110,9 +110,13 @@ class DiffusionSampler:
         # (the partition depends on the model and the device only, NOT on the arithmetic mode: a seed then gives the fp32 parity
         # path and the bf16 path the same launches, Philox keys and noise -- tests/test_gpu_bf16_distribution.py couples the two)
         try:
-            _desc, spw = model.plan(1 << 16, "bf16")
-        except Exception:       # no bf16 persistent kernel for this model (other backbones, widths): the reference's launches
+            _desc, spw = model.plan(1 << 16, "bf16")      # (a description: compiles nothing, fd_mega_rtc_get(compile = false))
+        except _C.FdError:      # no bf16 kernels for this model (FD_ERR_UNSUPPORTED: other backbones, widths): the reference's launches
             spw = 0
+        # (Known cost, ADVICE r5: a run that takes the step-by-step path with these merged launches -- fp32 parity mode, FDIFF_NO_MEGA --
+        # needs ~1.1 MB of workspace per series, 4-6 GB at the default model.  Capping the launches for that path was tried and
+        # reverted: the partition fixes the Philox key of every launch, and tests/test_gpu_bf16_distribution.py couples the fp32 and
+        # bf16 paths through identical launches.  merge_batches=False / FDIFF_SAMPLER_MERGE=0 keeps the reference's batches.)
         if spw <= 0:
             n = self.sample_batch_size
             return [n] * (total // n) + ([total % n] if total % n else [])

