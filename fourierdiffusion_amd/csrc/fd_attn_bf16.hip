@@ -27,6 +27,21 @@ namespace {
 
 constexpr float kNegBig = -1.0e30f;
 constexpr int NW = 8, NTH = NW * 64, NQ = 2;
+// Byte offset of the 8-byte K row of (key tile kt, token tok of the tile, lane group g) in the K image.  A score MFMA's A fragment
+// is one ds_read_b64 per lane, serviced in the lane groups {0-31}, {32-63} = the lane groups g in {0, 1} / {2, 3} of all 16 tokens:
+// in the natural order [token][g] (32 bytes per token) such a group reads the first / second 16 bytes of 16 rows, i.e. a 32-byte
+// stride, and tokens t and t + 8 share their banks -- a 2-way conflict on EVERY K read (63 % of the kernel's LDS-active cycles were
+// conflict cycles, profiles/r05_attn_long_pmc_summary.txt).  [tile][g >> 1][token][g & 1] makes each group 256 contiguous bytes.
+#ifndef FD_ATTN_KSWZ
+#define FD_ATTN_KSWZ 1
+#endif
+__device__ __forceinline__ size_t krow(int kt, int tok, int g) {
+#if FD_ATTN_KSWZ
+    return (size_t)kt * 512 + (size_t)((g >> 1) * 256 + tok * 16 + (g & 1) * 8);
+#else
+    return ((size_t)(kt * 16 + tok) * 4 + g) * 8;
+#endif
+}
 #ifndef FD_ATTN_LAG
 #define FD_ATTN_LAG 2
 #endif
@@ -128,16 +143,26 @@ template <int KS1, int ROWS = 0>
 __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const float* __restrict__ in, float* __restrict__ out, int T,
                                                            int H, int hd, int D, float qscale, int du_per_block, int exact_only,
                                                            fd_attn_w wimg, size_t pair_stride, int slices, int B, int out_bf16,
-                                                           const __bf16* __restrict__ xrows, int KTP) {
+                                                           const __bf16* __restrict__ xrows, int KTP, int nblk1, int B1, int slices2,
+                                                           int dpb2) {
     constexpr bool PROJ = KS1 > 0;
     constexpr int KSN = PROJ ? KS1 : 1;
     // Workgroup -> (series, head pair, query slice).  Hardware workgroup ids go round-robin over the 8 XCDs; all
     // NP * slices workgroups of a series are placed on ONE XCD (series s on XCD s % 8), so the series' x rows (and nothing
     // else) stream through that XCD's L2 once and are re-read from it by the other NP * slices - 1 workgroups.
+    // Two classes of workgroups (host: fd_attention_bf16): the first nblk1 blocks cover the series [0, B1) with `slices` query slices each,
+    // the rest cover [B1, B) with `slices2` = twice as many, half as long ones -- dispatched LAST, they fill every slot of the chip in the
+    // final round (768 equal workgroups on 512 slots ran a second round with half of the slots empty and the VALU half used).
+    int bidx = blockIdx.x, boff = 0, Bc = B1;
+    if (bidx >= nblk1) {
+        bidx -= nblk1; boff = B1; Bc = B - B1;
+        slices = slices2; du_per_block = dpb2;
+    }
     const int NPs = ((H + 1) >> 1) * slices;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int b = (slot / NPs) * 8 + xcd, wsl = slot % NPs;
-    if (b >= B) return;
+    const int xcd = bidx & 7, slot = bidx >> 3;
+    const int bl = (slot / NPs) * 8 + xcd, wsl = slot % NPs;
+    if (bl >= Bc) return;
+    const int b = boff + bl;
     const int pair = wsl / slices, slice = wsl % slices;
     const float* __restrict__ qkv = in;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -146,7 +171,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
     // KTP >= KT: key tiles in LDS.  A series whose last 128-key block is partial may be padded to whole blocks with all-zero key
     // tiles (host policy): the fast path then runs the block through the software pipeline instead of the rolled pair loop.
     const int KT = (T + 15) >> 4, NJ = (KTP + 1) >> 1, NTOK = KTP * 16;
-    char* const kbf = smem;                       // [NTOK][4 g][8 B]: lane group g = 2*hs + (d >> 2), element d & 3
+    char* const kbf = smem;                       // [key tile][g >> 1][16 tokens][g & 1][8 B] (krow): lane group g = 2*hs + (d >> 2), element d & 3
     char* const vbf = smem + (size_t)NTOK * 32;   // [NJ][4 g][16 dim slots][16 B]: (half, r) -> token (2jj+half)*16 + 4g + r
     char* const qbf = vbf + (size_t)NJ * 1024;    // [slice tile][64 lanes][8 B]: Q^T C tile as bf16 (scaled by log2e/sqrt(hd))
     // [2] max_j |k_j|^2 per head (bits).  With hd < 7 dim slot 7 of V^T is padding: its row feeds only output row 7, which
@@ -231,7 +256,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
                         if (isq) qa = MFMA(wqf[ks], xf, qa);
                     }
                     if (kt + NW * PB < kt_end) rload(kt + NW * PB, rr[p]);
-                    *reinterpret_cast<u32x2*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8) = u32x2{cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
+                    *reinterpret_cast<u32x2*>(kbf + krow(kt, tok, g)) = u32x2{cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
                     char* dst = vbf + ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16;
                     if (!(kmax_in_v && kt == 0 && lane == 7))          // (that row's first 8 bytes hold kmax)
                         *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = u32x2{cvt_pk_bf16(c[0], c[1]), cvt_pk_bf16(c[2], c[3])};
@@ -262,7 +287,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
                 c = MFMA(xf, wvf[ks], c);
                 if (isq) qa = MFMA(wqf[ks], xf, qa);
             }
-            *reinterpret_cast<u32x2*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8) = u32x2{cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
+            *reinterpret_cast<u32x2*>(kbf + krow(kt, tok, g)) = u32x2{cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
             char* dst = vbf + ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16;
             if (!(kmax_in_v && kt == 0 && lane == 7))          // (that row's first 8 bytes hold kmax)
                 *reinterpret_cast<u32x2*>(dst + 8 * (kt & 1)) = u32x2{cvt_pk_bf16(c[0], c[1]), cvt_pk_bf16(c[2], c[3])};
@@ -284,7 +309,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
         }
         // padding tiles: zero K rows and V^T halves (scores 0 -> exp2 = 1 against zero V^T / ones-row entries: no contribution)
         for (int kt = KT + wave; kt < KTP; kt += NW) {
-            *reinterpret_cast<u32x2*>(kbf + ((size_t)(kt * 16 + tok) * 4 + g) * 8) = u32x2{0u, 0u};
+            *reinterpret_cast<u32x2*>(kbf + krow(kt, tok, g)) = u32x2{0u, 0u};
             *reinterpret_cast<u32x2*>(vbf + ((size_t)((kt >> 1) * 4 + g) * 16 + tok) * 16 + 8 * (kt & 1)) = u32x2{0u, 0u};
         }
     } else {
@@ -298,7 +323,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
             const int d = 4 * (gq & 1) + r;
             kv[r] = (t < T && head < H) ? (d < hd ? base[(size_t)t * 3 * D + D + head * hd + d] : (d == hd ? 1.0f : 0.f)) : 0.f;
         }
-        *reinterpret_cast<u32x2*>(kbf + (size_t)i * 8) = u32x2{cvt_pk_bf16(kv[0], kv[1]), cvt_pk_bf16(kv[2], kv[3])};
+        *reinterpret_cast<u32x2*>(kbf + krow(t >> 4, t & 15, gq)) = u32x2{cvt_pk_bf16(kv[0], kv[1]), cvt_pk_bf16(kv[2], kv[3])};
         // |k_t|^2 of head gq>>1 (incl. the constant slot: the bound only grows): the two threads (gq even / odd) holding a
         // token's halves are lane neighbours
         float n2 = kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2] + kv[3] * kv[3];
@@ -366,7 +391,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
     auto kfrag_cold = [&](int kt) {
         int tl = tok, gl = g;
         asm volatile("" : "+v"(tl), "+v"(gl));
-        return *reinterpret_cast<const s16x4*>(kbf + ((size_t)(kt * 16 + tl) * 4 + gl) * 8);
+        return *reinterpret_cast<const s16x4*>(kbf + krow(kt, tl, gl));
     };
     auto vfrag_cold = [&](int jb) {
         int tl = tok, gl = g;
@@ -382,7 +407,7 @@ __global__ __launch_bounds__(NTH, FD_ATTN_WAVES) void k_attention_bf16(const flo
         // loop they were kept alive -- i.e. spilled -- across it, one VGPR per address stream of the key pipeline
         int tokd = tok, gd = g;
         asm volatile("" : "+v"(tokd), "+v"(gd));
-        auto kfrag = [&](int kt) { return *reinterpret_cast<const s16x4*>(kbf + ((size_t)(kt * 16 + tokd) * 4 + gd) * 8); };
+        auto kfrag = [&](int kt) { return *reinterpret_cast<const s16x4*>(kbf + krow(kt, tokd, gd)); };
         auto vfrag = [&](int jb) { return *reinterpret_cast<const bf16x8*>(vbf + ((size_t)(jb * 4 + gd) * 16 + tokd) * 16); };
         int qt[NQ];
         bool qv[NQ];
@@ -830,13 +855,34 @@ int fd_attention_bf16(fd_ctx* ctx, const float* in, float* out, int B, int T, in
     if (!slices) return FD_ERR_UNSUPPORTED;
     const int du_per_block = (DUS + slices - 1) / slices;
     const size_t lds = lds_kv + (size_t)du_per_block * NQ * 512;
+    // Tail split.  B NP slices equal workgroups on `slots` resident ones run ceil(n / slots) rounds, and a last round that fills half of
+    // the slots or less leaves the chip half empty for its whole length (T = 1024, B = 64: 768 workgroups, 512 slots).  The series
+    // whose workgroups would form that round get twice as many, half as long slices instead, launched behind the others: the last
+    // round then fills every slot with half-length workgroups.  MEASURED SLOWER and therefore OFF unless FDIFF_ATTN_TAIL_SPLIT=1
+    // (same box, alternating: 1.347 -> 1.494 ms per diffusion step at T = 1024, B = 64; +-0 at the droughts shape; profiles/
+    // r06_attn_long_tail_split_ab.txt): a workgroup that has its CU to itself runs its key loop almost twice as fast as two that
+    // share one -- the half-empty round is NOT half-wasted -- and a third more workgroups restage K / V.
+    int B1 = B, slices2 = slices, dpb2 = du_per_block;
+    {
+        static const bool tail_on = getenv("FDIFF_ATTN_TAIL_SPLIT") && atoi(getenv("FDIFF_ATTN_TAIL_SPLIT")) != 0;
+        const long long slots = (long long)ctx->num_cu * (lds <= 80 * 1024 ? 2 : 1);
+        const long long n = (long long)B * NP * slices, per_series = (long long)NP * slices;
+        const long long full = (n / slots) * slots, rest = n - full;
+        if (tail_on && full > 0 && rest > 0 && 2 * rest <= slots + per_series && DUS / (2 * slices) >= NW && fits(2 * slices)) {
+            const int Bsplit = (int)((rest + per_series / 2) / per_series);
+            if (Bsplit > 0 && Bsplit < B) {
+                B1 = B - Bsplit; slices2 = 2 * slices; dpb2 = (DUS + slices2 - 1) / slices2;
+            }
+        }
+    }
+    const int nblk1 = ((B1 + 7) / 8) * 8 * NP * slices, nblk2 = B1 < B ? ((B - B1 + 7) / 8) * 8 * NP * slices2 : 0;
     const float qscale = 1.4426950408889634f / sqrtf((float)hd);
     const int exact = getenv("FDIFF_ATTN_EXACT") ? 1 : 0;
     const fd_attn_w w{wk, wv, wq};
     const size_t pair_stride = (size_t)ks1 * 1024;
-    const dim3 grid((unsigned)(((B + 7) / 8) * 8 * NP * slices)), block(NTH);
+    const dim3 grid((unsigned)(nblk1 + nblk2)), block(NTH);
     const __bf16* xr = reinterpret_cast<const __bf16*>(in_rows);
-#define FD_ATT_GO(K, R) hipLaunchKernelGGL((k_attention_bf16<K, R>), grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B, out_bf16, xr, KTP)
+#define FD_ATT_GO(K, R) hipLaunchKernelGGL((k_attention_bf16<K, R>), grid, block, lds, s, in, out, T, H, hd, D, qscale, du_per_block, exact, w, pair_stride, slices, B, out_bf16, xr, KTP, nblk1, B1, slices2, dpb2)
     if (!proj) FD_ATT_GO(0, 0);
     else if (ks1 == 3) { if (rows) FD_ATT_GO(3, 1); else FD_ATT_GO(3, 0); }
     else { if (rows) FD_ATT_GO(2, 1); else FD_ATT_GO(2, 0); }
