@@ -530,6 +530,41 @@ void time_embed(const float* t, const float* W, const float* Wd, const float* bd
     hipLaunchKernelGGL(k_time_embed, dim3(B), dim3(128), D * sizeof(float), s, t, W, Wd, bd, (float*)nullptr, temb,
                        D);
 }
+// The weights-in-registers form for a channel count that is not a multiple of four (the reference's datasets: 1, 5, 13 channels;
+// BASELINE nasdaq: 6): scalar loads of the 4 x C weight slice and of the row's x, the same fma order over c -- bit-identical to
+// k_embed, which took 25 us at 16 128 tokens, C = 6 (one LDS round trip per channel) against ~10 us here.
+template <int C>
+__global__ __launch_bounds__(256) void k_embed_rows_c(const float* __restrict__ x, const float* __restrict__ We,
+                                                       const float* __restrict__ be, const float* __restrict__ pe,
+                                                       const float* __restrict__ temb, float* __restrict__ h, int M, int T, int D) {
+    const int D4 = D >> 2, RP = 256 / D4;
+    const int fg = threadIdx.x % D4, rl = threadIdx.x / D4;
+    if (rl >= RP) return;
+    const int d = 4 * fg;
+    float w[4][C];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < C; ++c) w[j][c] = We[(size_t)(d + j) * C + c];
+    const float4 bv = *reinterpret_cast<const float4*>(be + d);
+    for (int m = blockIdx.x * RP + rl; m < M; m += gridDim.x * RP) {
+        const int b = m / T, tt = m - b * T;
+        float xv[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) xv[c] = x[(size_t)m * C + c];
+        const float4 pv = pe ? *reinterpret_cast<const float4*>(pe + (size_t)tt * D + d) : float4{0.f, 0.f, 0.f, 0.f};
+        const float4 tv = *reinterpret_cast<const float4*>(temb + (size_t)b * D + d);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv[c], w[j][c], acc[j]);
+        float4 o;
+        o.x = ((acc[0] + bv.x) + pv.x) + tv.x; o.y = ((acc[1] + bv.y) + pv.y) + tv.y;
+        o.z = ((acc[2] + bv.z) + pv.z) + tv.z; o.w = ((acc[3] + bv.w) + pv.w) + tv.w;
+        *reinterpret_cast<float4*>(h + (size_t)m * D + d) = o;
+    }
+}
 void embed(const float* x, const float* We, const float* be, const float* pe, const float* temb, float* h, int M,
            int T, int C, int D, hipStream_t s) {
     const size_t n = (size_t)M * D;
@@ -555,6 +590,18 @@ void embed(const float* x, const float* We, const float* be, const float* pe, co
             FD_EMB(1) FD_EMB(2) FD_EMB(3) FD_EMB(4) FD_EMB(5) FD_EMB(6) FD_EMB(7) FD_EMB(8) FD_EMB(9) FD_EMB(10)
         }
 #undef FD_EMB
+    }
+    if ((C & 3) != 0 && C <= 15 && (D & 3) == 0 && D <= 256 && (al & 15) == 0 && !getenv("FDIFF_EMBED_LDS")) {
+        const int RP = 256 / (D >> 2);
+        int dev = 0, ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        const long long want = ((long long)M + RP - 1) / RP, cap = (long long)(ncu > 0 ? ncu : 256) * 4;
+        const unsigned g = (unsigned)(want < cap ? want : cap);
+#define FD_EMBC(C_) case C_: hipLaunchKernelGGL(k_embed_rows_c<C_>, dim3(g), dim3(256), 0, s, x, We, be, pe, temb, h, M, T, D); return;
+        switch (C) {
+            FD_EMBC(1) FD_EMBC(2) FD_EMBC(3) FD_EMBC(5) FD_EMBC(6) FD_EMBC(7) FD_EMBC(9) FD_EMBC(10) FD_EMBC(11) FD_EMBC(13) FD_EMBC(14) FD_EMBC(15)
+        }
+#undef FD_EMBC
     }
     const unsigned grid = use_lds ? (unsigned)((M + kEmbRows - 1) / kEmbRows) : (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_embed, dim3(grid), dim3(256), use_lds ? lds : 0, s, x, We, be, pe, temb, h, M, T, C, D, use_lds);
