@@ -47,9 +47,11 @@ const char* fd_last_error(fd_ctx* ctx);   /* host string, valid until the next c
 /* number of bytes currently held by the ctx workspace (activations, scratch) */
 size_t fd_ctx_workspace_bytes(fd_ctx* ctx);
 /* Asynchronous device-side errors recorded since the last report: FD_OK, or FD_ERR_STATE when a kernel of an earlier training
- * call gave up a bounded inter-workgroup wait (the F-split hand-over of the training FFN kernels: fd_last_error names the token
- * block; that step's gradients are invalid).  Never synchronises -- call it behind a stream synchronisation to cover everything
- * enqueued so far.  Every training / optimizer entry point performs the same check on entry.  (The reference has no
+ * call gave up a bounded inter-workgroup wait (the F-split hand-over of the training FFN kernels, or a cluster exchange of the
+ * persistent training forward: fd_last_error names the token block / layer and series; that step's gradients are invalid).  Never
+ * synchronises -- call it behind a stream synchronisation to cover everything enqueued so far.  Every training / optimizer entry
+ * point performs the same check on entry, i.e. DETECTION LAGS BY ONE CALL unless the stream is synchronised; the optimizer
+ * kernel itself tests a device-resident copy of the error word in stream order and skips the update of such a step.  (The reference has no
  * counterpart: torch autograd, src/fdiff/models/score_models.py:96-108, has no inter-workgroup protocol to fail.) */
 int fd_ctx_check(fd_ctx* ctx);
 
@@ -299,7 +301,9 @@ int fd_sampler_run_pc(fd_score* m, const fd_sde_params* sde, const float* G, con
  * (score_models.py:122-130, cmd/conf/trainer/default.yaml:4), fused over the flat buffer.
  * fd_grad_sqnorm: norm2_out[0] = sum(grads^2) (device float[1], fp32 accumulated in fp64 blocks).
  * fd_adamw_step : clip_coef is read from device: coef = min(1, max_norm/(sqrt(*sqnorm)+1e-6))
- *                 when sqnorm != NULL, else 1.  frozen [frozen_begin, frozen_end) is skipped. */
+ *                 when sqnorm != NULL, else 1.  frozen [frozen_begin, frozen_end) is skipped.
+ *                 The whole update is skipped ON THE DEVICE (parameters and moments unchanged) when a bounded wait of the
+ *                 training step whose gradients these are timed out (see fd_ctx_check): the host only reports it, one call later. */
 int fd_grad_sqnorm(fd_ctx* ctx, const float* grads, int64_t n, float* sqnorm_out, void* stream);
 int fd_adamw_step(fd_ctx* ctx, float* params, const float* grads, float* exp_avg,
                   float* exp_avg_sq, int64_t n, int step, float lr, float beta1, float beta2,
