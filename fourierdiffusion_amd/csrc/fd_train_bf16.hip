@@ -2014,7 +2014,7 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out, int mask_set 
 }
 
 // Events that order the step's streams against each other.  (A device-scope release per record -- hipEventReleaseToDevice -- instead of
-// the default system-scope fence was measured at +-0: 2.34 / 1.43 ms per step either way, scripts/gpu_r04_events.sh.)
+// the default system-scope fence was measured at +-0: 2.34 / 1.43 ms per step either way, scripts/archive/gpu_r04_events.sh.)
 static const unsigned kTrEventFlags = hipEventDisableTiming;
 
 // Side streams carry work that is OFF the step's critical path (dropout decisions one layer ahead, weight gradients behind the
@@ -2377,7 +2377,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             // Workgroups per CU of the decision kernel (persistent workgroups, VALU-bound, 66 VGPRs).  16 per CU hold most registers of
             // the chip while a decision kernel runs, and the forward chain's kernels beside them take 36-50 us instead of 29-41
             // (rocprofv3 time line) -- but fewer workgroups make the decisions later and the step slower: 16 / 8 / 4 / 2 / 1 per CU
-            // = 2.36 / 2.36 / 2.39 / 2.40 / 2.40 ms per step at T = 252 (scripts/gpu_r04_maskwgs.sh).
+            // = 2.36 / 2.36 / 2.39 / 2.40 / 2.40 ms per step at T = 252 (scripts/archive/gpu_r04_maskwgs.sh).
             static const int mask_wgs = getenv("FDIFF_TR_MASK_WGS") ? std::max(1, atoi(getenv("FDIFF_TR_MASK_WGS"))) : 16;
             const unsigned grid = (unsigned)std::min<long long>((tot / 2 + 255) / 256, (long long)ctx->num_cu * mask_wgs);
             hipLaunchKernelGGL(k_tr_masks, dim3(grid), dim3(256), 0, mstream, d, ma);

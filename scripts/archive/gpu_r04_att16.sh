@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: (1) attention-backward forms test, (2) attention output handed to k_ffn_ln as bf16 rows (default) against fp32 rows
-# (FDIFF_ATT_F32ROWS=1): parity tests of the per-layer path, configs[4] A/B.  usage: bash scripts/gpu_r04_att16.sh TAG
+# (FDIFF_ATT_F32ROWS=1): parity tests of the per-layer path, configs[4] A/B.  usage: bash scripts/archive/gpu_r04_att16.sh TAG
 TAG=${1:-att16}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # end-of-round evidence: full GPU suite, the round script (bench line + kernel stats + training), and rocprofv3 kernel stats of the
-# 1000-step configs[4] run (the profile the bench row's per-kernel numbers are to be held against).  usage: bash scripts/gpu_r04_final.sh TAG
+# 1000-step configs[4] run (the profile the bench row's per-kernel numbers are to be held against).  usage: bash scripts/archive/gpu_r04_final.sh TAG
 TAG=${1:-r04d}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: attention backward forms (FDIFF_TR_ATTN_OH = 0 pair, 1 one head + fp32 parts, 2 one head + bf16 parts), the fixed
-# k_tr_masks_T, and one weight-gradient workgroup per CU (FDIFF_TR_WG_LDS_KB=84).  usage: bash scripts/gpu_r04_oh2.sh TAG
+# k_tr_masks_T, and one weight-gradient workgroup per CU (FDIFF_TR_WG_LDS_KB=84).  usage: bash scripts/archive/gpu_r04_oh2.sh TAG
 TAG=${1:-oh2}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: training step, this session's library against the round's starting one (fourierdiffusion_amd/libfdiff_hip_old.so = commit
-# 687aa5a) on ONE box, alternating; what the dropout decisions cost (FDIFF_DROPOUT=0); solo kernel times.  usage: bash scripts/gpu_r04_train_ab.sh TAG
+# 687aa5a) on ONE box, alternating; what the dropout decisions cost (FDIFF_DROPOUT=0); solo kernel times.  usage: bash scripts/archive/gpu_r04_train_ab.sh TAG
 TAG=${1:-trab}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT

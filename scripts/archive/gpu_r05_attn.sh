@@ -1,6 +1,6 @@
 #!/bin/bash
 # configs[4]'s attention kernel: query-slice sensitivity (how much of the launch is replicated K/V staging and how much round
-# quantisation) and the in-kernel phase clocks (-DFD_ATTN_ABL=3 variant).  usage: bash scripts/gpu_r05_attn.sh [TAG]
+# quantisation) and the in-kernel phase clocks (-DFD_ATTN_ABL=3 variant).  usage: bash scripts/archive/gpu_r05_attn.sh [TAG]
 TAG=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT

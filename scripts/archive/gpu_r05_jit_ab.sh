@@ -1,6 +1,6 @@
 #!/bin/bash
 # hipcc (library, ROCm 7.2 clang) against hiprtc (torch's bundled ROCm 7.0 image / the system's 7.2 image) on the SAME kernel text:
-# the headline ecg shape (FDIFF_MEGA_JIT=force) and the nasdaq shape, alternating on one box.  usage: bash scripts/gpu_r05_jit_ab.sh [TAG]
+# the headline ecg shape (FDIFF_MEGA_JIT=force) and the nasdaq shape, alternating on one box.  usage: bash scripts/archive/gpu_r05_jit_ab.sh [TAG]
 TAG=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The reference's dataset shapes on the persistent kernel: run-time-shape instantiation of the library (FDIFF_MEGA_JIT=0) against the
-# hiprtc ShapeStatic instantiation (auto policy: 200-step sampler runs), alternating on ONE box.  usage: bash scripts/gpu_r05_shapes.sh [TAG]
+# hiprtc ShapeStatic instantiation (auto policy: 200-step sampler runs), alternating on ONE box.  usage: bash scripts/archive/gpu_r05_shapes.sh [TAG]
 TAG=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT

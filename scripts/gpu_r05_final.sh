@@ -52,4 +52,4 @@ for shp in nasdaq ecg; do
   echo "== solo (FDIFF_TR_SERIAL=1) $shp"; python scripts/kstats.py $OUT/serial_$shp/s_kernel_stats.csv 8 | cut -c1-70,100-140
   rm -f $OUT/serial_$shp/s_kernel_trace.csv
 done
-bash scripts/gpu_r05_shapes.sh $TAG 2>&1 | tail -3
+bash scripts/archive/gpu_r05_shapes.sh $TAG 2>&1 | tail -3
