@@ -46,6 +46,9 @@ __device__ __forceinline__ void st_coh8(void* p, u32x2 v) {     // 8 bytes, agen
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifndef FD_TRP_ABL
+#define FD_TRP_ABL 0        // timing ablations of the chunk loop (wrong results): 1 no weight DMA inside the loop, 2 no per-step barrier, 4 no relu /
+#endif                      // dropout / activity block, 8 no fragment prefetch reads (the same registers every step)
 #ifndef FD_TRP_UNROLL1
 #define FD_TRP_UNROLL1 1    // unroll of the units' key loops (pass 1: row maxima; pass 2: exp + P V)
 #endif
@@ -557,6 +560,7 @@ __global__ __launch_bounds__(512, 2) void k_tr_fwd_layers(const TrDims d, const 
         }
         // ---- (5) FFN over this wave's part of the hidden dimension (k_tr_ffn_fwd's chunk loop; no ballots)
         unsigned bits_cur = 0u;
+        u32x2 kq0 = {0u, 0u}, kq1 = {0u, 0u};
         auto frags = [&](int c, bf16x8 (&w1)[2 * KS1], bf16x8 (&w2)[DT]) {
             const int cc = c < NSTEP ? c : NSTEP - 1;
             const char* wb = ring + (cc % NBUF) * SB + (sub * 2 + fhw) * NB * 1024 + lane * 16;
@@ -572,8 +576,8 @@ __global__ __launch_bounds__(512, 2) void k_tr_fwd_layers(const TrDims d, const 
         // caught by the run-to-run comparison of tests/test_gpu_benched_shapes.py at the full grid).
         constexpr bool PREF = PD >= 3;
         auto step = [&](int c, bf16x8 (&w1)[2 * KS1], bf16x8 (&w2)[DT], bf16x8 (&n1)[2 * KS1], bf16x8 (&n2)[DT]) {
-            if (c + PD < NSTEP) issue(c + PD);
-            if constexpr (PREF) frags(c + 1, n1, n2);
+            if (!(FD_TRP_ABL & 1) && c + PD < NSTEP) issue(c + PD);
+            if constexpr (PREF) { if (!(FD_TRP_ABL & 8)) frags(c + 1, n1, n2); }
             else frags(c, w1, w2);
             f32x4 h0 = f4zero(), h1 = f4zero();
 #pragma unroll
@@ -585,15 +589,31 @@ __global__ __launch_bounds__(512, 2) void k_tr_fwd_layers(const TrDims d, const 
             cs -= (cs >= NSTEP) ? NSTEP : 0;
             int cn = cs + 1;                                           // next step's chunk (clamped read after the last step)
             cn -= (cn >= NSTEP) ? NSTEP : 0;
-            const int ce = cs * CPS + sub, cne = cn * CPS + sub;
-            const unsigned bits = bits_cur;
-            bits_cur = actB[lane * NS + cne];
+            const int ce = cs * CPS + sub;
+            // The keep masks of this step's eight hidden values (lane masks of packed bf16 pairs, by nibble of the keep byte) were read
+            // from the table one step AHEAD, like the byte itself: between the H MFMAs and the W2 MFMAs that need the masked values
+            // sits no LDS round trip any more (timing ablations of this loop, profiles/r06_train_fwd_layers_loop_ablations.txt: without
+            // the relu / dropout / activity block 39.7 -> 25.1 K cycles per layer, without the barrier 27.6, without the weight DMA
+            // 34.1, without the fragment reads 33.0, without all four 7.8)
+            // (two steps deep: the byte of step c + 2 is requested while the table entries of step c + 1 are looked up with the byte
+            // that arrived a step ago -- one LDS hop per step on either chain, none in front of this step's end-of-step wait)
+            const u32x2 k0 = kq0, k1 = kq1;
+            kq0 = *reinterpret_cast<const u32x2*>(klut + 2 * (bits_cur & 15u));
+            kq1 = *reinterpret_cast<const u32x2*>(klut + 2 * (bits_cur >> 4));
+            {
+                int c2 = cn + 1;
+                c2 -= (c2 >= NSTEP) ? NSTEP : 0;
+                bits_cur = actB[lane * NS + c2 * CPS + sub];
+            }
             u32x4 pk;
+#if FD_TRP_ABL & 4
+            pk = __builtin_bit_cast(u32x4, pack8(h0, h1));
+            (void)k0; (void)k1; (void)ce;
+#else
             {
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
                 pk = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, pack8(h0, h1)), z8));
-                const u32x2 k0 = *reinterpret_cast<const u32x2*>(klut + 2 * (bits & 15u)), k1 = *reinterpret_cast<const u32x2*>(klut + 2 * (bits >> 4));
                 pk = u32x4{pk[0] & k0[0], pk[1] & k0[1], pk[2] & k1[0], pk[3] & k1[1]};
             }
             {
@@ -603,18 +623,26 @@ __global__ __launch_bounds__(512, 2) void k_tr_fwd_layers(const TrDims d, const 
                 const unsigned tt = mm[0] | (mm[1] << 2) | (mm[2] << 4) | (mm[3] << 6);
                 actB[lane * NS + ce] = (unsigned char)((tt & 0x55u) | ((tt >> 15) & 0xAAu));
             }
+#endif
             const bf16x8 hb = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(w2[dt], hb, acc[dt]);
-            if (c + PD < NSTEP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            if (!(FD_TRP_ABL & 1) && c + PD < NSTEP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the prefetch reads and this step's LDS writes are done
-            __builtin_amdgcn_s_barrier();
+            if (!(FD_TRP_ABL & 2)) __builtin_amdgcn_s_barrier();
         };
         {
             bf16x8 wa1[2 * KS1], wa2[DT], wb1[2 * KS1], wb2[DT];
             if constexpr (PREF) frags(0, wa1, wa2);
-            bits_cur = actB[lane * NS + rot * CPS + sub];
+            bits_cur = actB[lane * NS + rot * CPS + sub];                 // step 0's byte -> its table entries; then step 1's byte
+            kq0 = *reinterpret_cast<const u32x2*>(klut + 2 * (bits_cur & 15u));
+            kq1 = *reinterpret_cast<const u32x2*>(klut + 2 * (bits_cur >> 4));
+            {
+                int c1 = rot + 1;
+                c1 -= (c1 >= NSTEP) ? NSTEP : 0;
+                bits_cur = actB[lane * NS + c1 * CPS + sub];
+            }
             for (int c = 0; c < NSTEP; c += 2) {         // (NSTEP is even: F % 1024 == 0)
                 step(c, wa1, wa2, wb1, wb2);
                 step(c + 1, wb1, wb2, wa1, wa2);
