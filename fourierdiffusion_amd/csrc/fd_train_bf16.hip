@@ -781,6 +781,14 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     char* const scratch2 = smem + NBUF * WB + SCR + TW * 64 * NS + 4 * 5 * 16 * DT * sizeof(float) + wave * KS1 * 1024;
     // (the second half of the scratch2 area belongs to the non-owner waves, which never use it: 4 KS1 KiB >= 4 x 512 DT bytes)
     char* const tscr = smem + NBUF * WB + SCR + TW * 64 * NS + 4 * 5 * 16 * DT * sizeof(float) + 4 * KS1 * 1024 + (wave & 3) * (32 * DT * 16);
+    // lane masks of four packed bf16 values by nibble of activity bits (as in the forward kernels): the recomputed d hidden values are
+    // cleared AFTER packing with table entries looked up a step ahead -- 4 ANDs between the H and the W1^T MFMAs instead of 8 x (bit
+    // test, compare, select)
+    unsigned* const klut = reinterpret_cast<unsigned*>(smem + NBUF * WB + SCR + TW * 64 * NS + 4 * 5 * 16 * DT * sizeof(float) + TW * KS1 * 1024);
+    if (threadIdx.x < 32) {
+        const unsigned n = threadIdx.x >> 1, hi = threadIdx.x & 1;
+        klut[threadIdx.x] = ((n >> (2 * hi)) & 1u ? 0x0000ffffu : 0u) | ((n >> (2 * hi + 1)) & 1u ? 0xffff0000u : 0u);
+    }
     // F-split (struct FSplit): token block, chunk range and role of this workgroup
     const int nsp = d.fsplit, blk = nsp == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, fq = nsp == 2 ? (int)(blockIdx.x & 1) : 0;
     const int NSH = NS / nsp, cbase = fq * NSH;
@@ -890,6 +898,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     // fragments and the activity byte of a chunk are read one step ahead (two register sets, two steps per trip); the keep
     // scale of the hidden units is applied once to the accumulators behind the loop.
     unsigned act_cur = 0u;
+    u32x2 kq0 = {0u, 0u}, kq1 = {0u, 0u};
     auto frags = [&](int c, bf16x8 (&w1)[2 * KS1], bf16x8 (&w2)[DT]) {
         const int cc = c < NSH ? c : NSH - 1;
         const char* wb = ring + (cc % NBUF) * WB + fhw * NB * 1024 + lane * 16;
@@ -909,17 +918,16 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
             h0 = MFMA(w1[ks], dfr[ks], h0);
             h1 = MFMA(w1[KS1 + ks], dfr[ks], h1);
         }
-        int cn = c + 1 + rot;
+        int cn = c + 2 + rot;                         // (two steps deep: this step's table entries were looked up a step ago with the
+        cn -= (cn >= NSH) ? NSH : 0;                  //  byte that had arrived by then; the byte of step c + 2 is requested now)
+        cn -= (cn >= NSH) ? NSH : 0;                  // (beyond the last step: clamped reads, unused)
         cn -= (cn >= NSH) ? NSH : 0;
-        cn -= (cn >= NSH) ? NSH : 0;                  // (c + 1 == NSH: the clamped read of the step after the last)
-        const unsigned act = act_cur;
+        const u32x2 k0 = kq0, k1 = kq1;
+        kq0 = *reinterpret_cast<const u32x2*>(klut + 2 * (act_cur & 15u));
+        kq1 = *reinterpret_cast<const u32x2*>(klut + 2 * (act_cur >> 4));
         act_cur = actB[lane * NS + cbase + cn];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            h0[r] = (act & (1u << r)) ? h0[r] : 0.f;
-            h1[r] = (act & (16u << r)) ? h1[r] : 0.f;
-        }
-        const bf16x8 hb = pack8(h0, h1);
+        const u32x4 pkh = __builtin_bit_cast(u32x4, pack8(h0, h1));
+        const bf16x8 hb = __builtin_bit_cast(bf16x8, u32x4{pkh[0] & k0[0], pkh[1] & k0[1], pkh[2] & k1[0], pkh[3] & k1[1]});
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[dt] = MFMA(w2[dt], hb, acc[dt]);
         if (c + 3 < NSH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
@@ -933,6 +941,13 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
         bf16x8 wa1[2 * KS1], wa2[DT], wb1[2 * KS1], wb2[DT];
         frags(0, wa1, wa2);
         act_cur = actB[lane * NS + cbase + rot];
+        kq0 = *reinterpret_cast<const u32x2*>(klut + 2 * (act_cur & 15u));
+        kq1 = *reinterpret_cast<const u32x2*>(klut + 2 * (act_cur >> 4));
+        {
+            int c1 = 1 + rot;
+            c1 -= (c1 >= NSH) ? NSH : 0;
+            act_cur = actB[lane * NS + cbase + c1];
+        }
         for (int c = 0; c < NSH; c += 2) {       // (NS = F / 64 is a multiple of 4: F % 1024 == 0)
             step(c, wa1, wa2, wb1, wb2);
             step(c + 1, wb1, wb2, wa1, wa2);
@@ -2543,7 +2558,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     const size_t scr = std::max((size_t)TW * KS1 * 1024, (size_t)4 * DT * 1024);
     const size_t NSh = (size_t)m->d.dim_ff / 64;
     const size_t lds_bwd = (size_t)4 * 2 * (2 * KS1 + DT) * 1024 + scr + (size_t)TW * 64 * NSh + (size_t)4 * 5 * 16 * DT * sizeof(float) +
-                           (size_t)TW * KS1 * 1024;
+                           (size_t)TW * KS1 * 1024 + 128;      // (+ the lane-mask table)
     const int attn_nw = tr_attn_waves(d.KT);
     const bool attn_oh = tr_attn_oh_mode(d.KT) != 0;
     const int attn_parts = attn_oh ? 2 * d.NP : d.NP;             // partial tensors of d x written by k_tr_attn_bwd
