@@ -48,6 +48,7 @@ _PROTOS = {
     "fd_last_error": (C.c_char_p, [_vp]),
     "fd_ctx_workspace_bytes": (C.c_size_t, [_vp]),
     "fd_ctx_check": (C.c_int, [_vp]),
+    "fd_ctx_rearm": (C.c_int, [_vp]),
     "fd_prof_shader_clock_mhz": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "fd_mega_jit_compile": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "fd_prof_begin": (C.c_int, [_vp]),

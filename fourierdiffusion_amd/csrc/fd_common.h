@@ -67,6 +67,7 @@ struct fd_ctx {
     unsigned long long* trp_flags = nullptr;
     size_t trp_flag_count = 0;
     unsigned long long trp_epoch = 0;
+    bool trp_disabled = false;            // a cluster wait of the persistent forward timed out once on this context: per-layer kernels from then on
     // FFT twiddle tables (T, device pointer), built on first use of a length
     std::vector<std::pair<int, void*>> fft_tw;
     // measurement hooks (fd_prof_begin / fd_prof_end)

@@ -50,12 +50,14 @@ int fd_train_async_check(fd_ctx* ctx) {
     if (!e) return FD_OK;
     __atomic_store_n(ctx->tr_err_host, 0u, __ATOMIC_RELAXED);
     if (ctx->tr_err_gpu) (void)hipMemsetAsync(ctx->tr_err_gpu, 0, sizeof(unsigned), nullptr);      // (reported: the optimizer may update again)
+    if (e & 0x40000000u) ctx->trp_disabled = true;      // (whatever kept a cluster from becoming resident may still be there)
     if (e & 0x40000000u)
         return fd_fail(ctx, FD_ERR_STATE,
                        "an earlier training step's persistent forward (k_tr_fwd_layers) gave up waiting in layer %u, series %u, for %s %u: a "
                        "workgroup of the series' cluster never published its rows (not scheduled -- CU-masked queue / partitioned device / a "
-                       "co-tenant kernel holding the CUs -- or faulted).  That step's gradients are invalid.  FDIFF_TR_PERSIST=0 selects the "
-                       "per-layer kernels, FDIFF_TR_TIMEOUT_MS (default 2000) sets the bound.",
+                       "co-tenant kernel holding the CUs -- or faulted).  That step's gradients are invalid (the optimizer skipped it).  This context "
+                       "uses the per-layer kernels from now on (FDIFF_TR_PERSIST=0 selects them from the start); FDIFF_TR_TIMEOUT_MS (default "
+                       "2000) sets the bound.",
                        (e >> 20) & 0x3ffu, (e >> 4) & 0xffffu, (e & 0x80000u) ? "the dropout decisions, lane" : "token tile", e & 15u);
     const unsigned id = e & 0x3fffffffu;
     return fd_fail(ctx, FD_ERR_STATE,
@@ -74,6 +76,12 @@ extern "C" int fd_prof_shader_clock_mhz(fd_ctx* ctx, double* mhz) {
 extern "C" int fd_ctx_check(fd_ctx* ctx) {
     if (!ctx) return FD_ERR_ARG;
     return fd_train_async_check(ctx);
+}
+
+extern "C" int fd_ctx_rearm(fd_ctx* ctx) {
+    if (!ctx) return FD_ERR_ARG;
+    ctx->trp_disabled = false;
+    return FD_OK;
 }
 
 extern "C" const char* fd_last_error(fd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }

@@ -91,6 +91,7 @@ int fd_score_forward_any(fd_score* m, const float* x, const float* t, float* out
 bool fd_train_bf16_supported(const fd_score* m);
 bool fd_score_train_dsm_bf16_supported(const fd_score* m, int B);
 int fd_train_bf16_token_splits(const fd_score* m, int B, int* nblk);
+void fd_train_bf16_forward_plan(const fd_score* m, int B, char* out, size_t n);   // "k_tr_fwd_layers NT=.. x .." or "2 kernels per layer"
 int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, float* out, int B, float p, uint64_t seed,
                                 uint64_t offset, hipStream_t s);
 int fd_score_backward_bf16(fd_score* m, const float* dout, float* grads, int accumulate, hipStream_t s);

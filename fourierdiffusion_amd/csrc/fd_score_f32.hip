@@ -860,8 +860,11 @@ extern "C" int fd_score_train_plan(fd_score* m, int B, char* out, int* token_spl
     int nblk = 0;
     const int ts = fd_train_bf16_token_splits(m, B, &nblk);
     if (token_splits) *token_splits = ts;
-    snprintf(out, 192, "bf16 training: 5 kernels per layer, k_tr_wgrad token splits TS=%d over %d 32-token blocks, fused loss head %s",
-             ts, nblk, (m->prepared && fd_score_train_dsm_bf16_supported(m, B) && !getenv("FDIFF_TRAIN_DSM_UNFUSED")) ? "yes" : "no");
+    // forward: every layer in one persistent launch (fd_train_persist.hip) where it applies, else two kernels per layer
+    char fwd[64];
+    fd_train_bf16_forward_plan(m, B, fwd, sizeof fwd);
+    snprintf(out, 192, "bf16 training: forward %s; backward 3 kernels per layer, k_tr_wgrad token splits TS=%d over %d 32-token blocks, fused loss head %s",
+             fwd, ts, nblk, (m->prepared && fd_score_train_dsm_bf16_supported(m, B) && !getenv("FDIFF_TRAIN_DSM_UNFUSED")) ? "yes" : "no");
     return FD_OK;
 }
 

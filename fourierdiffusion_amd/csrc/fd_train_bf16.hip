@@ -2404,7 +2404,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
     // per layer (A/B runs and debugging: no inter-workgroup wait is ever exercised).  Read per call: the tests compare the forms.
     int trp_nq = 0, trp_spl = 0;
     const int trp_mode = [] { const char* e = getenv("FDIFF_TR_PERSIST"); return e ? atoi(e) : 1; }();
-    const int trp_nt = (trp_mode != 0 && L > 0) ? fd_trp_tiles(m, B, &trp_nq, &trp_spl) : 0;
+    const int trp_nt = (trp_mode != 0 && L > 0 && !ctx->trp_disabled) ? fd_trp_tiles(m, B, &trp_nq, &trp_spl) : 0;
     if (trp_nt) {
         if (int rc = tr_err_word(ctx)) return rc;
         const size_t nflag = (size_t)B * d.KT;
@@ -2843,6 +2843,14 @@ static bool tr_head_plan(const fd_score* m, int B, int* TS_out, int* kmax_out, s
 int fd_train_bf16_token_splits(const fd_score* m, int B, int* nblk) {
     if (nblk) *nblk = (int)(((long long)B * m->d.max_len + 31) / 32);
     return tr_TS(m, B);
+}
+void fd_train_bf16_forward_plan(const fd_score* m, int B, char* out, size_t n) {
+    int nq = 0, spl = 0;
+    const char* e = getenv("FDIFF_TR_PERSIST");
+    const int mode = e ? atoi(e) : 1;
+    const int nt = (mode != 0 && m->d.num_layers > 0 && !m->ctx->trp_disabled) ? fd_trp_tiles(m, B, &nq, &spl) : 0;
+    if (nt) snprintf(out, n, "k_tr_fwd_layers NT=%d, %d x %d workgroups%s", nt, nq, std::min(B, spl), mode == 2 ? " per layer" : "");
+    else snprintf(out, n, "2 kernels per layer%s", m->ctx->trp_disabled ? " (persistent form disabled after a timeout)" : "");
 }
 bool fd_score_train_dsm_bf16_supported(const fd_score* m, int B) {
     int TS, kmax;

@@ -54,6 +54,10 @@ size_t fd_ctx_workspace_bytes(fd_ctx* ctx);
  * kernel itself tests a device-resident copy of the error word in stream order and skips the update of such a step.  (The reference has no
  * counterpart: torch autograd, src/fdiff/models/score_models.py:96-108, has no inter-workgroup protocol to fail.) */
 int fd_ctx_check(fd_ctx* ctx);
+/* After a reported cluster timeout of the persistent training forward the context trains on the per-layer kernels (whatever kept a
+ * cluster from becoming resident -- a co-tenant process, a CU mask -- may still be there).  This re-arms the persistent form once the
+ * caller knows the cause is gone.  No reference counterpart (see fd_ctx_check). */
+int fd_ctx_rearm(fd_ctx* ctx);
 
 /* ---------------------------------------------------------- measurement hooks
  * bench.py's roofline leg: between fd_prof_begin and fd_prof_end the engine brackets every launch of its

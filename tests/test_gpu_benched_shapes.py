@@ -51,6 +51,8 @@ def test_training_gradients_at_the_benched_batch_vs_exact_f32_engine_reference_a
         desc, ts = m.train_plan(B)
         if prec == "bf16":
             assert ts == 20 and "TS=20" in desc, desc            # the shape bench.py --mode train runs
+            # ... with the forward of all layers as ONE persistent launch, 256 workgroups = one per CU at both shapes (round 6)
+            assert ("k_tr_fwd_layers NT=4, 4 x 64 workgroups" if name == "nasdaq" else "k_tr_fwd_layers NT=2, 4 x 64 workgroups") in desc, desc
             assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]), "bf16 step not bit-reproducible at ts = 20"
             _log(f"[parity] benched training shape {name} B={B}: {desc}; two runs bit-identical")
         else:

@@ -158,6 +158,7 @@ def test_persistent_forward_timeout_is_reported_and_the_update_is_skipped(monkey
     monkeypatch.setenv("FDIFF_TR_FSPLIT", "0")
     good = _step(m, fn, X, z, t, seed=92)[1]
     assert lib.fd_ctx_check(ctx) == 0
+    assert "k_tr_fwd_layers NT=2, 4 x 9 workgroups" in m.train_plan(B)[0], m.train_plan(B)[0]
     opt = FusedAdamW(m, lr=1e-3)
     before = m.flat_parameters.clone()
     monkeypatch.setenv("FDIFF_TR_PERSIST_TEST_STALL", "1")
@@ -176,6 +177,8 @@ def test_persistent_forward_timeout_is_reported_and_the_update_is_skipped(monkey
     with pytest.raises(_C.FdError, match="persistent forward .* gave up waiting"):
         _step(m, fn, X, z, t, seed=92)                 # the entry check of the next training call reports it ...
     assert lib.fd_ctx_check(ctx) == 0                  # ... once
+    # ... and the context trains on the per-layer kernels from now on (whatever kept the cluster apart may still be there)
+    assert "2 kernels per layer (persistent form disabled after a timeout)" in m.train_plan(B)[0], m.train_plan(B)[0]
     # the context works again.  (Not bit-equal to `good`: the optimizer call marked the parameters changed, and the next forward
     # re-applies the reference's max_norm renormalisation of the positional table -- transformer.py:13-15 -- to rows that sit AT the
     # bound, which moves their last bits.  Equal to itself run to run, and to `good` within fp32 rounding of that renormalisation.)
@@ -185,3 +188,8 @@ def test_persistent_forward_timeout_is_reported_and_the_update_is_skipped(monkey
     rel = float((g1 - good).abs().max() / good.abs().max())
     _log(f"[parity] persistent forward after a reported timeout vs before it: max |dg| / max |g| = {rel:.3e}")
     assert rel <= 2e-2
+    # re-armed (fd_ctx_rearm), the persistent form runs again -- and the other tests of this process get the context back as they expect it
+    assert lib.fd_ctx_rearm(ctx) == 0
+    assert "k_tr_fwd_layers NT=2" in m.train_plan(B)[0], m.train_plan(B)[0]
+    g3 = _step(m, fn, X, z, t, seed=92)[1]
+    assert float((g3 - good).abs().max() / good.abs().max()) <= 1e-3
