@@ -76,7 +76,7 @@ def hbm_traffic_per_launch():
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_hbm_traffic.json,
     collected with separate rocprofv3 --pmc runs of this same command; FETCH_SIZE doubled per the gfx950 note in
     MI355X_MICROARCH.md).  (None, None) when no measurement is committed; the second element names the source."""
-    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 v = json.load(f).get("hbm_bytes_per_launch")

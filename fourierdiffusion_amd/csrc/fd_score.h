@@ -30,6 +30,10 @@ struct fd_score {
     float* params = nullptr;        // caller-owned flat fp32 masters (set by fd_score_prepare)
     bool prepared = false;
     bool bf16_stale = true;         // bf16 weight images older than the fp32 masters (rebuilt lazily: training never reads them)
+    hipEvent_t prep_event = nullptr;   // completed by fd_score_prepare's last kernel (its launch's stop event): what a rebuild of the
+    void* prep_stream = nullptr;       // weight images on another stream waits for, without an event packet on the caller's stream
+    bool prep_event_bound = false;
+    hipEvent_t img_event = nullptr;    // completed by a rebuild of the bf16 weight images that runs on a side stream (fd_train_bf16.hip)
     fd_bf16_images* bf16 = nullptr; // engine-owned bf16 weight images (built by prepare)
     // ---- training state (valid between forward_train and backward)
     bool have_saved = false;

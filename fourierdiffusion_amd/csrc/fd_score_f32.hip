@@ -8,6 +8,8 @@
 
 #include "fd_gemm_f32.h"
 #include "fd_philox.h"
+#include <hip/hip_ext.h>
+
 #include "fd_score.h"
 
 // ------------------------------------------------------------------ layout
@@ -178,6 +180,8 @@ extern "C" int fd_score_create(fd_ctx* ctx, const fd_model_dims* dims, fd_score*
 extern "C" int fd_score_destroy(fd_score* m) {
     if (!m) return FD_ERR_ARG;
     fd_bf16_destroy(m);
+    if (m->prep_event) (void)hipEventDestroy(m->prep_event);
+    if (m->img_event) (void)hipEventDestroy(m->img_event);
     delete m;
     return FD_OK;
 }
@@ -762,9 +766,16 @@ extern "C" int fd_score_prepare(fd_score* m, const float* params, void* stream) 
     m->params = const_cast<float*>(params);
     // The reference renorms the looked-up rows of the positional table in place on every forward
     // (nn.Embedding(max_norm), transformer.py:13-15,27); all T rows are looked up, so do it here once.
-    if (m->backbone == FD_BACKBONE_TRANSFORMER)
-        hipLaunchKernelGGL(k_renorm_rows, dim3(m->d.max_len), dim3(64), 0, (hipStream_t)stream, m->params + m->pos,
-                           m->d.max_len, m->d.d_model, sqrtf((float)m->d.d_model));
+    m->prep_event_bound = false;
+    if (m->backbone == FD_BACKBONE_TRANSFORMER) {
+        // (the stop event: the bf16 training forward rebuilds the weight images on a side stream once THIS kernel has run,
+        // fd_train_bf16.hip -- an event recorded there would be a packet of its own in front of the step's first kernels)
+        if (!m->prep_event && hipEventCreateWithFlags(&m->prep_event, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) m->prep_event = nullptr;
+        hipExtLaunchKernelGGL(k_renorm_rows, dim3(m->d.max_len), dim3(64), 0, (hipStream_t)stream, nullptr, m->prep_event, 0,
+                              m->params + m->pos, m->d.max_len, m->d.d_model, sqrtf((float)m->d.d_model));
+        m->prep_event_bound = m->prep_event != nullptr;
+        m->prep_stream = stream;
+    }
     FD_LAUNCH_CHECK(ctx);
     m->bf16_stale = true;     // the bf16 MFMA entry points rebuild their images on first use (fd_bf16_refresh)
     m->prepared = true;

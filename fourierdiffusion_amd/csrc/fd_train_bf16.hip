@@ -24,6 +24,8 @@
 // with the constant 1.0 in k-slot D (the bias row of the weight images).  Dropout decisions are stored as bits by the forward
 // (hidden: kept AND h > 0; attention: kept) -- the two orientations in which the backward needs them (token on lane /
 // feature on lane) cannot both be regenerated from one counter layout without 4x the Philox evaluations.
+#include <hip/hip_ext.h>
+
 #include "fd_gemm_f32.h"
 #include "fd_train_dev.h"
 
@@ -2030,7 +2032,18 @@ size_t tr_carve(const fd_score* m, int B, char* base, TrBufs* out, int mask_set 
 
 // Events that order the step's streams against each other.  (A device-scope release per record -- hipEventReleaseToDevice -- instead of
 // the default system-scope fence was measured at +-0: 2.34 / 1.43 ms per step either way, scripts/archive/gpu_r04_events.sh.)
-static const unsigned kTrEventFlags = hipEventDisableTiming;
+// Events of the training path order work between streams of ONE device (never inspected by the host): without the system-scope fence
+// (FDIFF_TR_EVENT_FENCE=1 restores it).
+static const unsigned kTrEventFlags = hipEventDisableTiming | ((getenv("FDIFF_TR_EVENT_FENCE") && atoi(getenv("FDIFF_TR_EVENT_FENCE")) != 0) ? 0u : (unsigned)hipEventDisableSystemFence);
+// FDIFF_TR_LEAN_EVENTS (bits; default 26 = all three): 2 = the forward's "readers done" event is the persistent launch's stop event,
+// 8 = one join of the side streams in front of the optimizer, 16 = the image rebuild waits for fd_score_prepare's own stop event.
+// (Measured and dropped, profiles/r06_train_event_packets_ab.txt: bit 1 = `s` waits once for decisions + weight images through the
+// decision stream, +30 us; bit 4 = the backward's "readers done" event as layer 0's k_tr_attn_bwd's stop event, +8 / +18 us: the record
+// behind that kernel gives layer 0's weight-gradient launch a head start over the embedding backward.)
+static int tr_lean_bits() {
+    static const int v = getenv("FDIFF_TR_LEAN_EVENTS") ? atoi(getenv("FDIFF_TR_LEAN_EVENTS")) : 26;
+    return v;
+}
 
 // Side streams carry work that is OFF the step's critical path (dropout decisions one layer ahead, weight gradients behind the
 // input-gradient chain): lowest priority, so that the dispatcher hands free CU slots to the chain's workgroups first.
@@ -2338,7 +2351,20 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
     if (L > 0)
         hipLaunchKernelGGL((k_tr_prep<KS1, DT>), dim3((tb.Mpad / 16 + 3) / 4), dim3(256), 0, s, h0, tb.layers[0].x0rb, tb.layers[0].x0T,
                            M, tb.Mpad, D);
-    if (img_forked) FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[L + 2], 0));      // weight images rebuilt (side stream 2)
+    // Every event packet on `s` between two kernels of the chain is 4-5 us of an idle chip (round 6: 2.139 -> 2.094 ms per step at
+    // T = 252 for the ten records behind k_tr_attn_bwd alone, profiles/r06_train_event_packets_ab.txt).  FDIFF_TR_LEAN_EVENTS=0 keeps
+    // the round-5 form: a wait for the rebuilt weight images here, one for the dropout decisions in front of the first layer, a
+    // record behind the forward, two joins in front of the optimizer.
+    const int lean = tr_lean_bits();
+    // ---- every encoder layer as ONE persistent launch (fd_train_persist.hip) where it applies: T <= 256, the workgroups of a launch
+    // all resident.  FDIFF_TR_PERSIST: 0 = the per-layer kernels below, 1 (default) = persistent, 2 = the same kernel launched once
+    // per layer (A/B runs and debugging: no inter-workgroup wait is ever exercised).  Read per call: the tests compare the forms.
+    int trp_nq = 0, trp_spl = 0;
+    const int trp_mode = [] { const char* e = getenv("FDIFF_TR_PERSIST"); return e ? atoi(e) : 1; }();
+    const int trp_nt = (trp_mode != 0 && L > 0 && !ctx->trp_disabled) ? fd_trp_tiles(m, B, &trp_nq, &trp_spl) : 0;
+    // weight images rebuilt (side stream 2).  (Letting the decision stream wait for them, so that `s` waits once for that stream, made
+    // the step 30 us SLOWER, 2.09 -> 2.12 ms: profiles/r06_train_event_packets_ab.txt, bit 1.)
+    if (img_forked) FD_HIP(ctx, hipStreamWaitEvent(s, m->img_event, 0));
     const size_t lds_attn = (size_t)d.KT * 16 * 32 + (size_t)d.NJ * 1024 + 128;      // K rows, V^T blocks, keep-mask table
     const int attn_nw = tr_attn_waves(d.KT);
     const size_t scr = std::max((size_t)TW * KS1 * 1024, (size_t)4 * DT * 1024);
@@ -2399,12 +2425,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             FD_HIP(ctx, hipEventRecord(ctx->side_events[l], mstream));
         }
     }
-    // ---- every encoder layer as ONE persistent launch (fd_train_persist.hip) where it applies: T <= 256, the workgroups of a launch
-    // all resident.  FDIFF_TR_PERSIST: 0 = the per-layer kernels below, 1 (default) = persistent, 2 = the same kernel launched once
-    // per layer (A/B runs and debugging: no inter-workgroup wait is ever exercised).  Read per call: the tests compare the forms.
-    int trp_nq = 0, trp_spl = 0;
-    const int trp_mode = [] { const char* e = getenv("FDIFF_TR_PERSIST"); return e ? atoi(e) : 1; }();
-    const int trp_nt = (trp_mode != 0 && L > 0 && !ctx->trp_disabled) ? fd_trp_tiles(m, B, &trp_nq, &trp_spl) : 0;
+    hipEvent_t readers_done = nullptr;      // set when a launch carries the decision buffers' "readers done" event as its stop event
     if (trp_nt) {
         if (int rc = tr_err_word(ctx)) return rc;
         const size_t nflag = (size_t)B * d.KT;
@@ -2444,11 +2465,13 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
             if (trp_mode == 2) {
                 for (int l = 0; l < L; ++l) {
                     ta.l0 = l; ta.l1 = l + 1; ta.epoch = ++ctx->trp_epoch;
-                    if (int rc = fd_trp_forward(m, d, ta, trp_nt, trp_nq, trp_spl, s)) return rc;
+                    if (int rc = fd_trp_forward(m, d, ta, trp_nt, trp_nq, trp_spl, s, nullptr)) return rc;
                 }
             } else {
                 ta.l0 = 0; ta.l1 = L; ta.epoch = ++ctx->trp_epoch;
-                if (int rc = fd_trp_forward(m, d, ta, trp_nt, trp_nq, trp_spl, s)) return rc;
+                // the launch is the forward's last reader of the decision buffers: their "readers done" event is its stop event
+                if ((lean & 2) && p > 0.f) readers_done = ctx->tr_readers_event[mask_set];
+                if (int rc = fd_trp_forward(m, d, ta, trp_nt, trp_nq, trp_spl, s, readers_done)) return rc;
             }
         }
     }
@@ -2531,7 +2554,7 @@ int tr_forward_t(fd_score* m, const float* x, const float* t, float* out, int B,
     if (out) fdgemm::linear_fwd(tb.hL, P + m->un_w, P + m->un_b, out, M, C, D, false, s);      // (null: the fused loss head reads hL)
     FD_LAUNCH_CHECK(ctx);
     if (p > 0.f) {      // the dropout-decision buffers may be rewritten once everything enqueued so far has run
-        FD_HIP(ctx, hipEventRecord(ctx->tr_readers_event[mask_set], s));
+        if (!readers_done) FD_HIP(ctx, hipEventRecord(ctx->tr_readers_event[mask_set], s));
         ctx->tr_readers_event_valid[mask_set] = true;
         ctx->tr_readers_gen = ctx->ws_gen;
     }
@@ -2591,6 +2614,8 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     static const size_t wg_pad = getenv("FDIFF_TR_WG_LDS_KB") ? (size_t)atoi(getenv("FDIFF_TR_WG_LDS_KB")) * 1024 : (size_t)56 * 1024;
     const size_t lds_wg = std::max((size_t)FD_TR_WG_NBUF * StageL<KS1, DT>::bytes + 128 + FD_TR_WG_NBUF * 512, wg_pad);      // (ring + lane-mask table + activity words)
     static const bool serial = getenv("FDIFF_TR_SERIAL") != nullptr;
+    static const bool ext_event = !(getenv("FDIFF_TR_EXT_EVENT") && atoi(getenv("FDIFF_TR_EXT_EVENT")) == 0);
+    const int lean_b = tr_lean_bits();
     WgArgs wa{};
     wa.nparams = (long long)tb.layer_params; wa.TS = tb.TS; wa.nblk = (M + 31) / 32;
     RedArgs ra{};
@@ -2638,9 +2663,14 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
             // recomputed scores are not algorithmic work
             fd_prof_scope scope(ctx, s, "k_tr_attn_bwd (attention backward + in-proj^T, training backward)",
                                 (double)M * (8.0 * (double)T * D + 6.0 * D * D));
-            if (attn_oh) hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 4, 1>), dim3(2 * d.NP, B), dim3(256), lds_ab, s, d, ab);
-            else if (attn_nw == 8) hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 8, 0>), dim3(d.NP, B), dim3(512), lds_ab, s, d, ab);
-            else hipLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 4, 0>), dim3(d.NP, B), dim3(256), lds_ab, s, d, ab);
+            // The layer's weight-gradient launch (side stream) starts when this kernel has ended.  An event recorded behind the
+            // kernel is a packet of its own between this kernel and the next layer's k_tr_ffn_bwd (6-7 us of an idle chip per
+            // layer in the kernel trace); bound to the launch itself (hipExtLaunchKernelGGL's stop event) it is the kernel's own
+            // completion signal.  FDIFF_TR_EXT_EVENT=0: the recorded event.
+            hipEvent_t stop_ev = (ext_event && !serial) ? ctx->side_events[l] : nullptr;
+            if (attn_oh) hipExtLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 4, 1>), dim3(2 * d.NP, B), dim3(256), lds_ab, s, nullptr, stop_ev, 0, d, ab);
+            else if (attn_nw == 8) hipExtLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 8, 0>), dim3(d.NP, B), dim3(512), lds_ab, s, nullptr, stop_ev, 0, d, ab);
+            else hipExtLaunchKernelGGL((k_tr_attn_bwd<KS1, DT, 4, 0>), dim3(d.NP, B), dim3(256), lds_ab, s, nullptr, stop_ev, 0, d, ab);
 #ifdef FD_TR_PROF_ATTN
             {
                 static int calls = 0;
@@ -2674,8 +2704,8 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         static const int ts_last_env = getenv("FDIFF_TR_TS_LAST") ? atoi(getenv("FDIFF_TR_TS_LAST")) : 0;
         const int ts_l = (l == 0 && ts_last_env > 0) ? std::max(1, std::min({kMaxTS, ts_last_env, wa.nblk})) : tb.TS;
         wa.TS = ra.TS = ts_l;
-        FD_HIP(ctx, hipEventRecord(ctx->side_events[l], s));
-        FD_HIP(ctx, hipStreamWaitEvent(ws, ctx->side_events[l], 0));
+        if (!(ext_event && !serial)) FD_HIP(ctx, hipEventRecord(ctx->side_events[l], s));
+        if (ws != s) FD_HIP(ctx, hipStreamWaitEvent(ws, ctx->side_events[l], 0));
         {
             // measurement hook (bench.py --mode train): every weight gradient of one layer -- in_proj 2 M 3D D, out_proj 2 M D D,
             // linear1 + linear2 2 x 2 M D F (the recomputation of the hidden / d hidden blocks is not algorithmic work)
@@ -2722,7 +2752,13 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         (void)hipStreamSynchronize(ctx->side_stream2);
         return rc_embed;
     }
-    if (L > 0) {
+    if (L > 0 && (lean_b & 8) && !serial) {
+        // one join packet on `s`, not two: side stream 1 (layer 0's weight gradients, the step's last) first waits for side stream 2
+        FD_HIP(ctx, hipEventRecord(ctx->side_events[L + 2], ctx->side_stream2));
+        FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_events[L + 2], 0));
+        FD_HIP(ctx, hipEventRecord(ctx->side_events[L], ctx->side_stream));
+        FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[L], 0));
+    } else if (L > 0) {
         FD_HIP(ctx, hipEventRecord(ctx->side_events[L], ctx->side_stream));
         FD_HIP(ctx, hipStreamWaitEvent(s, ctx->side_events[L], 0));
         FD_HIP(ctx, hipEventRecord(ctx->side_events[L + 2], ctx->side_stream2));
@@ -2759,6 +2795,29 @@ size_t fd_train_bf16_workspace(const fd_score* m, int B) { return tr_carve(m, B,
         return fd_fail(m->ctx, FD_ERR_UNSUPPORTED, "bf16 training kernels not instantiated for this model"); \
     } while (0)
 
+// Rebuild of the bf16 weight images on side stream 2, behind everything `s` holds now; completes m->img_event.
+static int tr_fork_image_rebuild(fd_score* m, hipStream_t s) {
+    fd_ctx* ctx = m->ctx;
+    if (!ctx->side_stream2) FD_HIP(ctx, side_stream_create(&ctx->side_stream2));
+    if (!m->img_event) FD_HIP(ctx, hipEventCreateWithFlags(&m->img_event, kTrEventFlags));
+    while ((int)ctx->side_events.size() < m->d.num_layers + 3) {
+        hipEvent_t e;
+        FD_HIP(ctx, hipEventCreateWithFlags(&e, kTrEventFlags));
+        ctx->side_events.push_back(e);
+    }
+    // what the rebuild waits for: fd_score_prepare's kernel on this stream (behind the optimizer's), by that launch's own stop
+    // event where there is one -- no event packet on `s`
+    if ((tr_lean_bits() & 16) && m->prep_event_bound && m->prep_stream == (void*)s) {
+        FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream2, m->prep_event, 0));
+    } else {
+        FD_HIP(ctx, hipEventRecord(ctx->side_events[m->d.num_layers], s));
+        FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream2, ctx->side_events[m->d.num_layers], 0));
+    }
+    if (int rc = fd_bf16_refresh(m, ctx->side_stream2, true)) return rc;
+    FD_HIP(ctx, hipEventRecord(m->img_event, ctx->side_stream2));
+    return FD_OK;
+}
+
 int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, float* out, int B, float p, uint64_t seed,
                                 uint64_t offset, hipStream_t s) {
     fd_ctx* ctx = m->ctx;
@@ -2769,17 +2828,8 @@ int fd_score_forward_train_bf16(fd_score* m, const float* x, const float* t, flo
     // the images: the rebuild runs beside it on the second side stream and joins `s` in front of the first attention kernel.
     bool img_forked = false;
     if (m->bf16_stale && m->d.num_layers > 0 && !getenv("FDIFF_TR_SERIAL")) {
-        if (!ctx->side_stream2) FD_HIP(ctx, side_stream_create(&ctx->side_stream2));
-        while ((int)ctx->side_events.size() < m->d.num_layers + 3) {
-            hipEvent_t e;
-            FD_HIP(ctx, hipEventCreateWithFlags(&e, kTrEventFlags));
-            ctx->side_events.push_back(e);
-        }
-        FD_HIP(ctx, hipEventRecord(ctx->side_events[m->d.num_layers], s));
-        FD_HIP(ctx, hipStreamWaitEvent(ctx->side_stream2, ctx->side_events[m->d.num_layers], 0));
-        if (int rc = fd_bf16_refresh(m, ctx->side_stream2, true)) return rc;
-        FD_HIP(ctx, hipEventRecord(ctx->side_events[m->d.num_layers + 2], ctx->side_stream2));
-        img_forked = true;
+        if (int rc = tr_fork_image_rebuild(m, s)) return rc;
+        img_forked = true;          // (tr_forward_t waits for m->img_event in front of the first kernel that reads the images)
     } else if (int rc = fd_bf16_refresh(m, s, true)) {
         return rc;
     }

@@ -130,7 +130,8 @@ struct fd_trp_args {
 };
 size_t fd_trp_lds_bytes(int ks1, int dt, int kso, int NT, int T, int F, int NP);
 int fd_trp_tiles(const fd_score* m, int B, int* nq_out, int* series_per_launch);
-int fd_trp_forward(fd_score* m, const TrDims& d, fd_trp_args a, int NT, int nq, int series_per_launch, hipStream_t s);
+// `done` (may be null): an event completed by the LAST launch of the call (hipExtLaunchKernelGGL's stop event)
+int fd_trp_forward(fd_score* m, const TrDims& d, fd_trp_args a, int NT, int nq, int series_per_launch, hipStream_t s, hipEvent_t done);
 int fd_trp_set_flag(fd_ctx* ctx, unsigned long long* flag, unsigned long long value, hipStream_t s);
 namespace {
 

@@ -31,6 +31,8 @@
 // profiles/r05_train_ffn_fwd_ablations.txt) out of every forward chunk loop.
 // With FDIFF_TR_ROT=0 (natural chunk order in both forms) the saved activations and therefore the gradients are bit-identical to
 // the per-layer kernels' (tests/test_gpu_train_persist.py).
+#include <hip/hip_ext.h>
+
 #include "fd_train_dev.h"
 
 namespace {
@@ -786,11 +788,11 @@ __global__ void k_tr_set_flag(unsigned long long* flag, unsigned long long value
 }
 
 template <int KS1, int DT, int KSO, int NT>
-int trp_launch(fd_ctx* ctx, const TrDims& d, const fd_trp_args& a, int nq, int nseries, size_t lds, hipStream_t s) {
+int trp_launch(fd_ctx* ctx, const TrDims& d, const fd_trp_args& a, int nq, int nseries, size_t lds, hipStream_t s, hipEvent_t stop) {
     static unsigned long long attr = 0;
     if (fd_first_on_device(attr, ctx->device))
         FD_HIP(ctx, hipFuncSetAttribute((const void*)k_tr_fwd_layers<KS1, DT, KSO, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((k_tr_fwd_layers<KS1, DT, KSO, NT>), dim3(nq, nseries), dim3(512), lds, s, d, a);
+    hipExtLaunchKernelGGL((k_tr_fwd_layers<KS1, DT, KSO, NT>), dim3(nq, nseries), dim3(512), lds, s, nullptr, stop, 0, d, a);
     return FD_OK;
 }
 
@@ -829,17 +831,18 @@ int fd_trp_tiles(const fd_score* m, int B, int* nq_out, int* series_per_launch) 
     return 0;
 }
 
-int fd_trp_forward(fd_score* m, const TrDims& d, fd_trp_args a, int NT, int nq, int series_per_launch, hipStream_t s) {
+int fd_trp_forward(fd_score* m, const TrDims& d, fd_trp_args a, int NT, int nq, int series_per_launch, hipStream_t s, hipEvent_t done) {
     fd_ctx* ctx = m->ctx;
     const fd_bf16_images* im = m->bf16;
     const size_t lds = fd_trp_lds_bytes(im->ks1, im->dt, im->kso, NT, d.T, d.F, d.NP);
     for (int b0 = 0; b0 < d.B; b0 += series_per_launch) {
         a.b0 = b0;
         const int ns = std::min(series_per_launch, d.B - b0);
+        hipEvent_t stop = (b0 + series_per_launch >= d.B) ? done : nullptr;      // (bound to the LAST launch: no packet of its own on `s`)
         int rc = FD_ERR_UNSUPPORTED;
 #define TRP_CASE(K, T_, O)                                                                                     \
     if (im->ks1 == K && im->dt == T_ && im->kso == O)                                                          \
-        rc = NT == 4 ? trp_launch<K, T_, O, 4>(ctx, d, a, nq, ns, lds, s) : trp_launch<K, T_, O, 2>(ctx, d, a, nq, ns, lds, s);
+        rc = NT == 4 ? trp_launch<K, T_, O, 4>(ctx, d, a, nq, ns, lds, s, stop) : trp_launch<K, T_, O, 2>(ctx, d, a, nq, ns, lds, s, stop);
         TRP_CASE(3, 5, 3)
         TRP_CASE(3, 5, 2)
         TRP_CASE(2, 3, 1)

@@ -12,5 +12,5 @@ t0 = int(rows[a]["Start_Timestamp"])
 print(f"step: {b - a + 1} kernels, {(int(rows[b]['End_Timestamp']) - t0) / 1e3:.1f} us from the first start to the end of k_adamw")
 for r in rows[a:b + 1]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
-    name = r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "")[:60]
+    name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
     print(f"{s / 1e3:9.1f} {e / 1e3:9.1f} {(e - s) / 1e3:8.1f} us  q{r.get('Queue_Id', '?'):>3s}  {name}")
