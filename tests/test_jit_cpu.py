@@ -123,3 +123,32 @@ def test_compilations_do_not_hold_the_global_lock(tmp_path, monkeypatch):
     (a0, a1, _, _), (b0, b1, _, _) = spans
     overlap = min(a1, b1) - max(a0, b0)
     assert overlap > 0.25 * min(a1 - a0, b1 - b0), (a0, a1, b0, b1)
+
+
+def test_two_processes_share_one_cache_directory(tmp_path):
+    """The ranks of one node compile the same instantiation at the same time into one cache directory (bench.py --gpus N, cmd/train.py
+    under torch.distributed.run): each process compiles or reads a COMPLETE file (temporary name + rename), none fails, one file is
+    left, and a later process is served from it."""
+    import subprocess
+    import sys
+    cache = tmp_path / "cache"
+    prog = ("import ctypes as C, sys\n"
+            "from fourierdiffusion_amd import _C\n"
+            "lib = _C.lib()\n"
+            "msg = C.create_string_buffer(1200)\n"
+            f"rc = lib.fd_mega_jit_compile((C.c_int * 14)(*{KEY!r}), msg, 1200)\n"
+            "print(rc, msg.value.decode(errors='replace'))\n")
+    env = dict(os.environ, FDIFF_CACHE_DIR=str(cache))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    procs = [subprocess.Popen([sys.executable, "-c", prog], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for _ in range(3)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        line = [l for l in o.splitlines() if l.startswith("0 ") or l[:2] in ("-1", "-2", "-3", "-4", "-5", "-6")]
+        assert p.returncode == 0 and line and line[-1].startswith("0 "), o
+        assert "compiled in" in line[-1] or "code object from" in line[-1], o
+    files = glob.glob(str(cache / "*"))
+    assert len(files) == 1 and files[0].endswith(".fdco"), files           # no temporary file is left behind
+    out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600).stdout
+    assert "code object from" in out and files[0] in out, out
