@@ -82,7 +82,8 @@ class ScoreModule:
                                    self.dim_feedforward)
         self._layout, self._nparams = _C.score_layout(self._dims, self._backbone, self._d_mlp)
         self._flat = torch.zeros(self._nparams, dtype=torch.float32)
-        self.grads: Optional[torch.Tensor] = None
+        self._grads: Optional[torch.Tensor] = None
+        self._zero_pending = False
         self._views: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self._trainable: Dict[str, bool] = {}
         self._bind_views()
@@ -333,31 +334,57 @@ class ScoreModule:
         td = _C.dev_f32(timesteps.to(self.device), "timesteps")
         tg = _C.dev_f32(target, "target")
         sd = _C.dev_f32(std, "std")
-        if self.grads is None or self.grads.device != self.device:
-            self.grads = torch.zeros_like(self._flat)
+        grads, acc = self._grads_for_backward()
         loss = torch.empty(1, device=self.device, dtype=torch.float32)
         key, off = _rng.stream()
         rc = _C.lib().fd_score_train_dsm(h, Xd.data_ptr(), td.data_ptr(), tg.data_ptr(), sd.data_ptr(),
                                          1 if likelihood_weighting else 0, float(grad_weight), Xd.shape[0], float(self.dropout),
-                                         key, off, loss.data_ptr(), self.grads.data_ptr(), 1, _C.stream_of(Xd))
+                                         key, off, loss.data_ptr(), grads.data_ptr(), acc, _C.stream_of(Xd))
         _C.check(rc, ctx)
         self._train_inputs = (Xd, td, tg, sd)
         return loss[0]
 
+    @property
+    def grads(self) -> Optional[torch.Tensor]:
+        """The flat gradient buffer (same layout as ``flat_parameters``).  ``zero_grad()`` is lazy: the next backward OVERWRITES the
+        buffer (the engine's accumulate = 0 form, bit-identical to accumulating onto zeros: tests/test_gpu_train_bf16.py) instead of
+        a 13 MB fill kernel in front of every step plus a read of it in every reduce; anyone who looks at the buffer before that
+        backward gets the zeros here."""
+        if self._zero_pending and self._grads is not None:
+            self._grads.zero_()
+        self._zero_pending = False
+        return self._grads
+
+    @grads.setter
+    def grads(self, value: Optional[torch.Tensor]) -> None:
+        self._grads = value
+        self._zero_pending = False
+
+    def _grads_for_backward(self) -> Tuple[torch.Tensor, int]:
+        """(buffer, accumulate flag of the engine call) -- consumes a pending ``zero_grad()``."""
+        if self._grads is None or self._grads.device != self.device:
+            self._grads = torch.zeros_like(self._flat)
+            self._zero_pending = False
+        acc = 0 if self._zero_pending else 1
+        self._zero_pending = False
+        return self._grads, acc
+
     def zero_grad(self) -> None:
-        if self.grads is not None:
-            self.grads.zero_()
+        if self._grads is not None:
+            if os.environ.get("FDIFF_LAZY_ZERO_GRAD", "1") == "0":      # (A/B runs: the fill kernel of rounds 1-5)
+                self._grads.zero_()
+                self._zero_pending = False
+            else:
+                self._zero_pending = True
 
     def backward(self, dscore: torch.Tensor, accumulate: bool = True) -> torch.Tensor:
         """d loss / d params for the last training-mode forward; accumulates into ``self.grads``."""
         ctx, h = self._engine()
-        if self.grads is None or self.grads.device != self.device:
-            self.grads = torch.zeros_like(self._flat)
+        grads, acc = self._grads_for_backward()
         d = _C.dev_f32(dscore, "dscore")
-        rc = _C.lib().fd_score_backward(h, d.data_ptr(), self.grads.data_ptr(), 1 if accumulate else 0,
-                                        _C.stream_of(d))
+        rc = _C.lib().fd_score_backward(h, d.data_ptr(), grads.data_ptr(), acc if accumulate else 0, _C.stream_of(d))
         _C.check(rc, ctx)
-        return self.grads
+        return grads
 
     def grad_views(self) -> "OrderedDict[str, torch.Tensor]":
         assert self.grads is not None

@@ -373,6 +373,46 @@ def test_fused_training_call_equals_forward_loss_backward(shape, lw):
     _log(f"[parity] fused train call vs three calls {shape} lw={lw}: loss rel {abs(lf - lt) / abs(lt):.2e}, worst tensor max-err/max {worst:.2e}")
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_zero_grad_is_lazy_and_the_next_backward_overwrites(precision):
+    """ScoreModule.zero_grad() launches nothing: the next backward runs in the engine's overwrite form.  Same gradients, bit for bit, as
+    an explicit fill + accumulate; a reader of ``grads`` in between sees zeros; a second backward without zero_grad() accumulates."""
+    from fourierdiffusion_amd.utils.dataclasses import DiffusableBatch
+    from fourierdiffusion_amd.utils.losses import get_sde_loss_fn
+    cfg = dict(T=100, C=12, D=72, L=2, H=12)
+    B = 6
+    m, sch, _ = make_model(cfg, precision="bf16")
+    m.train_precision = precision
+    fn = get_sde_loss_fn(sch, train=True)
+    X = dev(W.randn("lz_x", (B, cfg["T"], cfg["C"]), 11))
+    t = dev(W.uniform("lz_t", (B,), 11, 0.05, 1.0))
+    z = dev(W.randn("lz_z", (B, cfg["T"], cfg["C"]), 11))
+
+    def run(lazy):
+        torch.manual_seed(77)
+        if lazy:
+            m.zero_grad()
+            assert m._zero_pending or m._grads is None
+        else:
+            if m.grads is None:
+                m.grads = torch.zeros_like(m.flat_parameters)
+            m.grads.fill_(0.0)
+            assert not m._zero_pending
+        loss = fn(m, DiffusableBatch(X=X, timesteps=t), noise=z)
+        return float(loss), m.grads.clone()
+    l0, g0 = run(False)            # (also allocates the buffer)
+    m.grads.fill_(123.0)           # garbage the overwrite form must not see
+    l1, g1 = run(True)
+    assert l0 == l1 and torch.equal(g0, g1) and float(g1.abs().max()) > 0
+    m.zero_grad()
+    assert float(m.grads.abs().max()) == 0.0 and not m._zero_pending       # a reader in between gets the zeros
+    torch.manual_seed(77)
+    fn(m, DiffusableBatch(X=X, timesteps=t), noise=z)
+    torch.manual_seed(77)
+    fn(m, DiffusableBatch(X=X, timesteps=t), noise=z)                        # no zero_grad(): accumulates
+    assert torch.allclose(m.grads, 2 * g0, rtol=1e-6, atol=0)
+
+
 def test_fused_training_call_overwrite_mode_through_the_c_abi():
     """fd_score_train_dsm with accumulate = 0 (a C-ABI caller that does not zero its gradient buffer): bit-identical to
     accumulate = 1 on a zeroed buffer, whatever the buffer held before; same Philox key."""
