@@ -713,6 +713,7 @@ struct FfnBwdArgs {
     const float* dyp;         // ... plus `npart` partial tensors (the next layer's attention backward, one per head pair)
     int npart; size_t part_stride;
     int part_bf16;            // the partial tensors are bf16 (one per head), part_stride in elements either way
+    int rowsum;               // 1: the partial tensors are summed as contiguous 16-byte units through LDS (default); 0: C-tile loads
     const float* s1; const float* s2;
     const unsigned char* active;
     float* datt;              // (M, D) gradient of the attention output
@@ -727,6 +728,17 @@ struct FfnBwdArgs {
 };
 
 // LayerNorm backward on a C-layout tile: dy -> ds (in place), xhat given; returns nothing (column sums done by the caller)
+#ifdef FD_TR_PROF_FB        // variant build: in-kernel phase clocks of k_tr_ffn_bwd (workgroup 7, waves 0 and 4), printed after 30 launches
+__device__ unsigned long long fd_tr_fb_dbg[2 * 8];
+#define TRFB_STAMP(slot, t_prev)                                                                          \
+    do {                                                                                                  \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                     \
+        if (blockIdx.x == 7 && lane == 0 && (wave & 3) == 0) fd_tr_fb_dbg[(wave >> 2) * 8 + (slot)] += now_ - (t_prev); \
+        (t_prev) = now_;                                                                                  \
+    } while (0)
+#else
+#define TRFB_STAMP(slot, t_prev) do { } while (0)
+#endif
 template <int DT>
 __device__ __forceinline__ void ln_bwd_tile(f32x4 (&dy)[DT], const f32x4 (&xhat)[DT], const float* __restrict__ gamma, float rstd,
                                             int D, int g) {
@@ -811,9 +823,16 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
             __builtin_amdgcn_global_load_lds(GLB_PTR(src + bb * 1024), LDS_PTR(dst + bb * 1024), 16, 0, 0);
         }
     };
-    issue(0);
-    if (NSH > 1) issue(1);
-    if (NSH > 2) issue(2);
+    unsigned long long tprev = __builtin_readcyclecounter();
+    (void)tprev;
+    // (with the row-linear sums below the first weight DMAs are issued BEHIND the prologue's register loads: vmcnt retires in order, and
+    //  a register load issued behind 66 KiB of DMA is only usable when those have landed)
+    const bool rowsum = a.rowsum && a.npart > 0;
+    if (!rowsum) {
+        issue(0);
+        if (NSH > 1) issue(1);
+        if (NSH > 2) issue(2);
+    }
     // column sums over this tile's 16 tokens -> colred[tile][slot][feature] (owner waves only)
     auto colsum = [&](int slot, const f32x4 (&t)[DT]) {
 #pragma unroll
@@ -824,19 +843,138 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
                 if (owner && tok == 0) colred[(tile * 5 + slot) * (16 * DT) + 16 * dt + 4 * g + r] = sres;
             }
     };
-    // this wave's keep bytes of the whole F-half -> LDS (no vector-memory traffic inside the loop)
-    if (valid) {
-        const unsigned char* srcb = a.active + ((size_t)m * 4 + g) * (2 * NS) + fhw * NS;
-        for (int c = 0; c < NS; c += 16) *reinterpret_cast<u32x4*>(actB + lane * NS + c) = *reinterpret_cast<const u32x4*>(srcb + c);
-    } else {
-        for (int c = 0; c < NS; c += 16) *reinterpret_cast<u32x4*>(actB + lane * NS + c) = u32x4{0u, 0u, 0u, 0u};
+    // this wave's keep bytes of the whole F-half -> LDS (no vector-memory traffic inside the loop): loaded here, stored below
+    constexpr int NAB = 4;                                  // 16-byte pieces held in registers (dim_ff <= 4096; longer rows: the loop below)
+    u32x4 abr[NAB];
+    {
+        const unsigned char* srcb = a.active + ((size_t)(valid ? m : 0) * 4 + g) * (2 * NS) + fhw * NS;
+#pragma unroll
+        for (int i = 0; i < NAB; ++i) abr[i] = *reinterpret_cast<const u32x4*>(srcb + (16 * i < NS ? 16 * i : 0));
     }
+    auto store_act = [&]() {
+#pragma unroll
+        for (int i = 0; i < NAB; ++i)
+            if (16 * i < NS) *reinterpret_cast<u32x4*>(actB + lane * NS + 16 * i) = valid ? abr[i] : u32x4{0u, 0u, 0u, 0u};
+        if (NS > 16 * NAB) {
+            const unsigned char* srcb = a.active + ((size_t)(valid ? m : 0) * 4 + g) * (2 * NS) + fhw * NS;
+            for (int c = 16 * NAB; c < NS; c += 16)
+                *reinterpret_cast<u32x4*>(actB + lane * NS + c) = valid ? *reinterpret_cast<const u32x4*>(srcb + c) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
     // ---- gradient of the layer output
     f32x4 dy[DT];
     load_ctile<DT>(a.dy0, m, valid, D, g, dy);
+    if (!rowsum) store_act();
+    if (rowsum) {
+        // The partial tensors (one per head or head pair, written by the next layer's k_tr_attn_bwd) as C tiles are DT 8-byte (bf16) /
+        // 16-byte (fp32) loads per lane and part, each walking 16 rows x 4 lane groups -- 60 narrow gathers per lane for 12 heads,
+        // issued by BOTH waves of a tile: 16.6 K of this kernel's 86 K cycles at T = 252 (phase clocks, -DFD_TR_PROF_FB,
+        // profiles/r06_train_ffn_bwd_phase_clocks.txt).  A tile's 16 rows of a part are ONE contiguous run (32 D or 64 D bytes):
+        // the two waves of a tile take alternate parts, add them up as 16-byte units in that linear order (the sum does not care about
+        // the layout), and exchange the two sums through LDS, from where they are read as C tiles.  Order of the additions:
+        // d y = (d y0 + (p0 + p2 + ...)) + (p1 + p3 + ...).
+        constexpr int NLB = (2 * 16 * DT + 63) / 64, NLF = (4 * 16 * DT + 63) / 64;       // 16-byte units per lane: bf16 / fp32 parts
+        const int m0t = (blk * 4 + tile) * 16;
+        // LDS: the fourth ring buffer (first written by step 0's DMA, behind the barrier in front of the loop) for the fhw = 0 waves,
+        // the epilogue's scratch2 area for the others
+        float* const rs = reinterpret_cast<float*>(fhw == 0 ? ring + 3 * WB + tile * (16 * 16 * DT * 4)
+                                                            : smem + NBUF * WB + SCR + TW * 64 * NS + 4 * 5 * 16 * DT * sizeof(float) + tile * (16 * 16 * DT * 4));
+        bool started = false;
+        auto start_ring = [&]() {
+            issue(0);
+            if (NSH > 1) issue(1);
+            if (NSH > 2) issue(2);
+            store_act();
+            started = true;
+        };
+        if (a.part_bf16) {
+            const int NU = 2 * D;                                          // 16-byte units of the tile's rows
+            const char* const pb = reinterpret_cast<const char*>(a.dyp);
+            // (a unit that BEGINS inside the part is read in place -- with 2 D % 16 != 0 the last valid row's last unit reaches up to 8 bytes
+            //  into the next part, or into the unused half of the fp32-sized parts buffer; units of rows beyond M read offset 0)
+            const size_t pbytes = a.part_stride * 2, tot = (size_t)M * D * 2;
+            float sum[NLB][8];
+#pragma unroll
+            for (int k = 0; k < NLB; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum[k][j] = 0.f;
+            for (int pi = fhw; pi < a.npart; pi += 12) {                   // six parts of this wave per trip (12 heads: one trip), all loads in flight
+                u32x4 raw[6][NLB];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const int pq = pi + 2 * q < a.npart ? pi + 2 * q : pi;
+#pragma unroll
+                    for (int k = 0; k < NLB; ++k) {
+                        const size_t off = (size_t)m0t * D * 2 + (size_t)(lane + 64 * k) * 16;
+                        raw[q][k] = *reinterpret_cast<const u32x4*>(pb + (size_t)pq * pbytes + (off < tot ? off : 0));
+                    }
+                }
+                if (!started) start_ring();                                // behind the first trip's loads: the weight ring and the keep bytes
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    if (pi + 2 * q < a.npart) {
+#pragma unroll
+                        for (int k = 0; k < NLB; ++k)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                sum[k][2 * j] += __builtin_bit_cast(float, raw[q][k][j] << 16);
+                                sum[k][2 * j + 1] += __builtin_bit_cast(float, raw[q][k][j] & 0xffff0000u);
+                            }
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < NLB; ++k)
+                if (lane + 64 * k < NU) {
+                    float4* dst = reinterpret_cast<float4*>(rs + (size_t)(lane + 64 * k) * 8);
+                    dst[0] = float4{sum[k][0], sum[k][1], sum[k][2], sum[k][3]};
+                    dst[1] = float4{sum[k][4], sum[k][5], sum[k][6], sum[k][7]};
+                }
+        } else {
+            const int NU = 4 * D;
+            const char* const pb = reinterpret_cast<const char*>(a.dyp);
+            const size_t pbytes = a.part_stride * 4, tot = (size_t)M * D * 4;          // (D % 4 == 0: no unit straddles two rows)
+            f32x4 sum[NLF];
+#pragma unroll
+            for (int k = 0; k < NLF; ++k) sum[k] = f4zero();
+            for (int pi = fhw; pi < a.npart; pi += 6) {                    // three parts of this wave per trip (6 head pairs: one trip)
+                f32x4 raw[3][NLF];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int pq = pi + 2 * q < a.npart ? pi + 2 * q : pi;
+#pragma unroll
+                    for (int k = 0; k < NLF; ++k) {
+                        const size_t off = (size_t)m0t * D * 4 + (size_t)(lane + 64 * k) * 16;
+                        raw[q][k] = *reinterpret_cast<const f32x4*>(pb + (size_t)pq * pbytes + (off < tot ? off : 0));
+                    }
+                }
+                if (!started) start_ring();
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (pi + 2 * q < a.npart) {
+#pragma unroll
+                        for (int k = 0; k < NLF; ++k) sum[k] += raw[q][k];
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < NLF; ++k)
+                if (lane + 64 * k < NU) *reinterpret_cast<f32x4*>(rs + (size_t)(lane + 64 * k) * 4) = sum[k];
+        }
+        if (!started) start_ring();                                        // (a wave without a part: one head pair)
+        __syncthreads();
+        const float* const r0 = reinterpret_cast<const float*>(ring + 3 * WB + tile * (16 * 16 * DT * 4));
+        const float* const r1 = reinterpret_cast<const float*>(smem + NBUF * WB + SCR + TW * 64 * NS + 4 * 5 * 16 * DT * sizeof(float) + tile * (16 * 16 * DT * 4));
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            if (d0 < D && valid) {
+                dy[dt] += *reinterpret_cast<const f32x4*>(r0 + tok * D + d0);
+                if (a.npart > 1) dy[dt] += *reinterpret_cast<const f32x4*>(r1 + tok * D + d0);
+            }
+        }
+    }
     // (four partial tensors per trip, every load of the trip in flight at once: one exposed round trip per four parts; the order
     // of the additions is the part order either way)
-    for (int pi = 0; pi < a.npart; pi += 4) {
+    for (int pi = 0; pi < (a.rowsum ? 0 : a.npart); pi += 4) {
         f32x4 t[4][DT];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -851,6 +989,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
                 for (int dt = 0; dt < DT; ++dt) dy[dt] += t[q][dt];
             }
     }
+    TRFB_STAMP(0, tprev);          // d y + its partial tensors
     // ---- LayerNorm2 backward
     f32x4 xh[DT];
     float rstd2;
@@ -894,8 +1033,10 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     f32x4 acc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f4zero();
+    TRFB_STAMP(1, tprev);          // LN2 backward, column sums, d f fragments
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    TRFB_STAMP(2, tprev);          // DMA wait + barrier
     // ---- d x1 += W1^T (active . W2^T d f) over this wave's F-half: d hidden lives in registers only.  As in k_tr_ffn_fwd the
     // fragments and the activity byte of a chunk are read one step ahead (two register sets, two steps per trip); the keep
     // scale of the hidden units is applied once to the accumulators behind the loop.
@@ -957,12 +1098,14 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[dt] *= d.keep_scale;
     }
+    TRFB_STAMP(3, tprev);          // chunk loop
     __syncthreads();
     if (!owner) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) xch[(tile * DT + dt) * 64 + lane] = acc[dt];
     }
     __syncthreads();
+    TRFB_STAMP(4, tprev);          // exchange of the halves
     if (nsp == 2 && !finisher) {          // F-split producer: hand the FFN branch's partial d x1 over and leave (every wave of it)
         if (owner) {
 #pragma unroll
@@ -999,6 +1142,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
             colsum(4, t);                                // d gamma1
         }
         ln_bwd_tile<DT>(dy, xh, a.g1, rstd1, D, g);      // dy = d s1
+        TRFB_STAMP(5, tprev);      // stage rows, LN1 backward
         store_ctile<DT>(a.dres, m, valid, D, g, dy);
         // ---- d o (out-projection output after its dropout) -> d att = d o W_o
 #pragma unroll
@@ -1018,6 +1162,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
         }
         store_ctile<DT>(a.datt, m, valid, D, g, acc);
     }
+    TRFB_STAMP(6, tprev);          // d o T-blocks, out-proj^T, stores
     // ---- column sums of the workgroup, tiles added in a fixed order
     __syncthreads();
     for (int i = threadIdx.x; i < 5 * 16 * DT; i += TW * 64) {
@@ -1026,6 +1171,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
         for (int w = 0; w < 4; ++w) sres += colred[(w * 5 + slot) * (16 * DT) + f];
         if (f < D) a.vecpart[((size_t)blk * 5 + slot) * D + f] = sres;
     }
+    TRFB_STAMP(7, tprev);          // barrier + column sums
 }
 
 // ------------------------------------------------------------------------------------------------ attention backward
@@ -2616,6 +2762,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     static const bool serial = getenv("FDIFF_TR_SERIAL") != nullptr;
     static const bool ext_event = !(getenv("FDIFF_TR_EXT_EVENT") && atoi(getenv("FDIFF_TR_EXT_EVENT")) == 0);
     const int lean_b = tr_lean_bits();
+    const bool fb_rowsum = [] { const char* e = getenv("FDIFF_TR_FB_ROWSUM"); return !(e && atoi(e) == 0); }();      // (read per call: A/B, tests)
     WgArgs wa{};
     wa.nparams = (long long)tb.layer_params; wa.TS = tb.TS; wa.nblk = (M + 31) / 32;
     RedArgs ra{};
@@ -2638,6 +2785,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         if (l == L - 1) { fa.dy0 = tb.dh; fa.dyp = nullptr; fa.npart = 0; }
         else { fa.dy0 = tb.dres[par ^ 1]; fa.dyp = tb.dxp[par ^ 1]; fa.npart = attn_parts; }
         fa.part_stride = tb.part_stride; fa.part_bf16 = part_bf16;
+        fa.rowsum = fb_rowsum && (D % 4 == 0) ? 1 : 0;
         fa.s1 = b.s1; fa.s2 = b.s2; fa.active = b.active;
         fa.datt = tb.datt; fa.dres = tb.dres[par];
         fa.stage = b.stage; fa.doT = b.doT;
@@ -2652,6 +2800,24 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
                                 (double)M * (4.0 * D * F + 2.0 * D * D));
             if (int rc = tr_fsplit_prepare(ctx, d, tb.nwg, DT, &fa.fs, s)) return rc;
             hipLaunchKernelGGL((k_tr_ffn_bwd<KS1, DT>), dim3(tb.nwg * d.fsplit), dim3(TW * 64), lds_bwd, s, d, fa);
+#ifdef FD_TR_PROF_FB
+            {
+                static int calls = 0;
+                if (++calls == 300) {
+                    unsigned long long h[16];
+                    hipStreamSynchronize(s);
+                    hipMemcpyFromSymbol(h, HIP_SYMBOL(fd_tr_fb_dbg), sizeof(h));
+                    static const char* nm[8] = {"d y + partial tensors", "LN2 bwd + d f fragments", "DMA wait + barrier", "chunk loop", "exchange",
+                                                "stage rows + LN1 bwd", "d o T-blocks + out-proj^T + stores", "barrier + column sums"};
+                    fprintf(stderr, "[k_tr_ffn_bwd phase clocks, workgroup 7, K cycles, average of %d launches]\n", calls);
+                    for (int w = 0; w < 2; ++w) {
+                        fprintf(stderr, "  wave %d:", 4 * w);
+                        for (int q = 0; q < 8; ++q) fprintf(stderr, " %s %.1f |", nm[q], (double)h[w * 8 + q] / calls / 1000.0);
+                        fprintf(stderr, "\n");
+                    }
+                }
+            }
+#endif
         }
         AttnBwdArgs ab{};
         ab.x0rb = b.x0rb; ab.att = b.att; ab.datt = tb.datt; ab.lse2 = b.lse2; ab.pmask = b.pmask;
