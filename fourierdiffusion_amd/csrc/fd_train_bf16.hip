@@ -739,18 +739,19 @@ __device__ unsigned long long fd_tr_fb_dbg[2 * 8];
 #else
 #define TRFB_STAMP(slot, t_prev) do { } while (0)
 #endif
+// (gamma: unconditional loads from clamped addresses, all issued before the first use -- inside the lane-divergent branch of
+//  ln_bwd_tile each of them was waited for at the end of its branch, DT dependent L2 round trips per call)
 template <int DT>
-__device__ __forceinline__ void ln_bwd_tile(f32x4 (&dy)[DT], const f32x4 (&xhat)[DT], const float* __restrict__ gamma, float rstd,
-                                            int D, int g) {
-    float s1 = 0.f, s2 = 0.f;
-    // (gamma: unconditional loads from clamped addresses, all issued before the first use -- inside the lane-divergent branch below
-    //  each of them was waited for at the end of its branch, DT dependent L2 round trips per call)
-    float4 gm4[DT];
+__device__ __forceinline__ void ln_gamma_load(const float* __restrict__ gamma, int D, int g, float4 (&gm4)[DT]) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
         const int d0 = 16 * dt + 4 * g;
         gm4[dt] = *reinterpret_cast<const float4*>(gamma + (d0 < D ? d0 : 0));
     }
+}
+template <int DT>
+__device__ __forceinline__ void ln_bwd_tile(f32x4 (&dy)[DT], const f32x4 (&xhat)[DT], const float4 (&gm4)[DT], float rstd, int D, int g) {
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
         const int d0 = 16 * dt + 4 * g;
@@ -802,6 +803,13 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     if (threadIdx.x < 32) {
         const unsigned n = threadIdx.x >> 1, hi = threadIdx.x & 1;
         klut[threadIdx.x] = ((n >> (2 * hi)) & 1u ? 0x0000ffffu : 0u) | ((n >> (2 * hi + 1)) & 1u ? 0xffff0000u : 0u);
+    }
+    // gamma2 | gamma1 behind the table: read by every lane as float4 where the LayerNorm backward needs them (as registers loaded at
+    // the top they cost 20 VGPRs each across the prologue -- the kernel spilled; read from global where used, a memory round trip each)
+    float* const gvec = reinterpret_cast<float*>(klut + 32);
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 2 * 16 * DT) {
+        const int i = threadIdx.x - 64, which = i / (16 * DT), f = i - which * (16 * DT);
+        gvec[i] = f < d.D ? (which ? a.g1 : a.g2)[f] : 0.f;
     }
     // F-split (struct FSplit): token block, chunk range and role of this workgroup
     const int nsp = d.fsplit, blk = nsp == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, fq = nsp == 2 ? (int)(blockIdx.x & 1) : 0;
@@ -861,9 +869,22 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
                 *reinterpret_cast<u32x4*>(actB + lane * NS + c) = valid ? *reinterpret_cast<const u32x4*>(srcb + c) : u32x4{0u, 0u, 0u, 0u};
         }
     };
-    // ---- gradient of the layer output
+    // ---- gradient of the layer output.  EVERY global read of the prologue is issued here, in front of the first wait: the LayerNorm2
+    // input, the dropout bits of the FFN output, gamma2 and the owner's LayerNorm1 input / out-projection dropout bits were read where
+    // they are used -- three dependent memory round trips inside "LN2 bwd + d f fragments" (14 K of the kernel's 86 K cycles at T = 252,
+    // profiles/r06_train_ffn_bwd_phase_clocks.txt) and one more in front of the loop.
     f32x4 dy[DT];
     load_ctile<DT>(a.dy0, m, valid, D, g, dy);
+    f32x4 xh[DT];
+    load_ctile<DT>(a.s2, m, valid, D, g, xh);
+    unsigned bits3[DT];
+    row_drop_bits<DT>(d, a.rb3, m, valid, g, bits3);
+    f32x4 s1t[DT];
+    unsigned bits1[DT];
+    if (owner) {
+        load_ctile<DT>(a.s1, m, valid, D, g, s1t);
+        row_drop_bits<DT>(d, a.rb1, m, valid, g, bits1);
+    }
     if (!rowsum) store_act();
     if (rowsum) {
         // The partial tensors (one per head or head pair, written by the next layer's k_tr_attn_bwd) as C tiles are DT 8-byte (bf16) /
@@ -989,13 +1010,12 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
                 for (int dt = 0; dt < DT; ++dt) dy[dt] += t[q][dt];
             }
     }
+    if (!rowsum) __syncthreads();  // (gvec: the row-linear form above has its own barrier)
     TRFB_STAMP(0, tprev);          // d y + its partial tensors
     // ---- LayerNorm2 backward
-    f32x4 xh[DT];
     float rstd2;
     {
         float mean;
-        load_ctile<DT>(a.s2, m, valid, D, g, xh);
         ln_stats<DT>(xh, D, g, mean, rstd2);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -1009,27 +1029,21 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
         for (int dt = 0; dt < DT; ++dt) t[dt] = dy[dt] * xh[dt];
         colsum(2, t);                                // d gamma2
     }
-    ln_bwd_tile<DT>(dy, xh, a.g2, rstd2, D, g);      // dy = d s2
+    {
+        float4 g2v[DT];
+        ln_gamma_load<DT>(gvec, D, g, g2v);          // (LDS: written at the top, two barriers ago)
+        ln_bwd_tile<DT>(dy, xh, g2v, rstd2, D, g);   // dy = d s2
+    }
     // ---- d f (FFN output after its dropout)
     f32x4 df[DT];
-    {
-        unsigned bits[DT];
-        row_drop_bits<DT>(d, a.rb3, m, valid, g, bits);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) df[dt][r] = ((bits[dt] >> r) & 1u) ? dy[dt][r] * d.keep_scale : 0.f;
-    }
+        for (int r = 0; r < 4; ++r) df[dt][r] = ((bits3[dt] >> r) & 1u) ? dy[dt][r] * d.keep_scale : 0.f;
     colsum(0, df);                                   // d b2
     // (the stores of d f follow the loop -- see k_tr_ffn_fwd -- and the epilogue's inputs are fetched now)
     bf16x8 dfr[KS1];
     ctile_to_frags<DT, KS1>(scratch, lane, D, df, false, dfr);
-    f32x4 s1t[DT];
-    unsigned bits1[DT];
-    if (owner) {
-        load_ctile<DT>(a.s1, m, valid, D, g, s1t);
-        row_drop_bits<DT>(d, a.rb1, m, valid, g, bits1);
-    }
     f32x4 acc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f4zero();
@@ -1141,7 +1155,11 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
             for (int dt = 0; dt < DT; ++dt) t[dt] = dy[dt] * xh[dt];
             colsum(4, t);                                // d gamma1
         }
-        ln_bwd_tile<DT>(dy, xh, a.g1, rstd1, D, g);      // dy = d s1
+        {
+            float4 g1v[DT];
+            ln_gamma_load<DT>(gvec + 16 * DT, D, g, g1v);
+            ln_bwd_tile<DT>(dy, xh, g1v, rstd1, D, g);   // dy = d s1
+        }
         TRFB_STAMP(5, tprev);      // stage rows, LN1 backward
         store_ctile<DT>(a.dres, m, valid, D, g, dy);
         // ---- d o (out-projection output after its dropout) -> d att = d o W_o
@@ -2727,7 +2745,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     const size_t scr = std::max((size_t)TW * KS1 * 1024, (size_t)4 * DT * 1024);
     const size_t NSh = (size_t)m->d.dim_ff / 64;
     const size_t lds_bwd = (size_t)4 * 2 * (2 * KS1 + DT) * 1024 + scr + (size_t)TW * 64 * NSh + (size_t)4 * 5 * 16 * DT * sizeof(float) +
-                           (size_t)TW * KS1 * 1024 + 128;      // (+ the lane-mask table)
+                           (size_t)TW * KS1 * 1024 + 128 + (size_t)2 * 16 * DT * sizeof(float);      // (+ the lane-mask table, + gamma2 | gamma1)
     const int attn_nw = tr_attn_waves(d.KT);
     const bool attn_oh = tr_attn_oh_mode(d.KT) != 0;
     const int attn_parts = attn_oh ? 2 * d.NP : d.NP;             // partial tensors of d x written by k_tr_attn_bwd
