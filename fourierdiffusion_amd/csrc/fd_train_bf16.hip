@@ -714,6 +714,9 @@ struct FfnBwdArgs {
     int npart; size_t part_stride;
     int part_bf16;            // the partial tensors are bf16 (one per head), part_stride in elements either way
     int rowsum;               // 1: the partial tensors are summed as contiguous 16-byte units through LDS (default); 0: C-tile loads
+    const __bf16* dqkvR;      // dxg: the next layer's d(q | k | v) rows (see AttnBwdArgs) instead of partial tensors ...
+    const char* winT;         // ... and that layer's in_proj^T image ([pair][which][DT] half blocks): d y += rows . in_proj^T here
+    int dxg;
     const float* s1; const float* s2;
     const unsigned char* active;
     float* datt;              // (M, D) gradient of the attention output
@@ -835,8 +838,9 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
     (void)tprev;
     // (with the row-linear sums below the first weight DMAs are issued BEHIND the prologue's register loads: vmcnt retires in order, and
     //  a register load issued behind 66 KiB of DMA is only usable when those have landed)
-    const bool rowsum = a.rowsum && a.npart > 0;
-    if (!rowsum) {
+    const bool dxg = a.dxg != 0;
+    const bool rowsum = !dxg && a.rowsum && a.npart > 0;
+    if (!rowsum && !dxg) {
         issue(0);
         if (NSH > 1) issue(1);
         if (NSH > 2) issue(2);
@@ -885,7 +889,66 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
         load_ctile<DT>(a.s1, m, valid, D, g, s1t);
         row_drop_bits<DT>(d, a.rb1, m, valid, g, bits1);
     }
-    if (!rowsum) store_act();
+    if (!rowsum && !dxg) store_act();
+    if (dxg) {
+        // ---- d y += (d q | d k | d v of the next layer, all heads) . in_proj^T: the K = 16 MFMAs k_tr_attn_bwd used to run per head, here
+        // once per token tile with fp32 accumulation over all heads.  The image (NP x 3 x DT half blocks, 45 KiB at 12 heads) goes
+        // through the first three ring buffers, which the FFN weights take over afterwards; the two waves of a tile split the
+        // (which, pair) combinations and exchange their partial sums through LDS like the row-linear sums below.
+        const int NC = 3 * d.NP, NI = (NC + 1) / 2, NI0 = (NI + 1) / 2;      // combinations; 16-byte pairs of them; the first wave's share
+        const int img_bytes = NC * DT * 512;
+        for (int i = wave; i * 1024 < img_bytes; i += TW) {
+            const int off = i * 1024 + lane * 16;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a.winT + (off < img_bytes ? off : 0)), LDS_PTR(ring + i * 1024), 16, 0, 0);
+        }
+        constexpr int MAXI = 6;                                              // NP <= 8: at most 12 pairs of combinations, 6 per wave
+        u32x4 bb[MAXI];
+        const int i0 = fhw ? NI0 : 0, cnt = fhw ? NI - NI0 : NI0;
+        {
+            const char* rowp = reinterpret_cast<const char*>(a.dqkvR) + ((size_t)(valid ? m : 0) * 4 + g) * NC * 8;
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) bb[i] = *reinterpret_cast<const u32x4*>(rowp + (size_t)(i < cnt ? i0 + i : i0) * 16);
+        }
+        store_act();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x4 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = f4zero();
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+            if (i < cnt) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int c = 2 * (i0 + i) + h;
+                    if (c < NC) {
+                        const int wh = c / d.NP, pr = c - wh * d.NP;
+                        const u32x2 bw = {valid ? bb[i][2 * h] : 0u, valid ? bb[i][2 * h + 1] : 0u};
+                        const s16x4 bf = __builtin_bit_cast(s16x4, bw);
+                        const char* ab = ring + ((size_t)((pr * 3 + wh) * DT) * 64 + lane) * 8;
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) o[dt] = MFMA16(*reinterpret_cast<const s16x4*>(ab + (size_t)dt * 512), bf, o[dt]);
+                    }
+                }
+            }
+        f32x4* const xs = reinterpret_cast<f32x4*>(fhw == 0 ? ring + 3 * WB + tile * (16 * 16 * DT * 4)
+                                                            : smem + NBUF * WB + SCR + TW * 64 * NS + 4 * 5 * 16 * DT * sizeof(float) + tile * (16 * 16 * DT * 4));
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) xs[dt * 64 + lane] = o[dt];
+        __syncthreads();
+        {
+            const f32x4* const x0 = reinterpret_cast<const f32x4*>(ring + 3 * WB + tile * (16 * 16 * DT * 4));
+            const f32x4* const x1 = reinterpret_cast<const f32x4*>(smem + NBUF * WB + SCR + TW * 64 * NS + 4 * 5 * 16 * DT * sizeof(float) + tile * (16 * 16 * DT * 4));
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                dy[dt] += x0[dt * 64 + lane];
+                dy[dt] += x1[dt * 64 + lane];
+            }
+        }
+        issue(0);                                      // (the image has been read: every wave is behind the barrier above)
+        if (NSH > 1) issue(1);
+        if (NSH > 2) issue(2);
+    }
     if (rowsum) {
         // The partial tensors (one per head or head pair, written by the next layer's k_tr_attn_bwd) as C tiles are DT 8-byte (bf16) /
         // 16-byte (fp32) loads per lane and part, each walking 16 rows x 4 lane groups -- 60 narrow gathers per lane for 12 heads,
@@ -1010,7 +1073,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
                 for (int dt = 0; dt < DT; ++dt) dy[dt] += t[q][dt];
             }
     }
-    if (!rowsum) __syncthreads();  // (gvec: the row-linear form above has its own barrier)
+    if (!rowsum && !dxg) __syncthreads();  // (gvec: the other forms above have their own barriers)
     TRFB_STAMP(0, tprev);          // d y + its partial tensors
     // ---- LayerNorm2 backward
     float rstd2;
@@ -1205,6 +1268,11 @@ struct AttnBwdArgs {
     const char* wk; const char* wv; const char* wq;
     const char* winT;         // [pair][which][DT] half blocks
     size_t part_stride;
+    // dxg != 0 (default): no partial tensors -- the d(q | k | v) values of every token go out ONCE more, as rows [token][lane group g]
+    // [which * NP + pair][4 bf16] (the K = 16 MFMA's B operand of lane (token, g), 144 contiguous bytes per (token, g) at 12 heads), and
+    // the consumer of d x (the next k_tr_ffn_bwd, k_tr_dx0 behind layer 0) multiplies them by in_proj^T itself: 576 B per token written
+    // and read instead of H x 144 B (12 heads: 1728 B), and the in-proj^T MFMAs of all heads accumulate in fp32.
+    __bf16* dqkvR; int dxg;
 };
 
 #ifdef FD_TR_PROF_ATTN      // variant build: in-kernel phase clocks of k_tr_attn_bwd (workgroup (0, 0), per wave), printed after 30 launches
@@ -1512,7 +1580,7 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
         // in-proj^T fragments of the epilogue, requested here: their L2 round trip runs under the key-owner sweep (as 15 loads at the
         // head of every tile's epilogue they were exposed: 3.1 K of a tile's 20 K clocks went into the epilogue)
         s16x4 wie[3][DT];
-        {
+        if (!a.dxg) {
             const char* wbase = a.winT + (size_t)pair * 3 * DT * 512;
 #pragma unroll
             for (int wh = 0; wh < 3; ++wh)
@@ -1605,9 +1673,17 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
                     }
                 }
             }
+            if (a.dxg) {
+                if (tv && mineR) {
+                    u32x2* row = reinterpret_cast<u32x2*>(a.dqkvR) + ((size_t)mm * 4 + g) * (3 * d.NP) + pair;
+                    row[0] = __builtin_bit_cast(u32x2, bq);
+                    row[d.NP] = __builtin_bit_cast(u32x2, bk);
+                    row[2 * d.NP] = __builtin_bit_cast(u32x2, bv);
+                }
+            }
             const size_t pidx = OH ? (size_t)bx : (size_t)pair;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
+            for (int dt = 0; dt < (a.dxg ? 0 : DT); ++dt) {
                 f32x4 o = f4zero();
                 o = MFMA16(wie[0][dt], bq, o);
                 o = MFMA16(wie[1][dt], bk, o);
@@ -2095,6 +2171,41 @@ __global__ __launch_bounds__(256) void k_tr_sum_parts_bf16(const float* __restri
             out[j] = v;
         }
     }
+}
+
+// Behind layer 0 (dxg form): gradient of the first layer's input = residual path + d(q | k | v) rows . in_proj^T (k_tr_ffn_bwd's prologue
+// does the same for the layers above).  One token tile per wave, the image fragments straight from the L2.
+template <int DT>
+__global__ __launch_bounds__(256) void k_tr_dx0(const TrDims d, const float* __restrict__ dres, const __bf16* __restrict__ dqkvR,
+                                                const char* __restrict__ winT, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = ((int)blockIdx.x * 4 + wave) * 16 + tok;
+    const bool valid = m < d.M;
+    const int NC = 3 * d.NP, NI = (NC + 1) / 2;
+    f32x4 dy[DT], o[DT];
+    load_ctile<DT>(dres, m, valid, d.D, g, dy);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f4zero();
+    const char* rowp = reinterpret_cast<const char*>(dqkvR) + ((size_t)(valid ? m : 0) * 4 + g) * NC * 8;
+    for (int i = 0; i < NI; ++i) {
+        const u32x4 bb = *reinterpret_cast<const u32x4*>(rowp + (size_t)i * 16);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = 2 * i + h;
+            if (c < NC) {
+                const int wh = c / d.NP, pr = c - wh * d.NP;
+                const u32x2 bw = {valid ? bb[2 * h] : 0u, valid ? bb[2 * h + 1] : 0u};
+                const char* ab = winT + ((size_t)((pr * 3 + wh) * DT) * 64 + lane) * 8;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    o[dt] = MFMA16(*reinterpret_cast<const s16x4*>(ab + (size_t)dt * 512), __builtin_bit_cast(s16x4, bw), o[dt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dy[dt] += o[dt];
+    store_ctile<DT>(out, m, valid, d.D, g, dy);
 }
 
 }  // namespace
@@ -2750,6 +2861,11 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     const bool attn_oh = tr_attn_oh_mode(d.KT) != 0;
     const int attn_parts = attn_oh ? 2 * d.NP : d.NP;             // partial tensors of d x written by k_tr_attn_bwd
     const int part_bf16 = tr_attn_oh_mode(d.KT) == 2 ? 1 : 0;
+    // d x of a layer's attention side as ONE product with in_proj^T in its consumer instead of per-head partial tensors: the default where
+    // the attention backward runs one head per workgroup (>= 12 token tiles: 12 bf16 tensors of d x per layer at 12 heads) -- same box,
+    // B = 64: T = 252 2.091 -> 2.042 ms per step; T = 100 (head pairs: 6 fp32 tensors, 100 workgroups in k_tr_ffn_bwd: its prologue is
+    // not bandwidth-bound there) 1.184 -> 1.195 ms (profiles/r06_train_dx_product_ab.txt).  FDIFF_TR_DX_GEMM=0 / 1 forces a form.
+    const bool dxg = [&] { const char* e = getenv("FDIFF_TR_DX_GEMM"); return e ? atoi(e) != 0 : attn_oh; }() && d.NP <= 8;
     const size_t lds_ab = tr_attn_bwd_lds(d.T, attn_oh);
     if (lds_ab > 160 * 1024)
         return fd_fail(ctx, FD_ERR_UNSUPPORTED, "k_tr_attn_bwd: %zu bytes of LDS for max_len %d (form %d)", lds_ab, d.T, tr_attn_oh_mode(d.KT));
@@ -2804,6 +2920,9 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         else { fa.dy0 = tb.dres[par ^ 1]; fa.dyp = tb.dxp[par ^ 1]; fa.npart = attn_parts; }
         fa.part_stride = tb.part_stride; fa.part_bf16 = part_bf16;
         fa.rowsum = fb_rowsum && (D % 4 == 0) ? 1 : 0;
+        fa.dxg = (dxg && l + 1 < L) ? 1 : 0;
+        fa.dqkvR = reinterpret_cast<const __bf16*>(tb.dxp[par ^ 1]);      // (the rows of layer l + 1 live where its partial tensors would)
+        fa.winT = l + 1 < L ? im->bimg + (size_t)(l + 1) * im->b_layer_stride + im->boff_win : nullptr;
         fa.s1 = b.s1; fa.s2 = b.s2; fa.active = b.active;
         fa.datt = tb.datt; fa.dres = tb.dres[par];
         fa.stage = b.stage; fa.doT = b.doT;
@@ -2842,6 +2961,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         ab.dxp = tb.dxp[par]; ab.dqkvT = b.dqkvT;
         ab.wk = limg + im->off_wk; ab.wv = limg + im->off_wv; ab.wq = limg + im->off_wq;
         ab.winT = bl + im->boff_win; ab.part_stride = tb.part_stride; ab.part_bf16 = part_bf16;
+        ab.dqkvR = reinterpret_cast<__bf16*>(tb.dxp[par]); ab.dxg = dxg ? 1 : 0;
         {
             // measurement hook: dP = dO V^T, dV = P^T dO, dQ = dS K, dK = dS^T Q (2 T D each per token) + the in-proj^T GEMM; the
             // recomputed scores are not algorithmic work
@@ -2914,7 +3034,10 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
     if (L > 0) {
         // gradient of the first layer's input = residual path + the pairs' in_proj contributions
         const size_t nn = (size_t)M * D;
-        if (part_bf16)
+        if (dxg)
+            hipLaunchKernelGGL((k_tr_dx0<DT>), dim3((unsigned)((M + 63) / 64)), dim3(256), 0, s, d, (const float*)tb.dres[0],
+                               reinterpret_cast<const __bf16*>(tb.dxp[0]), im->bimg + im->boff_win, tb.dh);
+        else if (part_bf16)
             hipLaunchKernelGGL(k_tr_sum_parts_bf16, dim3((unsigned)((nn / 4 + 256) / 256)), dim3(256), 0, s, tb.dres[0],
                                reinterpret_cast<const __bf16*>(tb.dxp[0]), attn_parts, tb.part_stride, tb.dh, nn);
         else

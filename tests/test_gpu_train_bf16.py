@@ -166,6 +166,42 @@ def test_attention_backward_forms_agree(monkeypatch, cfg, B, p):
         assert worst <= tol, (form, worst)
 
 
+@pytest.mark.parametrize("cfg,B,p", [(dict(T=37, C=5, D=72, L=2, H=12), 7, 0.0), (dict(T=252, C=6, D=72, L=3, H=12), 3, 0.1),
+                                      (dict(T=50, C=3, D=60, L=3, H=12), 5, 0.1), (dict(T=100, C=2, D=24, L=2, H=3), 4, 0.1),
+                                      (dict(T=20, C=3, D=8, L=2, H=4), 6, 0.1)])
+def test_attention_input_gradient_as_one_product_agrees_with_the_partial_tensors(monkeypatch, cfg, B, p):
+    """Round 6: k_tr_attn_bwd writes the d(q | k | v) rows and the CONSUMER of d x (the next k_tr_ffn_bwd's prologue; k_tr_dx0 behind
+    layer 0) multiplies them by in_proj^T with fp32 accumulation over all heads (default), instead of one partial tensor of d x per
+    head / head pair (FDIFF_TR_DX_GEMM=0).  Against the partial-tensor form with fp32 parts (the pair form: the exact one) the
+    difference is the order of fp32 additions in d x, which flips single bf16 operand roundings downstream; both are bit-reproducible.
+    Covers ragged T, a length that is not a multiple of 16 at 16 tiles (one head per workgroup), an odd head count, head_dim 2."""
+    from fourierdiffusion_amd.utils.losses import get_sde_loss_fn
+    tag = f"T{cfg['T']}_D{cfg['D']}_H{cfg['H']}_p{p}"
+    X = W.randn(f"dxg_x_{tag}", (B, cfg["T"], cfg["C"]), 3)
+    z = W.randn(f"dxg_z_{tag}", (B, cfg["T"], cfg["C"]), 3)
+    t = W.uniform(f"dxg_t_{tag}", (B,), 3, 0.05, 1.0)
+    m, sch, _ = make_model(cfg, precision="bf16")
+    m.dropout = p
+    fn = get_sde_loss_fn(sch, train=True)
+    res = {}
+    for key, env in (("parts", {"FDIFF_TR_DX_GEMM": "0", "FDIFF_TR_ATTN_OH": "0"}), ("gemm", {"FDIFF_TR_DX_GEMM": "1"}),
+                     ("gemm2", {"FDIFF_TR_DX_GEMM": "1"})):
+        monkeypatch.delenv("FDIFF_TR_ATTN_OH", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m.zero_grad()
+        torch.manual_seed(77)
+        loss = fn(m, batch_of(X, t), noise=dev(z)).item()
+        assert m.train_mode_effective == "bf16"
+        res[key] = (loss, m.grads.clone(), _grads_of(m))
+    assert res["gemm"][0] == res["gemm2"][0] and torch.equal(res["gemm"][1], res["gemm2"][1]), "not bit-reproducible"
+    assert res["gemm"][0] == res["parts"][0]                       # the forward does not depend on the backward form
+    assert not torch.equal(res["gemm"][1], res["parts"][1]) or cfg["L"] == 1, "the product form did not run (same bits as the parts)"
+    worst = max(np.abs(res["gemm"][2][k] - r).max() / max(np.abs(r).max(), 1e-20) for k, r in res["parts"][2].items())
+    _log(f"[parity] d x as rows . in_proj^T vs fp32 partial tensors ({tag}): worst max-rel over the tensors {worst:.3e}")
+    assert worst <= 2e-3, worst
+
+
 @pytest.mark.parametrize("cfg,B,p", [(dict(T=100, C=12, D=72, L=3, H=12), 9, 0.1), (dict(T=37, C=5, D=72, L=2, H=12), 7, 0.0),
                                       (dict(T=48, C=3, D=32, L=2, H=4), 5, 0.1)])
 def test_ffn_f_split_agrees_with_the_unsplit_kernels(monkeypatch, cfg, B, p):
