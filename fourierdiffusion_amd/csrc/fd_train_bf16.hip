@@ -2174,35 +2174,50 @@ __global__ __launch_bounds__(256) void k_tr_sum_parts_bf16(const float* __restri
 }
 
 // Behind layer 0 (dxg form): gradient of the first layer's input = residual path + d(q | k | v) rows . in_proj^T (k_tr_ffn_bwd's prologue
-// does the same for the layers above).  One token tile per wave, the image fragments straight from the L2.
+// does the same for the layers above).  One token tile per wave; the image (NP x 3 x DT half blocks) goes through LDS once per workgroup
+// (as fragments straight from the L2 every one of the NC x DT products waited for its own load: the kernel is on the step's tail).
 template <int DT>
 __global__ __launch_bounds__(256) void k_tr_dx0(const TrDims d, const float* __restrict__ dres, const __bf16* __restrict__ dqkvR,
                                                 const char* __restrict__ winT, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = ((int)blockIdx.x * 4 + wave) * 16 + tok;
     const bool valid = m < d.M;
-    const int NC = 3 * d.NP, NI = (NC + 1) / 2;
+    const int NC = 3 * d.NP, NI = (NC + 1) / 2, img_bytes = NC * DT * 512;
+    for (int i = wave; i * 1024 < img_bytes; i += 4) {
+        const int off = i * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(winT + (off < img_bytes ? off : 0)), LDS_PTR(smem + i * 1024), 16, 0, 0);
+    }
     f32x4 dy[DT], o[DT];
     load_ctile<DT>(dres, m, valid, d.D, g, dy);
+    constexpr int MAXI = 12;                                   // NP <= 8
+    u32x4 bb[MAXI];
+    {
+        const char* rowp = reinterpret_cast<const char*>(dqkvR) + ((size_t)(valid ? m : 0) * 4 + g) * NC * 8;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) bb[i] = *reinterpret_cast<const u32x4*>(rowp + (size_t)(i < NI ? i : 0) * 16);
+    }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[dt] = f4zero();
-    const char* rowp = reinterpret_cast<const char*>(dqkvR) + ((size_t)(valid ? m : 0) * 4 + g) * NC * 8;
-    for (int i = 0; i < NI; ++i) {
-        const u32x4 bb = *reinterpret_cast<const u32x4*>(rowp + (size_t)i * 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c = 2 * i + h;
-            if (c < NC) {
-                const int wh = c / d.NP, pr = c - wh * d.NP;
-                const u32x2 bw = {valid ? bb[2 * h] : 0u, valid ? bb[2 * h + 1] : 0u};
-                const char* ab = winT + ((size_t)((pr * 3 + wh) * DT) * 64 + lane) * 8;
+    for (int i = 0; i < MAXI; ++i)
+        if (i < NI) {
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-                    o[dt] = MFMA16(*reinterpret_cast<const s16x4*>(ab + (size_t)dt * 512), __builtin_bit_cast(s16x4, bw), o[dt]);
+            for (int h = 0; h < 2; ++h) {
+                const int c = 2 * i + h;
+                if (c < NC) {
+                    const int wh = c / d.NP, pr = c - wh * d.NP;
+                    const u32x2 bw = {valid ? bb[i][2 * h] : 0u, valid ? bb[i][2 * h + 1] : 0u};
+                    const char* ab = smem + ((size_t)((pr * 3 + wh) * DT) * 64 + lane) * 8;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+                        o[dt] = MFMA16(*reinterpret_cast<const s16x4*>(ab + (size_t)dt * 512), __builtin_bit_cast(s16x4, bw), o[dt]);
+                }
             }
         }
-    }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dy[dt] += o[dt];
     store_ctile<DT>(out, m, valid, d.D, g, dy);
@@ -3035,7 +3050,7 @@ int tr_backward_t(fd_score* m, const float* dout, float* grads, int accumulate, 
         // gradient of the first layer's input = residual path + the pairs' in_proj contributions
         const size_t nn = (size_t)M * D;
         if (dxg)
-            hipLaunchKernelGGL((k_tr_dx0<DT>), dim3((unsigned)((M + 63) / 64)), dim3(256), 0, s, d, (const float*)tb.dres[0],
+            hipLaunchKernelGGL((k_tr_dx0<DT>), dim3((unsigned)((M + 63) / 64)), dim3(256), ((size_t)3 * d.NP * DT * 512 + 1023) & ~(size_t)1023, s, d, (const float*)tb.dres[0],
                                reinterpret_cast<const __bf16*>(tb.dxp[0]), im->bimg + im->boff_win, tb.dh);
         else if (part_bf16)
             hipLaunchKernelGGL(k_tr_sum_parts_bf16, dim3((unsigned)((nn / 4 + 256) / 256)), dim3(256), 0, s, tb.dres[0],
