@@ -1320,8 +1320,12 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
     if (threadIdx.x < 64) lut[threadIdx.x] = ((threadIdx.x >> 2) >> (threadIdx.x & 3)) & 1u ? d.keep_scale : 0.f;
     // key-oriented copy of the same bits for the key-owner sweep, [NHS][NTOK keys][NJ][4]: byte (key, jq, gq) = bits of queries
     // 32 jq + 4 gq + r (bit r) and 32 jq + 16 + 4 gq + r (bit 4 + r); built from `pm` by the workgroup itself once it has landed
+    // (round 6: [query block jq][key + key / 32] dwords, byte gq -- a key's dword sat at a 32-byte stride, so the 16 keys a wave reads
+    //  per sweep iteration shared four banks and the 64 lanes of a transposition store ONE; now consecutive keys are consecutive
+    //  dwords, and the + key / 32 spreads the transposition's keys 32 apart over different banks)
     unsigned char* const pmT = reinterpret_cast<unsigned char*>(lut + 64);
-    const int PTH = NTOK * NJ * 4;                               // bytes per head
+    const int PTRS = NTOK + (NTOK >> 5) + 1;                     // dwords per query block
+    const int PTH = NJ * PTRS * 4;                               // bytes per head
     const size_t pstride = (size_t)KS1 * 1024;
     auto wfrag = [&](const char* img, int ks) { return *reinterpret_cast<const bf16x8*>(img + pair * pstride + ((size_t)ks * 64 + lane) * 16); };
     unsigned long long tprev = 0;
@@ -1473,27 +1477,52 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
     // transposed in registers (three masked exchange steps on a 64-bit word), written as eight bytes (one per key).
     if (d.p > 0.f) {
         const int RB = NJ * 4;
-        for (int hi = 0; hi < NHS; ++hi) {
-            const unsigned char* src = pm + hi * PMH;
-            unsigned char* dst = pmT + hi * PTH;
-            for (int jq = wave; jq < NJ; jq += NW)                     // (no run-time division: a wave takes whole query blocks)
-            for (int rest = lane; rest < NJ * 16; rest += 64) {
-                const int jb = rest >> 4, gk = (rest >> 2) & 3, gq = rest & 3;
-                unsigned lo = 0u, hi32 = 0u;
+        // tasks (head, query block jq, key block jb, query lane group gq) over all threads of the workgroup: NHS x NJ x NJ x 4 of them
+        // (256 at T = 252 with one head per workgroup, 128 at T = 100 with a head pair); a quad = gq 0..3 of one (head, jq, jb)
+        const float inv_rb = 1.0f / (float)RB;
+        for (int task = threadIdx.x; task < NHS * NJ * RB; task += NW * 64) {
+            {
+                const int hj = (int)(((float)task + 0.5f) * inv_rb);      // (head, jq): exact for these small integers
+                const int rest = task - hj * RB;
+                const int hi = NHS == 1 ? 0 : (hj >= NJ ? 1 : 0), jq = hj - hi * NJ;
+                const unsigned char* src = pm + hi * PMH;
+                unsigned char* dst = pmT + hi * PTH;
+                // a lane = (key block jb, query lane group gq): the eight query rows' DWORDS hold the bytes of all four key lane groups gk
+                // (eight 4-byte reads for four items; the first form read eight single bytes per item)
+                const int jb = rest >> 2, gq = rest & 3;
+                unsigned qw[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int q0 = min(32 * jq + 4 * gq + e, T - 1), q1 = min(32 * jq + 16 + 4 * gq + e, T - 1);
-                    lo |= (unsigned)src[q0 * RB + jb * 4 + gk] << (8 * e);
-                    hi32 |= (unsigned)src[q1 * RB + jb * 4 + gk] << (8 * e);
+                    qw[e] = *reinterpret_cast<const unsigned*>(src + q0 * RB + jb * 4);
+                    qw[4 + e] = *reinterpret_cast<const unsigned*>(src + q1 * RB + jb * 4);
                 }
-                unsigned long long x = (unsigned long long)lo | ((unsigned long long)hi32 << 32), t;
-                t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;  x = x ^ t ^ (t << 7);
-                t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x = x ^ t ^ (t << 14);
-                t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x = x ^ t ^ (t << 28);
+                unsigned* const dw = reinterpret_cast<unsigned*>(dst) + jq * PTRS;
 #pragma unroll
-                for (int f = 0; f < 8; ++f) {
-                    const int key = 32 * jb + (f >> 2) * 16 + 4 * gk + (f & 3);
-                    if (key < NTOK) dst[(key * NJ + jq) * 4 + gq] = (unsigned char)(x >> (8 * f));
+                for (int gk = 0; gk < 4; ++gk) {
+                    unsigned lo = 0u, hi32 = 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lo |= ((qw[e] >> (8 * gk)) & 0xffu) << (8 * e);
+                        hi32 |= ((qw[4 + e] >> (8 * gk)) & 0xffu) << (8 * e);
+                    }
+                    unsigned long long x = (unsigned long long)lo | ((unsigned long long)hi32 << 32), t;
+                    t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;  x = x ^ t ^ (t << 7);
+                    t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x = x ^ t ^ (t << 14);
+                    t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x = x ^ t ^ (t << 28);
+                    // byte f of x = the bits of key f of this item for the queries of lane group gq; the four lanes of a quad are gq = 0..3
+                    // of one jb: a 4 x 4 byte transposition inside the quad (two masked exchanges per 32-bit half) leaves lane gq with the
+                    // complete dwords of keys f = gq and f = 4 + gq -- two 4-byte stores per item instead of eight single bytes
+                    auto quad_t = [&](unsigned v) {
+                        const unsigned a = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+                        v = (gq & 1) ? (((a >> 8) & 0x00FF00FFu) | (v & 0xFF00FF00u)) : ((v & 0x00FF00FFu) | ((a & 0x00FF00FFu) << 8));
+                        const unsigned c = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+                        return (gq & 2) ? ((c >> 16) | (v & 0xFFFF0000u)) : ((v & 0x0000FFFFu) | (c << 16));
+                    };
+                    const unsigned w0 = quad_t((unsigned)x), w1 = quad_t((unsigned)(x >> 32));
+                    const int k0 = 32 * jb + 4 * gk + gq, k1 = k0 + 16;
+                    if (k0 < NTOK) dw[k0 + (k0 >> 5)] = w0;
+                    if (k1 < NTOK) dw[k1 + (k1 >> 5)] = w1;
                 }
             }
         }
@@ -1603,7 +1632,7 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
             unsigned wn[NHS];
 #pragma unroll
             for (int hi = 0; hi < NHS; ++hi) {
-                pt[hi] = pmT + hi * PTH + (kt * 16 + tok) * NJ * 4;
+                pt[hi] = pmT + hi * PTH + ((kt * 16 + tok) + ((kt * 16 + tok) >> 5)) * 4;
                 wn[hi] = 0xffffffffu;
                 if (d.p > 0.f) wn[hi] = *reinterpret_cast<const unsigned*>(pt[hi]);
             }
@@ -1613,7 +1642,7 @@ __global__ __launch_bounds__(NW * 64, OH ? FD_TR_ATTN_OH_MINW : (NW == 8 ? FD_TR
 #pragma unroll
                 for (int hi = 0; hi < NHS; ++hi) {
                     wc[hi] = wn[hi];
-                    if (d.p > 0.f && jq + 1 < NJ) wn[hi] = *reinterpret_cast<const unsigned*>(pt[hi] + (jq + 1) * 4);
+                    if (d.p > 0.f && jq + 1 < NJ) wn[hi] = *reinterpret_cast<const unsigned*>(pt[hi] + (size_t)(jq + 1) * PTRS * 4);
                 }
                 const s16x4 qfa = rfrag_loop(qR, qa_t), qfb = rfrag_loop(qR, qb_t), ofa = rfrag_loop(oR, qa_t), ofb = rfrag_loop(oR, qb_t);
                 const bf16x8 qcf = cfrag(qC, jq), ocf = cfrag(oC, jq);
@@ -2365,7 +2394,7 @@ int tr_attn_oh_mode(int KT) {
 size_t tr_attn_bwd_lds(int T, bool one_head) {
     const size_t KT = (size_t)(T + 15) / 16, NJ = (KT + 1) / 2, nhs = one_head ? 1 : 2;
     return 4 * KT * 16 * (one_head ? 16 : 32) + 3 * NJ * (one_head ? 512 : 1024) + 2 * nhs * KT * 16 * sizeof(float) +
-           nhs * (size_t)T * NJ * 4 + 16 + 256 + nhs * KT * 16 * NJ * 4;
+           nhs * (size_t)T * NJ * 4 + 16 + 256 + nhs * NJ * (KT * 16 + (KT * 16) / 32 + 1) * 4;
 }
 
 // the context's error word of the device-side bounded waits (pinned, mapped into the device)
