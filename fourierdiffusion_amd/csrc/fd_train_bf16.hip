@@ -1191,8 +1191,18 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
         }
         return;
     }
+    // The tile's second wave used to idle from here to the last barrier (14.7 K of the kernel's 79 K cycles at T = 252): it now takes
+    // the out-projection^T product d att = d o W_o -- its fragments requested here, d o read from the owner's LDS fragments behind a
+    // barrier -- while the owner stores d s1 and the d o T-blocks.
+    bf16x8 wotf[DT][KS1];
+    if (!owner) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) wotf[dt][ks] = *reinterpret_cast<const bf16x8*>(a.wot + ((size_t)(dt * KS1 + ks) * 64 + lane) * 16);
+    }
+    const int m0w = (blk * 4 + tile) * 16;
     if (owner) {
-        const int m0w = (blk * 4 + tile) * 16;
         stage_rows<DT, KS1>(a.stage, StageL<KS1, DT>::off_dr, m, valid, D, g, df, false);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[dt] += xch[(tile * DT + dt) * 64 + lane];
@@ -1230,15 +1240,21 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_bwd(const TrDims d, const
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) df[dt][r] = ((bits1[dt] >> r) & 1u) ? dy[dt][r] * d.keep_scale : 0.f;
-        store_T16<DT>(tscr, a.doT + ((size_t)(m0w >> 5) * (16 * DT)) * 32 + (m0w & 31), 32, lane, D, df, false, valid);
         // (a second scratch: the first one is aliased by the exchange area, which other owners may still be reading)
         ctile_to_frags<DT, KS1>(scratch2, lane, D, df, false, dfr);
+    }
+    __syncthreads();                   // the d o fragments of the four tiles are in LDS
+    if (owner) {
+        store_T16<DT>(tscr, a.doT + ((size_t)(m0w >> 5) * (16 * DT)) * 32 + (m0w & 31), 32, lane, D, df, false, valid);
+    } else {
+        const char* const osc = scratch2 - 4 * KS1 * 1024;          // the owner's (wave `tile`) scratch
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) dfr[ks] = *reinterpret_cast<const bf16x8*>(osc + (ks * 64 + lane) * 16);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             f32x4 o = f4zero();
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks)
-                o = MFMA(*reinterpret_cast<const bf16x8*>(a.wot + ((size_t)(dt * KS1 + ks) * 64 + lane) * 16), dfr[ks], o);
+            for (int ks = 0; ks < KS1; ++ks) o = MFMA(wotf[dt][ks], dfr[ks], o);
             acc[dt] = o;
         }
         store_ctile<DT>(a.datt, m, valid, D, g, acc);
