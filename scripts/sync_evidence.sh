@@ -17,6 +17,6 @@ cp $R/stats_train/train_nasdaq_kernel_stats.csv profiles/${P}_train_nasdaq_kerne
 cp $R/serial_ecg/s_kernel_stats.csv profiles/${P}_train_ecg_serial_kernel_stats.csv
 cp $R/serial_nasdaq/s_kernel_stats.csv profiles/${P}_train_nasdaq_serial_kernel_stats.csv
 grep -v "^$" $R/ab.txt | cut -c1-220 > profiles/${P}_train_persist_final_ab.txt
-cp $R/phase_clocks.txt profiles/${P}_train_fwd_layers_phase_clocks_final.txt
+[ -f $R/phase_clocks.txt ] && cp $R/phase_clocks.txt profiles/${P}_train_fwd_layers_phase_clocks_final.txt || true      # (only when the -DFD_TRP_PROF variant library was built for the run)
 cp $R/gpu_suite.txt profiles/${P}_gpu_suite.txt
 git status --short profiles | head -30
