@@ -361,7 +361,7 @@ __global__ __launch_bounds__(TW * 64, 2) void k_tr_ffn_fwd(const TrDims d, const
     const int lane = threadIdx.x & 63, tok = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile = wave & 3, fhw = wave >> 2;
-    const int D = d.D, M = d.M, NS = d.F / 64, F = d.F;
+    const int D = d.D, M = d.M, NS = d.F / 64;
     unsigned long long tprev = __builtin_readcyclecounter();
     (void)tprev;
     char* const ring = smem;
