@@ -1039,12 +1039,14 @@ void fd_bf16_destroy(fd_score* m) {
 int fd_bf16_prepare(fd_score* m, hipStream_t s, bool training_only, bool ffn32_only) {
     fd_bf16_images* im = m->bf16;
     if (!im || !im->supported) return FD_OK;
-    // Images only the INFERENCE kernels read -- the step-by-step path's FFN image, the persistent kernel's pair-form FFN image and
-    // fp32 layer vectors, the embedding / unembedding images, the projection images of the other widths -- are skipped by a training
-    // step's rebuild (`training_only`: it sits on the step's critical path, in front of the first attention kernel: 53 us of builds
-    // on a side stream against 81 us of prologue on the caller's, rocprofv3 time line) and left marked stale; the next inference
-    // call then builds just those (`ffn32_only` = inference-only part; the parameters have not changed in between).
-    im->ffn32_stale = training_only;
+    // Images only the INFERENCE kernels read -- the step-by-step path's FFN image, the persistent kernel's pair-form FFN image, the
+    // embedding / unembedding images, the projection images of the other widths -- are skipped by a training step's rebuild
+    // (`training_only`: it sits on the step's critical path, in front of the first attention kernel: 53 us of builds on a side stream
+    // against 81 us of prologue on the caller's, rocprofv3 time line) and left marked stale; the next inference call then builds just
+    // those (`ffn32_only` = inference-only part; the parameters have not changed in between).  The persistent kernel's fp32 layer
+    // vectors (n_lp blocks, a few KiB) sit between the training images in the block list and are built by BOTH rebuilds.  Something is
+    // skipped only for a model with the persistent-kernel images (B.mega below): without them a training rebuild builds everything.
+    im->ffn32_stale = training_only && im->mimg != nullptr;
     const int D = m->d.d_model, F = m->d.dim_ff, H = m->d.n_head, C = m->d.n_channels, hd = D / H, L = m->d.num_layers;
     const int NB = 2 * im->ks1 + im->dt;
     const float* P = m->params;
